@@ -1,0 +1,240 @@
+/* oracle/sfx_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C) of the hot path of BurntSushi/suffix, used ONLY as
+ * the checker in tests/, in __graft_entry__.smoke() and as bench.py's
+ * `cpu_baseline` leg.  Nothing under suffix_amd/ may link, import or call it.
+ *
+ * Parity pin: the reference (Rust) cannot be compiled in this image (no
+ * rustc/cargo), so this restatement is pinned against (1) every known-answer
+ * literal of the reference's own tests (/root/reference/tests/tests.rs:22-70,
+ * :100-168, :181-213 and the doc-tests), (2) the reference's own oracle,
+ * `naive_table` (src/table.rs:367-376), restated below as orc_naive_sa, on
+ * thousands of random byte/UTF-8 strings, and (3) the two FASTA fixtures'
+ * SA/LCP sha256 values derived from the definition.
+ * LCP: the reference has no test asserting lcp_lens() values ("parity
+ * unpinned" by the reference itself); the definition at src/table.rs:352-359
+ * is the pin.
+ *
+ * Functions and the reference code each one follows:
+ *   orc_naive_sa        src/table.rs:367-376  naive_table
+ *   orc_sais            src/table.rs:378-386  sais_table -> :388-574 sais
+ *   orc_lcp_quadratic   src/table.rs:348-365  lcp_lens_quadratic + lcp_len
+ *   orc_lcp_kasai       src/table.rs:314-346  (commented-out linear variant)
+ *   orc_positions       src/table.rs:223-259  positions + :900-914 binary_search
+ *   orc_any_position    src/table.rs:279-293  any_position (contains = found)
+ */
+#define _GNU_SOURCE
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { TY_ASC = 0, TY_DESC = 1, TY_VALLEY = 2 };      /* SuffixType :580-585 */
+
+/* PartialEq for SuffixType, src/table.rs:663-669: Valley counts as Ascending */
+static inline int ty_same_class(uint8_t a, uint8_t b)
+{
+    return (a == TY_DESC) == (b == TY_DESC);
+}
+
+/* SuffixTypes (:576-578) + Bins (:671-675), shared by all recursion levels */
+typedef struct {
+    uint8_t  *types;
+    uint32_t *sizes;  size_t sizes_len;
+    uint32_t *ptrs;   size_t ptrs_len, ptrs_cap;
+    uint32_t *alphas; size_t n_alpha, alphas_cap;
+} orc_ctx;
+
+static void orc_grow_sizes(orc_ctx *cx, size_t want)
+{
+    size_t cap = cx->sizes_len ? cx->sizes_len : 256;
+    while (cap < want) cap *= 2;
+    cx->sizes = (uint32_t *)realloc(cx->sizes, cap * sizeof(uint32_t));
+    memset(cx->sizes + cx->sizes_len, 0, (cap - cx->sizes_len) * sizeof(uint32_t));
+    cx->sizes_len = cap;
+}
+static void orc_reserve_alphas(orc_ctx *cx, size_t want)
+{
+    if (want > cx->alphas_cap) {
+        cx->alphas = (uint32_t *)realloc(cx->alphas, want * sizeof(uint32_t));
+        cx->alphas_cap = want;
+    }
+}
+static void orc_reset_ptrs(orc_ctx *cx, size_t len)
+{
+    if (len > cx->ptrs_cap) {
+        cx->ptrs = (uint32_t *)realloc(cx->ptrs, len * sizeof(uint32_t));
+        cx->ptrs_cap = len;
+    }
+    memset(cx->ptrs, 0, len * sizeof(uint32_t));
+    cx->ptrs_len = len;
+}
+/* find_head_pointers :706-712 / find_tail_pointers :714-720 */
+static void orc_head_ptrs(orc_ctx *cx)
+{
+    uint32_t sum = 0;
+    for (size_t k = 0; k < cx->n_alpha; k++) {
+        uint32_t c = cx->alphas[k];
+        cx->ptrs[c] = sum;
+        sum += cx->sizes[c];
+    }
+}
+static void orc_tail_ptrs(orc_ctx *cx)
+{
+    uint32_t sum = 0;
+    for (size_t k = 0; k < cx->n_alpha; k++) {
+        uint32_t c = cx->alphas[k];
+        sum += cx->sizes[c];
+        cx->ptrs[c] = sum - 1;
+    }
+}
+/* head_insert :723-727 / tail_insert :730-736 */
+static inline void orc_head_insert(orc_ctx *cx, uint32_t *sa, uint32_t i, uint32_t c)
+{
+    sa[cx->ptrs[c]++] = i;
+}
+static inline void orc_tail_insert(orc_ctx *cx, uint32_t *sa, uint32_t i, uint32_t c)
+{
+    uint32_t p = cx->ptrs[c];
+    sa[p] = i;
+    if (p > 0) cx->ptrs[c] = p - 1;
+}
+
+static void sais_u32(orc_ctx *cx, const uint32_t *t, uint32_t n, uint32_t *sa);
+
+#define CH_T uint8_t
+#define FN(name) name##_u8
+#include "sais_level.inc"
+#undef CH_T
+#undef FN
+#define CH_T uint32_t
+#define FN(name) name##_u32
+#include "sais_level.inc"
+#undef CH_T
+#undef FN
+
+/* sais_table, src/table.rs:378-386.  Returns 0, or -1 if n > u32::MAX (:380). */
+int orc_sais(const uint8_t *text, uint64_t n, uint32_t *sa)
+{
+    if (n > 0xFFFFFFFFull) return -1;
+    orc_ctx cx;
+    memset(&cx, 0, sizeof cx);
+    cx.types = (uint8_t *)malloc(n ? n : 1);
+    sais_u8(&cx, text, (uint32_t)n, sa);
+    free(cx.types); free(cx.sizes); free(cx.ptrs); free(cx.alphas);
+    return 0;
+}
+
+/* naive_table, src/table.rs:367-376: comparison sort of all byte suffixes;
+ * a proper prefix sorts first (Rust slice Ord). */
+typedef struct { const uint8_t *text; uint64_t n; } cmp_env;
+static int cmp_suffix(const void *pa, const void *pb, void *envp)
+{
+    const cmp_env *e = (const cmp_env *)envp;
+    uint32_t a = *(const uint32_t *)pa, b = *(const uint32_t *)pb;
+    uint64_t la = e->n - a, lb = e->n - b;
+    int r = memcmp(e->text + a, e->text + b, la < lb ? la : lb);
+    if (r) return r;
+    return (la < lb) ? -1 : (la > lb);
+}
+int orc_naive_sa(const uint8_t *text, uint64_t n, uint32_t *sa)
+{
+    if (n > 0xFFFFFFFFull) return -1;
+    for (uint64_t i = 0; i < n; i++) sa[i] = (uint32_t)i;
+    cmp_env env = { text, n };
+    qsort_r(sa, n, sizeof(uint32_t), cmp_suffix, &env);
+    return 0;
+}
+
+/* lcp_lens_quadratic + lcp_len, src/table.rs:348-365 */
+void orc_lcp_quadratic(const uint8_t *text, uint64_t n, const uint32_t *sa, uint32_t *lcp)
+{
+    if (n == 0) return;
+    lcp[0] = 0;
+    for (uint64_t r = 1; r < n; r++) {
+        uint64_t a = sa[r - 1], b = sa[r], k = 0;
+        while (a + k < n && b + k < n && text[a + k] == text[b + k]) k++;
+        lcp[r] = (uint32_t)k;
+    }
+}
+
+/* The linear-time variant the reference keeps commented out (:314-346), on
+ * bytes.  `inv` is scratch of n entries (the inverse SA the reference builds at
+ * :131-134 and then never uses). */
+void orc_lcp_kasai(const uint8_t *text, uint64_t n, const uint32_t *sa,
+                   uint32_t *inv, uint32_t *lcp)
+{
+    if (n == 0) return;
+    for (uint64_t r = 0; r < n; r++) inv[sa[r]] = (uint32_t)r;
+    lcp[0] = 0;
+    uint64_t h = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t r = inv[i];
+        if (r == 0) { h = 0; continue; }
+        uint64_t j = sa[r - 1];
+        while (i + h < n && j + h < n && text[i + h] == text[j + h]) h++;
+        lcp[r] = (uint32_t)h;
+        if (h) h--;
+    }
+}
+
+/* Rust `a <= b` / `a < b` on byte slices: lexicographic, prefix sorts first. */
+static int bytes_cmp(const uint8_t *a, uint64_t la, const uint8_t *b, uint64_t lb)
+{
+    int r = memcmp(a, b, la < lb ? la : lb);
+    if (r) return r;
+    return (la < lb) ? -1 : (la > lb);
+}
+static int starts_with(const uint8_t *s, uint64_t ls, const uint8_t *q, uint64_t lq)
+{
+    return ls >= lq && memcmp(s, q, lq) == 0;
+}
+
+/* positions, src/table.rs:223-259 (with binary_search :900-914): writes the
+ * half-open SA interval [*start, *end).  Empty result => *start == *end == 0. */
+void orc_positions(const uint8_t *text, uint64_t n, const uint32_t *sa,
+                   const uint8_t *q, uint64_t m, uint64_t *start, uint64_t *end)
+{
+    *start = *end = 0;
+    if (n == 0 || m == 0) return;                                   /* :228-229 */
+    const uint8_t *s0 = text + sa[0];       uint64_t l0 = n - sa[0];
+    const uint8_t *sl = text + sa[n - 1];   uint64_t ll = n - sa[n - 1];
+    if ((bytes_cmp(q, m, s0, l0) < 0 && !starts_with(s0, l0, q, m)) /* :230-231 */
+        || bytes_cmp(q, m, sl, ll) > 0)                             /* :232 */
+        return;
+    uint64_t lo = 0, hi = n;                                        /* :244-246 */
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) / 2;
+        if (bytes_cmp(q, m, text + sa[mid], n - sa[mid]) <= 0) hi = mid; else lo = mid + 1;
+    }
+    uint64_t st = lo;
+    lo = 0; hi = n - st;                                            /* :247-250 */
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) / 2;
+        uint32_t s = sa[st + mid];
+        if (!starts_with(text + s, n - s, q, m)) hi = mid; else lo = mid + 1;
+    }
+    uint64_t en = st + lo;
+    if (st > en) return;                                            /* :254-255 */
+    if (st == en) return;
+    *start = st; *end = en;
+}
+
+/* any_position, src/table.rs:279-293: std binary_search_by comparing the first
+ * m bytes of each suffix with the query.  Returns 1 and *pos when found.  The
+ * index returned is "arbitrary" by contract (:261-262); callers may only check
+ * that it is a real occurrence. */
+int orc_any_position(const uint8_t *text, uint64_t n, const uint32_t *sa,
+                     const uint8_t *q, uint64_t m, uint32_t *pos)
+{
+    if (m == 0) return 0;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint64_t mid = lo + (hi - lo) / 2;
+        uint32_t s = sa[mid];
+        uint64_t ls = n - s, take = ls < m ? ls : m;
+        int r = bytes_cmp(text + s, take, q, m);
+        if (r == 0) { *pos = s; return 1; }
+        if (r < 0) lo = mid + 1; else hi = mid;
+    }
+    return 0;
+}
