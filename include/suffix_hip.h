@@ -1,0 +1,142 @@
+/* include/suffix_hip.h -- C ABI of libsuffix_hip.so, the MI355X (gfx950) engine
+ * that replaces the suffix-array hot path of BurntSushi/suffix v1.3.0.
+ *
+ * The reference is pure Rust with no FFI of its own; these entry points are
+ * what a Rust `extern "C"` block binds at the private seams listed below
+ * (citations are /root/reference/src/table.rs; the Rust side a maintainer
+ * would add is shown in INTEGRATION.md and rust/suffix_hip_shim.rs).
+ *
+ * Conventions
+ *  - caller allocates, callee fills (mirrors `vec![0u32; n]` at :381);
+ *  - every function returns an `int` status, 0 == SFX_OK (the reference panics,
+ *    :380 / :117; the shim turns non-zero into panic!);
+ *  - plain pointers and sizes only; `void* stream` is a hipStream_t (NULL = the
+ *    default stream);
+ *  - "*_dev" entry points take DEVICE pointers (inputs already resident in HBM,
+ *    outputs left in HBM) plus a caller-provided device workspace; the others
+ *    take HOST pointers and stage through HBM themselves;
+ *  - re-entrant: no global mutable state except the optional profiler.
+ */
+#ifndef SUFFIX_HIP_H
+#define SUFFIX_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    SFX_OK = 0,
+    SFX_ERR_ARG = 1,          /* null pointer / inconsistent sizes            */
+    SFX_ERR_TOO_LARGE = 2,    /* n > u32::MAX on a u32 entry point (:380)     */
+    SFX_ERR_NO_DEVICE = 3,    /* no HIP device visible                        */
+    SFX_ERR_HIP = 4,          /* a HIP runtime call or kernel failed          */
+    SFX_ERR_WORKSPACE = 5,    /* caller workspace smaller than *_workspace_bytes */
+    SFX_ERR_INTERNAL = 6      /* engine invariant violated (bug)              */
+};
+
+const char* sfx_strerror(int status);
+int sfx_device_count(void);
+/* text of the last HIP error seen by this thread ("" if none) */
+const char* sfx_last_hip_error(void);
+
+/* ---- SuffixTable::new -> sais_table (:378-386): suffix array, u32 indices ---- */
+/* Host buffers.  Replaces the body of sais_table after `vec![0u32; n]` (:381-385).
+ * n == 0 and n == 1 succeed (:395-402).  sa_out[r] = start of the r-th smallest
+ * byte suffix, "shorter prefix sorts first" (naive_table :367-376). */
+int sfx_build_sa_u32(const uint8_t* text, uint64_t n, uint32_t* sa_out);
+/* Device-resident variant: d_text (n bytes) -> d_sa (n u32), all in HBM. */
+uint64_t sfx_sa_workspace_bytes(uint64_t n);
+int sfx_build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa,
+                         void* d_workspace, uint64_t workspace_bytes, void* stream);
+
+/* ---- lcp_lens (:130-138 -> lcp_lens_quadratic :348-361): LCP array ---------- */
+/* lcp_out[0] = 0, lcp_out[r] = |lcp(text[sa[r-1]..], text[sa[r]..])| in bytes. */
+int sfx_build_lcp_u32(const uint8_t* text, uint64_t n, const uint32_t* sa, uint32_t* lcp_out);
+uint64_t sfx_lcp_workspace_bytes(uint64_t n);
+int sfx_build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa,
+                          uint32_t* d_lcp, void* d_workspace, uint64_t workspace_bytes,
+                          void* stream);
+
+/* ---- positions / contains / any_position (:223-293), batched ---------------- */
+/* Device-resident index = text + suffix array kept in HBM across calls. */
+typedef struct sfx_index sfx_index;
+/* sa == NULL => build it on the device.  Host pointers. */
+int sfx_index_create(const uint8_t* text, uint64_t n, const uint32_t* sa, sfx_index** out);
+void sfx_index_destroy(sfx_index* ix);
+uint64_t sfx_index_len(const sfx_index* ix);
+/* copy the index's suffix array back to the host (n u32) */
+int sfx_index_table(const sfx_index* ix, uint32_t* sa_out);
+/* Queries are concatenated in `qbytes`; query k is qbytes[qoff[k] .. qoff[k+1]).
+ * positions(q) == table[start_out[k] .. end_out[k]) exactly as :244-258; an empty
+ * result is reported as start == end == 0.  found_out[k] = contains(q) (:197-199);
+ * any_out[k] = any_position(q) or UINT32_MAX for None (:279-293; which occurrence
+ * is "arbitrary" by contract, :261-262).  Output arrays may be NULL to skip. */
+int sfx_positions_batch(const sfx_index* ix, const uint8_t* qbytes, const uint64_t* qoff,
+                        uint64_t nq, uint32_t* start_out, uint32_t* end_out);
+int sfx_contains_batch(const sfx_index* ix, const uint8_t* qbytes, const uint64_t* qoff,
+                       uint64_t nq, uint8_t* found_out, uint32_t* any_out);
+/* all-device variant of the above (d_qbytes, d_qoff, outputs in HBM) */
+int sfx_query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa,
+                        const uint8_t* d_qbytes, const uint64_t* d_qoff, uint64_t nq,
+                        uint32_t* d_start, uint32_t* d_end, uint8_t* d_found,
+                        uint32_t* d_any, void* stream);
+
+/* ---- range-partitioned construction (multi-GPU, one rank per GPU) ----------- */
+/* Every rank holds the whole text in HBM (all-gathered over RCCL) and owns the
+ * text shard [shard_begin, shard_end).
+ * Step 1  sfx_byte_histogram_dev: 256 u64 byte counts of the rank's shard
+ *         (cf. Bins::find_sizes :686-704).  Ranks all-reduce(sum) them; the
+ *         result defines the dense symbol codes, identically on every rank.
+ * Step 2  sfx_key_histogram_dev: every suffix has a key = its first k symbols
+ *         packed big-endian (k fixed by the global alphabet and n); this counts,
+ *         for the suffixes starting in the rank's shard, the top `top_bits`
+ *         (<= 14) bits of that key into 2^top_bits u64 bins.  Ranks all-reduce
+ *         them = the bucket-boundary histogram exchange.
+ * Step 3  the host splits the bins into contiguous, balanced ranges, one per rank.
+ * Step 4  sfx_build_sa_range_u32_dev: sort ONLY the suffixes whose bin lies in
+ *         [bin_lo, bin_hi).  Writes them, fully sorted, to d_sa_part (capacity
+ *         entries available) and their number to *count_out (host pointer):
+ *         d_sa_part is this rank's contiguous slice of the global suffix array. */
+int sfx_byte_histogram_dev(const uint8_t* d_text, uint64_t shard_begin, uint64_t shard_end,
+                           uint64_t* d_bins256, void* stream);
+int sfx_key_histogram_dev(const uint8_t* d_text, uint64_t n, uint64_t shard_begin,
+                          uint64_t shard_end, const uint64_t* d_global_byte_bins256,
+                          int top_bits, uint64_t* d_bins, void* stream);
+uint64_t sfx_sa_range_workspace_bytes(uint64_t capacity);
+int sfx_build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n,
+                               const uint64_t* d_global_byte_bins256, int top_bits,
+                               uint32_t bin_lo, uint32_t bin_hi, uint64_t capacity,
+                               uint32_t* d_sa_part, uint64_t* count_out, void* d_workspace,
+                               uint64_t workspace_bytes, void* stream);
+
+/* ---- profiling (per-kernel HIP-event timing; off by default) ---------------- */
+/* When enabled every kernel launch is bracketed by hipEvents on its stream.
+ * sfx_profile_report writes up to `cap` records and returns how many exist. */
+typedef struct {
+    char     name[48];
+    uint64_t launches;
+    double   total_ms;
+    double   algo_bytes;      /* algorithmic bytes summed over launches */
+} sfx_kernel_stat;
+void sfx_profile_enable(int on);
+void sfx_profile_reset(void);
+int  sfx_profile_report(sfx_kernel_stat* out, int cap);
+/* per-build statistics of the most recent SA construction on this thread */
+typedef struct {
+    uint64_t n;
+    uint32_t sigma;           /* distinct byte values                          */
+    uint32_t bits_per_symbol;
+    uint32_t key_bits;        /* width of the initial k-mer key (32 or 64)     */
+    uint32_t symbols_per_key; /* k                                             */
+    uint32_t rounds;          /* refinement rounds after the initial sort      */
+    uint32_t reserved;
+    uint64_t active_after_initial;
+    uint64_t radix_passes;
+    uint64_t elements_sorted; /* sum over passes of elements moved             */
+} sfx_build_stats;
+void sfx_last_build_stats(sfx_build_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUFFIX_HIP_H */

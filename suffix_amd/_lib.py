@@ -1,0 +1,134 @@
+"""ctypes binding of libsuffix_hip.so (C ABI: include/suffix_hip.h).
+
+The product loads exactly one native library: the in-tree `libsuffix_hip.so`
+built by hipcc for gfx950 (`python -c "import __graft_entry__ as g; g.build()"`).
+There is NO CPU fallback: if the library is missing, or no HIP device is
+visible, every compute entry point raises.
+
+`Engine(lib_path=...)` exists so the test-suite can bind the same ABI exported
+by the kernel-logic emulator (tests/emu/libsuffix_emu.so); product code never
+passes it.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libsuffix_hip.so")
+
+SFX_OK = 0
+SFX_ERR_TOO_LARGE = 2
+SFX_ERR_NO_DEVICE = 3
+
+_vp, _u64, _u32, _int = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+
+
+class KernelStat(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("launches", _u64),
+                ("total_ms", ctypes.c_double), ("algo_bytes", ctypes.c_double)]
+
+
+class BuildStats(ctypes.Structure):
+    _fields_ = [("n", _u64), ("sigma", _u32), ("bits_per_symbol", _u32), ("key_bits", _u32),
+                ("symbols_per_key", _u32), ("rounds", _u32), ("reserved", _u32),
+                ("active_after_initial", _u64), ("radix_passes", _u64),
+                ("elements_sorted", _u64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+
+
+# every symbol include/suffix_hip.h declares: (name, restype, argtypes)
+ABI = [
+    ("sfx_strerror", ctypes.c_char_p, [_int]),
+    ("sfx_device_count", _int, []),
+    ("sfx_last_hip_error", ctypes.c_char_p, []),
+    ("sfx_build_sa_u32", _int, [_vp, _u64, _vp]),
+    ("sfx_sa_workspace_bytes", _u64, [_u64]),
+    ("sfx_build_sa_u32_dev", _int, [_vp, _u64, _vp, _vp, _u64, _vp]),
+    ("sfx_build_lcp_u32", _int, [_vp, _u64, _vp, _vp]),
+    ("sfx_lcp_workspace_bytes", _u64, [_u64]),
+    ("sfx_build_lcp_u32_dev", _int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp]),
+    ("sfx_index_create", _int, [_vp, _u64, _vp, ctypes.POINTER(_vp)]),
+    ("sfx_index_destroy", None, [_vp]),
+    ("sfx_index_len", _u64, [_vp]),
+    ("sfx_index_table", _int, [_vp, _vp]),
+    ("sfx_positions_batch", _int, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    ("sfx_contains_batch", _int, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    ("sfx_query_batch_dev", _int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    ("sfx_byte_histogram_dev", _int, [_vp, _u64, _u64, _vp, _vp]),
+    ("sfx_key_histogram_dev", _int, [_vp, _u64, _u64, _u64, _vp, _int, _vp, _vp]),
+    ("sfx_sa_range_workspace_bytes", _u64, [_u64]),
+    ("sfx_build_sa_range_u32_dev", _int, [_vp, _u64, _vp, _int, _u32, _u32, _u64, _vp,
+                                          ctypes.POINTER(_u64), _vp, _u64, _vp]),
+    ("sfx_profile_enable", None, [_int]),
+    ("sfx_profile_reset", None, []),
+    ("sfx_profile_report", _int, [ctypes.POINTER(KernelStat), _int]),
+    ("sfx_last_build_stats", None, [ctypes.POINTER(BuildStats)]),
+]
+
+
+class SuffixHipError(RuntimeError):
+    pass
+
+
+class Engine:
+    """One loaded copy of the C ABI."""
+
+    def __init__(self, lib_path=None):
+        path = lib_path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise SuffixHipError(
+                f"{path} not found: the HIP extension is not built (run "
+                f"`python -c 'import __graft_entry__ as g; g.build()'`). "
+                f"suffix_amd has no CPU fallback.")
+        self.path = path
+        self.lib = ctypes.CDLL(path)
+        for name, restype, argtypes in ABI:
+            fn = getattr(self.lib, name)          # AttributeError = ABI symbol missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+
+    # -- helpers -----------------------------------------------------------------
+    def check(self, status, what):
+        if status != SFX_OK:
+            msg = self.lib.sfx_strerror(status).decode()
+            detail = self.lib.sfx_last_hip_error().decode()
+            if status == SFX_ERR_TOO_LARGE:
+                # the reference panics here (src/table.rs:380)
+                raise OverflowError(f"{what}: {msg}")
+            raise SuffixHipError(f"{what}: {msg}" + (f" [{detail}]" if detail else ""))
+
+    def device_count(self):
+        return int(self.lib.sfx_device_count())
+
+    def require_device(self):
+        if self.device_count() <= 0:
+            raise SuffixHipError("no HIP device visible; suffix_amd has no CPU fallback")
+
+    def build_stats(self):
+        s = BuildStats()
+        self.lib.sfx_last_build_stats(ctypes.byref(s))
+        return s.as_dict()
+
+    def profile(self, on):
+        self.lib.sfx_profile_enable(1 if on else 0)
+
+    def profile_reset(self):
+        self.lib.sfx_profile_reset()
+
+    def profile_report(self):
+        arr = (KernelStat * 64)()
+        n = self.lib.sfx_profile_report(arr, 64)
+        return [{"name": arr[i].name.decode(), "launches": int(arr[i].launches),
+                 "total_ms": float(arr[i].total_ms), "algo_bytes": float(arr[i].algo_bytes)}
+                for i in range(min(n, 64))]
+
+
+_default = None
+
+
+def default_engine():
+    global _default
+    if _default is None:
+        _default = Engine()
+    return _default

@@ -1,0 +1,345 @@
+// sfx_api.hip -- the extern "C" boundary (include/suffix_hip.h): argument
+// checking, host<->HBM staging for the host-pointer entry points, the
+// device-resident index handle, error text and the event profiler.
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sfx_host.hpp"
+
+namespace sfx {
+
+// ---- error capture ---------------------------------------------------------------
+static thread_local char tls_hip_error[512] = "";
+
+void note_hip_error(hipError_t e, const char* what, const char* file, int line)
+{
+    snprintf(tls_hip_error, sizeof(tls_hip_error), "%s (%d) at %s:%d in `%s`", hipGetErrorString(e),
+             (int)e, file, line, what);
+}
+
+sfx_build_stats& tls_build_stats()
+{
+    static thread_local sfx_build_stats s;
+    return s;
+}
+
+// ---- profiler ---------------------------------------------------------------------
+struct ProfRecord {
+    const char* name;
+    double bytes;
+    hipEvent_t a, b;
+};
+static bool g_profile = false;
+static std::mutex g_prof_mu;
+static std::vector<ProfRecord> g_prof_open;      // recorded, not yet folded
+struct ProfStat { std::string name; uint64_t launches; double ms, bytes; };
+static std::vector<ProfStat> g_prof_stats;
+
+bool profile_on() { return g_profile; }
+
+void profile_begin(const char* name, hipStream_t st, double algo_bytes)
+{
+    ProfRecord r;
+    r.name = name;
+    r.bytes = algo_bytes;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_open.push_back(r);
+}
+void profile_end(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_open.empty()) (void)hipEventRecord(g_prof_open.back().b, st);
+}
+static void profile_fold()
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (ProfRecord& r : g_prof_open) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.b);
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+        ProfStat* s = nullptr;
+        for (ProfStat& t : g_prof_stats) if (t.name == r.name) { s = &t; break; }
+        if (!s) { g_prof_stats.push_back(ProfStat{r.name, 0, 0.0, 0.0}); s = &g_prof_stats.back(); }
+        s->launches++;
+        s->ms += ms;
+        s->bytes += r.bytes;
+    }
+    g_prof_open.clear();
+}
+
+// ---- small RAII for the host-pointer entry points ------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(uint64_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) { note_hip_error(e, "hipMalloc", __FILE__, __LINE__); p = nullptr; return SFX_ERR_HIP; }
+        return SFX_OK;
+    }
+};
+
+static int check_device()
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return SFX_ERR_NO_DEVICE;
+    return SFX_OK;
+}
+
+}  // namespace sfx
+
+using namespace sfx;
+
+struct sfx_index {
+    uint8_t* d_text = nullptr;
+    uint32_t* d_sa = nullptr;
+    uint64_t n = 0;
+};
+
+extern "C" {
+
+const char* sfx_strerror(int status)
+{
+    switch (status) {
+    case SFX_OK: return "ok";
+    case SFX_ERR_ARG: return "invalid argument";
+    case SFX_ERR_TOO_LARGE: return "text longer than u32::MAX bytes";
+    case SFX_ERR_NO_DEVICE: return "no HIP device available";
+    case SFX_ERR_HIP: return "HIP runtime error (see sfx_last_hip_error)";
+    case SFX_ERR_WORKSPACE: return "device workspace too small";
+    case SFX_ERR_INTERNAL: return "internal invariant violated";
+    default: return "unknown status";
+    }
+}
+
+int sfx_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+const char* sfx_last_hip_error(void) { return tls_hip_error; }
+
+// ---- suffix array --------------------------------------------------------------------
+uint64_t sfx_sa_workspace_bytes(uint64_t n) { return sa_workspace_bytes(n); }
+
+int sfx_build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* d_workspace,
+                         uint64_t workspace_bytes, void* stream)
+{
+    return build_sa_u32_dev(d_text, n, d_sa, d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int sfx_build_sa_u32(const uint8_t* text, uint64_t n, uint32_t* sa_out)
+{
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    if (n == 0) return SFX_OK;
+    if (!text || !sa_out) return SFX_ERR_ARG;
+    SFX_TRY(check_device());
+    DevBuf dt, ds, dw;
+    uint64_t wsb = sa_workspace_bytes(n);
+    SFX_TRY(dt.alloc(n));
+    SFX_TRY(ds.alloc(n * sizeof(uint32_t)));
+    SFX_TRY(dw.alloc(wsb));
+    hipStream_t st = nullptr;
+    SFX_HIP(hipMemcpyAsync(dt.p, text, n, hipMemcpyHostToDevice, st));
+    SFX_TRY(build_sa_u32_dev((const uint8_t*)dt.p, n, (uint32_t*)ds.p, dw.p, wsb, st));
+    SFX_HIP(hipMemcpyAsync(sa_out, ds.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SFX_HIP(hipStreamSynchronize(st));
+    return SFX_OK;
+}
+
+// ---- LCP ---------------------------------------------------------------------------------
+uint64_t sfx_lcp_workspace_bytes(uint64_t n) { return lcp_workspace_bytes(n); }
+
+int sfx_build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint32_t* d_lcp,
+                          void* d_workspace, uint64_t workspace_bytes, void* stream)
+{
+    return build_lcp_u32_dev(d_text, n, d_sa, d_lcp, d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int sfx_build_lcp_u32(const uint8_t* text, uint64_t n, const uint32_t* sa, uint32_t* lcp_out)
+{
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    if (n == 0) return SFX_OK;
+    if (!text || !sa || !lcp_out) return SFX_ERR_ARG;
+    SFX_TRY(check_device());
+    DevBuf dt, ds, dl, dw;
+    uint64_t wsb = lcp_workspace_bytes(n);
+    SFX_TRY(dt.alloc(n));
+    SFX_TRY(ds.alloc(n * sizeof(uint32_t)));
+    SFX_TRY(dl.alloc(n * sizeof(uint32_t)));
+    SFX_TRY(dw.alloc(wsb));
+    hipStream_t st = nullptr;
+    SFX_HIP(hipMemcpyAsync(dt.p, text, n, hipMemcpyHostToDevice, st));
+    SFX_HIP(hipMemcpyAsync(ds.p, sa, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    SFX_TRY(build_lcp_u32_dev((const uint8_t*)dt.p, n, (const uint32_t*)ds.p, (uint32_t*)dl.p, dw.p,
+                              wsb, st));
+    SFX_HIP(hipMemcpyAsync(lcp_out, dl.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SFX_HIP(hipStreamSynchronize(st));
+    return SFX_OK;
+}
+
+// ---- index + queries ---------------------------------------------------------------------
+int sfx_index_create(const uint8_t* text, uint64_t n, const uint32_t* sa, sfx_index** out)
+{
+    if (!out) return SFX_ERR_ARG;
+    *out = nullptr;
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    if (n && !text) return SFX_ERR_ARG;
+    SFX_TRY(check_device());
+    sfx_index* ix = new sfx_index();
+    ix->n = n;
+    int rc = SFX_OK;
+    if (n) {
+        hipStream_t st = nullptr;
+        DevBuf dw;
+        do {
+            if (hipMalloc((void**)&ix->d_text, n) != hipSuccess ||
+                hipMalloc((void**)&ix->d_sa, n * sizeof(uint32_t)) != hipSuccess) { rc = SFX_ERR_HIP; break; }
+            if (hipMemcpyAsync(ix->d_text, text, n, hipMemcpyHostToDevice, st) != hipSuccess) { rc = SFX_ERR_HIP; break; }
+            if (sa) {
+                if (hipMemcpyAsync(ix->d_sa, sa, n * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess) { rc = SFX_ERR_HIP; break; }
+            } else {
+                uint64_t wsb = sa_workspace_bytes(n);
+                rc = dw.alloc(wsb);
+                if (rc != SFX_OK) break;
+                rc = build_sa_u32_dev(ix->d_text, n, ix->d_sa, dw.p, wsb, st);
+                if (rc != SFX_OK) break;
+            }
+            if (hipStreamSynchronize(st) != hipSuccess) { rc = SFX_ERR_HIP; break; }
+        } while (0);
+    }
+    if (rc != SFX_OK) { sfx_index_destroy(ix); return rc; }
+    *out = ix;
+    return SFX_OK;
+}
+
+void sfx_index_destroy(sfx_index* ix)
+{
+    if (!ix) return;
+    if (ix->d_text) (void)hipFree(ix->d_text);
+    if (ix->d_sa) (void)hipFree(ix->d_sa);
+    delete ix;
+}
+
+uint64_t sfx_index_len(const sfx_index* ix) { return ix ? ix->n : 0; }
+
+int sfx_index_table(const sfx_index* ix, uint32_t* sa_out)
+{
+    if (!ix || (ix->n && !sa_out)) return SFX_ERR_ARG;
+    if (ix->n == 0) return SFX_OK;
+    SFX_HIP(hipMemcpy(sa_out, ix->d_sa, ix->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SFX_OK;
+}
+
+int sfx_query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa,
+                        const uint8_t* d_qbytes, const uint64_t* d_qoff, uint64_t nq,
+                        uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any,
+                        void* stream)
+{
+    return query_batch_dev(d_text, n, d_sa, d_qbytes, d_qoff, nq, d_start, d_end, d_found, d_any,
+                           (hipStream_t)stream);
+}
+
+static int query_host(const sfx_index* ix, const uint8_t* qbytes, const uint64_t* qoff, uint64_t nq,
+                      uint32_t* start_out, uint32_t* end_out, uint8_t* found_out, uint32_t* any_out)
+{
+    if (!ix || (nq && !qoff)) return SFX_ERR_ARG;
+    if (nq == 0) return SFX_OK;
+    uint64_t qtotal = qoff[nq];
+    if (qtotal && !qbytes) return SFX_ERR_ARG;
+    for (uint64_t k = 0; k < nq; k++) if (qoff[k + 1] < qoff[k]) return SFX_ERR_ARG;
+    DevBuf dq, doff, ds, de, df, da;
+    SFX_TRY(dq.alloc(qtotal));
+    SFX_TRY(doff.alloc((nq + 1) * sizeof(uint64_t)));
+    if (start_out) SFX_TRY(ds.alloc(nq * 4));
+    if (end_out) SFX_TRY(de.alloc(nq * 4));
+    if (found_out) SFX_TRY(df.alloc(nq));
+    if (any_out) SFX_TRY(da.alloc(nq * 4));
+    hipStream_t st = nullptr;
+    if (qtotal) SFX_HIP(hipMemcpyAsync(dq.p, qbytes, qtotal, hipMemcpyHostToDevice, st));
+    SFX_HIP(hipMemcpyAsync(doff.p, qoff, (nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    SFX_TRY(query_batch_dev(ix->d_text, ix->n, ix->d_sa, (const uint8_t*)dq.p, (const uint64_t*)doff.p,
+                            nq, (uint32_t*)ds.p, (uint32_t*)de.p, (uint8_t*)df.p, (uint32_t*)da.p, st));
+    if (start_out) SFX_HIP(hipMemcpyAsync(start_out, ds.p, nq * 4, hipMemcpyDeviceToHost, st));
+    if (end_out) SFX_HIP(hipMemcpyAsync(end_out, de.p, nq * 4, hipMemcpyDeviceToHost, st));
+    if (found_out) SFX_HIP(hipMemcpyAsync(found_out, df.p, nq, hipMemcpyDeviceToHost, st));
+    if (any_out) SFX_HIP(hipMemcpyAsync(any_out, da.p, nq * 4, hipMemcpyDeviceToHost, st));
+    SFX_HIP(hipStreamSynchronize(st));
+    return SFX_OK;
+}
+
+int sfx_positions_batch(const sfx_index* ix, const uint8_t* qbytes, const uint64_t* qoff,
+                        uint64_t nq, uint32_t* start_out, uint32_t* end_out)
+{
+    return query_host(ix, qbytes, qoff, nq, start_out, end_out, nullptr, nullptr);
+}
+
+int sfx_contains_batch(const sfx_index* ix, const uint8_t* qbytes, const uint64_t* qoff,
+                       uint64_t nq, uint8_t* found_out, uint32_t* any_out)
+{
+    return query_host(ix, qbytes, qoff, nq, nullptr, nullptr, found_out, any_out);
+}
+
+// ---- partitioned build ---------------------------------------------------------------------
+int sfx_byte_histogram_dev(const uint8_t* d_text, uint64_t shard_begin, uint64_t shard_end,
+                           uint64_t* d_bins256, void* stream)
+{
+    return byte_histogram_dev(d_text, shard_begin, shard_end, d_bins256, (hipStream_t)stream);
+}
+int sfx_key_histogram_dev(const uint8_t* d_text, uint64_t n, uint64_t shard_begin,
+                          uint64_t shard_end, const uint64_t* d_global_byte_bins256, int top_bits,
+                          uint64_t* d_bins, void* stream)
+{
+    return key_histogram_dev(d_text, n, shard_begin, shard_end, d_global_byte_bins256, top_bits,
+                             d_bins, (hipStream_t)stream);
+}
+uint64_t sfx_sa_range_workspace_bytes(uint64_t capacity) { return sa_range_workspace_bytes(capacity); }
+int sfx_build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n,
+                               const uint64_t* d_global_byte_bins256, int top_bits, uint32_t bin_lo,
+                               uint32_t bin_hi, uint64_t capacity, uint32_t* d_sa_part,
+                               uint64_t* count_out, void* d_workspace, uint64_t workspace_bytes,
+                               void* stream)
+{
+    return build_sa_range_u32_dev(d_text, n, d_global_byte_bins256, top_bits, bin_lo, bin_hi, capacity,
+                                  d_sa_part, count_out, d_workspace, workspace_bytes,
+                                  (hipStream_t)stream);
+}
+
+// ---- profiling --------------------------------------------------------------------------------
+void sfx_profile_enable(int on) { g_profile = on != 0; }
+void sfx_profile_reset(void)
+{
+    profile_fold();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_stats.clear();
+}
+int sfx_profile_report(sfx_kernel_stat* out, int cap)
+{
+    profile_fold();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = (int)g_prof_stats.size();
+    for (int i = 0; i < n && i < cap && out; i++) {
+        memset(&out[i], 0, sizeof(out[i]));
+        snprintf(out[i].name, sizeof(out[i].name), "%s", g_prof_stats[i].name.c_str());
+        out[i].launches = g_prof_stats[i].launches;
+        out[i].total_ms = g_prof_stats[i].ms;
+        out[i].algo_bytes = g_prof_stats[i].bytes;
+    }
+    return n;
+}
+void sfx_last_build_stats(sfx_build_stats* out)
+{
+    if (out) *out = tls_build_stats();
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// sfx_device.hpp -- wave64 / workgroup primitives shared by every kernel.
+//
+// gfx950 (CDNA4): a wavefront is 64 lanes, __ballot() is a 64-bit mask, a
+// 256-thread workgroup is 4 waves (one per SIMD).  All constants below are
+// written for that machine; nothing here is warp-32 shaped.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sfx {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;               // threads per workgroup used by every kernel
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ unsigned wave_id() { return threadIdx.x >> 6; }
+
+// Orders LDS traffic between the lanes of ONE wave (lanes execute in lock-step;
+// this only stops the compiler from moving memory operations across the point).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class T> __host__ __device__ __forceinline__ T dmin(T a, T b) { return a < b ? a : b; }
+template <class T> __host__ __device__ __forceinline__ T dmax(T a, T b) { return a > b ? a : b; }
+
+// ---- wave-level inclusive scans (6 shuffle steps over 64 lanes) -------------
+template <class T> __device__ __forceinline__ T wave_scan_add(T v)
+{
+    const unsigned lane = lane_id();
+#pragma unroll
+    for (unsigned d = 1; d < 64; d <<= 1) {
+        T o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+template <class T> __device__ __forceinline__ T wave_scan_max(T v)
+{
+    const unsigned lane = lane_id();
+#pragma unroll
+    for (unsigned d = 1; d < 64; d <<= 1) {
+        T o = __shfl_up(v, d);
+        if (lane >= d) v = dmax(v, o);
+    }
+    return v;
+}
+
+// ---- workgroup-level scans over one value per thread -------------------------
+// `part` is kWavesPerBlock entries of LDS.  Both return the EXCLUSIVE prefix of
+// the calling thread and the workgroup aggregate; two barriers each, so `part`
+// may be reused immediately afterwards.
+template <class T>
+__device__ __forceinline__ T block_scan_add_excl(T v, T* part, T& total)
+{
+    T incl = wave_scan_add(v);
+    if (lane_id() == 63) part[wave_id()] = incl;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (unsigned w = 0; w < (unsigned)kWavesPerBlock; w++) {
+        T p = part[w];
+        if (w < wave_id()) base += p;
+        tot += p;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+// max-scan: returns the max over all EARLIER threads (identity 0) and the aggregate
+template <class T>
+__device__ __forceinline__ T block_scan_max_excl(T v, T* part, T& total)
+{
+    T incl = wave_scan_max(v);
+    T prev = __shfl_up(incl, 1u);
+    if (lane_id() == 0) prev = 0;
+    if (lane_id() == 63) part[wave_id()] = incl;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (unsigned w = 0; w < (unsigned)kWavesPerBlock; w++) {
+        T p = part[w];
+        if (w < wave_id()) base = dmax(base, p);
+        tot = dmax(tot, p);
+    }
+    __syncthreads();
+    total = tot;
+    return dmax(base, prev);
+}
+
+// number of bits needed to represent values in [0, v]
+__host__ __device__ inline int bits_for(uint64_t v)
+{
+    int b = 0;
+    while (v) { b++; v >>= 1; }
+    return b ? b : 1;
+}
+
+}  // namespace sfx

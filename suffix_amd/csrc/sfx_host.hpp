@@ -1,0 +1,126 @@
+// sfx_host.hpp -- host-side plumbing shared by the translation units of
+// libsuffix_hip.so: status codes, HIP error capture, a bump allocator over the
+// caller's device workspace, and the optional per-kernel event profiler.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/suffix_hip.h"
+#include "sfx_device.hpp"
+
+namespace sfx {
+
+// ---- error capture -----------------------------------------------------------
+void note_hip_error(hipError_t e, const char* what, const char* file, int line);
+
+#define SFX_HIP(expr)                                                   \
+    do {                                                                \
+        hipError_t e_ = (expr);                                         \
+        if (e_ != hipSuccess) {                                         \
+            ::sfx::note_hip_error(e_, #expr, __FILE__, __LINE__);       \
+            return SFX_ERR_HIP;                                         \
+        }                                                               \
+    } while (0)
+
+#define SFX_TRY(expr)                       \
+    do {                                    \
+        int s_ = (expr);                    \
+        if (s_ != SFX_OK) return s_;        \
+    } while (0)
+
+// ---- device workspace carving --------------------------------------------------
+// All device scratch comes from one caller-provided allocation (torch tensor in
+// bench.py, hipMalloc in the host-pointer entry points): nothing is allocated
+// inside a build, so the build is a pure kernel/memcpy sequence on one stream.
+struct Arena {
+    char* base = nullptr;
+    uint64_t size = 0, used = 0;
+    bool overflow = false;
+    Arena() {}
+    Arena(void* p, uint64_t bytes) : base((char*)p), size(bytes) {}
+    template <class T> T* take(uint64_t count)
+    {
+        uint64_t bytes = (count * sizeof(T) + 255) & ~uint64_t(255);   // 256-B aligned carves
+        if (used + bytes > size) { overflow = true; return nullptr; }
+        T* p = (T*)(base + used);
+        used += bytes;
+        return p;
+    }
+};
+// same arithmetic without memory, for *_workspace_bytes()
+struct ArenaSizer {
+    uint64_t used = 0;
+    template <class T> void take(uint64_t count) { used += (count * sizeof(T) + 255) & ~uint64_t(255); }
+};
+
+// ---- launch geometry -----------------------------------------------------------
+// Streaming kernels use a fixed-size grid of persistent workgroups, each owning a
+// contiguous chunk (256 CUs x 8 resident 256-thread workgroups = 2048), so
+// per-workgroup partials stay tiny and chunk carries need one small scan.
+constexpr unsigned kMaxGrid = 2048;
+constexpr int kRadixBits = 8;             // key bits consumed per radix pass
+constexpr int kRadix = 1 << kRadixBits;   // buckets per pass
+
+struct Chunking {
+    unsigned blocks;        // workgroups launched
+    uint64_t tiles;         // total tiles
+    uint64_t tiles_per_block;
+};
+inline Chunking make_chunking(uint64_t items, uint64_t tile, unsigned max_blocks = kMaxGrid)
+{
+    Chunking c;
+    c.tiles = (items + tile - 1) / tile;
+    if (c.tiles == 0) c.tiles = 1;
+    c.tiles_per_block = (c.tiles + max_blocks - 1) / max_blocks;
+    c.blocks = (unsigned)((c.tiles + c.tiles_per_block - 1) / c.tiles_per_block);
+    return c;
+}
+
+// ---- profiler ---------------------------------------------------------------------
+bool profile_on();
+void profile_begin(const char* name, hipStream_t st, double algo_bytes);
+void profile_end(hipStream_t st);
+
+// Launch wrapper: every kernel in the library goes through this.
+#define SFX_LAUNCH(name, algo_bytes, kernel, grid, block, stream, ...)                  \
+    do {                                                                                \
+        if (::sfx::profile_on()) ::sfx::profile_begin(name, stream, (double)(algo_bytes)); \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__);    \
+        if (::sfx::profile_on()) ::sfx::profile_end(stream);                            \
+        SFX_HIP(hipGetLastError());                                                     \
+    } while (0)
+
+// ---- cross-TU entry points ----------------------------------------------------------
+struct BuildStats;   // = sfx_build_stats
+
+// radix sort of (key, value) pairs on bits [bit_lo, bit_hi) of the key.
+// Buffers ping-pong between (k0,v0) and (k1,v1); on return *result_in_1 tells
+// which pair holds the sorted data.  `hist` is 256 * kMaxGrid u32 of scratch.
+template <class KeyT>
+int radix_sort_pairs(KeyT* k0, uint32_t* v0, KeyT* k1, uint32_t* v1, uint64_t m, int bit_lo,
+                     int bit_hi, uint32_t* hist, hipStream_t st, int* result_in_1,
+                     sfx_build_stats* stats);
+inline int radix_pass_count(int bit_lo, int bit_hi) { return (bit_hi - bit_lo + 7) / 8; }
+
+uint64_t sa_workspace_bytes(uint64_t n);
+int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,
+                     hipStream_t st);
+uint64_t lcp_workspace_bytes(uint64_t n);
+int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint32_t* d_lcp,
+                      void* ws, uint64_t ws_bytes, hipStream_t st);
+int query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint8_t* d_q,
+                    const uint64_t* d_qoff, uint64_t nq, uint32_t* d_start, uint32_t* d_end,
+                    uint8_t* d_found, uint32_t* d_any, hipStream_t st);
+int byte_histogram_dev(const uint8_t* d_text, uint64_t begin, uint64_t end, uint64_t* d_bins,
+                       hipStream_t st);
+int key_histogram_dev(const uint8_t* d_text, uint64_t n, uint64_t begin, uint64_t end,
+                      const uint64_t* d_byte_bins, int top_bits, uint64_t* d_bins, hipStream_t st);
+uint64_t sa_range_workspace_bytes(uint64_t max_count);
+int build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint64_t* d_byte_bins,
+                           int top_bits, uint32_t bin_lo, uint32_t bin_hi, uint64_t capacity,
+                           uint32_t* d_sa_part, uint64_t* count_out, void* ws, uint64_t ws_bytes,
+                           hipStream_t st);
+
+sfx_build_stats& tls_build_stats();
+
+}  // namespace sfx

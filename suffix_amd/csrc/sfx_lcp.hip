@@ -1,0 +1,102 @@
+// sfx_lcp.hip -- LCP array on the device (replaces lcp_lens ->
+// lcp_lens_quadratic, /root/reference/src/table.rs:130-138, :348-365).
+//
+// The reference compares every adjacent pair of suffixes from scratch
+// (quadratic on repetitive text) and builds an inverse suffix array it never
+// uses (:131-134).  The engine computes the same array with the Phi/PLCP
+// formulation of the linear algorithm the reference keeps commented out
+// (:314-346), which is exact on bytes:
+//   k_phi_scatter  phi[sa[r]] = sa[r-1]            (the predecessor in SA order)
+//   k_plcp         PLCP in TEXT order: each thread walks 32 consecutive text
+//                  positions carrying h (PLCP[i+1] >= PLCP[i]-1), restarting
+//                  from h=0 only at the start of its run; phi/PLCP tiles are
+//                  staged through LDS so global traffic is coalesced
+//   k_lcp_gather   lcp[r] = PLCP[sa[r]]
+// Algorithmic bytes per text byte: 8 (phi) + 4+4+2 (plcp) + 4+4+4 (gather) = 30.
+#include "sfx_host.hpp"
+
+namespace sfx {
+
+constexpr uint32_t kNoPhi = 0xFFFFFFFFu;
+constexpr int kRun = 32;                         // consecutive text positions per thread
+constexpr int kPlcpTile = kBlock * kRun;         // 8192 positions per workgroup step
+
+__global__ void __launch_bounds__(kBlock)
+k_phi_scatter(const uint32_t* __restrict__ sa, uint64_t n, uint32_t* __restrict__ phi)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride)
+        phi[sa[r]] = r ? sa[r - 1] : kNoPhi;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_plcp(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ phi_plcp,
+       uint64_t tiles_per_block)
+{
+    __shared__ uint32_t s[kBlock * (kRun + 1)];          // +1 pad: conflict-free per-thread rows
+    const unsigned tid = threadIdx.x;
+    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kPlcpTile;
+    uint64_t end = begin + tiles_per_block * kPlcpTile;
+    if (end > n) end = n;
+    for (uint64_t tile = begin; tile < end; tile += kPlcpTile) {
+        for (unsigned j = tid; j < (unsigned)kPlcpTile; j += kBlock) {
+            uint64_t g = tile + j;
+            s[(j / kRun) * (kRun + 1) + (j % kRun)] = (g < end) ? phi_plcp[g] : kNoPhi;
+        }
+        __syncthreads();
+        uint64_t h = 0;
+        for (int k = 0; k < kRun; k++) {
+            uint64_t i = tile + (uint64_t)tid * kRun + k;
+            if (i >= end) break;
+            uint32_t j = s[tid * (kRun + 1) + k];
+            if (j == kNoPhi) {
+                h = 0;
+            } else {
+                while (i + h < n && (uint64_t)j + h < n && text[i + h] == text[(uint64_t)j + h]) h++;
+            }
+            s[tid * (kRun + 1) + k] = (uint32_t)h;
+            if (h) h--;
+        }
+        __syncthreads();
+        for (unsigned j = tid; j < (unsigned)kPlcpTile; j += kBlock) {
+            uint64_t g = tile + j;
+            if (g < end) phi_plcp[g] = s[(j / kRun) * (kRun + 1) + (j % kRun)];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_lcp_gather(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ plcp, uint64_t n,
+             uint32_t* __restrict__ lcp)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride)
+        lcp[r] = plcp[sa[r]];
+}
+
+uint64_t lcp_workspace_bytes(uint64_t n)
+{
+    return ((n * sizeof(uint32_t) + 255) & ~uint64_t(255)) + 256;
+}
+
+int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint32_t* d_lcp,
+                      void* ws, uint64_t ws_bytes, hipStream_t st)
+{
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    if (n == 0) return SFX_OK;
+    if (!d_text || !d_sa || !d_lcp) return SFX_ERR_ARG;
+    if (!ws || ws_bytes < lcp_workspace_bytes(n)) return SFX_ERR_WORKSPACE;
+    Arena ar(ws, ws_bytes);
+    uint32_t* phi = ar.take<uint32_t>(n);
+    if (ar.overflow) return SFX_ERR_WORKSPACE;
+    unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
+    SFX_LAUNCH("phi_scatter", (double)n * 8, k_phi_scatter, grid, kBlock, st, d_sa, n, phi);
+    Chunking ch = make_chunking(n, kPlcpTile);
+    SFX_LAUNCH("plcp", (double)n * 10, k_plcp, ch.blocks, kBlock, st, d_text, n, phi,
+               ch.tiles_per_block);
+    SFX_LAUNCH("lcp_gather", (double)n * 12, k_lcp_gather, grid, kBlock, st, d_sa, phi, n, d_lcp);
+    return SFX_OK;
+}
+
+}  // namespace sfx

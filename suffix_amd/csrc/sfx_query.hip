@@ -1,0 +1,87 @@
+// sfx_query.hip -- batched positions() / contains() / any_position()
+// (/root/reference/src/table.rs:223-293, binary_search :900-914).
+//
+// One query per lane.  positions(q) is the half-open SA interval
+//   start = #suffixes < q            (first suffix with q <= suffix,   :244-246)
+//   end   = start + #suffixes having q as a prefix                     (:247-250)
+// The reference's range early-outs (:228-235) are pure optimisations and never
+// change the result, so the kernel only keeps the empty-text / empty-query case.
+// contains(q) == (end > start); any_position(q) returns table[start] -- the
+// reference documents the choice as arbitrary (:261-262).
+// Algorithmic bytes per query: 2*ceil(log2 n) probes x (4 B SA entry + compared bytes).
+#include "sfx_host.hpp"
+
+namespace sfx {
+
+// query <= suffix ?  (Rust slice Ord: lexicographic, a proper prefix is smaller)
+__device__ __forceinline__ bool query_le_suffix(const uint8_t* __restrict__ q, uint64_t m,
+                                                const uint8_t* __restrict__ text, uint64_t n,
+                                                uint64_t s)
+{
+    uint64_t len = n - s, k = 0, lim = m < len ? m : len;
+    while (k < lim) {
+        uint8_t a = q[k], b = text[s + k];
+        if (a != b) return a < b;
+        k++;
+    }
+    return m <= len;
+}
+__device__ __forceinline__ bool suffix_starts_with(const uint8_t* __restrict__ q, uint64_t m,
+                                                   const uint8_t* __restrict__ text, uint64_t n,
+                                                   uint64_t s)
+{
+    if (n - s < m) return false;
+    for (uint64_t k = 0; k < m; k++)
+        if (q[k] != text[s + k]) return false;
+    return true;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_query_batch(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa,
+              const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, uint64_t nq,
+              uint32_t* __restrict__ start_out, uint32_t* __restrict__ end_out,
+              uint8_t* __restrict__ found_out, uint32_t* __restrict__ any_out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < nq; k += stride) {
+        const uint8_t* q = qbytes + qoff[k];
+        uint64_t m = qoff[k + 1] - qoff[k];
+        uint64_t start = 0, end = 0;
+        if (n != 0 && m != 0) {                                     // :228-229
+            uint64_t lo = 0, hi = n;                                // :244-246, :900-914
+            while (lo < hi) {
+                uint64_t mid = (lo + hi) >> 1;
+                if (query_le_suffix(q, m, text, n, sa[mid])) hi = mid; else lo = mid + 1;
+            }
+            start = lo;
+            lo = 0; hi = n - start;                                 // :247-250
+            while (lo < hi) {
+                uint64_t mid = (lo + hi) >> 1;
+                if (!suffix_starts_with(q, m, text, n, sa[start + mid])) hi = mid; else lo = mid + 1;
+            }
+            end = start + lo;
+        }
+        bool found = end > start;
+        if (!found) start = end = 0;
+        if (start_out) start_out[k] = (uint32_t)start;
+        if (end_out) end_out[k] = (uint32_t)end;
+        if (found_out) found_out[k] = found ? 1 : 0;
+        if (any_out) any_out[k] = found ? sa[start] : 0xFFFFFFFFu;
+    }
+}
+
+int query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint8_t* d_q,
+                    const uint64_t* d_qoff, uint64_t nq, uint32_t* d_start, uint32_t* d_end,
+                    uint8_t* d_found, uint32_t* d_any, hipStream_t st)
+{
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    if (nq == 0) return SFX_OK;
+    if (!d_qoff || (n && (!d_text || !d_sa))) return SFX_ERR_ARG;
+    unsigned grid = (unsigned)dmin<uint64_t>((nq + kBlock - 1) / kBlock, kMaxGrid);
+    double probes = 2.0 * bits_for(n ? n : 1);
+    SFX_LAUNCH("query_batch", (double)nq * probes * 12.0, k_query_batch, grid, kBlock, st, d_text, n,
+               d_sa, d_q, d_qoff, nq, d_start, d_end, d_found, d_any);
+    return SFX_OK;
+}
+
+}  // namespace sfx

@@ -1,0 +1,749 @@
+// sfx_sa.hip -- suffix-array construction on the device (replaces sais_table /
+// sais, /root/reference/src/table.rs:378-574).
+//
+// The suffix array of a text is unique (all suffixes differ; order = bytewise
+// lexicographic with a proper prefix first, naive_table :367-376), so the engine
+// is free in HOW it sorts; only the final u32 array must be identical.  SA-IS's
+// L-then-S induction (:419-448, :544-573) is a serial pointer chase through the
+// buckets, so the MI355X engine keeps the reference's *bucket* structure but
+// replaces induction by whole-array bucket refinement, every step a streaming
+// scan / histogram / scatter kernel:
+//
+//   1. alphabet:   byte histogram (cf. Bins::find_sizes :686-704) -> dense symbol
+//                  codes of `bits` bits each (sigma = 4 -> 2 bits).
+//   2. initial buckets: every suffix gets a key = its first k symbols packed
+//                  big-endian (k = 16 for DNA in 32 bits); one LSD radix sort
+//                  (sfx_radix.hip) puts all suffixes in k-symbol bucket order --
+//                  the bucket sort of the reference's level 0 plus its first
+//                  recursion levels in one step.
+//   3. bucket ranks ("naming", cf. :465-482): adjacent-compare flags + device
+//                  scan give every suffix the SA slot of its bucket head:
+//                  ISA[suffix] = head slot.  Buckets of size 1 are final.
+//   4. refinement rounds (the "recursive sort", cf. :496-500): suffixes still
+//                  sharing a bucket are compacted; each gets the composite key
+//                  (dense bucket id, rank of the suffix h symbols further on);
+//                  radix sort; new flags/scan split the buckets; h doubles.
+//                  Terminates when every bucket is a singleton (<= log2 n rounds).
+//
+// Short suffixes: keys are zero-padded past the end of the text; a suffix whose
+// first h symbols run off the end ("consumed") gets key2 = n-1-i, which is
+// smaller than every real key2 and decreasing in i, i.e. "shorter first",
+// exactly how the reference's virtual sentinel orders them (:422-425).
+//
+// The same kernels serve the range-partitioned (multi-GPU) build, where a rank
+// sorts only the suffixes whose leading key bits fall in its bucket range and
+// refines with text symbols (no ranks of foreign suffixes needed).
+#include <string.h>
+
+#include "sfx_host.hpp"
+
+namespace sfx {
+
+constexpr int kKmerTile = 4096;          // text positions per tile
+constexpr int kMaxSymsPerKey = 64;
+constexpr int kMaxTopBits = 14;          // 16384 u32 bins = 64 KiB of LDS
+
+// ---------------------------------------------------------------------------------
+// 1. alphabet
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_byte_hist(const uint8_t* __restrict__ text, uint64_t begin, uint64_t end,
+            unsigned long long* __restrict__ bins)
+{
+    __shared__ uint32_t h[kWavesPerBlock][256];
+    const unsigned tid = threadIdx.x, w = wave_id();
+    for (unsigned i = tid; i < kWavesPerBlock * 256; i += kBlock) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = begin + (uint64_t)blockIdx.x * kBlock + tid; i < end; i += stride)
+        atomicAdd(&h[w][text[i]], 1u);
+    __syncthreads();
+    uint32_t c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+    if (c) atomicAdd(&bins[tid], (unsigned long long)c);
+}
+
+// dense symbol codes from the 256 global byte counts (one workgroup, thread = byte value)
+__global__ void __launch_bounds__(kBlock)
+k_make_lut(const unsigned long long* __restrict__ bins, uint8_t* __restrict__ lut)
+{
+    __shared__ uint32_t part[kWavesPerBlock];
+    uint32_t present = bins[threadIdx.x] ? 1u : 0u, total;
+    uint32_t code = block_scan_add_excl(present, part, total);
+    lut[threadIdx.x] = (uint8_t)code;
+}
+
+// ---------------------------------------------------------------------------------
+// 2. k-symbol keys
+// ---------------------------------------------------------------------------------
+// Stage the symbol codes of text[tile, tile + kKmerTile + cpk - 1) in LDS (0 past
+// the end).  Caller places barriers.
+__device__ __forceinline__ void load_codes(const uint8_t* __restrict__ text, uint64_t n, uint64_t tile,
+                                           int cpk, const uint8_t* s_lut, uint8_t* codes)
+{
+    for (unsigned j = threadIdx.x; j < (unsigned)(kKmerTile + cpk - 1); j += kBlock) {
+        uint64_t g = tile + j;
+        codes[j] = (g < n) ? s_lut[text[g]] : (uint8_t)0;
+    }
+}
+template <class KeyT>
+__device__ __forceinline__ KeyT key_from_codes(const uint8_t* codes, unsigned p, int bits, int cpk)
+{
+    KeyT key = 0;
+    for (int j = 0; j < cpk; j++) key = (KeyT)(key << bits) | (KeyT)codes[p + j];
+    return key;
+}
+
+// keys[i] = first `cpk` symbols of suffix i, `bits` bits each, big-endian in the
+// low cpk*bits bits, zero-padded past the end; vals[i] = i.
+template <class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_kmer_keys_tiled(const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ lut,
+                  int bits, int cpk, uint64_t tiles_per_block, KeyT* __restrict__ keys,
+                  uint32_t* __restrict__ vals)
+{
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t codes[kKmerTile + kMaxSymsPerKey];
+    const unsigned tid = threadIdx.x;
+    s_lut[tid] = lut[tid];
+    __syncthreads();
+    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kKmerTile;
+    uint64_t end = begin + tiles_per_block * kKmerTile;
+    if (end > n) end = n;
+    for (uint64_t tile = begin; tile < end; tile += kKmerTile) {
+        load_codes(text, n, tile, cpk, s_lut, codes);
+        __syncthreads();
+        for (unsigned p = tid; p < (unsigned)kKmerTile; p += kBlock) {
+            uint64_t i = tile + p;
+            if (i < end) {
+                keys[i] = key_from_codes<KeyT>(codes, p, bits, cpk);
+                vals[i] = (uint32_t)i;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Bucket-boundary histogram for the partitioned build: counts the top `top_bits`
+// bits of the key of every suffix starting in [begin, end).  Bins are privatised
+// in LDS (2^top_bits u32 <= 64 KiB) and flushed once per workgroup.
+template <class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_key_hist(const uint8_t* __restrict__ text, uint64_t n, uint64_t begin, uint64_t end,
+           const uint8_t* __restrict__ lut, int bits, int cpk, int top_bits,
+           uint64_t tiles_per_block, unsigned long long* __restrict__ bins)
+{
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t codes[kKmerTile + kMaxSymsPerKey];
+    __shared__ uint32_t h[1 << kMaxTopBits];
+    const unsigned tid = threadIdx.x, nbins = 1u << top_bits;
+    const int shift = bits * cpk - top_bits;
+    s_lut[tid] = lut[tid];
+    for (unsigned i = tid; i < nbins; i += kBlock) h[i] = 0;
+    __syncthreads();
+    uint64_t cb = begin + (uint64_t)blockIdx.x * tiles_per_block * kKmerTile;
+    uint64_t ce = cb + tiles_per_block * kKmerTile;
+    if (ce > end) ce = end;
+    for (uint64_t tile = cb; tile < ce; tile += kKmerTile) {
+        load_codes(text, n, tile, cpk, s_lut, codes);
+        __syncthreads();
+        for (unsigned p = tid; p < (unsigned)kKmerTile; p += kBlock) {
+            if (tile + p < ce) {
+                KeyT key = key_from_codes<KeyT>(codes, p, bits, cpk);
+                atomicAdd(&h[(unsigned)(key >> shift)], 1u);
+            }
+        }
+        __syncthreads();
+    }
+    for (unsigned i = tid; i < nbins; i += kBlock)
+        if (h[i]) atomicAdd(&bins[i], (unsigned long long)h[i]);
+}
+
+// Partitioned build: emit (key, suffix) for the suffixes whose top key bits fall
+// in [bin_lo, bin_hi).  phase 0 counts per workgroup, phase 1 writes at the
+// scanned offsets (stream compaction; order = text order).
+template <class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_range_filter(const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ lut,
+               int bits, int cpk, int top_bits, uint32_t bin_lo, uint32_t bin_hi,
+               uint64_t tiles_per_block, int phase, uint32_t* __restrict__ block_counts,
+               uint64_t capacity, KeyT* __restrict__ kout, uint32_t* __restrict__ vout)
+{
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t codes[kKmerTile + kMaxSymsPerKey];
+    __shared__ uint32_t part[kWavesPerBlock];
+    const unsigned tid = threadIdx.x;
+    const int shift = bits * cpk - top_bits;
+    s_lut[tid] = lut[tid];
+    __syncthreads();
+    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kKmerTile;
+    uint64_t end = begin + tiles_per_block * kKmerTile;
+    if (end > n) end = n;
+    uint64_t running = (phase == 1) ? (uint64_t)block_counts[blockIdx.x] : 0ull;
+    for (uint64_t tile = begin; tile < end; tile += kKmerTile) {
+        load_codes(text, n, tile, cpk, s_lut, codes);
+        __syncthreads();
+        for (unsigned base = 0; base < (unsigned)kKmerTile; base += kBlock) {
+            unsigned p = base + tid;
+            uint64_t i = tile + p;
+            KeyT key = 0;
+            bool keep = false;
+            if (i < end) {
+                key = key_from_codes<KeyT>(codes, p, bits, cpk);
+                uint32_t bin = (uint32_t)(key >> shift);
+                keep = bin >= bin_lo && bin < bin_hi;
+            }
+            uint32_t total;
+            uint32_t ex = block_scan_add_excl<uint32_t>(keep ? 1u : 0u, part, total);
+            if (phase == 1 && keep && running + ex < capacity) {
+                kout[running + ex] = key;
+                vout[running + ex] = (uint32_t)i;
+            }
+            running += total;
+        }
+        __syncthreads();
+    }
+    if (phase == 0 && tid == 0) block_counts[blockIdx.x] = (uint32_t)running;
+}
+
+// exclusive scan of <= kMaxGrid per-workgroup counts (single workgroup); total -> out_total
+__global__ void __launch_bounds__(kBlock)
+k_scan_block_counts(uint32_t* __restrict__ counts, unsigned nb, uint32_t* __restrict__ out_total)
+{
+    __shared__ uint32_t part[kWavesPerBlock];
+    uint32_t carry = 0;
+    for (unsigned base = 0; base < nb; base += kBlock) {
+        unsigned i = base + threadIdx.x;
+        uint32_t v = (i < nb) ? counts[i] : 0u, total;
+        uint32_t ex = block_scan_add_excl(v, part, total);
+        if (i < nb) counts[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *out_total = carry;
+}
+
+// ---------------------------------------------------------------------------------
+// 4a. composite keys for a refinement round
+// ---------------------------------------------------------------------------------
+// rank mode: key2 = rank of suffix i+h (+h), or n-1-i when i+h runs off the text.
+__global__ void __launch_bounds__(kBlock)
+k_compose_rank_keys(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ gid, uint64_t m,
+                    const uint32_t* __restrict__ isa, uint64_t n, uint64_t h, int key2_bits,
+                    uint64_t* __restrict__ keys)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < m; q += stride) {
+        uint64_t i = suf[q];
+        uint64_t p = i + h;
+        uint64_t key2 = (p < n) ? (uint64_t)isa[p] + h : (n - 1 - i);
+        keys[q] = ((uint64_t)gid[q] << key2_bits) | key2;
+    }
+}
+
+// text mode (partitioned build): key2 = (1 << flag_shift) | next cpk symbols at
+// offset h, or n-1-i (< 2^flag_shift) when the suffix is consumed.
+__global__ void __launch_bounds__(kBlock)
+k_compose_text_keys(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ gid, uint64_t m,
+                    const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ lut,
+                    int bits, int cpk, uint64_t h, int flag_shift, int key2_bits,
+                    uint64_t* __restrict__ keys)
+{
+    __shared__ uint8_t s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < m; q += stride) {
+        uint64_t i = suf[q];
+        uint64_t p = i + h;
+        uint64_t key2;
+        if (p < n) {
+            uint64_t kmer = 0;
+            for (int j = 0; j < cpk; j++) {
+                uint64_t g = p + (uint64_t)j;
+                kmer = (kmer << bits) | ((g < n) ? (uint64_t)s_lut[text[g]] : 0ull);
+            }
+            key2 = (1ull << flag_shift) | kmer;
+        } else {
+            key2 = n - 1 - i;
+        }
+        keys[q] = ((uint64_t)gid[q] << key2_bits) | key2;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// 3./4b. bucket boundaries, ranks, singleton removal  (reduce -> scan -> apply)
+// ---------------------------------------------------------------------------------
+constexpr int kGroupTile = kBlock;       // one element per thread per step
+
+template <class KeyT>
+__device__ __forceinline__ void group_flags(const KeyT* __restrict__ K, uint64_t i, uint64_t m,
+                                            bool& head, bool& single)
+{
+    KeyT k = K[i];
+    head = (i == 0) || (K[i - 1] != k);
+    bool next_head = (i + 1 == m) || (K[i + 1] != k);
+    single = head && next_head;
+}
+
+// per-workgroup partials: last bucket-head index (+1) in the chunk, #kept, #kept bucket heads
+template <class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t tiles_per_block,
+                uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep,
+                uint32_t* __restrict__ part_ghead)
+{
+    __shared__ uint32_t red[3][kWavesPerBlock];
+    const unsigned tid = threadIdx.x;
+    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kGroupTile;
+    uint64_t end = begin + tiles_per_block * kGroupTile;
+    if (end > m) end = m;
+    uint32_t last_head = 0, keep = 0, ghead = 0;
+    for (uint64_t i = begin + tid; i < end; i += kBlock) {
+        bool head, single;
+        group_flags(K, i, m, head, single);
+        if (head) last_head = (uint32_t)i + 1u;          // i ascends per thread
+        keep += single ? 0u : 1u;
+        ghead += (head && !single) ? 1u : 0u;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        last_head = dmax(last_head, __shfl_xor(last_head, d));
+        keep += __shfl_xor(keep, d);
+        ghead += __shfl_xor(ghead, d);
+    }
+    if (lane_id() == 0) {
+        red[0][wave_id()] = last_head;
+        red[1][wave_id()] = keep;
+        red[2][wave_id()] = ghead;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t a = 0, b = 0, c = 0;
+        for (int w = 0; w < kWavesPerBlock; w++) { a = dmax(a, red[0][w]); b += red[1][w]; c += red[2][w]; }
+        part_head[blockIdx.x] = a;
+        part_keep[blockIdx.x] = b;
+        part_ghead[blockIdx.x] = c;
+    }
+}
+
+// single workgroup: turn the partials into carries (exclusive max / sums); totals[0..1]
+__global__ void __launch_bounds__(kBlock)
+k_groups_scan(uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep,
+              uint32_t* __restrict__ part_ghead, unsigned nb, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t part[kWavesPerBlock];
+    uint32_t c_head = 0, c_keep = 0, c_ghead = 0;
+    for (unsigned base = 0; base < nb; base += kBlock) {
+        unsigned i = base + threadIdx.x;
+        bool valid = i < nb;
+        uint32_t vh = valid ? part_head[i] : 0u, vk = valid ? part_keep[i] : 0u,
+                 vg = valid ? part_ghead[i] : 0u, th, tk, tg;
+        uint32_t eh = block_scan_max_excl(vh, part, th);
+        uint32_t ek = block_scan_add_excl(vk, part, tk);
+        uint32_t eg = block_scan_add_excl(vg, part, tg);
+        if (valid) {
+            part_head[i] = dmax(c_head, eh);
+            part_keep[i] = c_keep + ek;
+            part_ghead[i] = c_ghead + eg;
+        }
+        c_head = dmax(c_head, th);
+        c_keep += tk;
+        c_ghead += tg;
+    }
+    if (threadIdx.x == 0) { totals[0] = c_keep; totals[1] = c_ghead; }
+}
+
+// K,V: sorted keys / suffixes of the m active elements; S: their SA slots in
+// ascending order (nullptr = identity).  Writes SA[slot] = suffix, ISA[suffix] =
+// slot of its bucket head (if isa != nullptr), and compacts the elements of
+// non-singleton buckets into (S_next, V_next, G_next = dense bucket id).
+template <class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
+               const uint32_t* __restrict__ S, uint64_t m, uint64_t tiles_per_block,
+               const uint32_t* __restrict__ part_head, const uint32_t* __restrict__ part_keep,
+               const uint32_t* __restrict__ part_ghead, uint32_t* __restrict__ sa,
+               uint32_t* __restrict__ isa, uint32_t* __restrict__ S_next,
+               uint32_t* __restrict__ V_next, uint32_t* __restrict__ G_next)
+{
+    __shared__ uint32_t part[kWavesPerBlock];
+    const unsigned tid = threadIdx.x;
+    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kGroupTile;
+    uint64_t end = begin + tiles_per_block * kGroupTile;
+    if (end > m) end = m;
+    uint32_t c_head = part_head[blockIdx.x];     // index+1 of the last head before the chunk
+    uint32_t c_keep = part_keep[blockIdx.x];
+    uint32_t c_ghead = part_ghead[blockIdx.x];
+    for (uint64_t tile = begin; tile < end; tile += kGroupTile) {
+        uint64_t i = tile + tid;
+        bool valid = i < end, head = false, single = false;
+        if (valid) group_flags(K, i, m, head, single);
+        bool keep = valid && !single, ghead = valid && head && !single;
+        uint32_t hv = (valid && head) ? (uint32_t)i + 1u : 0u, tot_h, tot_c;
+        uint32_t eh = block_scan_max_excl(hv, part, tot_h);
+        uint32_t packed = (keep ? 1u : 0u) | (ghead ? 0x10000u : 0u);
+        uint32_t ec = block_scan_add_excl(packed, part, tot_c);
+        if (valid) {
+            uint32_t my_head = dmax(dmax(c_head, eh), hv) - 1u;      // index of my bucket head
+            uint32_t slot = S ? S[i] : (uint32_t)i;
+            uint32_t head_slot = S ? S[my_head] : my_head;
+            uint32_t suffix = V[i];
+            sa[slot] = suffix;
+            if (isa) isa[suffix] = head_slot;
+            if (keep) {
+                uint32_t pos = c_keep + (ec & 0xFFFFu);
+                S_next[pos] = slot;
+                V_next[pos] = suffix;
+                G_next[pos] = c_ghead + (ec >> 16) + (ghead ? 1u : 0u) - 1u;
+            }
+        }
+        c_head = dmax(c_head, tot_h);
+        c_keep += tot_c & 0xFFFFu;
+        c_ghead += tot_c >> 16;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------
+struct Alphabet {
+    unsigned sigma;
+    int bits;
+};
+
+static Alphabet make_alphabet(const unsigned long long* bins)
+{
+    Alphabet a;
+    a.sigma = 0;
+    for (int c = 0; c < 256; c++) if (bins[c]) a.sigma++;
+    a.bits = bits_for(a.sigma > 1 ? a.sigma - 1 : 1);
+    return a;
+}
+
+// 32-bit keys when k = floor(32/bits) symbols are expected to separate most
+// suffixes of a random text over this alphabet (k*floor(log2 sigma) >= log2 n + 3),
+// else 64-bit keys.  Depends only on (alphabet, n): identical on every rank.
+static void choose_key(const Alphabet& a, uint64_t n, int* key_bits, int* cpk)
+{
+    int k32 = 32 / a.bits, k64 = 64 / a.bits;
+    if (k64 > kMaxSymsPerKey) k64 = kMaxSymsPerKey;
+    if (k32 > kMaxSymsPerKey) k32 = kMaxSymsPerKey;
+    int l2 = bits_for(a.sigma) - 1;                 // floor(log2 sigma), sigma >= 1
+    if (l2 < 1) l2 = 1;
+    if (k32 * l2 >= bits_for(n) + 3) { *key_bits = 32; *cpk = k32; }
+    else { *key_bits = 64; *cpk = k64; }
+}
+
+struct SaBuffers {
+    uint64_t* K0; uint64_t* K1;                         // key ping-pong (8 B per element)
+    uint32_t* VA; uint32_t* VB;                         // suffix ping-pong
+    uint32_t* S0; uint32_t* S1;                         // slot lists
+    uint32_t* G;                                        // dense bucket ids
+    uint32_t* isa;
+    uint32_t* hist;                                     // 256*kMaxGrid + 256
+    uint32_t* part_head; uint32_t* part_keep; uint32_t* part_ghead;   // kMaxGrid each
+    uint32_t* totals;
+    unsigned long long* bins;                           // 256
+    uint8_t* lut;                                       // 256
+};
+
+struct SizerArena : ArenaSizer {
+    template <class T> T* take(uint64_t c) { ArenaSizer::take<T>(c); return nullptr; }
+};
+
+template <class A> static void carve_sa(A& ar, uint64_t cap, uint64_t isa_len, SaBuffers* b)
+{
+    uint64_t* K0 = ar.template take<uint64_t>(cap);
+    uint64_t* K1 = ar.template take<uint64_t>(cap);
+    uint32_t* VA = ar.template take<uint32_t>(cap);
+    uint32_t* VB = ar.template take<uint32_t>(cap);
+    uint32_t* S0 = ar.template take<uint32_t>(cap);
+    uint32_t* S1 = ar.template take<uint32_t>(cap);
+    uint32_t* G = ar.template take<uint32_t>(cap);
+    uint32_t* isa = ar.template take<uint32_t>(isa_len);
+    uint32_t* hist = ar.template take<uint32_t>((uint64_t)kRadix * kMaxGrid + kRadix);
+    uint32_t* ph = ar.template take<uint32_t>(kMaxGrid);
+    uint32_t* pk = ar.template take<uint32_t>(kMaxGrid);
+    uint32_t* pg = ar.template take<uint32_t>(kMaxGrid);
+    uint32_t* totals = ar.template take<uint32_t>(64);
+    unsigned long long* bins = ar.template take<unsigned long long>(256);
+    uint8_t* lut = ar.template take<uint8_t>(256);
+    if (b) {
+        b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G;
+        b->isa = isa; b->hist = hist; b->part_head = ph; b->part_keep = pk; b->part_ghead = pg;
+        b->totals = totals; b->bins = bins; b->lut = lut;
+    }
+}
+
+uint64_t sa_workspace_bytes(uint64_t n)
+{
+    SizerArena s;
+    uint64_t cap = n < 2 ? 2 : n;
+    carve_sa(s, cap, cap, (SaBuffers*)nullptr);
+    return s.used + 256;
+}
+uint64_t sa_range_workspace_bytes(uint64_t max_count)
+{
+    SizerArena s;
+    carve_sa(s, max_count < 2 ? 2 : max_count, 0, (SaBuffers*)nullptr);
+    s.take<uint32_t>(kMaxGrid);
+    return s.used + 256;
+}
+
+// finalize one round: flags -> carries -> apply; reads back {kept, kept buckets}.
+template <class KeyT>
+static int finish_round(const KeyT* K, const uint32_t* V, const uint32_t* S, uint64_t m,
+                        SaBuffers& b, uint32_t* sa, uint32_t* isa, uint32_t* S_next,
+                        uint32_t* V_next, hipStream_t st, uint64_t* kept, uint64_t* kept_groups)
+{
+    Chunking ch = make_chunking(m, kGroupTile);
+    SFX_LAUNCH("groups_reduce", (double)m * sizeof(KeyT), (k_groups_reduce<KeyT>), ch.blocks, kBlock,
+               st, K, m, ch.tiles_per_block, b.part_head, b.part_keep, b.part_ghead);
+    SFX_LAUNCH("groups_scan", 0.0, k_groups_scan, 1, kBlock, st, b.part_head, b.part_keep,
+               b.part_ghead, ch.blocks, b.totals);
+    SFX_LAUNCH("groups_apply", (double)m * (sizeof(KeyT) + 4 + 4 + (isa ? 4 : 0) + (S ? 4 : 0)),
+               (k_groups_apply<KeyT>), ch.blocks, kBlock, st, K, V, S, m, ch.tiles_per_block,
+               b.part_head, b.part_keep, b.part_ghead, sa, isa, S_next, V_next, b.G);
+    uint32_t host_totals[2] = {0, 0};
+    SFX_HIP(hipMemcpyAsync(host_totals, b.totals, sizeof(host_totals), hipMemcpyDeviceToHost, st));
+    SFX_HIP(hipStreamSynchronize(st));
+    *kept = host_totals[0];
+    *kept_groups = host_totals[1];
+    return SFX_OK;
+}
+
+// alphabet from device-resident global byte counts
+static int alphabet_from_bins(const unsigned long long* d_bins, SaBuffers& b, hipStream_t st,
+                              Alphabet* alpha)
+{
+    unsigned long long host_bins[256];
+    SFX_HIP(hipMemcpyAsync(host_bins, d_bins, sizeof(host_bins), hipMemcpyDeviceToHost, st));
+    SFX_LAUNCH("make_lut", 0.0, k_make_lut, 1, kBlock, st, d_bins, b.lut);
+    SFX_HIP(hipStreamSynchronize(st));
+    *alpha = make_alphabet(host_bins);
+    return SFX_OK;
+}
+
+int byte_histogram_dev(const uint8_t* d_text, uint64_t begin, uint64_t end, uint64_t* d_bins,
+                       hipStream_t st)
+{
+    if (!d_bins || (end > begin && !d_text)) return SFX_ERR_ARG;
+    SFX_HIP(hipMemsetAsync(d_bins, 0, 256 * sizeof(uint64_t), st));
+    if (end <= begin) return SFX_OK;
+    uint64_t cnt = end - begin;
+    unsigned grid = (unsigned)dmin<uint64_t>((cnt + kBlock * 16 - 1) / (kBlock * 16), kMaxGrid);
+    SFX_LAUNCH("byte_hist", (double)cnt, k_byte_hist, grid, kBlock, st, d_text, begin, end,
+               (unsigned long long*)d_bins);
+    return SFX_OK;
+}
+
+// refinement rounds shared by the full and the partitioned build.
+//   rank mode (isa != nullptr): key2 from ISA, h doubles
+//   text mode (isa == nullptr): key2 = next cpk_r symbols, h += cpk_r
+static int refine(const uint8_t* d_text, uint64_t n, const Alphabet& alpha, int cpk, SaBuffers& b,
+                  uint32_t* sa, uint32_t* isa, uint32_t* S_cur, uint32_t* V_cur, uint64_t m,
+                  uint64_t groups, hipStream_t st, sfx_build_stats& stats)
+{
+    uint64_t h = (uint64_t)cpk;
+    int cpk_r = 32 / alpha.bits;                       // text mode: <= 32 key bits per round
+    if (cpk_r > cpk) cpk_r = cpk;
+    const int flag_shift = dmax(alpha.bits * cpk_r, bits_for(n));
+    int rounds = 0;
+    while (m > 0) {
+        // rank mode at most ~log2(n) rounds; text mode is bounded by the longest repeat
+        if (++rounds > (isa ? 80 : 1 << 20)) return SFX_ERR_INTERNAL;
+        int key2_bits = isa ? bits_for(n - 1 + h) : flag_shift + 1;
+        int gid_bits = bits_for(groups > 0 ? groups - 1 : 0);
+        if (key2_bits + gid_bits > 64) return SFX_ERR_INTERNAL;
+        unsigned grid = (unsigned)dmin<uint64_t>((m + kBlock - 1) / kBlock, kMaxGrid);
+        if (isa) {
+            SFX_LAUNCH("compose_rank_keys", (double)m * 20, k_compose_rank_keys, grid, kBlock, st,
+                       V_cur, b.G, m, isa, n, h, key2_bits, b.K0);
+        } else {
+            SFX_LAUNCH("compose_text_keys", (double)m * (16 + cpk_r), k_compose_text_keys, grid, kBlock,
+                       st, V_cur, b.G, m, d_text, n, b.lut, alpha.bits, cpk_r, h, flag_shift,
+                       key2_bits, b.K0);
+        }
+        uint32_t* V_other = (V_cur == b.VA) ? b.VB : b.VA;
+        int in1 = 0;
+        SFX_TRY(radix_sort_pairs<uint64_t>(b.K0, V_cur, b.K1, V_other, m, 0, key2_bits + gid_bits,
+                                           b.hist, st, &in1, &stats));
+        const uint64_t* Kr = in1 ? b.K1 : b.K0;
+        uint32_t* Vr = in1 ? V_other : V_cur;
+        uint32_t* V_next = in1 ? V_cur : V_other;
+        uint32_t* S_next = (S_cur == b.S0) ? b.S1 : b.S0;
+        uint64_t kept = 0, kept_groups = 0;
+        SFX_TRY(finish_round<uint64_t>(Kr, Vr, S_cur, m, b, sa, isa, S_next, V_next, st, &kept,
+                                       &kept_groups));
+        S_cur = S_next;
+        V_cur = V_next;
+        m = kept;
+        groups = kept_groups;
+        h = isa ? h * 2 : h + (uint64_t)cpk_r;
+        stats.rounds++;
+    }
+    return SFX_OK;
+}
+
+// initial sort + first bucket pass + refinement, for `count` (key, suffix) pairs
+// already sitting in (K0 as KeyT, VA).
+template <class KeyT>
+static int sort_and_refine(const uint8_t* d_text, uint64_t n, const Alphabet& alpha, int cpk,
+                           uint64_t count, SaBuffers& b, uint32_t* sa, uint32_t* isa, hipStream_t st,
+                           sfx_build_stats& stats)
+{
+    KeyT* k0 = (KeyT*)b.K0;
+    KeyT* k1 = (KeyT*)b.K1;
+    int in1 = 0;
+    SFX_TRY(radix_sort_pairs<KeyT>(k0, b.VA, k1, b.VB, count, 0, alpha.bits * cpk, b.hist, st, &in1,
+                                   &stats));
+    uint64_t kept = 0, groups = 0;
+    uint32_t* V_next = in1 ? b.VA : b.VB;
+    SFX_TRY(finish_round<KeyT>(in1 ? k1 : k0, in1 ? b.VB : b.VA, nullptr, count, b, sa, isa, b.S0,
+                               V_next, st, &kept, &groups));
+    stats.active_after_initial = kept;
+    return refine(d_text, n, alpha, cpk, b, sa, isa, b.S0, V_next, kept, groups, st, stats);
+}
+
+int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,
+                     hipStream_t st)
+{
+    sfx_build_stats& stats = tls_build_stats();
+    memset(&stats, 0, sizeof(stats));
+    stats.n = n;
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;            // src/table.rs:380
+    if (n == 0) return SFX_OK;                                  // :396
+    if (!d_text || !d_sa) return SFX_ERR_ARG;
+    if (n == 1) {                                               // :397-400
+        SFX_HIP(hipMemsetAsync(d_sa, 0, sizeof(uint32_t), st));
+        return SFX_OK;
+    }
+    if (!ws || ws_bytes < sa_workspace_bytes(n)) return SFX_ERR_WORKSPACE;
+
+    Arena ar(ws, ws_bytes);
+    SaBuffers b;
+    carve_sa(ar, n, n, &b);
+    if (ar.overflow) return SFX_ERR_WORKSPACE;
+
+    SFX_TRY(byte_histogram_dev(d_text, 0, n, (uint64_t*)b.bins, st));
+    Alphabet alpha;
+    SFX_TRY(alphabet_from_bins(b.bins, b, st, &alpha));
+    int key_bits, cpk;
+    choose_key(alpha, n, &key_bits, &cpk);
+    stats.sigma = alpha.sigma;
+    stats.bits_per_symbol = (uint32_t)alpha.bits;
+    stats.key_bits = (uint32_t)key_bits;
+    stats.symbols_per_key = (uint32_t)cpk;
+
+    Chunking ch = make_chunking(n, kKmerTile);
+    if (key_bits == 32) {
+        SFX_LAUNCH("kmer_keys", (double)n * 9, (k_kmer_keys_tiled<uint32_t>), ch.blocks, kBlock, st,
+                   d_text, n, b.lut, alpha.bits, cpk, ch.tiles_per_block, (uint32_t*)b.K0, b.VA);
+        return sort_and_refine<uint32_t>(d_text, n, alpha, cpk, n, b, d_sa, b.isa, st, stats);
+    }
+    SFX_LAUNCH("kmer_keys", (double)n * 13, (k_kmer_keys_tiled<uint64_t>), ch.blocks, kBlock, st,
+               d_text, n, b.lut, alpha.bits, cpk, ch.tiles_per_block, b.K0, b.VA);
+    return sort_and_refine<uint64_t>(d_text, n, alpha, cpk, n, b, d_sa, b.isa, st, stats);
+}
+
+// ---- partitioned build -----------------------------------------------------------
+int key_histogram_dev(const uint8_t* d_text, uint64_t n, uint64_t begin, uint64_t end,
+                      const uint64_t* d_byte_bins, int top_bits, uint64_t* d_bins, hipStream_t st)
+{
+    if (!d_text || !d_byte_bins || !d_bins || begin > end || end > n) return SFX_ERR_ARG;
+    if (top_bits < 1 || top_bits > kMaxTopBits) return SFX_ERR_ARG;
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    SFX_HIP(hipMemsetAsync(d_bins, 0, sizeof(uint64_t) << top_bits, st));
+    if (begin == end) return SFX_OK;
+    // the LUT needs 256 B of device scratch: borrow the tail of the caller's bin array?  No --
+    // keep the ABI simple: a small static-size device allocation per call.
+    uint8_t* d_lut = nullptr;
+    SFX_HIP(hipMalloc((void**)&d_lut, 256));
+    unsigned long long host_bins[256];
+    int rc = SFX_OK;
+    do {
+        if (hipMemcpyAsync(host_bins, d_byte_bins, sizeof(host_bins), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = SFX_ERR_HIP; break; }
+        Alphabet alpha = make_alphabet(host_bins);
+        int key_bits, cpk;
+        choose_key(alpha, n, &key_bits, &cpk);
+        if (alpha.bits * cpk < top_bits) { rc = SFX_ERR_ARG; break; }
+        hipLaunchKernelGGL(k_make_lut, dim3(1), dim3(kBlock), 0, st,
+                           (const unsigned long long*)d_byte_bins, d_lut);
+        Chunking ch = make_chunking(end - begin, kKmerTile, 256);   // one flush per CU
+        if (key_bits == 32) {
+            hipLaunchKernelGGL((k_key_hist<uint32_t>), dim3(ch.blocks), dim3(kBlock), 0, st, d_text, n,
+                               begin, end, (const uint8_t*)d_lut, alpha.bits, cpk, top_bits,
+                               ch.tiles_per_block, (unsigned long long*)d_bins);
+        } else {
+            hipLaunchKernelGGL((k_key_hist<uint64_t>), dim3(ch.blocks), dim3(kBlock), 0, st, d_text, n,
+                               begin, end, (const uint8_t*)d_lut, alpha.bits, cpk, top_bits,
+                               ch.tiles_per_block, (unsigned long long*)d_bins);
+        }
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SFX_ERR_HIP;
+    } while (0);
+    (void)hipFree(d_lut);
+    return rc;
+}
+
+template <class KeyT>
+static int range_build(const uint8_t* d_text, uint64_t n, const Alphabet& alpha, int cpk, int top_bits,
+                       uint32_t bin_lo, uint32_t bin_hi, uint64_t capacity, uint32_t* d_sa_part,
+                       uint64_t* count_out, SaBuffers& b, uint32_t* block_counts, hipStream_t st,
+                       sfx_build_stats& stats)
+{
+    Chunking ch = make_chunking(n, kKmerTile);
+    KeyT* k0 = (KeyT*)b.K0;
+    SFX_LAUNCH("range_count", (double)n, (k_range_filter<KeyT>), ch.blocks, kBlock, st, d_text, n,
+               b.lut, alpha.bits, cpk, top_bits, bin_lo, bin_hi, ch.tiles_per_block, 0, block_counts,
+               capacity, k0, b.VA);
+    SFX_LAUNCH("range_scan", 0.0, k_scan_block_counts, 1, kBlock, st, block_counts, ch.blocks, b.totals);
+    uint32_t host_total = 0;
+    SFX_HIP(hipMemcpyAsync(&host_total, b.totals, sizeof(host_total), hipMemcpyDeviceToHost, st));
+    SFX_HIP(hipStreamSynchronize(st));
+    *count_out = host_total;
+    if (host_total > capacity) return SFX_ERR_WORKSPACE;
+    if (host_total == 0) return SFX_OK;
+    SFX_LAUNCH("range_emit", (double)n + (double)host_total * (sizeof(KeyT) + 4), (k_range_filter<KeyT>),
+               ch.blocks, kBlock, st, d_text, n, b.lut, alpha.bits, cpk, top_bits, bin_lo, bin_hi,
+               ch.tiles_per_block, 1, block_counts, capacity, k0, b.VA);
+    return sort_and_refine<KeyT>(d_text, n, alpha, cpk, host_total, b, d_sa_part, nullptr, st, stats);
+}
+
+int build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint64_t* d_byte_bins,
+                           int top_bits, uint32_t bin_lo, uint32_t bin_hi, uint64_t capacity,
+                           uint32_t* d_sa_part, uint64_t* count_out, void* ws, uint64_t ws_bytes,
+                           hipStream_t st)
+{
+    sfx_build_stats& stats = tls_build_stats();
+    memset(&stats, 0, sizeof(stats));
+    stats.n = n;
+    if (!count_out) return SFX_ERR_ARG;
+    *count_out = 0;
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    if (n == 0 || bin_lo >= bin_hi) return SFX_OK;
+    if (!d_text || !d_byte_bins || !d_sa_part || capacity == 0) return SFX_ERR_ARG;
+    if (top_bits < 1 || top_bits > kMaxTopBits || bin_hi > (1u << top_bits)) return SFX_ERR_ARG;
+    if (!ws || ws_bytes < sa_range_workspace_bytes(capacity)) return SFX_ERR_WORKSPACE;
+
+    Arena ar(ws, ws_bytes);
+    SaBuffers b;
+    carve_sa(ar, capacity < 2 ? 2 : capacity, 0, &b);
+    uint32_t* block_counts = ar.take<uint32_t>(kMaxGrid);
+    if (ar.overflow) return SFX_ERR_WORKSPACE;
+
+    Alphabet alpha;
+    SFX_TRY(alphabet_from_bins((const unsigned long long*)d_byte_bins, b, st, &alpha));
+    int key_bits, cpk;
+    choose_key(alpha, n, &key_bits, &cpk);
+    if (alpha.bits * cpk < top_bits) return SFX_ERR_ARG;
+    stats.sigma = alpha.sigma;
+    stats.bits_per_symbol = (uint32_t)alpha.bits;
+    stats.key_bits = (uint32_t)key_bits;
+    stats.symbols_per_key = (uint32_t)cpk;
+    if (key_bits == 32)
+        return range_build<uint32_t>(d_text, n, alpha, cpk, top_bits, bin_lo, bin_hi, capacity,
+                                     d_sa_part, count_out, b, block_counts, st, stats);
+    return range_build<uint64_t>(d_text, n, alpha, cpk, top_bits, bin_lo, bin_hi, capacity, d_sa_part,
+                                 count_out, b, block_counts, st, stats);
+}
+
+}  // namespace sfx

@@ -1,0 +1,84 @@
+"""Device-resident entry points: torch tensors are used only as HBM buffers and
+for the current HIP stream; all compute is the C ABI's `*_dev` functions.
+
+Inputs stay in HBM, outputs are left in HBM, scratch comes from a caller-owned
+(or freshly allocated) workspace tensor -- the engine itself never allocates
+device memory on this path, so a build is a pure kernel sequence on the
+caller's stream.
+"""
+import ctypes
+
+import torch
+
+from ._lib import default_engine
+
+
+def _stream_ptr(t):
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(0)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() else 0)
+
+
+def _check_u8(text):
+    if text.dtype != torch.uint8 or text.dim() != 1 or not text.is_contiguous():
+        raise TypeError("text must be a contiguous 1-D uint8 tensor")
+
+
+def sa_workspace(n, device, engine=None):
+    eng = engine or default_engine()
+    return torch.empty(int(eng.lib.sfx_sa_workspace_bytes(int(n))), dtype=torch.uint8, device=device)
+
+
+def build_sa(text, out=None, workspace=None, engine=None):
+    """Suffix array (uint32, viewed through torch.int32 storage) of a uint8 tensor."""
+    eng = engine or default_engine()
+    _check_u8(text)
+    n = text.numel()
+    if text.is_cuda:
+        eng.require_device()
+    if out is None:
+        out = torch.empty(n, dtype=torch.int32, device=text.device)
+    if workspace is None:
+        workspace = sa_workspace(n, text.device, eng)
+    eng.check(eng.lib.sfx_build_sa_u32_dev(_p(text), n, _p(out), _p(workspace), workspace.numel(),
+                                           _stream_ptr(text)), "sfx_build_sa_u32_dev")
+    return out
+
+
+def lcp_workspace(n, device, engine=None):
+    eng = engine or default_engine()
+    return torch.empty(int(eng.lib.sfx_lcp_workspace_bytes(int(n))), dtype=torch.uint8, device=device)
+
+
+def build_lcp(text, sa, out=None, workspace=None, engine=None):
+    eng = engine or default_engine()
+    _check_u8(text)
+    n = text.numel()
+    if out is None:
+        out = torch.empty(n, dtype=torch.int32, device=text.device)
+    if workspace is None:
+        workspace = lcp_workspace(n, text.device, eng)
+    eng.check(eng.lib.sfx_build_lcp_u32_dev(_p(text), n, _p(sa), _p(out), _p(workspace),
+                                            workspace.numel(), _stream_ptr(text)),
+              "sfx_build_lcp_u32_dev")
+    return out
+
+
+def query_batch(text, sa, qbytes, qoff, engine=None):
+    """qbytes: uint8 tensor, qoff: int64 tensor of nq+1 offsets (same device as text).
+    -> (start, end, found, any) tensors; positions(q_k) = sa[start[k]:end[k]]."""
+    eng = engine or default_engine()
+    nq = qoff.numel() - 1
+    dev = text.device
+    start = torch.empty(nq, dtype=torch.int32, device=dev)
+    end = torch.empty(nq, dtype=torch.int32, device=dev)
+    found = torch.empty(nq, dtype=torch.uint8, device=dev)
+    anyp = torch.empty(nq, dtype=torch.int32, device=dev)
+    eng.check(eng.lib.sfx_query_batch_dev(_p(text), text.numel(), _p(sa), _p(qbytes), _p(qoff), nq,
+                                          _p(start), _p(end), _p(found), _p(anyp), _stream_ptr(text)),
+              "sfx_query_batch_dev")
+    return start, end, found, anyp

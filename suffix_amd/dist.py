@@ -1,0 +1,102 @@
+"""Range-partitioned suffix-array construction across the GPUs of one node:
+one process per GPU, torch.distributed over RCCL ("nccl" backend on ROCm).
+
+SA-IS induction does not shard (it sweeps all buckets left-to-right then
+right-to-left, src/table.rs:426-448), but the *suffix array itself* does,
+because it is unique: split the SA index space at bucket boundaries.
+
+    1. every rank owns a contiguous shard of the byte stream; the shards are
+       all-gathered so each GPU holds the whole text in HBM (the one bulk
+       exchange: n/G bytes per rank over xGMI);
+    2. each rank histograms the bytes of ITS shard; all-reduce(sum) of 256 bins
+       -> the global alphabet (dense symbol codes), identical everywhere;
+    3. each rank histograms the top `top_bits` key bits of the suffixes starting
+       in ITS shard; all-reduce(sum) of 2^top_bits bins = the bucket-boundary
+       histogram exchange;
+    4. the bins are cut into G contiguous ranges of (nearly) equal suffix count;
+    5. rank r sorts only the suffixes of range r (radix sort + text refinement,
+       no further communication) -> its slice SA[offset_r : offset_r + count_r].
+
+The collectives move 2 KiB + 128 KiB per rank (latency-bound); the data path has
+no collective after step 1.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from ._lib import default_engine
+from .device import _p, _stream_ptr
+
+TOP_BITS = 14
+
+
+def plan_ranges(bins, world):
+    """Cut cumulative bin counts into `world` contiguous bin ranges with balanced totals.
+    bins: 1-D int64 CPU tensor.  -> list of (bin_lo, bin_hi, offset, count)."""
+    csum = torch.cumsum(bins, 0)
+    total = int(csum[-1]) if bins.numel() else 0
+    cuts = [0]
+    for r in range(1, world):
+        target = (total * r) // world
+        # first bin index whose cumulative count exceeds the target
+        idx = int(torch.searchsorted(csum, torch.tensor(target, dtype=csum.dtype), right=True))
+        cuts.append(max(cuts[-1], min(idx, bins.numel())))
+    cuts.append(bins.numel())
+    out = []
+    for r in range(world):
+        lo, hi = cuts[r], cuts[r + 1]
+        off = int(csum[lo - 1]) if lo > 0 else 0
+        cnt = (int(csum[hi - 1]) if hi > 0 else 0) - off
+        out.append((lo, hi, off, cnt))
+    return out
+
+
+def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS):
+    """shard: this rank's contiguous uint8 piece of the text (all ranks the same
+    length), on this rank's device.  Returns (sa_part, offset, n): sa_part is an
+    int32-storage tensor holding u32 suffix indices, the slice
+    SA[offset : offset + sa_part.numel()] of the global suffix array."""
+    eng = engine or default_engine()
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = shard.device
+    m = shard.numel()
+    n = m * world
+    if n > 0xFFFFFFFF:
+        raise OverflowError("text longer than u32::MAX bytes")     # src/table.rs:380
+    stream = _stream_ptr(shard)
+
+    # 1. whole text on every GPU
+    text = torch.empty(n, dtype=torch.uint8, device=dev)
+    dist.all_gather(list(text.split(m)), shard.contiguous(), group=group)
+
+    # 2. global alphabet
+    byte_bins = torch.zeros(256, dtype=torch.int64, device=dev)
+    eng.check(eng.lib.sfx_byte_histogram_dev(_p(text), rank * m, (rank + 1) * m, _p(byte_bins), stream),
+              "sfx_byte_histogram_dev")
+    dist.all_reduce(byte_bins, op=dist.ReduceOp.SUM, group=group)
+
+    # 3. bucket-boundary histogram
+    sigma = int((byte_bins > 0).sum())
+    sym_bits = max(1, (max(sigma, 2) - 1).bit_length())
+    tb = min(top_bits, sym_bits * max(1, 32 // sym_bits))
+    key_bins = torch.zeros(1 << tb, dtype=torch.int64, device=dev)
+    eng.check(eng.lib.sfx_key_histogram_dev(_p(text), n, rank * m, (rank + 1) * m, _p(byte_bins), tb,
+                                            _p(key_bins), stream), "sfx_key_histogram_dev")
+    dist.all_reduce(key_bins, op=dist.ReduceOp.SUM, group=group)
+
+    # 4. plan (tiny, on the host; identical on every rank)
+    lo, hi, offset, count = plan_ranges(key_bins.cpu(), world)[rank]
+
+    # 5. this rank's slice
+    cap = max(count, 1)
+    sa_part = torch.empty(cap, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
+    got = ctypes.c_uint64(0)
+    eng.check(eng.lib.sfx_build_sa_range_u32_dev(_p(text), n, _p(byte_bins), tb, lo, hi, cap,
+                                                 _p(sa_part), ctypes.byref(got), _p(ws), ws.numel(),
+                                                 stream), "sfx_build_sa_range_u32_dev")
+    if int(got.value) != count:
+        raise RuntimeError(f"rank {rank}: range build produced {got.value} suffixes, plan said {count}")
+    return sa_part[:count], offset, n

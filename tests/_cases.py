@@ -1,0 +1,146 @@
+"""Parity cases shared by the CPU (emulator) and GPU test modules.  Every
+function takes an `Engine` (suffix_amd._lib.Engine): the GPU tests pass the
+product's libsuffix_hip.so, the CPU tests the same sources compiled against the
+fiber emulator (tests/emu).  Expected values always come from the oracle
+(oracle/, the C restatement of the reference) or from tests/golden/."""
+import hashlib
+import random
+
+import numpy as np
+
+import _gen
+from suffix_amd import SuffixTable
+
+
+def sha_u32(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype="<u4").tobytes()).hexdigest()
+
+
+def check_text(eng, orc, text, lcp=True, queries=()):
+    """Build SA (+LCP, + queries) with the engine; compare bit-exactly with the oracle."""
+    st = SuffixTable(text, engine=eng)
+    exp = orc.sais(st._text)
+    assert st.len() == len(st._text)                                    # prop_length
+    assert np.array_equal(st.table(), exp), f"SA mismatch on {st._text[:40]!r}..."
+    if lcp:
+        assert np.array_equal(st.lcp_lens(), orc.lcp_quadratic(st._text, exp))
+    if queries:
+        s, e = st.positions_batch(queries)
+        found, anyp = st.contains_batch(queries)
+        for k, q in enumerate(queries):
+            es, ee = orc.positions(st._text, exp, q)
+            assert (int(s[k]), int(e[k])) == (es, ee), (q, int(s[k]), int(e[k]), es, ee)
+            ea = orc.any_position(st._text, exp, q)
+            assert bool(found[k]) == (ea is not None)
+            if ea is not None:
+                qb = q.encode() if isinstance(q, str) else bytes(q)
+                a = int(anyp[k])
+                assert st._text[a:a + len(qb)] == qb                    # "arbitrary" occurrence
+            else:
+                assert int(anyp[k]) == 0xFFFFFFFF
+    return st
+
+
+def literals(eng, orc, golden):
+    # tests/tests.rs:22-70 + parts()
+    for s, exp in golden["sa_literals"].items():
+        st = SuffixTable(s, engine=eng)
+        assert st.table().tolist() == exp["sa"], s
+        assert st.lcp_lens().tolist() == exp["lcp"], s
+        naive = SuffixTable.from_parts(s, orc.naive_sa(s), engine=eng)   # new == new_naive
+        assert st == naive
+
+
+def search_known_answers(eng, golden):
+    # tests/tests.rs:100-168, :181-213, doc-tests
+    for text, query, pos, found in golden["search"]:
+        st = SuffixTable(text, engine=eng)
+        assert st.positions(query).tolist() == pos, (text, query)
+        assert st.contains(query) == found, (text, query)
+        ap = st.any_position(query)
+        assert (ap is not None) == found
+        if found:
+            assert ap in pos
+
+
+def parts_roundtrip(eng):
+    # tests/tests.rs:170-179
+    sa = SuffixTable("poëzie", engine=eng)
+    text, table = sa.into_parts()
+    sa3 = SuffixTable.from_parts(text, table, engine=eng)
+    assert sa == sa3
+    try:
+        SuffixTable.from_parts("abc", np.zeros(2, dtype=np.uint32), engine=eng)
+        raise RuntimeError("from_parts accepted mismatched lengths")
+    except AssertionError:
+        pass
+
+
+def fasta_fixture(eng, orc, golden, fasta, name):
+    g = golden["fixtures"][name]
+    text = fasta[name]
+    st = SuffixTable(text, engine=eng)
+    assert sha_u32(st.table()) == g["sha256_sa"]
+    assert st.table()[:6].tolist() == g["sa_head"] and st.table()[-4:].tolist() == g["sa_tail"]
+    lcp = st.lcp_lens()
+    assert sha_u32(lcp) == g["sha256_lcp"] and int(lcp.max()) == g["max_lcp"]
+    # tests/bench.rs queries
+    assert st.positions("ACTTACGTGTCTGC").tolist() == [1825]
+    assert st.positions("H").size == 0 and not st.contains("H")
+    assert st.positions("C").size == text.count(b"C") and st.contains("C")
+    assert sorted(st.positions("C").tolist()) == [i for i in range(len(text)) if text[i:i + 1] == b"C"]
+
+
+def random_small(eng, orc, iters, max_len, seed):
+    # mirrors prop_naive_equals_sais / prop_matches_naive / prop_contains / prop_positions
+    rnd = random.Random(seed)
+    for _ in range(iters):
+        n = rnd.randint(0, max_len)
+        sigma = rnd.choice([1, 2, 3, 4, 5, 16, 97, 256])
+        t = bytes(rnd.randrange(sigma) for _ in range(n))
+        qs = []
+        for _ in range(4):
+            if n and rnd.random() < 0.7:
+                a = rnd.randrange(n)
+                qs.append(t[a:a + rnd.randint(1, 6)])
+            else:
+                qs.append(bytes(rnd.randrange(sigma) for _ in range(rnd.randint(0, 4))))
+        check_text(eng, orc, t, queries=qs)
+
+
+def unicode_strings(eng, orc, iters, seed):
+    rnd = random.Random(seed)
+    pools = [range(0x20, 0x7F), range(0xA0, 0x250), range(0x4E00, 0x4E40),
+             range(0x1F300, 0x1F320), [0, 0x2603]]
+    for _ in range(iters):
+        n = rnd.randint(0, 24)
+        s = "".join(chr(rnd.choice(list(rnd.choice(pools)))) for _ in range(n))
+        c = chr(rnd.randrange(128))
+        st = check_text(eng, orc, s, queries=[c, s[:2], s[-3:]])
+        b = s.encode("utf-8")
+        assert st.contains(c) == (c.encode() in b)                      # prop_contains
+        exp = [i for i in range(len(b)) if b[i:i + 1] == c.encode()]
+        assert sorted(st.positions(c).tolist()) == exp                  # prop_positions
+
+
+def structured(eng, orc, scale):
+    """Adversarial shapes: long runs, periodic, Fibonacci/Thue-Morse (deep recursion in
+    SA-IS), texts ending in the smallest symbol (zero-padded key ties)."""
+    cases = [b"a" * (37 * scale), b"ab" * (29 * scale), b"abc" * (17 * scale) + b"a",
+             _gen.fibonacci_string(8 + scale.bit_length()), _gen.thue_morse(100 * scale).tobytes(),
+             bytes(range(256)) * 2, bytes(reversed(range(256))),
+             b"\x00" * (10 * scale) + b"\xff" * (10 * scale),
+             b"\xff" * (10 * scale) + b"\x00" * (10 * scale),
+             b"ACGT" * (8 * scale) + b"AAAA", b"TTTTGGGGCCCCAAAA" * scale + b"A" * 40,
+             b"A" * 33 + b"C" + b"A" * 34, (b"x" * 70 + b"y") * (2 * scale)]
+    for t in cases:
+        check_text(eng, orc, t, queries=[t[:3], t[-5:], b"zz", t[len(t) // 2:len(t) // 2 + 9]])
+
+
+def generated(eng, orc, n_dna, n_text):
+    check_text(eng, orc, _gen.dna(n_dna).tobytes(), queries=[b"ACGT", b"TTTTTTTTTTTTTTTTTTTTTT", b"G"])
+    check_text(eng, orc, _gen.english_like(n_text).tobytes(), queries=[b"the", b" a ", b". T", b"qzx"])
+    check_text(eng, orc, _gen.utf8_mixed(n_text).tobytes(),
+               queries=["日".encode(), b" ", "я".encode(), b"\xf0\x9f"])
+    check_text(eng, orc, _gen.uniform_bytes(n_text, 256, 11).tobytes(), queries=[b"\x00", b"\xff\xff"])
+    check_text(eng, orc, _gen.uniform_bytes(n_text, 2, 12, base=ord("a")).tobytes(), queries=[b"abab", b"bbbbbbbbb"])

@@ -1,0 +1,89 @@
+"""CPU tests of the KERNEL LOGIC: the product's .hip sources compiled unchanged
+against the fiber emulator (tests/emu), driven through the same C ABI and the
+same SuffixTable host mirror, compared bit-exactly with the oracle.  Sizes are
+small because every work-item is a fiber on one CPU core."""
+import os
+import subprocess
+
+import pytest
+
+import _cases
+from suffix_amd import Engine
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+
+
+@pytest.fixture(scope="session")
+def emu():
+    subprocess.check_call(["make", "-s", "-j8", "-C", EMU_DIR])
+    return Engine(os.path.join(EMU_DIR, "libsuffix_emu.so"))
+
+
+def test_literals(emu, oracle, golden):
+    _cases.literals(emu, oracle, golden)
+
+
+def test_search_known_answers(emu, golden):
+    _cases.search_known_answers(emu, golden)
+
+
+def test_parts_roundtrip(emu):
+    _cases.parts_roundtrip(emu)
+
+
+def test_fasta_10k(emu, oracle, golden, fasta):
+    _cases.fasta_fixture(emu, oracle, golden, fasta, "AP009048_10000")
+
+
+def test_random_small(emu, oracle):
+    _cases.random_small(emu, oracle, iters=150, max_len=90, seed=101)
+
+
+def test_unicode(emu, oracle):
+    _cases.unicode_strings(emu, oracle, iters=60, seed=5)
+
+
+def test_structured(emu, oracle):
+    _cases.structured(emu, oracle, scale=3)
+
+
+def test_generated(emu, oracle):
+    _cases.generated(emu, oracle, n_dna=9000, n_text=6000)
+
+
+def test_multi_tile_and_multi_block(emu, oracle):
+    # > 4096-key radix tiles, several persistent workgroups, u32 and u64 initial keys
+    import _gen
+    _cases.check_text(emu, oracle, _gen.dna(13000, seed=77).tobytes())
+    _cases.check_text(emu, oracle, _gen.uniform_bytes(9000, 200, 78).tobytes())
+
+
+def test_error_paths(emu):
+    import ctypes
+    import numpy as np
+    lib = emu.lib
+    assert lib.sfx_build_sa_u32(None, 5, None) == 1                      # SFX_ERR_ARG
+    assert lib.sfx_build_sa_u32(None, 0, None) == 0                      # n == 0 is fine
+    assert lib.sfx_build_sa_u32(None, 1 << 32, None) == 2                # > u32::MAX (:380)
+    t = np.frombuffer(b"banana", dtype=np.uint8)
+    sa = np.zeros(6, dtype=np.uint32)
+    ws = np.zeros(16, dtype=np.uint8)
+    rc = lib.sfx_build_sa_u32_dev(t.ctypes.data, 6, sa.ctypes.data, ws.ctypes.data, 16, None)
+    assert rc == 5                                                       # SFX_ERR_WORKSPACE
+    assert b"workspace" in lib.sfx_strerror(5)
+    with pytest.raises(OverflowError):
+        emu.check(2, "x")
+
+
+def test_build_stats_and_profile(emu):
+    import _gen
+    from suffix_amd import SuffixTable
+    emu.profile(True)
+    emu.profile_reset()
+    SuffixTable(_gen.dna(5000).tobytes(), engine=emu)
+    st = emu.build_stats()
+    assert st["n"] == 5000 and st["sigma"] == 4 and st["bits_per_symbol"] == 2
+    assert st["key_bits"] == 32 and st["symbols_per_key"] == 16
+    rep = {r["name"]: r for r in emu.profile_report()}
+    emu.profile(False)
+    assert rep["radix_scatter"]["launches"] >= 4 and rep["radix_scatter"]["algo_bytes"] > 0
