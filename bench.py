@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the suffix-array hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size BYTES]
+
+A "step" is one full pass of the hot path -- SuffixTable::new, i.e. suffix-array
+construction -- over one batch of synthetic input that is ALREADY RESIDENT IN
+HBM when the timed region starts (device text -> device SA; no PCIe inside the
+timed region).  N = 1 runs BASELINE.json configs[1]: 100 MB synthetic DNA
+(sigma = 4, uniform, splitmix64 seed per SURVEY.md 8d), u32 indices.  N > 1
+(launched by torch.distributed.run, one rank per GPU) runs the range-partitioned
+build of suffix_amd/dist.py: every rank contributes a 100 MB shard, the job
+builds the SA of the N*100 MB text, each rank producing its contiguous slice
+("weak" scaling: suffixes sorted per GPU stay fixed).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "MB of input text/sec for SuffixTable::new (SA-IS+LCP), 1 GPU; bit-exact SA"
+
+
+def verify_sa_on_device(torch, sdev, text, sa, n_samples=20000, seed=1):
+    """Size-independent correctness gate for a full-size SA held in HBM:
+    (1) it is a permutation of 0..n-1; (2) with LCP from the engine, every adjacent
+    pair is in strictly increasing suffix order (next symbol after the common prefix
+    is larger, or the left suffix ended); (3) the LCP values themselves are checked
+    on the host, byte by byte, for a random sample of pairs."""
+    n = text.numel()
+    sa64 = sa.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    cnt = torch.zeros(n, dtype=torch.int32, device=text.device)
+    cnt.index_add_(0, sa64, torch.ones(n, dtype=torch.int32, device=text.device))
+    if not bool((cnt == 1).all()):
+        return False, "not a permutation"
+    lcp = sdev.build_lcp(text, sa)
+    lcp64 = lcp.to(torch.int64) & 0xFFFFFFFF
+    a, b, h = sa64[:-1], sa64[1:], lcp64[1:]
+    pa, pb = a + h, b + h
+    a_end = pa >= n
+    if bool((pb >= n).any()):
+        return False, "right suffix exhausted before left one"
+    ca = text[torch.clamp(pa, max=n - 1)].to(torch.int32)
+    cb = text[pb].to(torch.int32)
+    ok = a_end | (ca < cb)
+    if not bool(ok.all()):
+        return False, "adjacent suffixes out of order"
+    rng = np.random.default_rng(seed)
+    rs = rng.integers(1, n, size=min(n_samples, n - 1))
+    t_host = text.cpu().numpy()
+    sa_h = sa64[torch.from_numpy(rs).to(text.device)].cpu().numpy()
+    sb_h = sa64[torch.from_numpy(rs - 1).to(text.device)].cpu().numpy()
+    l_h = lcp64[torch.from_numpy(rs).to(text.device)].cpu().numpy()
+    for x, y, l in zip(sb_h.tolist(), sa_h.tolist(), l_h.tolist()):
+        if t_host[x:x + l].tobytes() != t_host[y:y + l].tobytes():
+            return False, "LCP overstates a common prefix"
+    return True, "permutation + adjacent-order (all pairs) + sampled LCP bytes"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=100_000_000, help="bytes of text per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=50_000_000,
+                    help="bytes of the same text the CPU baseline is timed on (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import _gen
+    import suffix_amd
+    from suffix_amd import device as sdev
+    from suffix_amd import dist as sdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    eng = suffix_amd.default_engine()
+    eng.require_device()                       # no CPU fallback: fail loudly without a GPU
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_local = args.size
+    seed = 0x5AF1C5 + 1 + rank                 # seed = 0x5AF1C5 + config index
+    host_text = _gen.dna(n_local, seed=seed)
+    text = torch.from_numpy(host_text).to(dev)
+    n_total = n_local * world
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        ws = sdev.sa_workspace(n_local, dev)
+        sa = torch.empty(n_local, dtype=torch.int32, device=dev)
+
+        def step():
+            sdev.build_sa(text, out=sa, workspace=ws)
+    else:
+        result = {}
+
+        def step():
+            result["part"] = sdist.build_sa_partitioned(text)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
+    value = n_total * args.steps / elapsed / 1e6
+    stats = eng.build_stats()
+
+    # ---- per-kernel roofline: HIP events on the launch stream, separate untimed build ----
+    eng.profile(True)
+    eng.profile_reset()
+    step()
+    torch.cuda.synchronize()
+    rep = eng.profile_report()
+    eng.profile(False)
+    kernels = {r["name"]: r for r in rep}
+    total_ms = sum(r["total_ms"] for r in rep) or 1.0
+    dom = max(rep, key=lambda r: r["total_ms"])
+    per_launch_bytes = dom["algo_bytes"] / max(dom["launches"], 1)
+    per_launch_ms = dom["total_ms"] / max(dom["launches"], 1)
+    achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "launches_per_step": dom["launches"], "avg_launch_ms": round(per_launch_ms, 4),
+        "algo_bytes_per_launch": per_launch_bytes,
+        "share_of_step": round(dom["total_ms"] / total_ms, 3),
+        "kernel_ms": {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items())},
+        # whole path at SURVEY.md 8d's figure (65 algorithmic B per input byte, u32 DNA)
+        "whole_path": {"algo_bytes_per_input_byte": 65.0,
+                       "achieved": round(65.0 * value / 1e3, 1), "unit": "GB/s",
+                       "frac": round(65.0 * value / 1e3 / HBM_PEAK_GBS, 4)},
+    }
+
+    # ---- correctness gates ----
+    verified, how = None, "skipped"
+    if not args.no_verify:
+        if world == 1:
+            verified, how = verify_sa_on_device(torch, sdev, text, sa)
+        else:
+            part, offset, n_all = result["part"]
+            tot = torch.tensor([part.numel()], dtype=torch.int64, device=dev)
+            dist.all_reduce(tot)
+            verified, how = bool(int(tot.item()) == n_all), "slice sizes sum to n (full parity: tests/)"
+
+    # ---- CPU baseline: the oracle (C restatement of the reference's sais), 1 thread ----
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        import oracle
+        m = min(args.cpu_sample, n_local)
+        sample = host_text[:m]
+        tc = time.perf_counter()
+        exp = oracle.sais(sample)
+        cpu_s = time.perf_counter() - tc
+        sub = torch.from_numpy(np.ascontiguousarray(sample)).to(dev)
+        got = sdev.build_sa(sub).cpu().numpy().view(np.uint32)
+        torch.cuda.synchronize()
+        same = bool(np.array_equal(got, exp))
+        verified = bool(verified) and same if verified is not None else same
+        how += "; SA of the CPU sample bit-exact vs oracle" if same else "; MISMATCH vs oracle on CPU sample"
+        cpu = {"value": round(m / cpu_s / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+               "sample": f"first {m} bytes of the same DNA text, oracle.sais (C restatement of "
+                         f"src/table.rs:388-574, gcc -O3 -march=native), {cpu_s:.1f} s",
+               "host_cpus": os.cpu_count()}
+
+    if rank == 0:
+        out = {
+            "metric": METRIC, "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"{n_local} B synthetic DNA (sigma=4, uniform, splitmix64) per GPU, "
+                                   f"u32 indices, device-resident text -> device SA"
+                                   + ("" if world == 1 else f"; range-partitioned over {world} GPUs, "
+                                      f"text {n_total} B"),
+                       "text_bytes_total": n_total, "build": stats},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "verified": verified, "verification": how,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

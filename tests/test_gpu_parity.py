@@ -1,0 +1,144 @@
+"""GPU parity tests (run with -m gpu on a real MI355X): the product library
+through the C ABI vs the oracle / golden vectors -- bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import _cases
+import _gen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import suffix_amd
+    e = suffix_amd.default_engine()
+    e.require_device()                      # fail loudly: no CPU fallback
+    assert e.path.endswith("libsuffix_hip.so")
+    return e
+
+
+def test_literals(eng, oracle, golden):
+    _cases.literals(eng, oracle, golden)
+
+
+def test_search_known_answers(eng, golden):
+    _cases.search_known_answers(eng, golden)
+
+
+def test_parts_roundtrip(eng):
+    _cases.parts_roundtrip(eng)
+
+
+@pytest.mark.parametrize("name", ["AP009048_10000", "AP009048_100000"])
+def test_fasta_fixtures(eng, oracle, golden, fasta, name):
+    _cases.fasta_fixture(eng, oracle, golden, fasta, name)
+
+
+def test_random_small(eng, oracle):
+    _cases.random_small(eng, oracle, iters=600, max_len=200, seed=2026)
+
+
+def test_unicode(eng, oracle):
+    _cases.unicode_strings(eng, oracle, iters=300, seed=9)
+
+
+def test_structured(eng, oracle):
+    _cases.structured(eng, oracle, scale=40)
+
+
+def test_generated_medium(eng, oracle):
+    _cases.generated(eng, oracle, n_dna=3_000_000, n_text=1_500_000)
+
+
+def test_long_runs_and_repeats(eng, oracle):
+    # worst cases for prefix doubling / PLCP: every round keeps every suffix active
+    _cases.check_text(eng, oracle, b"a" * 200_000)
+    _cases.check_text(eng, oracle, (b"ACGTTGCA" * 8 + b"N") * 3000)
+    rep = _gen.english_like(40_000).tobytes()
+    _cases.check_text(eng, oracle, rep * 5)
+
+
+def test_dna_20mb_full_compare(eng, oracle):
+    from suffix_amd import SuffixTable
+    text = _gen.dna(20_000_000, seed=4242).tobytes()
+    st = SuffixTable(text, engine=eng)
+    exp = oracle.sais(text)
+    assert hashlib.sha256(st.table().tobytes()).hexdigest() == hashlib.sha256(exp.tobytes()).hexdigest()
+    assert np.array_equal(st.lcp_lens(), oracle.lcp_kasai(text, exp))
+    stats = eng.build_stats()
+    assert stats["sigma"] == 4 and stats["key_bits"] == 32 and stats["symbols_per_key"] == 16
+
+
+def test_device_resident_100mb_properties(eng):
+    """BASELINE config 2 at full size, checked through size-independent properties."""
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from suffix_amd import device as sdev
+    text = torch.from_numpy(_gen.dna(100_000_000)).cuda()
+    sa = sdev.build_sa(text)
+    torch.cuda.synchronize()
+    ok, how = bench.verify_sa_on_device(torch, sdev, text, sa)
+    assert ok, how
+    # idempotence: a second build gives the same array
+    sa2 = sdev.build_sa(text)
+    assert torch.equal(sa, sa2)
+
+
+def test_batched_queries_device(eng, oracle):
+    import torch
+    from suffix_amd import device as sdev
+    text = _gen.utf8_mixed(400_000).tobytes()
+    exp = oracle.sais(text)
+    rng = np.random.default_rng(3)
+    qs = []
+    for _ in range(2000):
+        a = int(rng.integers(0, len(text)))
+        q = text[a:a + int(rng.integers(1, 20))]
+        if rng.random() < 0.3:
+            q = q[:-1] + bytes([q[-1] ^ 0x55])
+        qs.append(q)
+    off = np.zeros(len(qs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(q) for q in qs])
+    t = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+    sa = sdev.build_sa(t)
+    assert np.array_equal(sa.cpu().numpy().view(np.uint32), exp)
+    qb = torch.frombuffer(bytearray(b"".join(qs)), dtype=torch.uint8).cuda()
+    s, e, f, a = sdev.query_batch(t, sa, qb, torch.from_numpy(off).cuda())
+    s, e, f = s.cpu().numpy(), e.cpu().numpy(), f.cpu().numpy()
+    for k, q in enumerate(qs):
+        assert (int(s[k]), int(e[k])) == oracle.positions(text, exp, q)
+        assert bool(f[k]) == (q in text)
+
+
+def test_partitioned_build_single_rank_slices(eng, oracle):
+    """The multi-GPU range build, driven for 3 'virtual ranks' on one GPU: the
+    slices concatenate to the oracle's SA."""
+    import ctypes
+    import torch
+    from suffix_amd import dist as sdist
+    from suffix_amd.device import _p
+    for text in (_gen.dna(500_000, seed=5).tobytes() + b"AAAA",
+                 _gen.english_like(300_000).tobytes()):
+        exp = oracle.sais(text)
+        n = len(text)
+        t = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+        bb = torch.zeros(256, dtype=torch.int64, device="cuda")
+        eng.check(eng.lib.sfx_byte_histogram_dev(_p(t), 0, n, _p(bb), None), "bh")
+        kb = torch.zeros(1 << 14, dtype=torch.int64, device="cuda")
+        eng.check(eng.lib.sfx_key_histogram_dev(_p(t), n, 0, n, _p(bb), 14, _p(kb), None), "kh")
+        assert int(kb.sum()) == n
+        pieces = []
+        for lo, hi, off, cnt in sdist.plan_ranges(kb.cpu(), 3):
+            part = torch.empty(max(cnt, 1), dtype=torch.int32, device="cuda")
+            ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(max(cnt, 1))), dtype=torch.uint8, device="cuda")
+            got = ctypes.c_uint64(0)
+            eng.check(eng.lib.sfx_build_sa_range_u32_dev(_p(t), n, _p(bb), 14, lo, hi, max(cnt, 1), _p(part),
+                                                         ctypes.byref(got), _p(ws), ws.numel(), None), "range")
+            assert int(got.value) == cnt
+            pieces.append(part[:cnt].cpu().numpy().view(np.uint32))
+        assert np.array_equal(np.concatenate(pieces), exp)
