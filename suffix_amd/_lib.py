@@ -82,6 +82,14 @@ class Engine:
                 f"`python -c 'import __graft_entry__ as g; g.build()'`). "
                 f"suffix_amd has no CPU fallback.")
         self.path = path
+        # PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).
+        # Two HIP runtimes in one process do not share the GPU ("No HIP GPUs are
+        # available" from whichever initialises second), so let torch's copy load
+        # first: the dynamic loader then resolves our NEEDED libamdhip64.so.7 to it.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         self.lib = ctypes.CDLL(path)
         for name, restype, argtypes in ABI:
             fn = getattr(self.lib, name)          # AttributeError = ABI symbol missing

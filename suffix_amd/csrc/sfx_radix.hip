@@ -184,11 +184,12 @@ int radix_sort_pairs(KeyT* k0, uint32_t* v0, KeyT* k1, uint32_t* v1, uint64_t m,
     for (int shift = bit_lo; shift < bit_hi; shift += kRadixBits) {
         int nb = bit_hi - shift < kRadixBits ? bit_hi - shift : kRadixBits;
         unsigned mask = (1u << nb) - 1u;
-        SFX_LAUNCH("radix_hist", (double)m * sizeof(KeyT), (k_radix_hist<KeyT>), ch.blocks, kBlock, st,
+        SFX_LAUNCH(sizeof(KeyT) == 4 ? "radix_hist_u32" : "radix_hist_u64", (double)m * sizeof(KeyT), (k_radix_hist<KeyT>), ch.blocks, kBlock, st,
                    kin, m, shift, mask, ch.tiles_per_block, hist);
         SFX_LAUNCH("radix_scan", (double)kRadix * ch.blocks * 8, k_radix_scan, kRadix, kBlock, st,
                    hist, ch.blocks, digit_total);
-        SFX_LAUNCH("radix_scatter", 2.0 * (double)m * (sizeof(KeyT) + 4), (k_radix_scatter<KeyT>),
+        SFX_LAUNCH(sizeof(KeyT) == 4 ? "radix_scatter_u32" : "radix_scatter_u64",
+                   2.0 * (double)m * (sizeof(KeyT) + 4), (k_radix_scatter<KeyT>),
                    ch.blocks, kBlock, st, kin, vin, kout, vout, m, shift, mask,
                    ch.tiles_per_block, hist, digit_total);
         KeyT* tk = kin; kin = kout; kout = tk;

@@ -86,4 +86,4 @@ def test_build_stats_and_profile(emu):
     assert st["key_bits"] == 32 and st["symbols_per_key"] == 16
     rep = {r["name"]: r for r in emu.profile_report()}
     emu.profile(False)
-    assert rep["radix_scatter"]["launches"] >= 4 and rep["radix_scatter"]["algo_bytes"] > 0
+    assert rep["radix_scatter_u32"]["launches"] >= 4 and rep["radix_scatter_u32"]["algo_bytes"] > 0

@@ -4,6 +4,7 @@ import hashlib
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (first: one HIP runtime per process, see suffix_amd/_lib.py)
 
 import _cases
 import _gen
@@ -55,7 +56,7 @@ def test_generated_medium(eng, oracle):
 
 def test_long_runs_and_repeats(eng, oracle):
     # worst cases for prefix doubling / PLCP: every round keeps every suffix active
-    _cases.check_text(eng, oracle, b"a" * 200_000)
+    _cases.check_text(eng, oracle, b"a" * 50_000)   # (the oracle's LCP is quadratic here)
     _cases.check_text(eng, oracle, (b"ACGTTGCA" * 8 + b"N") * 3000)
     rep = _gen.english_like(40_000).tobytes()
     _cases.check_text(eng, oracle, rep * 5)
