@@ -272,16 +272,38 @@ k_compose_text_keys(const uint32_t* __restrict__ suf, const uint32_t* __restrict
 // ---------------------------------------------------------------------------------
 // 3./4b. bucket boundaries, ranks, singleton removal  (reduce -> scan -> apply)
 // ---------------------------------------------------------------------------------
-constexpr int kGroupTile = kBlock;       // one element per thread per step
+constexpr int kGroupItems = 4;                       // consecutive elements per thread
+constexpr int kGroupTile = kBlock * kGroupItems;     // 1024 elements per workgroup step
 
+// Loads the thread's 4 consecutive keys plus both neighbours and derives, per item,
+// "first of its bucket" (head) and "bucket of size one" (single).  K is a workspace
+// array (256-B aligned) and tile bases are multiples of 1024, so the 4-key group is
+// 16-B (u32) / 32-B (u64) aligned and fetched with wide loads.
 template <class KeyT>
-__device__ __forceinline__ void group_flags(const KeyT* __restrict__ K, uint64_t i, uint64_t m,
-                                            bool& head, bool& single)
+__device__ __forceinline__ void group_flags4(const KeyT* __restrict__ K, uint64_t i0, uint64_t m,
+                                             bool (&head)[kGroupItems], bool (&single)[kGroupItems])
 {
-    KeyT k = K[i];
-    head = (i == 0) || (K[i - 1] != k);
-    bool next_head = (i + 1 == m) || (K[i + 1] != k);
-    single = head && next_head;
+    KeyT k[kGroupItems + 2];
+    if (i0 + kGroupItems <= m) {
+        struct alignas(sizeof(KeyT) * kGroupItems) Vec { KeyT v[kGroupItems]; };
+        Vec q = *reinterpret_cast<const Vec*>(K + i0);
+#pragma unroll
+        for (int j = 0; j < kGroupItems; j++) k[j + 1] = q.v[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kGroupItems; j++) k[j + 1] = (i0 + j < m) ? K[i0 + j] : KeyT(0);
+    }
+    k[0] = (i0 > 0 && i0 <= m) ? K[i0 - 1] : KeyT(0);
+    k[kGroupItems + 1] = (i0 + kGroupItems < m) ? K[i0 + kGroupItems] : KeyT(0);
+#pragma unroll
+    for (int j = 0; j < kGroupItems; j++) {
+        uint64_t i = i0 + j;
+        bool valid = i < m;
+        bool h = valid && ((i == 0) || (k[j] != k[j + 1]));
+        bool nh = (i + 1 >= m) || (k[j + 2] != k[j + 1]);
+        head[j] = h;
+        single[j] = h && nh;
+    }
 }
 
 // per-workgroup partials: last bucket-head index (+1) in the chunk, #kept, #kept bucket heads
@@ -297,12 +319,16 @@ k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t tiles_per_block
     uint64_t end = begin + tiles_per_block * kGroupTile;
     if (end > m) end = m;
     uint32_t last_head = 0, keep = 0, ghead = 0;
-    for (uint64_t i = begin + tid; i < end; i += kBlock) {
-        bool head, single;
-        group_flags(K, i, m, head, single);
-        if (head) last_head = (uint32_t)i + 1u;          // i ascends per thread
-        keep += single ? 0u : 1u;
-        ghead += (head && !single) ? 1u : 0u;
+    for (uint64_t i0 = begin + (uint64_t)tid * kGroupItems; i0 < end; i0 += kGroupTile) {
+        bool head[kGroupItems], single[kGroupItems];
+        group_flags4(K, i0, m, head, single);
+#pragma unroll
+        for (int j = 0; j < kGroupItems; j++) {
+            bool valid = i0 + j < m;
+            if (head[j]) last_head = (uint32_t)(i0 + j) + 1u;       // ascending per thread
+            keep += (valid && !single[j]) ? 1u : 0u;
+            ghead += (head[j] && !single[j]) ? 1u : 0u;
+        }
     }
     for (int d = 32; d >= 1; d >>= 1) {
         last_head = dmax(last_head, __shfl_xor(last_head, d));
@@ -352,9 +378,10 @@ k_groups_scan(uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep
 }
 
 // K,V: sorted keys / suffixes of the m active elements; S: their SA slots in
-// ascending order (nullptr = identity).  Writes SA[slot] = suffix, ISA[suffix] =
-// slot of its bucket head (if isa != nullptr), and compacts the elements of
-// non-singleton buckets into (S_next, V_next, G_next = dense bucket id).
+// ascending order (nullptr = identity).  Writes SA[slot] = suffix; if isa:
+// ISA[suffix] = slot of its bucket head; and compacts the elements of
+// non-singleton buckets into (S_next, V_next, G_next = dense bucket id, and, if
+// R_next, R_next = slot of the bucket head).
 template <class KeyT>
 __global__ void __launch_bounds__(kBlock)
 k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
@@ -362,7 +389,8 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                const uint32_t* __restrict__ part_head, const uint32_t* __restrict__ part_keep,
                const uint32_t* __restrict__ part_ghead, uint32_t* __restrict__ sa,
                uint32_t* __restrict__ isa, uint32_t* __restrict__ S_next,
-               uint32_t* __restrict__ V_next, uint32_t* __restrict__ G_next)
+               uint32_t* __restrict__ V_next, uint32_t* __restrict__ G_next,
+               uint32_t* __restrict__ R_next)
 {
     __shared__ uint32_t part[kWavesPerBlock];
     const unsigned tid = threadIdx.x;
@@ -373,32 +401,69 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     uint32_t c_keep = part_keep[blockIdx.x];
     uint32_t c_ghead = part_ghead[blockIdx.x];
     for (uint64_t tile = begin; tile < end; tile += kGroupTile) {
-        uint64_t i = tile + tid;
-        bool valid = i < end, head = false, single = false;
-        if (valid) group_flags(K, i, m, head, single);
-        bool keep = valid && !single, ghead = valid && head && !single;
-        uint32_t hv = (valid && head) ? (uint32_t)i + 1u : 0u, tot_h, tot_c;
-        uint32_t eh = block_scan_max_excl(hv, part, tot_h);
-        uint32_t packed = (keep ? 1u : 0u) | (ghead ? 0x10000u : 0u);
-        uint32_t ec = block_scan_add_excl(packed, part, tot_c);
-        if (valid) {
-            uint32_t my_head = dmax(dmax(c_head, eh), hv) - 1u;      // index of my bucket head
-            uint32_t slot = S ? S[i] : (uint32_t)i;
-            uint32_t head_slot = S ? S[my_head] : my_head;
-            uint32_t suffix = V[i];
-            sa[slot] = suffix;
-            if (isa) isa[suffix] = head_slot;
-            if (keep) {
-                uint32_t pos = c_keep + (ec & 0xFFFFu);
-                S_next[pos] = slot;
-                V_next[pos] = suffix;
-                G_next[pos] = c_ghead + (ec >> 16) + (ghead ? 1u : 0u) - 1u;
+        const uint64_t i0 = tile + (uint64_t)tid * kGroupItems;
+        bool head[kGroupItems], single[kGroupItems];
+        group_flags4(K, i0, m, head, single);
+        uint32_t hmax = 0, cnt = 0;                     // thread aggregates
+#pragma unroll
+        for (int j = 0; j < kGroupItems; j++) {
+            bool valid = i0 + j < m;
+            if (head[j]) hmax = (uint32_t)(i0 + j) + 1u;
+            cnt += ((valid && !single[j]) ? 1u : 0u) | ((head[j] && !single[j]) ? 0x10000u : 0u);
+        }
+        uint32_t tot_h, tot_c;
+        uint32_t eh = block_scan_max_excl(hmax, part, tot_h);
+        uint32_t ec = block_scan_add_excl(cnt, part, tot_c);
+        uint32_t run_head = dmax(c_head, eh);           // index+1 of the last head before item 0
+        uint32_t run_keep = c_keep + (ec & 0xFFFFu);
+        uint32_t run_ghead = c_ghead + (ec >> 16);
+#pragma unroll
+        for (int j = 0; j < kGroupItems; j++) {
+            uint64_t i = i0 + j;
+            if (i < m) {
+                if (head[j]) run_head = (uint32_t)i + 1u;
+                bool keep = !single[j];
+                if (head[j] && keep) run_ghead++;
+                uint32_t my_head = run_head - 1u;
+                uint32_t slot = S ? S[i] : (uint32_t)i;
+                uint32_t suffix = V[i];
+                sa[slot] = suffix;
+                if (isa || (keep && R_next)) {
+                    uint32_t head_slot = S ? S[my_head] : my_head;
+                    if (isa) isa[suffix] = head_slot;
+                    if (keep && R_next) R_next[run_keep] = head_slot;
+                }
+                if (keep) {
+                    S_next[run_keep] = slot;
+                    V_next[run_keep] = suffix;
+                    G_next[run_keep] = run_ghead - 1u;
+                    run_keep++;
+                }
             }
         }
         c_head = dmax(c_head, tot_h);
         c_keep += tot_c & 0xFFFFu;
         c_ghead += tot_c >> 16;
     }
+}
+
+// (Re)build the rank array when refinement switches from text symbols to ranks:
+// every slot is its own rank ...
+__global__ void __launch_bounds__(kBlock)
+k_isa_from_sa(const uint32_t* __restrict__ sa, uint64_t n, uint32_t* __restrict__ isa)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < n; s += stride)
+        isa[sa[s]] = (uint32_t)s;
+}
+// ... except the members of still-unresolved buckets, which share their head's slot.
+__global__ void __launch_bounds__(kBlock)
+k_isa_fix_active(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ head_slot,
+                 uint64_t m, uint32_t* __restrict__ isa)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < m; q += stride)
+        isa[suf[q]] = head_slot[q];
 }
 
 // ---------------------------------------------------------------------------------
@@ -432,11 +497,17 @@ static void choose_key(const Alphabet& a, uint64_t n, int* key_bits, int* cpk)
     else { *key_bits = 64; *cpk = k64; }
 }
 
+// A full build whose initial sort leaves at most 1/kTextFirstDivisor of the suffixes
+// unresolved spends its first refinement round on text symbols: that round needs no
+// rank array, so the n-element ISA scatter is skipped unless a further round is needed.
+constexpr uint64_t kTextFirstDivisor = 8;
+
 struct SaBuffers {
     uint64_t* K0; uint64_t* K1;                         // key ping-pong (8 B per element)
     uint32_t* VA; uint32_t* VB;                         // suffix ping-pong
     uint32_t* S0; uint32_t* S1;                         // slot lists
     uint32_t* G;                                        // dense bucket ids
+    uint32_t* R;                                        // bucket-head slots (text rounds of a full build)
     uint32_t* isa;
     uint32_t* hist;                                     // 256*kMaxGrid + 256
     uint32_t* part_head; uint32_t* part_keep; uint32_t* part_ghead;   // kMaxGrid each
@@ -458,6 +529,7 @@ template <class A> static void carve_sa(A& ar, uint64_t cap, uint64_t isa_len, S
     uint32_t* S0 = ar.template take<uint32_t>(cap);
     uint32_t* S1 = ar.template take<uint32_t>(cap);
     uint32_t* G = ar.template take<uint32_t>(cap);
+    uint32_t* R = ar.template take<uint32_t>(isa_len ? cap / kTextFirstDivisor + 1024 : 0);
     uint32_t* isa = ar.template take<uint32_t>(isa_len);
     uint32_t* hist = ar.template take<uint32_t>((uint64_t)kRadix * kMaxGrid + kRadix);
     uint32_t* ph = ar.template take<uint32_t>(kMaxGrid);
@@ -467,7 +539,7 @@ template <class A> static void carve_sa(A& ar, uint64_t cap, uint64_t isa_len, S
     unsigned long long* bins = ar.template take<unsigned long long>(256);
     uint8_t* lut = ar.template take<uint8_t>(256);
     if (b) {
-        b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G;
+        b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->R = R;
         b->isa = isa; b->hist = hist; b->part_head = ph; b->part_keep = pk; b->part_ghead = pg;
         b->totals = totals; b->bins = bins; b->lut = lut;
     }
@@ -488,25 +560,34 @@ uint64_t sa_range_workspace_bytes(uint64_t max_count)
     return s.used + 256;
 }
 
-// finalize one round: flags -> carries -> apply; reads back {kept, kept buckets}.
+// bucket statistics of the sorted active list: reduce -> scan -> {kept, kept buckets} on the host
 template <class KeyT>
-static int finish_round(const KeyT* K, const uint32_t* V, const uint32_t* S, uint64_t m,
-                        SaBuffers& b, uint32_t* sa, uint32_t* isa, uint32_t* S_next,
-                        uint32_t* V_next, hipStream_t st, uint64_t* kept, uint64_t* kept_groups)
+static int round_totals(const KeyT* K, uint64_t m, SaBuffers& b, hipStream_t st, uint64_t* kept,
+                        uint64_t* kept_groups)
 {
     Chunking ch = make_chunking(m, kGroupTile);
     SFX_LAUNCH("groups_reduce", (double)m * sizeof(KeyT), (k_groups_reduce<KeyT>), ch.blocks, kBlock,
                st, K, m, ch.tiles_per_block, b.part_head, b.part_keep, b.part_ghead);
     SFX_LAUNCH("groups_scan", 0.0, k_groups_scan, 1, kBlock, st, b.part_head, b.part_keep,
                b.part_ghead, ch.blocks, b.totals);
-    SFX_LAUNCH("groups_apply", (double)m * (sizeof(KeyT) + 4 + 4 + (isa ? 4 : 0) + (S ? 4 : 0)),
-               (k_groups_apply<KeyT>), ch.blocks, kBlock, st, K, V, S, m, ch.tiles_per_block,
-               b.part_head, b.part_keep, b.part_ghead, sa, isa, S_next, V_next, b.G);
     uint32_t host_totals[2] = {0, 0};
     SFX_HIP(hipMemcpyAsync(host_totals, b.totals, sizeof(host_totals), hipMemcpyDeviceToHost, st));
     SFX_HIP(hipStreamSynchronize(st));
     *kept = host_totals[0];
     *kept_groups = host_totals[1];
+    return SFX_OK;
+}
+// write SA (+ ranks) and compact the unresolved buckets for the next round
+template <class KeyT>
+static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint64_t m, SaBuffers& b,
+                       uint32_t* sa, uint32_t* isa, uint32_t* S_next, uint32_t* V_next,
+                       uint32_t* R_next, hipStream_t st)
+{
+    Chunking ch = make_chunking(m, kGroupTile);
+    SFX_LAUNCH(sizeof(KeyT) == 4 ? "groups_apply_u32" : "groups_apply_u64",
+               (double)m * (sizeof(KeyT) + 4 + 4 + (isa ? 4 : 0) + (S ? 4 : 0)),
+               (k_groups_apply<KeyT>), ch.blocks, kBlock, st, K, V, S, m, ch.tiles_per_block,
+               b.part_head, b.part_keep, b.part_ghead, sa, isa, S_next, V_next, b.G, R_next);
     return SFX_OK;
 }
 
@@ -536,31 +617,34 @@ int byte_histogram_dev(const uint8_t* d_text, uint64_t begin, uint64_t end, uint
 }
 
 // refinement rounds shared by the full and the partitioned build.
-//   rank mode (isa != nullptr): key2 from ISA, h doubles
-//   text mode (isa == nullptr): key2 = next cpk_r symbols, h += cpk_r
+//   rank round: key2 = rank of the suffix h symbols on (needs ISA), h doubles
+//   text round: key2 = the next cpk_r symbols (needs only the text), h += cpk_r
+// The partitioned build (isa == nullptr) only has text rounds.  A full build runs
+// `text_rounds` text rounds first (0 or 1, see kTextFirstDivisor) and rank rounds after.
 static int refine(const uint8_t* d_text, uint64_t n, const Alphabet& alpha, int cpk, SaBuffers& b,
-                  uint32_t* sa, uint32_t* isa, uint32_t* S_cur, uint32_t* V_cur, uint64_t m,
-                  uint64_t groups, hipStream_t st, sfx_build_stats& stats)
+                  uint32_t* sa, uint32_t* isa, int text_rounds, uint32_t* S_cur, uint32_t* V_cur,
+                  uint64_t m, uint64_t groups, hipStream_t st, sfx_build_stats& stats)
 {
     uint64_t h = (uint64_t)cpk;
-    int cpk_r = 32 / alpha.bits;                       // text mode: <= 32 key bits per round
+    int cpk_r = 32 / alpha.bits;                       // text round: <= 32 key bits
     if (cpk_r > cpk) cpk_r = cpk;
     const int flag_shift = dmax(alpha.bits * cpk_r, bits_for(n));
     int rounds = 0;
     while (m > 0) {
-        // rank mode at most ~log2(n) rounds; text mode is bounded by the longest repeat
+        // rank rounds: <= ~log2(n); text rounds are bounded by the longest repeat
         if (++rounds > (isa ? 80 : 1 << 20)) return SFX_ERR_INTERNAL;
-        int key2_bits = isa ? bits_for(n - 1 + h) : flag_shift + 1;
+        const bool text_round = !isa || text_rounds > 0;
+        int key2_bits = text_round ? flag_shift + 1 : bits_for(n - 1 + h);
         int gid_bits = bits_for(groups > 0 ? groups - 1 : 0);
         if (key2_bits + gid_bits > 64) return SFX_ERR_INTERNAL;
         unsigned grid = (unsigned)dmin<uint64_t>((m + kBlock - 1) / kBlock, kMaxGrid);
-        if (isa) {
-            SFX_LAUNCH("compose_rank_keys", (double)m * 20, k_compose_rank_keys, grid, kBlock, st,
-                       V_cur, b.G, m, isa, n, h, key2_bits, b.K0);
-        } else {
+        if (text_round) {
             SFX_LAUNCH("compose_text_keys", (double)m * (16 + cpk_r), k_compose_text_keys, grid, kBlock,
                        st, V_cur, b.G, m, d_text, n, b.lut, alpha.bits, cpk_r, h, flag_shift,
                        key2_bits, b.K0);
+        } else {
+            SFX_LAUNCH("compose_rank_keys", (double)m * 20, k_compose_rank_keys, grid, kBlock, st,
+                       V_cur, b.G, m, isa, n, h, key2_bits, b.K0);
         }
         uint32_t* V_other = (V_cur == b.VA) ? b.VB : b.VA;
         int in1 = 0;
@@ -571,13 +655,23 @@ static int refine(const uint8_t* d_text, uint64_t n, const Alphabet& alpha, int 
         uint32_t* V_next = in1 ? V_cur : V_other;
         uint32_t* S_next = (S_cur == b.S0) ? b.S1 : b.S0;
         uint64_t kept = 0, kept_groups = 0;
-        SFX_TRY(finish_round<uint64_t>(Kr, Vr, S_cur, m, b, sa, isa, S_next, V_next, st, &kept,
-                                       &kept_groups));
+        SFX_TRY(round_totals<uint64_t>(Kr, m, b, st, &kept, &kept_groups));
+        const bool full_text_round = isa && text_round;
+        SFX_TRY(round_apply<uint64_t>(Kr, Vr, S_cur, m, b, sa, (isa && !text_round) ? isa : nullptr,
+                                      S_next, V_next, full_text_round ? b.R : nullptr, st));
+        h = text_round ? h + (uint64_t)cpk_r : h * 2;
+        if (full_text_round && --text_rounds == 0 && kept > 0) {
+            // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
+            unsigned g1 = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
+            unsigned g2 = (unsigned)dmin<uint64_t>((kept + kBlock - 1) / kBlock, kMaxGrid);
+            SFX_LAUNCH("isa_from_sa", (double)n * 8, k_isa_from_sa, g1, kBlock, st, sa, n, isa);
+            SFX_LAUNCH("isa_fix_active", (double)kept * 12, k_isa_fix_active, g2, kBlock, st, V_next,
+                       b.R, kept, isa);
+        }
         S_cur = S_next;
         V_cur = V_next;
         m = kept;
         groups = kept_groups;
-        h = isa ? h * 2 : h + (uint64_t)cpk_r;
         stats.rounds++;
     }
     return SFX_OK;
@@ -595,12 +689,16 @@ static int sort_and_refine(const uint8_t* d_text, uint64_t n, const Alphabet& al
     int in1 = 0;
     SFX_TRY(radix_sort_pairs<KeyT>(k0, b.VA, k1, b.VB, count, 0, alpha.bits * cpk, b.hist, st, &in1,
                                    &stats));
+    const KeyT* Kr = in1 ? k1 : k0;
     uint64_t kept = 0, groups = 0;
-    uint32_t* V_next = in1 ? b.VA : b.VB;
-    SFX_TRY(finish_round<KeyT>(in1 ? k1 : k0, in1 ? b.VB : b.VA, nullptr, count, b, sa, isa, b.S0,
-                               V_next, st, &kept, &groups));
+    SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups));
     stats.active_after_initial = kept;
-    return refine(d_text, n, alpha, cpk, b, sa, isa, b.S0, V_next, kept, groups, st, stats);
+    // few unresolved suffixes: one text round first, ISA only if that does not finish the job
+    const int text_rounds = (isa && kept * kTextFirstDivisor <= count) ? 1 : 0;
+    uint32_t* V_next = in1 ? b.VA : b.VB;
+    SFX_TRY(round_apply<KeyT>(Kr, in1 ? b.VB : b.VA, nullptr, count, b, sa,
+                              (isa && !text_rounds) ? isa : nullptr, b.S0, V_next, nullptr, st));
+    return refine(d_text, n, alpha, cpk, b, sa, isa, text_rounds, b.S0, V_next, kept, groups, st, stats);
 }
 
 int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,

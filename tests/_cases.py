@@ -137,6 +137,19 @@ def structured(eng, orc, scale):
         check_text(eng, orc, t, queries=[t[:3], t[-5:], b"zz", t[len(t) // 2:len(t) // 2 + 9]])
 
 
+def planted_repeats(eng, orc, n):
+    """Mostly-random text with a few long planted repeats: the initial sort resolves
+    almost everything (text-first round), the repeats then force the switch to rank
+    rounds (ISA rebuilt from SA + unresolved buckets)."""
+    d = _gen.dna(n, seed=31).tobytes()
+    t = d + d[n // 3:n // 3 + 400] + b"G" + d[n // 2:n // 2 + 90] + d[n // 3 + 10:n // 3 + 300]
+    check_text(eng, orc, t, queries=[d[n // 3:n // 3 + 50], d[n // 2:n // 2 + 91]])
+    st = eng.build_stats()
+    assert st["rounds"] >= 3, st
+    u = _gen.uniform_bytes(n, 256, 5).tobytes()
+    check_text(eng, orc, u + u[100:700] + b"\x00\x00", queries=[u[100:130]])
+
+
 def generated(eng, orc, n_dna, n_text):
     check_text(eng, orc, _gen.dna(n_dna).tobytes(), queries=[b"ACGT", b"TTTTTTTTTTTTTTTTTTTTTT", b"G"])
     check_text(eng, orc, _gen.english_like(n_text).tobytes(), queries=[b"the", b" a ", b". T", b"qzx"])

@@ -54,6 +54,10 @@ def test_generated_medium(eng, oracle):
     _cases.generated(eng, oracle, n_dna=3_000_000, n_text=1_500_000)
 
 
+def test_planted_repeats_switch_text_to_rank_rounds(eng, oracle):
+    _cases.planted_repeats(eng, oracle, 2_000_000)
+
+
 def test_long_runs_and_repeats(eng, oracle):
     # worst cases for prefix doubling / PLCP: every round keeps every suffix active
     _cases.check_text(eng, oracle, b"a" * 50_000)   # (the oracle's LCP is quadratic here)
