@@ -102,7 +102,7 @@ int sfx_byte_histogram_dev(const uint8_t* d_text, uint64_t shard_begin, uint64_t
 int sfx_key_histogram_dev(const uint8_t* d_text, uint64_t n, uint64_t shard_begin,
                           uint64_t shard_end, const uint64_t* d_global_byte_bins256,
                           int top_bits, uint64_t* d_bins, void* stream);
-uint64_t sfx_sa_range_workspace_bytes(uint64_t capacity);
+uint64_t sfx_sa_range_workspace_bytes(uint64_t n, uint64_t capacity);
 int sfx_build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n,
                                const uint64_t* d_global_byte_bins256, int top_bits,
                                uint32_t bin_lo, uint32_t bin_hi, uint64_t capacity,

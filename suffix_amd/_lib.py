@@ -57,7 +57,7 @@ ABI = [
     ("sfx_query_batch_dev", _int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     ("sfx_byte_histogram_dev", _int, [_vp, _u64, _u64, _vp, _vp]),
     ("sfx_key_histogram_dev", _int, [_vp, _u64, _u64, _u64, _vp, _int, _vp, _vp]),
-    ("sfx_sa_range_workspace_bytes", _u64, [_u64]),
+    ("sfx_sa_range_workspace_bytes", _u64, [_u64, _u64]),
     ("sfx_build_sa_range_u32_dev", _int, [_vp, _u64, _vp, _int, _u32, _u32, _u64, _vp,
                                           ctypes.POINTER(_u64), _vp, _u64, _vp]),
     ("sfx_profile_enable", None, [_int]),

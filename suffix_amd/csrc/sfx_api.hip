@@ -303,7 +303,7 @@ int sfx_key_histogram_dev(const uint8_t* d_text, uint64_t n, uint64_t shard_begi
     return key_histogram_dev(d_text, n, shard_begin, shard_end, d_global_byte_bins256, top_bits,
                              d_bins, (hipStream_t)stream);
 }
-uint64_t sfx_sa_range_workspace_bytes(uint64_t capacity) { return sa_range_workspace_bytes(capacity); }
+uint64_t sfx_sa_range_workspace_bytes(uint64_t n, uint64_t capacity) { return sa_range_workspace_bytes(n, capacity); }
 int sfx_build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n,
                                const uint64_t* d_global_byte_bins256, int top_bits, uint32_t bin_lo,
                                uint32_t bin_hi, uint64_t capacity, uint32_t* d_sa_part,

@@ -95,11 +95,14 @@ struct BuildStats;   // = sfx_build_stats
 
 // radix sort of (key, value) pairs on bits [bit_lo, bit_hi) of the key.
 // Buffers ping-pong between (k0,v0) and (k1,v1); on return *result_in_1 tells
-// which pair holds the sorted data.  `hist` is 256 * kMaxGrid u32 of scratch.
+// which pair holds the sorted data.  `hist` is 256 * kMaxGrid + 256 u32 of scratch.
+// With `src` the first pass reads nothing from (k0,v0): element i is
+// (packed_key<KeyT>(*src, i), i), i.e. the suffix keys come straight from the
+// packed text and are never materialised unsorted.
 template <class KeyT>
 int radix_sort_pairs(KeyT* k0, uint32_t* v0, KeyT* k1, uint32_t* v1, uint64_t m, int bit_lo,
                      int bit_hi, uint32_t* hist, hipStream_t st, int* result_in_1,
-                     sfx_build_stats* stats);
+                     sfx_build_stats* stats, const PackedText* src = nullptr);
 inline int radix_pass_count(int bit_lo, int bit_hi) { return (bit_hi - bit_lo + 7) / 8; }
 
 uint64_t sa_workspace_bytes(uint64_t n);
@@ -115,7 +118,7 @@ int byte_histogram_dev(const uint8_t* d_text, uint64_t begin, uint64_t end, uint
                        hipStream_t st);
 int key_histogram_dev(const uint8_t* d_text, uint64_t n, uint64_t begin, uint64_t end,
                       const uint64_t* d_byte_bins, int top_bits, uint64_t* d_bins, hipStream_t st);
-uint64_t sa_range_workspace_bytes(uint64_t max_count);
+uint64_t sa_range_workspace_bytes(uint64_t n, uint64_t max_count);
 int build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint64_t* d_byte_bins,
                            int top_bits, uint32_t bin_lo, uint32_t bin_hi, uint64_t capacity,
                            uint32_t* d_sa_part, uint64_t* count_out, void* ws, uint64_t ws_bytes,

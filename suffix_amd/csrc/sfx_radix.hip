@@ -31,9 +31,9 @@
 namespace sfx {
 
 // --------------------------------------------------------------------------------------
-template <class KeyT>
+template <class KeyT, bool FROM_TEXT>
 __global__ void __launch_bounds__(kBlock)
-k_radix_hist(const KeyT* __restrict__ keys, uint64_t m, int shift, unsigned mask,
+k_radix_hist(const KeyT* __restrict__ keys, PackedText src, uint64_t m, int shift, unsigned mask,
              uint64_t chunk, uint32_t* __restrict__ hist)
 {
     constexpr int kVec = 16 / sizeof(KeyT);                    // keys per 16-byte load
@@ -45,14 +45,19 @@ k_radix_hist(const KeyT* __restrict__ keys, uint64_t m, int shift, unsigned mask
     uint64_t begin = (uint64_t)blockIdx.x * chunk;             // chunk is a multiple of the tile
     uint64_t end = begin + chunk;
     if (end > m) end = m;
-    uint64_t vec_end = begin + ((end > begin ? end - begin : 0) / kVec) * kVec;
-    for (uint64_t i = begin + (uint64_t)tid * kVec; i < vec_end; i += (uint64_t)kBlock * kVec) {
-        Vec q = *reinterpret_cast<const Vec*>(keys + i);
+    if (FROM_TEXT) {
+        for (uint64_t i = begin + tid; i < end; i += kBlock)
+            atomicAdd(&h[w][(unsigned)(packed_key<KeyT>(src, i) >> shift) & mask], 1u);
+    } else {
+        uint64_t vec_end = begin + ((end > begin ? end - begin : 0) / kVec) * kVec;
+        for (uint64_t i = begin + (uint64_t)tid * kVec; i < vec_end; i += (uint64_t)kBlock * kVec) {
+            Vec q = *reinterpret_cast<const Vec*>(keys + i);
 #pragma unroll
-        for (int j = 0; j < kVec; j++) atomicAdd(&h[w][(unsigned)(q.v[j] >> shift) & mask], 1u);
+            for (int j = 0; j < kVec; j++) atomicAdd(&h[w][(unsigned)(q.v[j] >> shift) & mask], 1u);
+        }
+        for (uint64_t i = vec_end + tid; i < end; i += kBlock)
+            atomicAdd(&h[w][(unsigned)(keys[i] >> shift) & mask], 1u);
     }
-    for (uint64_t i = vec_end + tid; i < end; i += kBlock)
-        atomicAdd(&h[w][(unsigned)(keys[i] >> shift) & mask], 1u);
     __syncthreads();
     uint32_t c = 0;
 #pragma unroll
@@ -79,9 +84,9 @@ k_radix_scan(uint32_t* __restrict__ hist, unsigned nblocks, uint32_t* __restrict
 }
 
 // --------------------------------------------------------------------------------------
-template <class KeyT, int KPT, int WPS>      // WPS: waves per SIMD the register budget must allow
+template <class KeyT, int KPT, int WPS, bool FROM_TEXT>   // WPS: waves/SIMD the registers must allow
 __global__ void __launch_bounds__(kBlock, WPS)
-k_radix_scatter(const KeyT* __restrict__ kin, const uint32_t* __restrict__ vin,
+k_radix_scatter(const KeyT* __restrict__ kin, const uint32_t* __restrict__ vin, PackedText src,
                 KeyT* __restrict__ kout, uint32_t* __restrict__ vout, uint64_t m, int shift,
                 unsigned mask, uint64_t chunk, const uint32_t* __restrict__ hist,
                 const uint32_t* __restrict__ digit_total)
@@ -119,7 +124,8 @@ k_radix_scatter(const KeyT* __restrict__ kin, const uint32_t* __restrict__ vin,
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
             unsigned idx = w * (kWave * KPT) + r * kWave + lane;
-            key[r] = (idx < nvalid) ? kin[tile + idx] : ~KeyT(0);   // padding sorts last in the tile
+            if (FROM_TEXT) key[r] = (idx < nvalid) ? packed_key<KeyT>(src, tile + idx) : ~KeyT(0);
+            else key[r] = (idx < nvalid) ? kin[tile + idx] : ~KeyT(0);   // padding sorts last in the tile
         }
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
@@ -143,7 +149,8 @@ k_radix_scatter(const KeyT* __restrict__ kin, const uint32_t* __restrict__ vin,
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
             unsigned idx = w * (kWave * KPT) + r * kWave + lane;
-            val[r] = (idx < nvalid) ? vin[tile + idx] : 0u;
+            if (FROM_TEXT) val[r] = (uint32_t)(tile + idx);
+            else val[r] = (idx < nvalid) ? vin[tile + idx] : 0u;
         }
         __syncthreads();
 
@@ -193,7 +200,7 @@ k_radix_scatter(const KeyT* __restrict__ kin, const uint32_t* __restrict__ vin,
 
 // --------------------------------------------------------------------------------------
 // Tuning knob (development only): SFX_RADIX_VARIANT picks the scatter geometry.
-//   0 (default)  auto: by key width and input size
+//   0 (default)  = 3
 //   1  8 keys/thread, 6 waves/SIMD     2  16 keys/thread, 4 waves/SIMD
 //   3  16 keys/thread, 3 waves/SIMD    4  32 keys/thread, 2 waves/SIMD
 static int radix_variant(size_t key_bytes, uint64_t m)
@@ -202,15 +209,16 @@ static int radix_variant(size_t key_bytes, uint64_t m)
     int forced = e ? atoi(e) : 0;
     if (forced >= 1 && forced <= 4) return forced;
     (void)key_bytes; (void)m;
-    return 2;
+    return 3;
 }
 
 template <class KeyT, int KPT, int WPS>
 static int radix_sort_impl(KeyT* k0, uint32_t* v0, KeyT* k1, uint32_t* v1, uint64_t m, int bit_lo,
                            int bit_hi, uint32_t* hist, hipStream_t st, int* result_in_1,
-                           sfx_build_stats* stats)
+                           sfx_build_stats* stats, const PackedText* src)
 {
     constexpr int kTile = kBlock * KPT;
+    PackedText none = {nullptr, 0, 0, 0, 0};
     Chunking ch = make_chunking(m, kTile);
     const uint64_t chunk = ch.tiles_per_block * kTile;
     uint32_t* digit_total = hist + (uint64_t)kRadix * kMaxGrid;
@@ -220,13 +228,31 @@ static int radix_sort_impl(KeyT* k0, uint32_t* v0, KeyT* k1, uint32_t* v1, uint6
     for (int shift = bit_lo; shift < bit_hi; shift += kRadixBits) {
         int nb = bit_hi - shift < kRadixBits ? bit_hi - shift : kRadixBits;
         unsigned mask = (1u << nb) - 1u;
-        SFX_LAUNCH(sizeof(KeyT) == 4 ? "radix_hist_u32" : "radix_hist_u64", (double)m * sizeof(KeyT),
-                   (k_radix_hist<KeyT>), ch.blocks, kBlock, st, kin, m, shift, mask, chunk, hist);
+        const bool from_text = src && shift == bit_lo;
+        // algorithmic bytes: a text-fed pass reads bits/8 bytes per element instead of key (+value)
+        const double in_key = from_text ? src->bits / 8.0 : (double)sizeof(KeyT);
+        if (from_text) {
+            SFX_LAUNCH(sizeof(KeyT) == 4 ? "radix_hist_text_u32" : "radix_hist_text_u64", (double)m * in_key,
+                       (k_radix_hist<KeyT, true>), ch.blocks, kBlock, st, kin, *src, m, shift, mask,
+                       chunk, hist);
+        } else {
+            SFX_LAUNCH(sizeof(KeyT) == 4 ? "radix_hist_u32" : "radix_hist_u64", (double)m * in_key,
+                       (k_radix_hist<KeyT, false>), ch.blocks, kBlock, st, kin, none, m, shift, mask,
+                       chunk, hist);
+        }
         SFX_LAUNCH("radix_scan", (double)kRadix * ch.blocks * 8, k_radix_scan, kRadix, kBlock, st,
                    hist, ch.blocks, digit_total);
-        SFX_LAUNCH(sizeof(KeyT) == 4 ? "radix_scatter_u32" : "radix_scatter_u64",
-                   2.0 * (double)m * (sizeof(KeyT) + 4), (k_radix_scatter<KeyT, KPT, WPS>), ch.blocks,
-                   kBlock, st, kin, vin, kout, vout, m, shift, mask, chunk, hist, digit_total);
+        if (from_text) {
+            SFX_LAUNCH(sizeof(KeyT) == 4 ? "radix_scatter_text_u32" : "radix_scatter_text_u64",
+                       (double)m * (in_key + sizeof(KeyT) + 4), (k_radix_scatter<KeyT, KPT, WPS, true>),
+                       ch.blocks, kBlock, st, kin, vin, *src, kout, vout, m, shift, mask, chunk, hist,
+                       digit_total);
+        } else {
+            SFX_LAUNCH(sizeof(KeyT) == 4 ? "radix_scatter_u32" : "radix_scatter_u64",
+                       2.0 * (double)m * (sizeof(KeyT) + 4), (k_radix_scatter<KeyT, KPT, WPS, false>),
+                       ch.blocks, kBlock, st, kin, vin, none, kout, vout, m, shift, mask, chunk, hist,
+                       digit_total);
+        }
         KeyT* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
         flips ^= 1;
@@ -239,22 +265,24 @@ static int radix_sort_impl(KeyT* k0, uint32_t* v0, KeyT* k1, uint32_t* v1, uint6
 template <class KeyT>
 int radix_sort_pairs(KeyT* k0, uint32_t* v0, KeyT* k1, uint32_t* v1, uint64_t m, int bit_lo,
                      int bit_hi, uint32_t* hist, hipStream_t st, int* result_in_1,
-                     sfx_build_stats* stats)
+                     sfx_build_stats* stats, const PackedText* src)
 {
     *result_in_1 = 0;
     if (m == 0 || bit_hi <= bit_lo) return SFX_OK;
     if (m > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
     switch (radix_variant(sizeof(KeyT), m)) {
-    case 1: return radix_sort_impl<KeyT, 8, 6>(k0, v0, k1, v1, m, bit_lo, bit_hi, hist, st, result_in_1, stats);
-    case 3: return radix_sort_impl<KeyT, 16, 3>(k0, v0, k1, v1, m, bit_lo, bit_hi, hist, st, result_in_1, stats);
-    case 4: return radix_sort_impl<KeyT, 32, 2>(k0, v0, k1, v1, m, bit_lo, bit_hi, hist, st, result_in_1, stats);
-    default: return radix_sort_impl<KeyT, 16, 4>(k0, v0, k1, v1, m, bit_lo, bit_hi, hist, st, result_in_1, stats);
+    case 1: return radix_sort_impl<KeyT, 8, 6>(k0, v0, k1, v1, m, bit_lo, bit_hi, hist, st, result_in_1, stats, src);
+    case 2: return radix_sort_impl<KeyT, 16, 4>(k0, v0, k1, v1, m, bit_lo, bit_hi, hist, st, result_in_1, stats, src);
+    case 4: return radix_sort_impl<KeyT, 32, 2>(k0, v0, k1, v1, m, bit_lo, bit_hi, hist, st, result_in_1, stats, src);
+    default: return radix_sort_impl<KeyT, 16, 3>(k0, v0, k1, v1, m, bit_lo, bit_hi, hist, st, result_in_1, stats, src);
     }
 }
 
 template int radix_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint64_t, int,
-                                        int, uint32_t*, hipStream_t, int*, sfx_build_stats*);
+                                        int, uint32_t*, hipStream_t, int*, sfx_build_stats*,
+                                        const PackedText*);
 template int radix_sort_pairs<uint64_t>(uint64_t*, uint32_t*, uint64_t*, uint32_t*, uint64_t, int,
-                                        int, uint32_t*, hipStream_t, int*, sfx_build_stats*);
+                                        int, uint32_t*, hipStream_t, int*, sfx_build_stats*,
+                                        const PackedText*);
 
 }  // namespace sfx

@@ -10,20 +10,25 @@
 // scan / histogram / scatter kernel:
 //
 //   1. alphabet:   byte histogram (cf. Bins::find_sizes :686-704) -> dense symbol
-//                  codes of `bits` bits each (sigma = 4 -> 2 bits).
-//   2. initial buckets: every suffix gets a key = its first k symbols packed
-//                  big-endian (k = 16 for DNA in 32 bits); one LSD radix sort
-//                  (sfx_radix.hip) puts all suffixes in k-symbol bucket order --
-//                  the bucket sort of the reference's level 0 plus its first
-//                  recursion levels in one step.
+//                  codes of `bits` bits each (sigma = 4 -> 2 bits); the text is
+//                  packed once, 2^k symbols per 32-bit word (PackedText).
+//   2. initial buckets: every suffix gets a key = its first k symbols (k = 16
+//                  for DNA in 32 bits), read straight out of the packed text by
+//                  the first pass of one LSD radix sort (sfx_radix.hip): all
+//                  suffixes land in k-symbol bucket order -- the bucket sort of
+//                  the reference's level 0 plus its first recursion levels at once.
 //   3. bucket ranks ("naming", cf. :465-482): adjacent-compare flags + device
-//                  scan give every suffix the SA slot of its bucket head:
-//                  ISA[suffix] = head slot.  Buckets of size 1 are final.
+//                  scan find the bucket heads; buckets of size 1 are final.
 //   4. refinement rounds (the "recursive sort", cf. :496-500): suffixes still
 //                  sharing a bucket are compacted; each gets the composite key
-//                  (dense bucket id, rank of the suffix h symbols further on);
-//                  radix sort; new flags/scan split the buckets; h doubles.
-//                  Terminates when every bucket is a singleton (<= log2 n rounds).
+//                  (dense bucket id, key2); radix sort; new flags/scan split the
+//                  buckets.  key2 is either the NEXT k symbols (text round, h += k;
+//                  needs nothing but the packed text) or the RANK of the suffix h
+//                  symbols further on (rank round, h doubles; needs ISA[suffix] =
+//                  head slot of its bucket).  When the initial sort leaves few
+//                  suffixes unresolved the first round is a text round and the
+//                  n-element ISA scatter is skipped unless a later round needs it.
+//                  Terminates when every bucket is a singleton (<= log2 n rank rounds).
 //
 // Short suffixes: keys are zero-padded past the end of the text; a suffix whose
 // first h symbols run off the end ("consumed") gets key2 = n-1-i, which is
@@ -32,19 +37,18 @@
 //
 // The same kernels serve the range-partitioned (multi-GPU) build, where a rank
 // sorts only the suffixes whose leading key bits fall in its bucket range and
-// refines with text symbols (no ranks of foreign suffixes needed).
+// refines with text rounds only (no ranks of foreign suffixes needed).
 #include <string.h>
 
 #include "sfx_host.hpp"
 
 namespace sfx {
 
-constexpr int kKmerTile = 4096;          // text positions per tile
-constexpr int kMaxSymsPerKey = 64;
+constexpr int kPackTile = 4096;          // text positions per workgroup step in k_pack_text
 constexpr int kMaxTopBits = 14;          // 16384 u32 bins = 64 KiB of LDS
 
 // ---------------------------------------------------------------------------------
-// 1. alphabet
+// 1. alphabet and packed text
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_byte_hist(const uint8_t* __restrict__ text, uint64_t begin, uint64_t end,
@@ -72,135 +76,97 @@ k_make_lut(const unsigned long long* __restrict__ bins, uint8_t* __restrict__ lu
     lut[threadIdx.x] = (uint8_t)code;
 }
 
-// ---------------------------------------------------------------------------------
-// 2. k-symbol keys
-// ---------------------------------------------------------------------------------
-// Stage the symbol codes of text[tile, tile + kKmerTile + cpk - 1) in LDS (0 past
-// the end).  Caller places barriers.
-__device__ __forceinline__ void load_codes(const uint8_t* __restrict__ text, uint64_t n, uint64_t tile,
-                                           int cpk, const uint8_t* s_lut, uint8_t* codes)
-{
-    for (unsigned j = threadIdx.x; j < (unsigned)(kKmerTile + cpk - 1); j += kBlock) {
-        uint64_t g = tile + j;
-        codes[j] = (g < n) ? s_lut[text[g]] : (uint8_t)0;
-    }
-}
-template <class KeyT>
-__device__ __forceinline__ KeyT key_from_codes(const uint8_t* codes, unsigned p, int bits, int cpk)
-{
-    KeyT key = 0;
-    for (int j = 0; j < cpk; j++) key = (KeyT)(key << bits) | (KeyT)codes[p + j];
-    return key;
-}
-
-// keys[i] = first `cpk` symbols of suffix i, `bits` bits each, big-endian in the
-// low cpk*bits bits, zero-padded past the end; vals[i] = i.
-template <class KeyT>
+// words[j] = symbols of positions [j*spw, (j+1)*spw), big-endian, `bits` bits each,
+// 0 past the end; plus 3 trailing zero words (see PackedText).
 __global__ void __launch_bounds__(kBlock)
-k_kmer_keys_tiled(const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ lut,
-                  int bits, int cpk, uint64_t tiles_per_block, KeyT* __restrict__ keys,
-                  uint32_t* __restrict__ vals)
+k_pack_text(const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ lut, int bits,
+            int spw_log2, uint64_t tiles_per_block, uint64_t n_words_total,
+            uint32_t* __restrict__ words)
 {
     __shared__ uint8_t s_lut[256];
-    __shared__ uint8_t codes[kKmerTile + kMaxSymsPerKey];
-    const unsigned tid = threadIdx.x;
+    __shared__ uint8_t codes[kPackTile];
+    const unsigned tid = threadIdx.x, spw = 1u << spw_log2;
     s_lut[tid] = lut[tid];
     __syncthreads();
-    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kKmerTile;
-    uint64_t end = begin + tiles_per_block * kKmerTile;
-    if (end > n) end = n;
-    for (uint64_t tile = begin; tile < end; tile += kKmerTile) {
-        load_codes(text, n, tile, cpk, s_lut, codes);
+    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kPackTile;
+    uint64_t end = begin + tiles_per_block * kPackTile;
+    uint64_t limit = n_words_total << spw_log2;           // positions covered by the word array
+    if (end > limit) end = limit;
+    for (uint64_t tile = begin; tile < end; tile += kPackTile) {
+        for (unsigned j = tid; j < (unsigned)kPackTile; j += kBlock) {
+            uint64_t g = tile + j;
+            codes[j] = (g < n) ? s_lut[text[g]] : (uint8_t)0;
+        }
         __syncthreads();
-        for (unsigned p = tid; p < (unsigned)kKmerTile; p += kBlock) {
-            uint64_t i = tile + p;
-            if (i < end) {
-                keys[i] = key_from_codes<KeyT>(codes, p, bits, cpk);
-                vals[i] = (uint32_t)i;
+        for (unsigned wj = tid; wj < ((unsigned)kPackTile >> spw_log2); wj += kBlock) {
+            uint64_t gw = (tile >> spw_log2) + wj;
+            if (gw < n_words_total) {
+                uint32_t w = 0;
+                for (unsigned s = 0; s < spw; s++) w = (w << bits) | codes[wj * spw + s];
+                words[gw] = w;
             }
         }
         __syncthreads();
     }
 }
 
-// Bucket-boundary histogram for the partitioned build: counts the top `top_bits`
-// bits of the key of every suffix starting in [begin, end).  Bins are privatised
-// in LDS (2^top_bits u32 <= 64 KiB) and flushed once per workgroup.
+// ---------------------------------------------------------------------------------
+// 2. partitioned build: bucket-boundary histogram and range filter
+// ---------------------------------------------------------------------------------
+// Counts the top `top_bits` bits of the key of every suffix starting in [begin, end).
+// Bins are privatised in LDS (2^top_bits u32 <= 64 KiB) and flushed once per workgroup.
 template <class KeyT>
 __global__ void __launch_bounds__(kBlock)
-k_key_hist(const uint8_t* __restrict__ text, uint64_t n, uint64_t begin, uint64_t end,
-           const uint8_t* __restrict__ lut, int bits, int cpk, int top_bits,
-           uint64_t tiles_per_block, unsigned long long* __restrict__ bins)
+k_key_hist(PackedText src, uint64_t begin, uint64_t end, int key_bits_used, int top_bits,
+           uint64_t chunk, unsigned long long* __restrict__ bins)
 {
-    __shared__ uint8_t s_lut[256];
-    __shared__ uint8_t codes[kKmerTile + kMaxSymsPerKey];
     __shared__ uint32_t h[1 << kMaxTopBits];
     const unsigned tid = threadIdx.x, nbins = 1u << top_bits;
-    const int shift = bits * cpk - top_bits;
-    s_lut[tid] = lut[tid];
+    const int shift = key_bits_used - top_bits;
     for (unsigned i = tid; i < nbins; i += kBlock) h[i] = 0;
     __syncthreads();
-    uint64_t cb = begin + (uint64_t)blockIdx.x * tiles_per_block * kKmerTile;
-    uint64_t ce = cb + tiles_per_block * kKmerTile;
+    uint64_t cb = begin + (uint64_t)blockIdx.x * chunk;
+    uint64_t ce = cb + chunk;
     if (ce > end) ce = end;
-    for (uint64_t tile = cb; tile < ce; tile += kKmerTile) {
-        load_codes(text, n, tile, cpk, s_lut, codes);
-        __syncthreads();
-        for (unsigned p = tid; p < (unsigned)kKmerTile; p += kBlock) {
-            if (tile + p < ce) {
-                KeyT key = key_from_codes<KeyT>(codes, p, bits, cpk);
-                atomicAdd(&h[(unsigned)(key >> shift)], 1u);
-            }
-        }
-        __syncthreads();
-    }
+    for (uint64_t i = cb + tid; i < ce; i += kBlock)
+        atomicAdd(&h[(unsigned)(packed_key<KeyT>(src, i) >> shift)], 1u);
+    __syncthreads();
     for (unsigned i = tid; i < nbins; i += kBlock)
         if (h[i]) atomicAdd(&bins[i], (unsigned long long)h[i]);
 }
 
-// Partitioned build: emit (key, suffix) for the suffixes whose top key bits fall
-// in [bin_lo, bin_hi).  phase 0 counts per workgroup, phase 1 writes at the
-// scanned offsets (stream compaction; order = text order).
+// Emit (key, suffix) for the suffixes whose top key bits fall in [bin_lo, bin_hi).
+// phase 0 counts per workgroup, phase 1 writes at the scanned offsets (stream
+// compaction; order = text order).
 template <class KeyT>
 __global__ void __launch_bounds__(kBlock)
-k_range_filter(const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ lut,
-               int bits, int cpk, int top_bits, uint32_t bin_lo, uint32_t bin_hi,
-               uint64_t tiles_per_block, int phase, uint32_t* __restrict__ block_counts,
-               uint64_t capacity, KeyT* __restrict__ kout, uint32_t* __restrict__ vout)
+k_range_filter(PackedText src, int key_bits_used, int top_bits, uint32_t bin_lo, uint32_t bin_hi,
+               uint64_t chunk, int phase, uint32_t* __restrict__ block_counts, uint64_t capacity,
+               KeyT* __restrict__ kout, uint32_t* __restrict__ vout)
 {
-    __shared__ uint8_t s_lut[256];
-    __shared__ uint8_t codes[kKmerTile + kMaxSymsPerKey];
     __shared__ uint32_t part[kWavesPerBlock];
     const unsigned tid = threadIdx.x;
-    const int shift = bits * cpk - top_bits;
-    s_lut[tid] = lut[tid];
-    __syncthreads();
-    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kKmerTile;
-    uint64_t end = begin + tiles_per_block * kKmerTile;
-    if (end > n) end = n;
+    const int shift = key_bits_used - top_bits;
+    uint64_t begin = (uint64_t)blockIdx.x * chunk;
+    uint64_t end = begin + chunk;
+    if (end > src.n) end = src.n;
     uint64_t running = (phase == 1) ? (uint64_t)block_counts[blockIdx.x] : 0ull;
-    for (uint64_t tile = begin; tile < end; tile += kKmerTile) {
-        load_codes(text, n, tile, cpk, s_lut, codes);
-        __syncthreads();
-        for (unsigned base = 0; base < (unsigned)kKmerTile; base += kBlock) {
-            unsigned p = base + tid;
-            uint64_t i = tile + p;
-            KeyT key = 0;
-            bool keep = false;
-            if (i < end) {
-                key = key_from_codes<KeyT>(codes, p, bits, cpk);
-                uint32_t bin = (uint32_t)(key >> shift);
-                keep = bin >= bin_lo && bin < bin_hi;
-            }
-            uint32_t total;
-            uint32_t ex = block_scan_add_excl<uint32_t>(keep ? 1u : 0u, part, total);
-            if (phase == 1 && keep && running + ex < capacity) {
-                kout[running + ex] = key;
-                vout[running + ex] = (uint32_t)i;
-            }
-            running += total;
+    for (uint64_t base = begin; base < end; base += kBlock) {
+        uint64_t i = base + tid;
+        KeyT key = 0;
+        bool keep = false;
+        if (i < end) {
+            key = packed_key<KeyT>(src, i);
+            uint32_t bin = (uint32_t)(key >> shift);
+            keep = bin >= bin_lo && bin < bin_hi;
         }
-        __syncthreads();
+        uint32_t total;
+        uint32_t ex = block_scan_add_excl<uint32_t>(keep ? 1u : 0u, part, total);
+        if (phase == 1 && keep && running + ex < capacity) {
+            kout[running + ex] = key;
+            vout[running + ex] = (uint32_t)i;
+        }
+        running += total;
     }
     if (phase == 0 && tid == 0) block_counts[blockIdx.x] = (uint32_t)running;
 }
@@ -224,7 +190,7 @@ k_scan_block_counts(uint32_t* __restrict__ counts, unsigned nb, uint32_t* __rest
 // ---------------------------------------------------------------------------------
 // 4a. composite keys for a refinement round
 // ---------------------------------------------------------------------------------
-// rank mode: key2 = rank of suffix i+h (+h), or n-1-i when i+h runs off the text.
+// rank round: key2 = rank of suffix i+h (+h), or n-1-i when i+h runs off the text.
 __global__ void __launch_bounds__(kBlock)
 k_compose_rank_keys(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ gid, uint64_t m,
                     const uint32_t* __restrict__ isa, uint64_t n, uint64_t h, int key2_bits,
@@ -239,32 +205,19 @@ k_compose_rank_keys(const uint32_t* __restrict__ suf, const uint32_t* __restrict
     }
 }
 
-// text mode (partitioned build): key2 = (1 << flag_shift) | next cpk symbols at
-// offset h, or n-1-i (< 2^flag_shift) when the suffix is consumed.
+// text round: key2 = (1 << flag_shift) | the spw symbols at offset h, or n-1-i
+// (< 2^flag_shift) when the suffix is consumed.
 __global__ void __launch_bounds__(kBlock)
 k_compose_text_keys(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ gid, uint64_t m,
-                    const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ lut,
-                    int bits, int cpk, uint64_t h, int flag_shift, int key2_bits,
+                    PackedText src, uint64_t h, int flag_shift, int key2_bits,
                     uint64_t* __restrict__ keys)
 {
-    __shared__ uint8_t s_lut[256];
-    s_lut[threadIdx.x] = lut[threadIdx.x];
-    __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < m; q += stride) {
         uint64_t i = suf[q];
         uint64_t p = i + h;
-        uint64_t key2;
-        if (p < n) {
-            uint64_t kmer = 0;
-            for (int j = 0; j < cpk; j++) {
-                uint64_t g = p + (uint64_t)j;
-                kmer = (kmer << bits) | ((g < n) ? (uint64_t)s_lut[text[g]] : 0ull);
-            }
-            key2 = (1ull << flag_shift) | kmer;
-        } else {
-            key2 = n - 1 - i;
-        }
+        uint64_t key2 = (p < src.n) ? ((1ull << flag_shift) | (uint64_t)packed_key32(src, p))
+                                    : (src.n - 1 - i);
         keys[q] = ((uint64_t)gid[q] << key2_bits) | key2;
     }
 }
@@ -471,7 +424,9 @@ k_isa_fix_active(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ 
 // ---------------------------------------------------------------------------------
 struct Alphabet {
     unsigned sigma;
-    int bits;
+    int bits;           // bits per symbol
+    int spw_log2;       // log2(symbols per packed word): largest power of two <= 32/bits
+    int kbits;          // bits * 2^spw_log2 (<= 32)
 };
 
 static Alphabet make_alphabet(const unsigned long long* bins)
@@ -480,21 +435,28 @@ static Alphabet make_alphabet(const unsigned long long* bins)
     a.sigma = 0;
     for (int c = 0; c < 256; c++) if (bins[c]) a.sigma++;
     a.bits = bits_for(a.sigma > 1 ? a.sigma - 1 : 1);
+    a.spw_log2 = 0;
+    while ((2 << a.spw_log2) * a.bits <= 32) a.spw_log2++;
+    a.kbits = a.bits << a.spw_log2;
     return a;
 }
 
-// 32-bit keys when k = floor(32/bits) symbols are expected to separate most
-// suffixes of a random text over this alphabet (k*floor(log2 sigma) >= log2 n + 3),
-// else 64-bit keys.  Depends only on (alphabet, n): identical on every rank.
+// 32-bit keys (spw symbols) when they are expected to separate most suffixes of a
+// random text over this alphabet (spw*floor(log2 sigma) >= log2 n + 3), else 64-bit
+// keys (2*spw symbols).  Depends only on (alphabet, n): identical on every rank.
 static void choose_key(const Alphabet& a, uint64_t n, int* key_bits, int* cpk)
 {
-    int k32 = 32 / a.bits, k64 = 64 / a.bits;
-    if (k64 > kMaxSymsPerKey) k64 = kMaxSymsPerKey;
-    if (k32 > kMaxSymsPerKey) k32 = kMaxSymsPerKey;
+    int spw = 1 << a.spw_log2;
     int l2 = bits_for(a.sigma) - 1;                 // floor(log2 sigma), sigma >= 1
     if (l2 < 1) l2 = 1;
-    if (k32 * l2 >= bits_for(n) + 3) { *key_bits = 32; *cpk = k32; }
-    else { *key_bits = 64; *cpk = k64; }
+    if (spw * l2 >= bits_for(n) + 3) { *key_bits = 32; *cpk = spw; }
+    else { *key_bits = 64; *cpk = 2 * spw; }
+}
+
+static uint64_t packed_words(uint64_t n, const Alphabet* a)
+{
+    int lg = a ? a->spw_log2 : 2;                   // worst case: 4 symbols per word
+    return ((n + (1ull << lg) - 1) >> lg) + 3;
 }
 
 // A full build whose initial sort leaves at most 1/kTextFirstDivisor of the suffixes
@@ -509,6 +471,7 @@ struct SaBuffers {
     uint32_t* G;                                        // dense bucket ids
     uint32_t* R;                                        // bucket-head slots (text rounds of a full build)
     uint32_t* isa;
+    uint32_t* packed;                                   // PackedText words
     uint32_t* hist;                                     // 256*kMaxGrid + 256
     uint32_t* part_head; uint32_t* part_keep; uint32_t* part_ghead;   // kMaxGrid each
     uint32_t* totals;
@@ -520,7 +483,8 @@ struct SizerArena : ArenaSizer {
     template <class T> T* take(uint64_t c) { ArenaSizer::take<T>(c); return nullptr; }
 };
 
-template <class A> static void carve_sa(A& ar, uint64_t cap, uint64_t isa_len, SaBuffers* b)
+template <class A>
+static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffers* b)
 {
     uint64_t* K0 = ar.template take<uint64_t>(cap);
     uint64_t* K1 = ar.template take<uint64_t>(cap);
@@ -531,6 +495,7 @@ template <class A> static void carve_sa(A& ar, uint64_t cap, uint64_t isa_len, S
     uint32_t* G = ar.template take<uint32_t>(cap);
     uint32_t* R = ar.template take<uint32_t>(isa_len ? cap / kTextFirstDivisor + 1024 : 0);
     uint32_t* isa = ar.template take<uint32_t>(isa_len);
+    uint32_t* packed = ar.template take<uint32_t>(packed_words(n, nullptr));
     uint32_t* hist = ar.template take<uint32_t>((uint64_t)kRadix * kMaxGrid + kRadix);
     uint32_t* ph = ar.template take<uint32_t>(kMaxGrid);
     uint32_t* pk = ar.template take<uint32_t>(kMaxGrid);
@@ -540,8 +505,8 @@ template <class A> static void carve_sa(A& ar, uint64_t cap, uint64_t isa_len, S
     uint8_t* lut = ar.template take<uint8_t>(256);
     if (b) {
         b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->R = R;
-        b->isa = isa; b->hist = hist; b->part_head = ph; b->part_keep = pk; b->part_ghead = pg;
-        b->totals = totals; b->bins = bins; b->lut = lut;
+        b->isa = isa; b->packed = packed; b->hist = hist; b->part_head = ph; b->part_keep = pk;
+        b->part_ghead = pg; b->totals = totals; b->bins = bins; b->lut = lut;
     }
 }
 
@@ -549,13 +514,13 @@ uint64_t sa_workspace_bytes(uint64_t n)
 {
     SizerArena s;
     uint64_t cap = n < 2 ? 2 : n;
-    carve_sa(s, cap, cap, (SaBuffers*)nullptr);
+    carve_sa(s, cap, cap, cap, (SaBuffers*)nullptr);
     return s.used + 256;
 }
-uint64_t sa_range_workspace_bytes(uint64_t max_count)
+uint64_t sa_range_workspace_bytes(uint64_t n, uint64_t max_count)
 {
     SizerArena s;
-    carve_sa(s, max_count < 2 ? 2 : max_count, 0, (SaBuffers*)nullptr);
+    carve_sa(s, n < 2 ? 2 : n, max_count < 2 ? 2 : max_count, 0, (SaBuffers*)nullptr);
     s.take<uint32_t>(kMaxGrid);
     return s.used + 256;
 }
@@ -591,18 +556,6 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
     return SFX_OK;
 }
 
-// alphabet from device-resident global byte counts
-static int alphabet_from_bins(const unsigned long long* d_bins, SaBuffers& b, hipStream_t st,
-                              Alphabet* alpha)
-{
-    unsigned long long host_bins[256];
-    SFX_HIP(hipMemcpyAsync(host_bins, d_bins, sizeof(host_bins), hipMemcpyDeviceToHost, st));
-    SFX_LAUNCH("make_lut", 0.0, k_make_lut, 1, kBlock, st, d_bins, b.lut);
-    SFX_HIP(hipStreamSynchronize(st));
-    *alpha = make_alphabet(host_bins);
-    return SFX_OK;
-}
-
 int byte_histogram_dev(const uint8_t* d_text, uint64_t begin, uint64_t end, uint64_t* d_bins,
                        hipStream_t st)
 {
@@ -616,19 +569,41 @@ int byte_histogram_dev(const uint8_t* d_text, uint64_t begin, uint64_t end, uint
     return SFX_OK;
 }
 
+// alphabet (host) + LUT and packed text (device) from device-resident global byte counts
+static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long long* d_bins,
+                        uint8_t* d_lut, uint32_t* d_packed, hipStream_t st, Alphabet* alpha,
+                        PackedText* pt)
+{
+    unsigned long long host_bins[256];
+    SFX_HIP(hipMemcpyAsync(host_bins, d_bins, sizeof(host_bins), hipMemcpyDeviceToHost, st));
+    SFX_LAUNCH("make_lut", 0.0, k_make_lut, 1, kBlock, st, d_bins, d_lut);
+    SFX_HIP(hipStreamSynchronize(st));
+    *alpha = make_alphabet(host_bins);
+    uint64_t nw = packed_words(n, alpha);
+    Chunking ch = make_chunking(nw << alpha->spw_log2, kPackTile);
+    SFX_LAUNCH("pack_text", (double)n * (1.0 + alpha->bits / 8.0), k_pack_text, ch.blocks, kBlock, st,
+               d_text, n, d_lut, alpha->bits, alpha->spw_log2, ch.tiles_per_block, nw, d_packed);
+    pt->words = d_packed;
+    pt->n = n;
+    pt->bits = alpha->bits;
+    pt->spw_log2 = alpha->spw_log2;
+    pt->kbits = alpha->kbits;
+    return SFX_OK;
+}
+
 // refinement rounds shared by the full and the partitioned build.
 //   rank round: key2 = rank of the suffix h symbols on (needs ISA), h doubles
-//   text round: key2 = the next cpk_r symbols (needs only the text), h += cpk_r
+//   text round: key2 = the next spw symbols (needs only the packed text), h += spw
 // The partitioned build (isa == nullptr) only has text rounds.  A full build runs
 // `text_rounds` text rounds first (0 or 1, see kTextFirstDivisor) and rank rounds after.
-static int refine(const uint8_t* d_text, uint64_t n, const Alphabet& alpha, int cpk, SaBuffers& b,
-                  uint32_t* sa, uint32_t* isa, int text_rounds, uint32_t* S_cur, uint32_t* V_cur,
-                  uint64_t m, uint64_t groups, hipStream_t st, sfx_build_stats& stats)
+static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uint32_t* isa,
+                  int text_rounds, uint32_t* S_cur, uint32_t* V_cur, uint64_t m, uint64_t groups,
+                  hipStream_t st, sfx_build_stats& stats)
 {
+    const uint64_t n = pt.n;
     uint64_t h = (uint64_t)cpk;
-    int cpk_r = 32 / alpha.bits;                       // text round: <= 32 key bits
-    if (cpk_r > cpk) cpk_r = cpk;
-    const int flag_shift = dmax(alpha.bits * cpk_r, bits_for(n));
+    const int spw = 1 << pt.spw_log2;
+    const int flag_shift = dmax(pt.kbits, bits_for(n));
     int rounds = 0;
     while (m > 0) {
         // rank rounds: <= ~log2(n); text rounds are bounded by the longest repeat
@@ -639,9 +614,8 @@ static int refine(const uint8_t* d_text, uint64_t n, const Alphabet& alpha, int 
         if (key2_bits + gid_bits > 64) return SFX_ERR_INTERNAL;
         unsigned grid = (unsigned)dmin<uint64_t>((m + kBlock - 1) / kBlock, kMaxGrid);
         if (text_round) {
-            SFX_LAUNCH("compose_text_keys", (double)m * (16 + cpk_r), k_compose_text_keys, grid, kBlock,
-                       st, V_cur, b.G, m, d_text, n, b.lut, alpha.bits, cpk_r, h, flag_shift,
-                       key2_bits, b.K0);
+            SFX_LAUNCH("compose_text_keys", (double)m * 24, k_compose_text_keys, grid, kBlock, st, V_cur,
+                       b.G, m, pt, h, flag_shift, key2_bits, b.K0);
         } else {
             SFX_LAUNCH("compose_rank_keys", (double)m * 20, k_compose_rank_keys, grid, kBlock, st,
                        V_cur, b.G, m, isa, n, h, key2_bits, b.K0);
@@ -659,7 +633,7 @@ static int refine(const uint8_t* d_text, uint64_t n, const Alphabet& alpha, int 
         const bool full_text_round = isa && text_round;
         SFX_TRY(round_apply<uint64_t>(Kr, Vr, S_cur, m, b, sa, (isa && !text_round) ? isa : nullptr,
                                       S_next, V_next, full_text_round ? b.R : nullptr, st));
-        h = text_round ? h + (uint64_t)cpk_r : h * 2;
+        h = text_round ? h + (uint64_t)spw : h * 2;
         if (full_text_round && --text_rounds == 0 && kept > 0) {
             // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
             unsigned g1 = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
@@ -677,18 +651,18 @@ static int refine(const uint8_t* d_text, uint64_t n, const Alphabet& alpha, int 
     return SFX_OK;
 }
 
-// initial sort + first bucket pass + refinement, for `count` (key, suffix) pairs
-// already sitting in (K0 as KeyT, VA).
+// initial sort + first bucket pass + refinement.  from_text: the `count` = n elements
+// are (key of suffix i, i), fed to the first radix pass straight from the packed text;
+// otherwise `count` explicit (key, suffix) pairs already sit in (K0 as KeyT, VA).
 template <class KeyT>
-static int sort_and_refine(const uint8_t* d_text, uint64_t n, const Alphabet& alpha, int cpk,
-                           uint64_t count, SaBuffers& b, uint32_t* sa, uint32_t* isa, hipStream_t st,
-                           sfx_build_stats& stats)
+static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool from_text, SaBuffers& b,
+                           uint32_t* sa, uint32_t* isa, hipStream_t st, sfx_build_stats& stats)
 {
     KeyT* k0 = (KeyT*)b.K0;
     KeyT* k1 = (KeyT*)b.K1;
     int in1 = 0;
-    SFX_TRY(radix_sort_pairs<KeyT>(k0, b.VA, k1, b.VB, count, 0, alpha.bits * cpk, b.hist, st, &in1,
-                                   &stats));
+    SFX_TRY(radix_sort_pairs<KeyT>(k0, b.VA, k1, b.VB, count, 0, pt.bits * cpk, b.hist, st, &in1, &stats,
+                                   from_text ? &pt : nullptr));
     const KeyT* Kr = in1 ? k1 : k0;
     uint64_t kept = 0, groups = 0;
     SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups));
@@ -698,7 +672,7 @@ static int sort_and_refine(const uint8_t* d_text, uint64_t n, const Alphabet& al
     uint32_t* V_next = in1 ? b.VA : b.VB;
     SFX_TRY(round_apply<KeyT>(Kr, in1 ? b.VB : b.VA, nullptr, count, b, sa,
                               (isa && !text_rounds) ? isa : nullptr, b.S0, V_next, nullptr, st));
-    return refine(d_text, n, alpha, cpk, b, sa, isa, text_rounds, b.S0, V_next, kept, groups, st, stats);
+    return refine(pt, cpk, b, sa, isa, text_rounds, b.S0, V_next, kept, groups, st, stats);
 }
 
 int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,
@@ -718,28 +692,21 @@ int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws
 
     Arena ar(ws, ws_bytes);
     SaBuffers b;
-    carve_sa(ar, n, n, &b);
+    carve_sa(ar, n, n, n, &b);
     if (ar.overflow) return SFX_ERR_WORKSPACE;
 
     SFX_TRY(byte_histogram_dev(d_text, 0, n, (uint64_t*)b.bins, st));
     Alphabet alpha;
-    SFX_TRY(alphabet_from_bins(b.bins, b, st, &alpha));
+    PackedText pt;
+    SFX_TRY(prepare_text(d_text, n, b.bins, b.lut, b.packed, st, &alpha, &pt));
     int key_bits, cpk;
     choose_key(alpha, n, &key_bits, &cpk);
     stats.sigma = alpha.sigma;
     stats.bits_per_symbol = (uint32_t)alpha.bits;
     stats.key_bits = (uint32_t)key_bits;
     stats.symbols_per_key = (uint32_t)cpk;
-
-    Chunking ch = make_chunking(n, kKmerTile);
-    if (key_bits == 32) {
-        SFX_LAUNCH("kmer_keys", (double)n * 9, (k_kmer_keys_tiled<uint32_t>), ch.blocks, kBlock, st,
-                   d_text, n, b.lut, alpha.bits, cpk, ch.tiles_per_block, (uint32_t*)b.K0, b.VA);
-        return sort_and_refine<uint32_t>(d_text, n, alpha, cpk, n, b, d_sa, b.isa, st, stats);
-    }
-    SFX_LAUNCH("kmer_keys", (double)n * 13, (k_kmer_keys_tiled<uint64_t>), ch.blocks, kBlock, st,
-               d_text, n, b.lut, alpha.bits, cpk, ch.tiles_per_block, b.K0, b.VA);
-    return sort_and_refine<uint64_t>(d_text, n, alpha, cpk, n, b, d_sa, b.isa, st, stats);
+    if (key_bits == 32) return sort_and_refine<uint32_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats);
+    return sort_and_refine<uint64_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats);
 }
 
 // ---- partitioned build -----------------------------------------------------------
@@ -751,48 +718,46 @@ int key_histogram_dev(const uint8_t* d_text, uint64_t n, uint64_t begin, uint64_
     if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
     SFX_HIP(hipMemsetAsync(d_bins, 0, sizeof(uint64_t) << top_bits, st));
     if (begin == end) return SFX_OK;
-    // the LUT needs 256 B of device scratch: borrow the tail of the caller's bin array?  No --
-    // keep the ABI simple: a small static-size device allocation per call.
-    uint8_t* d_lut = nullptr;
-    SFX_HIP(hipMalloc((void**)&d_lut, 256));
-    unsigned long long host_bins[256];
+    // scratch for the LUT and the packed text: this entry point has no workspace argument
+    uint8_t* scratch = nullptr;
+    uint64_t packed_bytes = packed_words(n, nullptr) * sizeof(uint32_t);
+    SFX_HIP(hipMalloc((void**)&scratch, 256 + packed_bytes));
     int rc = SFX_OK;
     do {
-        if (hipMemcpyAsync(host_bins, d_byte_bins, sizeof(host_bins), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) { rc = SFX_ERR_HIP; break; }
-        Alphabet alpha = make_alphabet(host_bins);
+        Alphabet alpha;
+        PackedText pt;
+        rc = prepare_text(d_text, n, (const unsigned long long*)d_byte_bins, scratch,
+                          (uint32_t*)(scratch + 256), st, &alpha, &pt);
+        if (rc != SFX_OK) break;
         int key_bits, cpk;
         choose_key(alpha, n, &key_bits, &cpk);
         if (alpha.bits * cpk < top_bits) { rc = SFX_ERR_ARG; break; }
-        hipLaunchKernelGGL(k_make_lut, dim3(1), dim3(kBlock), 0, st,
-                           (const unsigned long long*)d_byte_bins, d_lut);
-        Chunking ch = make_chunking(end - begin, kKmerTile, 256);   // one flush per CU
+        Chunking ch = make_chunking(end - begin, 4096, 256);        // one LDS flush per CU
+        uint64_t chunk = ch.tiles_per_block * 4096;
         if (key_bits == 32) {
-            hipLaunchKernelGGL((k_key_hist<uint32_t>), dim3(ch.blocks), dim3(kBlock), 0, st, d_text, n,
-                               begin, end, (const uint8_t*)d_lut, alpha.bits, cpk, top_bits,
-                               ch.tiles_per_block, (unsigned long long*)d_bins);
+            hipLaunchKernelGGL((k_key_hist<uint32_t>), dim3(ch.blocks), dim3(kBlock), 0, st, pt, begin, end,
+                               alpha.bits * cpk, top_bits, chunk, (unsigned long long*)d_bins);
         } else {
-            hipLaunchKernelGGL((k_key_hist<uint64_t>), dim3(ch.blocks), dim3(kBlock), 0, st, d_text, n,
-                               begin, end, (const uint8_t*)d_lut, alpha.bits, cpk, top_bits,
-                               ch.tiles_per_block, (unsigned long long*)d_bins);
+            hipLaunchKernelGGL((k_key_hist<uint64_t>), dim3(ch.blocks), dim3(kBlock), 0, st, pt, begin, end,
+                               alpha.bits * cpk, top_bits, chunk, (unsigned long long*)d_bins);
         }
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SFX_ERR_HIP;
     } while (0);
-    (void)hipFree(d_lut);
+    (void)hipFree(scratch);
     return rc;
 }
 
 template <class KeyT>
-static int range_build(const uint8_t* d_text, uint64_t n, const Alphabet& alpha, int cpk, int top_bits,
-                       uint32_t bin_lo, uint32_t bin_hi, uint64_t capacity, uint32_t* d_sa_part,
-                       uint64_t* count_out, SaBuffers& b, uint32_t* block_counts, hipStream_t st,
-                       sfx_build_stats& stats)
+static int range_build(const PackedText& pt, int cpk, int top_bits, uint32_t bin_lo, uint32_t bin_hi,
+                       uint64_t capacity, uint32_t* d_sa_part, uint64_t* count_out, SaBuffers& b,
+                       uint32_t* block_counts, hipStream_t st, sfx_build_stats& stats)
 {
-    Chunking ch = make_chunking(n, kKmerTile);
+    const uint64_t n = pt.n;
+    Chunking ch = make_chunking(n, 4096);
+    const uint64_t chunk = ch.tiles_per_block * 4096;
     KeyT* k0 = (KeyT*)b.K0;
-    SFX_LAUNCH("range_count", (double)n, (k_range_filter<KeyT>), ch.blocks, kBlock, st, d_text, n,
-               b.lut, alpha.bits, cpk, top_bits, bin_lo, bin_hi, ch.tiles_per_block, 0, block_counts,
-               capacity, k0, b.VA);
+    SFX_LAUNCH("range_count", (double)n * pt.bits / 8.0, (k_range_filter<KeyT>), ch.blocks, kBlock, st, pt,
+               pt.bits * cpk, top_bits, bin_lo, bin_hi, chunk, 0, block_counts, capacity, k0, b.VA);
     SFX_LAUNCH("range_scan", 0.0, k_scan_block_counts, 1, kBlock, st, block_counts, ch.blocks, b.totals);
     uint32_t host_total = 0;
     SFX_HIP(hipMemcpyAsync(&host_total, b.totals, sizeof(host_total), hipMemcpyDeviceToHost, st));
@@ -800,10 +765,10 @@ static int range_build(const uint8_t* d_text, uint64_t n, const Alphabet& alpha,
     *count_out = host_total;
     if (host_total > capacity) return SFX_ERR_WORKSPACE;
     if (host_total == 0) return SFX_OK;
-    SFX_LAUNCH("range_emit", (double)n + (double)host_total * (sizeof(KeyT) + 4), (k_range_filter<KeyT>),
-               ch.blocks, kBlock, st, d_text, n, b.lut, alpha.bits, cpk, top_bits, bin_lo, bin_hi,
-               ch.tiles_per_block, 1, block_counts, capacity, k0, b.VA);
-    return sort_and_refine<KeyT>(d_text, n, alpha, cpk, host_total, b, d_sa_part, nullptr, st, stats);
+    SFX_LAUNCH("range_emit", (double)n * pt.bits / 8.0 + (double)host_total * (sizeof(KeyT) + 4),
+               (k_range_filter<KeyT>), ch.blocks, kBlock, st, pt, pt.bits * cpk, top_bits, bin_lo, bin_hi,
+               chunk, 1, block_counts, capacity, k0, b.VA);
+    return sort_and_refine<KeyT>(pt, cpk, host_total, false, b, d_sa_part, nullptr, st, stats);
 }
 
 int build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint64_t* d_byte_bins,
@@ -820,16 +785,18 @@ int build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint64_t* d_
     if (n == 0 || bin_lo >= bin_hi) return SFX_OK;
     if (!d_text || !d_byte_bins || !d_sa_part || capacity == 0) return SFX_ERR_ARG;
     if (top_bits < 1 || top_bits > kMaxTopBits || bin_hi > (1u << top_bits)) return SFX_ERR_ARG;
-    if (!ws || ws_bytes < sa_range_workspace_bytes(capacity)) return SFX_ERR_WORKSPACE;
+    if (!ws || ws_bytes < sa_range_workspace_bytes(n, capacity)) return SFX_ERR_WORKSPACE;
 
     Arena ar(ws, ws_bytes);
     SaBuffers b;
-    carve_sa(ar, capacity < 2 ? 2 : capacity, 0, &b);
+    carve_sa(ar, n < 2 ? 2 : n, capacity < 2 ? 2 : capacity, 0, &b);
     uint32_t* block_counts = ar.take<uint32_t>(kMaxGrid);
     if (ar.overflow) return SFX_ERR_WORKSPACE;
 
     Alphabet alpha;
-    SFX_TRY(alphabet_from_bins((const unsigned long long*)d_byte_bins, b, st, &alpha));
+    PackedText pt;
+    SFX_TRY(prepare_text(d_text, n, (const unsigned long long*)d_byte_bins, b.lut, b.packed, st, &alpha,
+                         &pt));
     int key_bits, cpk;
     choose_key(alpha, n, &key_bits, &cpk);
     if (alpha.bits * cpk < top_bits) return SFX_ERR_ARG;
@@ -838,10 +805,10 @@ int build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint64_t* d_
     stats.key_bits = (uint32_t)key_bits;
     stats.symbols_per_key = (uint32_t)cpk;
     if (key_bits == 32)
-        return range_build<uint32_t>(d_text, n, alpha, cpk, top_bits, bin_lo, bin_hi, capacity,
-                                     d_sa_part, count_out, b, block_counts, st, stats);
-    return range_build<uint64_t>(d_text, n, alpha, cpk, top_bits, bin_lo, bin_hi, capacity, d_sa_part,
-                                 count_out, b, block_counts, st, stats);
+        return range_build<uint32_t>(pt, cpk, top_bits, bin_lo, bin_hi, capacity, d_sa_part, count_out, b,
+                                     block_counts, st, stats);
+    return range_build<uint64_t>(pt, cpk, top_bits, bin_lo, bin_hi, capacity, d_sa_part, count_out, b,
+                                 block_counts, st, stats);
 }
 
 }  // namespace sfx

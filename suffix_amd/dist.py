@@ -92,7 +92,7 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS):
     # 5. this rank's slice
     cap = max(count, 1)
     sa_part = torch.empty(cap, dtype=torch.int32, device=dev)
-    ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
+    ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(n, cap)), dtype=torch.uint8, device=dev)
     got = ctypes.c_uint64(0)
     eng.check(eng.lib.sfx_build_sa_range_u32_dev(_p(text), n, _p(byte_bins), tb, lo, hi, cap,
                                                  _p(sa_part), ctypes.byref(got), _p(ws), ws.numel(),

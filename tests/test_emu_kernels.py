@@ -90,4 +90,5 @@ def test_build_stats_and_profile(emu):
     assert st["key_bits"] == 32 and st["symbols_per_key"] == 16
     rep = {r["name"]: r for r in emu.profile_report()}
     emu.profile(False)
-    assert rep["radix_scatter_u32"]["launches"] >= 4 and rep["radix_scatter_u32"]["algo_bytes"] > 0
+    assert rep["radix_scatter_text_u32"]["launches"] >= 1 and rep["radix_scatter_u32"]["launches"] >= 3
+    assert rep["radix_scatter_u32"]["algo_bytes"] > 0 and "pack_text" in rep

@@ -140,7 +140,7 @@ def test_partitioned_build_single_rank_slices(eng, oracle):
         pieces = []
         for lo, hi, off, cnt in sdist.plan_ranges(kb.cpu(), 3):
             part = torch.empty(max(cnt, 1), dtype=torch.int32, device="cuda")
-            ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(max(cnt, 1))), dtype=torch.uint8, device="cuda")
+            ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(n, max(cnt, 1))), dtype=torch.uint8, device="cuda")
             got = ctypes.c_uint64(0)
             eng.check(eng.lib.sfx_build_sa_range_u32_dev(_p(t), n, _p(bb), 14, lo, hi, max(cnt, 1), _p(part),
                                                          ctypes.byref(got), _p(ws), ws.numel(), None), "range")
