@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Full-size runs of BASELINE.json configs 3 and 5 (and a 1 GB DNA control) on one
+MI355X: device-resident SA (+LCP, + 1M batched queries), size-independent property
+checks, sampled comparison with the oracle.  Writes gpurun_out/big/results.jsonl."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _gen  # noqa: E402
+import bench  # noqa: E402
+import suffix_amd  # noqa: E402
+from suffix_amd import device as sdev  # noqa: E402
+
+OUT = os.path.join(ROOT, "gpurun_out", "big")
+os.makedirs(OUT, exist_ok=True)
+eng = suffix_amd.default_engine()
+eng.require_device()
+dev = torch.device("cuda", 0)
+
+
+def timed(fn, reps=1):
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return r, best
+
+
+def run(name, host_text, with_lcp=True, queries=0, reps=2):
+    n = host_text.size
+    rec = {"config": name, "n": int(n)}
+    text = torch.from_numpy(host_text).to(dev)
+    ws = sdev.sa_workspace(n, dev)
+    sa = torch.empty(n, dtype=torch.int32, device=dev)
+    _, t_sa = timed(lambda: sdev.build_sa(text, out=sa, workspace=ws), reps)
+    rec["sa_ms"] = round(t_sa * 1e3, 2)
+    rec["sa_MBps"] = round(n / t_sa / 1e6, 1)
+    rec["build"] = eng.build_stats()
+    eng.profile(True); eng.profile_reset()
+    sdev.build_sa(text, out=sa, workspace=ws); torch.cuda.synchronize()
+    rec["sa_kernel_ms"] = {r["name"]: round(r["total_ms"], 3) for r in eng.profile_report()}
+    eng.profile(False)
+    del ws
+    if with_lcp:
+        lws = sdev.lcp_workspace(n, dev)
+        lcp = torch.empty(n, dtype=torch.int32, device=dev)
+        _, t_lcp = timed(lambda: sdev.build_lcp(text, sa, out=lcp, workspace=lws), reps)
+        rec["lcp_ms"] = round(t_lcp * 1e3, 2)
+        rec["lcp_MBps"] = round(n / t_lcp / 1e6, 1)
+        rec["sa_plus_lcp_MBps"] = round(n / (t_sa + t_lcp) / 1e6, 1)
+        rec["max_lcp"] = int((lcp.to(torch.int64) & 0xFFFFFFFF).max())
+        rec["mean_lcp"] = float((lcp.to(torch.int64) & 0xFFFFFFFF).double().mean())
+        del lcp, lws
+    ok, how = bench.verify_sa_on_device(torch, sdev, text, sa)
+    rec["verified"], rec["verification"] = bool(ok), how
+    if queries:
+        import oracle
+        rng = np.random.default_rng(17)
+        starts = rng.integers(0, n - 64, size=queries)
+        lens = rng.integers(1, 33, size=queries)
+        # move to code-point boundaries (not a continuation byte) at both ends
+        for _ in range(3):
+            starts = np.where((host_text[starts] & 0xC0) == 0x80, starts + 1, starts)
+        ends = starts + lens
+        for _ in range(3):
+            ends = np.where((host_text[np.minimum(ends, n - 1)] & 0xC0) == 0x80, ends + 1, ends)
+        lens = (ends - starts).astype(np.int64)
+        off = np.zeros(queries + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens)
+        idx = np.arange(off[-1], dtype=np.int64) - np.repeat(off[:-1], lens) + np.repeat(starts, lens)
+        qb = host_text[idx].copy()
+        miss = np.arange(queries // 2, queries)               # second half: corrupt the last byte
+        qb[off[miss + 1] - 1] ^= 0x15
+        d_qb, d_off = torch.from_numpy(qb).to(dev), torch.from_numpy(off).to(dev)
+        (s, e, f, a), t_q = timed(lambda: sdev.query_batch(text, sa, d_qb, d_off), reps)
+        rec["queries"] = queries
+        rec["query_ms"] = round(t_q * 1e3, 2)
+        rec["Mqueries_per_s"] = round(queries / t_q / 1e6, 2)
+        rec["hit_fraction"] = float(f.float().mean())
+        s, e, f = s.cpu().numpy(), e.cpu().numpy(), f.cpu().numpy()
+        sa_h = sa.cpu().numpy().view(np.uint32)
+        tb = host_text.tobytes()
+        bad = 0
+        for k in rng.integers(0, queries, size=1500).tolist():
+            q = qb[off[k]:off[k + 1]].tobytes()
+            if (int(s[k]), int(e[k])) != oracle.positions(tb, sa_h, q):
+                bad += 1
+        rec["query_mismatches_vs_oracle_of_1500"] = bad
+    print(json.dumps(rec), flush=True)
+    with open(os.path.join(OUT, "results.jsonl"), "a") as fh:
+        fh.write(json.dumps(rec) + "\n")
+    del text, sa
+    torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c3", "c5", "dna1g"]
+    size = int(os.environ.get("SFX_BIG_N", "1000000000"))
+    if "c3" in which:
+        t0 = time.time(); h = _gen.english_like(size); print("gen english", round(time.time() - t0, 1), "s", flush=True)
+        run("config3: 1 GB English-like ASCII, SA + LCP", h)
+    if "c5" in which:
+        t0 = time.time(); h = _gen.utf8_mixed(size); print("gen utf8", round(time.time() - t0, 1), "s", flush=True)
+        run("config5: 1 GB UTF-8 mixed-script, SA + LCP + 1M positions() queries", h, queries=1_000_000)
+    if "dna1g" in which:
+        t0 = time.time(); h = _gen.dna(size, seed=0x5AF1C5 + 4); print("gen dna", round(time.time() - t0, 1), "s", flush=True)
+        run("control: 1 GB uniform DNA, SA + LCP", h)

@@ -94,7 +94,7 @@ __device__ __forceinline__ T block_scan_max_excl(T v, T* part, T& total)
 
 // ---- packed text -------------------------------------------------------------------
 // The text is re-coded once per build into dense symbol codes of `bits` bits and
-// packed big-endian, spw = 2^spw_log2 symbols per 32-bit word (DNA: 16 symbols per
+// packed big-endian, spw = floor(32/bits) symbols per 32-bit word (DNA: 16 symbols per
 // word, 25 MB for 100 MB of text -- resident in L2 / Infinity Cache).  Word j holds
 // positions [j*spw, (j+1)*spw) in its low kbits = bits*spw bits; positions past the
 // end of the text read as 0 and the array carries 3 extra zero words, so a key can be
@@ -103,29 +103,35 @@ struct PackedText {
     const uint32_t* words;
     uint64_t n;
     int bits;
-    int spw_log2;
-    int kbits;
+    int spw;            // symbols per word
+    int kbits;          // bits * spw  (<= 32)
+    double inv_spw;     // 1.0 / spw
 };
+
+// p / spw for any spw in 1..32, exact for p < 2^52: (p + 0.5) / spw is at least
+// 0.5/32 away from every integer, far more than the rounding error of the product.
+__device__ __forceinline__ uint64_t packed_word_index(const PackedText& t, uint64_t p)
+{
+    return (uint64_t)(((double)p + 0.5) * t.inv_spw);
+}
 
 // the spw symbols starting at position p, as a kbits-bit big-endian number
 __device__ __forceinline__ uint32_t packed_key32(const PackedText& t, uint64_t p)
 {
-    const unsigned spw = 1u << t.spw_log2;
-    const uint64_t q = p >> t.spw_log2;
-    const unsigned off = (unsigned)p & (spw - 1u);
+    const uint64_t q = packed_word_index(t, p);
+    const unsigned off = (unsigned)(p - q * (uint64_t)t.spw);
     const uint64_t both = ((uint64_t)t.words[q] << t.kbits) | (uint64_t)t.words[q + 1];
     const uint64_t mask = (1ull << t.kbits) - 1ull;
-    return (uint32_t)((both >> ((spw - off) * (unsigned)t.bits)) & mask);
+    return (uint32_t)((both >> (((unsigned)t.spw - off) * (unsigned)t.bits)) & mask);
 }
 // the 2*spw symbols starting at p, as a 2*kbits-bit number
 __device__ __forceinline__ uint64_t packed_key64(const PackedText& t, uint64_t p)
 {
-    const unsigned spw = 1u << t.spw_log2;
-    const uint64_t q = p >> t.spw_log2;
-    const unsigned off = (unsigned)p & (spw - 1u);
+    const uint64_t q = packed_word_index(t, p);
+    const unsigned off = (unsigned)(p - q * (uint64_t)t.spw);
     const uint64_t w0 = t.words[q], w1 = t.words[q + 1], w2 = t.words[q + 2];
     const uint64_t mask = (1ull << t.kbits) - 1ull;
-    const unsigned sh = (spw - off) * (unsigned)t.bits;
+    const unsigned sh = ((unsigned)t.spw - off) * (unsigned)t.bits;
     const uint64_t a = (((w0 << t.kbits) | w1) >> sh) & mask;
     const uint64_t b = (((w1 << t.kbits) | w2) >> sh) & mask;
     return (a << t.kbits) | b;

@@ -218,7 +218,7 @@ static int radix_sort_impl(KeyT* k0, uint32_t* v0, KeyT* k1, uint32_t* v1, uint6
                            sfx_build_stats* stats, const PackedText* src)
 {
     constexpr int kTile = kBlock * KPT;
-    PackedText none = {nullptr, 0, 0, 0, 0};
+    PackedText none = {nullptr, 0, 0, 1, 0, 1.0};
     Chunking ch = make_chunking(m, kTile);
     const uint64_t chunk = ch.tiles_per_block * kTile;
     uint32_t* digit_total = hist + (uint64_t)kRadix * kMaxGrid;

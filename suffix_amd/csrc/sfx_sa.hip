@@ -44,7 +44,7 @@
 
 namespace sfx {
 
-constexpr int kPackTile = 4096;          // text positions per workgroup step in k_pack_text
+constexpr int kPackWords = kBlock;       // packed words per workgroup step in k_pack_text
 constexpr int kMaxTopBits = 14;          // 16384 u32 bins = 64 KiB of LDS
 
 // ---------------------------------------------------------------------------------
@@ -77,34 +77,33 @@ k_make_lut(const unsigned long long* __restrict__ bins, uint8_t* __restrict__ lu
 }
 
 // words[j] = symbols of positions [j*spw, (j+1)*spw), big-endian, `bits` bits each,
-// 0 past the end; plus 3 trailing zero words (see PackedText).
+// 0 past the end; plus 3 trailing zero words (see PackedText).  A tile is
+// kPackWords words = kPackWords*spw text positions.
 __global__ void __launch_bounds__(kBlock)
 k_pack_text(const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ lut, int bits,
-            int spw_log2, uint64_t tiles_per_block, uint64_t n_words_total,
-            uint32_t* __restrict__ words)
+            int spw, uint64_t tiles_per_block, uint64_t n_words_total, uint32_t* __restrict__ words)
 {
     __shared__ uint8_t s_lut[256];
-    __shared__ uint8_t codes[kPackTile];
-    const unsigned tid = threadIdx.x, spw = 1u << spw_log2;
+    __shared__ uint8_t codes[kPackWords * 32];
+    const unsigned tid = threadIdx.x;
+    const unsigned tile_pos = (unsigned)kPackWords * (unsigned)spw;
     s_lut[tid] = lut[tid];
     __syncthreads();
-    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kPackTile;
-    uint64_t end = begin + tiles_per_block * kPackTile;
-    uint64_t limit = n_words_total << spw_log2;           // positions covered by the word array
-    if (end > limit) end = limit;
-    for (uint64_t tile = begin; tile < end; tile += kPackTile) {
-        for (unsigned j = tid; j < (unsigned)kPackTile; j += kBlock) {
+    uint64_t wbegin = (uint64_t)blockIdx.x * tiles_per_block * kPackWords;
+    uint64_t wend = wbegin + tiles_per_block * kPackWords;
+    if (wend > n_words_total) wend = n_words_total;
+    for (uint64_t wt = wbegin; wt < wend; wt += kPackWords) {
+        const uint64_t tile = wt * (uint64_t)spw;
+        for (unsigned j = tid; j < tile_pos; j += kBlock) {
             uint64_t g = tile + j;
             codes[j] = (g < n) ? s_lut[text[g]] : (uint8_t)0;
         }
         __syncthreads();
-        for (unsigned wj = tid; wj < ((unsigned)kPackTile >> spw_log2); wj += kBlock) {
-            uint64_t gw = (tile >> spw_log2) + wj;
-            if (gw < n_words_total) {
-                uint32_t w = 0;
-                for (unsigned s = 0; s < spw; s++) w = (w << bits) | codes[wj * spw + s];
-                words[gw] = w;
-            }
+        uint64_t gw = wt + tid;                         // kPackWords == kBlock: one word per thread
+        if (gw < wend) {
+            uint32_t w = 0;
+            for (int s = 0; s < spw; s++) w = (w << bits) | codes[tid * (unsigned)spw + s];
+            words[gw] = w;
         }
         __syncthreads();
     }
@@ -425,8 +424,8 @@ k_isa_fix_active(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ 
 struct Alphabet {
     unsigned sigma;
     int bits;           // bits per symbol
-    int spw_log2;       // log2(symbols per packed word): largest power of two <= 32/bits
-    int kbits;          // bits * 2^spw_log2 (<= 32)
+    int spw;            // symbols per packed word = floor(32/bits)
+    int kbits;          // bits * spw (<= 32)
 };
 
 static Alphabet make_alphabet(const unsigned long long* bins)
@@ -435,34 +434,36 @@ static Alphabet make_alphabet(const unsigned long long* bins)
     a.sigma = 0;
     for (int c = 0; c < 256; c++) if (bins[c]) a.sigma++;
     a.bits = bits_for(a.sigma > 1 ? a.sigma - 1 : 1);
-    a.spw_log2 = 0;
-    while ((2 << a.spw_log2) * a.bits <= 32) a.spw_log2++;
-    a.kbits = a.bits << a.spw_log2;
+    a.spw = 32 / a.bits;
+    a.kbits = a.bits * a.spw;
     return a;
 }
 
-// 32-bit keys (spw symbols) when they are expected to separate most suffixes of a
-// random text over this alphabet (spw*floor(log2 sigma) >= log2 n + 3), else 64-bit
-// keys (2*spw symbols).  Depends only on (alphabet, n): identical on every rank.
+// 32-bit keys (spw symbols) when they are expected to separate at least half of the
+// suffixes of a random text over this alphabet (spw*floor(log2 sigma) >= log2 n + 1):
+// 4 cheap passes plus a refinement round on the rest move fewer bytes than 8 passes
+// over 12-byte elements.  Else 64-bit keys (2*spw symbols).  Depends only on
+// (alphabet, n): identical on every rank.
 static void choose_key(const Alphabet& a, uint64_t n, int* key_bits, int* cpk)
 {
-    int spw = 1 << a.spw_log2;
+    int spw = a.spw;
     int l2 = bits_for(a.sigma) - 1;                 // floor(log2 sigma), sigma >= 1
     if (l2 < 1) l2 = 1;
-    if (spw * l2 >= bits_for(n) + 3) { *key_bits = 32; *cpk = spw; }
+    if (spw * l2 >= bits_for(n) + 1) { *key_bits = 32; *cpk = spw; }
     else { *key_bits = 64; *cpk = 2 * spw; }
 }
 
 static uint64_t packed_words(uint64_t n, const Alphabet* a)
 {
-    int lg = a ? a->spw_log2 : 2;                   // worst case: 4 symbols per word
-    return ((n + (1ull << lg) - 1) >> lg) + 3;
+    uint64_t spw = a ? (uint64_t)a->spw : 4;        // worst case: 4 symbols per word
+    return (n + spw - 1) / spw + 3;
 }
 
 // A full build whose initial sort leaves at most 1/kTextFirstDivisor of the suffixes
-// unresolved spends its first refinement round on text symbols: that round needs no
+// unresolved, over an alphabet small enough that one packed word carries >= 8 symbols
+// (sigma <= 16), spends its first refinement round on text symbols: that round needs no
 // rank array, so the n-element ISA scatter is skipped unless a further round is needed.
-constexpr uint64_t kTextFirstDivisor = 8;
+constexpr uint64_t kTextFirstDivisor = 4;
 
 struct SaBuffers {
     uint64_t* K0; uint64_t* K1;                         // key ping-pong (8 B per element)
@@ -580,14 +581,15 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
     SFX_HIP(hipStreamSynchronize(st));
     *alpha = make_alphabet(host_bins);
     uint64_t nw = packed_words(n, alpha);
-    Chunking ch = make_chunking(nw << alpha->spw_log2, kPackTile);
+    Chunking ch = make_chunking(nw, kPackWords);
     SFX_LAUNCH("pack_text", (double)n * (1.0 + alpha->bits / 8.0), k_pack_text, ch.blocks, kBlock, st,
-               d_text, n, d_lut, alpha->bits, alpha->spw_log2, ch.tiles_per_block, nw, d_packed);
+               d_text, n, d_lut, alpha->bits, alpha->spw, ch.tiles_per_block, nw, d_packed);
     pt->words = d_packed;
     pt->n = n;
     pt->bits = alpha->bits;
-    pt->spw_log2 = alpha->spw_log2;
+    pt->spw = alpha->spw;
     pt->kbits = alpha->kbits;
+    pt->inv_spw = 1.0 / alpha->spw;
     return SFX_OK;
 }
 
@@ -602,7 +604,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
 {
     const uint64_t n = pt.n;
     uint64_t h = (uint64_t)cpk;
-    const int spw = 1 << pt.spw_log2;
+    const int spw = pt.spw;
     const int flag_shift = dmax(pt.kbits, bits_for(n));
     int rounds = 0;
     while (m > 0) {
@@ -668,7 +670,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups));
     stats.active_after_initial = kept;
     // few unresolved suffixes: one text round first, ISA only if that does not finish the job
-    const int text_rounds = (isa && kept * kTextFirstDivisor <= count) ? 1 : 0;
+    const int text_rounds = (isa && kept * kTextFirstDivisor <= count && pt.spw >= 8) ? 1 : 0;
     uint32_t* V_next = in1 ? b.VA : b.VB;
     SFX_TRY(round_apply<KeyT>(Kr, in1 ? b.VB : b.VA, nullptr, count, b, sa,
                               (isa && !text_rounds) ? isa : nullptr, b.S0, V_next, nullptr, st));

@@ -96,7 +96,7 @@ def random_small(eng, orc, iters, max_len, seed):
     rnd = random.Random(seed)
     for _ in range(iters):
         n = rnd.randint(0, max_len)
-        sigma = rnd.choice([1, 2, 3, 4, 5, 16, 97, 256])
+        sigma = rnd.choice([1, 2, 3, 4, 5, 16, 20, 50, 97, 256])
         t = bytes(rnd.randrange(sigma) for _ in range(n))
         qs = []
         for _ in range(4):

@@ -39,77 +39,124 @@ _LFREQ = np.array([12.7, 9.1, 8.2, 7.5, 7.0, 6.7, 6.3, 6.1, 6.0, 4.3, 4.0, 2.8, 
                    2.4, 2.2, 2.0, 2.0, 1.9, 1.5, 1.0, 0.8, 0.15, 0.15, 0.1, 0.07])
 
 
+def _ragged_gather(pool, starts, lens):
+    """concatenate pool[starts[k] : starts[k]+lens[k]] for all k (vectorised)."""
+    total = int(lens.sum())
+    out_off = np.cumsum(lens) - lens
+    idx = np.arange(total, dtype=np.int64) - np.repeat(out_off, lens) + np.repeat(starts, lens)
+    return pool[idx]
+
+
 def english_like(n, seed=0x5AF1C5 + 2, vocab=50000):
-    """~n bytes of English-like ASCII: Zipf(1.0) draws from `vocab` pseudo-words of
-    length 1-12 built from English letter frequencies, joined by ' ', ', ' (p=.08)
-    or '. ' (p=.06, next word capitalised), '\\n' instead of the space roughly every
-    80 chars.  Exactly n bytes are returned."""
+    """Exactly n bytes of English-like ASCII: Zipf(1.0) draws
+    from `vocab` pseudo-words of length 1-12 built from English letter frequencies,
+    joined by ' ' / ', ' (p=.08) / '. ' (p=.06, next word capitalised); the separator's
+    space becomes '\n' roughly every 80 characters.  Fully vectorised (1 GB in ~1 min)."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    lens = rng.integers(1, 13, size=vocab)
+    wlen = rng.integers(1, 13, size=vocab).astype(np.int64)
     cdf = np.cumsum(_LFREQ) / _LFREQ.sum()
-    pool = _LETTERS[np.searchsorted(cdf, rng.random(int(lens.sum())))]
-    offs = np.concatenate(([0], np.cumsum(lens)))
-    words = [pool[offs[i]:offs[i + 1]].tobytes() for i in range(vocab)]
+    letters = _LETTERS[np.searchsorted(cdf, rng.random(int(wlen.sum())))]
+    wstart = np.cumsum(wlen) - wlen
+    # token pool: word (lower / capitalised) followed by one of 6 separators
+    seps = [b" ", b", ", b". ", b"\n", b",\n", b".\n"]
+    pool_parts, p_start, p_len = [], np.zeros((vocab, 2, 6), np.int64), np.zeros((vocab, 2, 6), np.int64)
+    lower = letters
+    upper = letters.copy()
+    upper[wstart] -= 32                                   # capitalise first letters
+    off = 0
+    for cap, src in enumerate((lower, upper)):
+        for si, sp in enumerate(seps):
+            lens = wlen + len(sp)
+            st = off + np.cumsum(lens) - lens
+            buf = np.empty(int(lens.sum()), dtype=np.uint8)
+            idx_word = _ragged_gather(np.arange(src.size, dtype=np.int64), wstart, wlen)
+            dst = np.arange(buf.size, dtype=np.int64)
+            is_sep = np.ones(buf.size, dtype=bool)
+            word_dst = _ragged_gather(dst, st - off, wlen)
+            buf[word_dst] = src[idx_word]
+            is_sep[word_dst] = False
+            buf[is_sep] = np.tile(np.frombuffer(sp, dtype=np.uint8), vocab)
+            pool_parts.append(buf)
+            p_start[:, cap, si] = st
+            p_len[:, cap, si] = lens
+            off += buf.size
+    pool = np.concatenate(pool_parts)
     zipf = 1.0 / np.arange(1, vocab + 1)
     zcdf = np.cumsum(zipf) / zipf.sum()
-    out = bytearray()
-    col = 0
-    cap = True
-    chunk = 1 << 16
-    while len(out) < n:
+    out = np.empty(n, dtype=np.uint8)
+    filled, col_base, prev_period = 0, 0, True
+    chunk = 1 << 22
+    while filled < n:
         ws = np.searchsorted(zcdf, rng.random(chunk))
         ps = rng.random(chunk)
-        for w, p in zip(ws.tolist(), ps.tolist()):
-            tok = words[w]
-            if cap:
-                tok = tok[:1].upper() + tok[1:]
-                cap = False
-            if p < 0.06:
-                sep = b". "
-                cap = True
-            elif p < 0.14:
-                sep = b", "
-            else:
-                sep = b" "
-            col += len(tok) + len(sep)
-            if col >= 80:
-                sep = sep[:-1] + b"\n"
-                col = 0
-            out += tok
-            out += sep
-            if len(out) >= n:
-                break
-    return np.frombuffer(bytes(out[:n]), dtype=np.uint8)
+        kind = np.where(ps < 0.06, 2, np.where(ps < 0.14, 1, 0))
+        cap = np.empty(chunk, dtype=np.int64)
+        cap[0] = 1 if prev_period else 0
+        cap[1:] = (kind[:-1] == 2)
+        base_len = wlen[ws] + np.where(kind == 0, 1, 2)
+        cum = np.cumsum(base_len) + col_base
+        nl = (cum // 80) != ((cum - base_len) // 80)        # crossed a multiple of 80 columns
+        si = kind + 3 * nl
+        starts = p_start[ws, cap, si]
+        lens = p_len[ws, cap, si]
+        piece = _ragged_gather(pool, starts, lens)
+        take = min(piece.size, n - filled)
+        out[filled:filled + take] = piece[:take]
+        filled += take
+        col_base = int(cum[-1] % 80)
+        prev_period = bool(kind[-1] == 2)
+    return out
 
 
 def utf8_mixed(n, seed=0x5AF1C5 + 5):
-    """<= n bytes of valid UTF-8 mixing 1/2/3/4-byte code points (config 5),
-    truncated at a code-point boundary."""
+    """<= n bytes of valid UTF-8 mixing 1/2/3/4-byte code points (SURVEY.md 8d, config
+    5): words of 1-8 code points, script per word 40% ASCII, 20% Cyrillic (2 B), 30% CJK
+    (3 B), 10% U+1F300.. (4 B), separated by spaces; truncated at a code-point boundary."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    out = []
-    size = 0
+    lo = np.array([0x61, 0x0410, 0x4E00, 0x1F300], dtype=np.int64)
+    span = np.array([26, 64, 2000, 0x300], dtype=np.int64)
+    parts, size = [], 0
     while size < n:
-        script = rng.random()
-        wl = int(rng.integers(1, 9))
-        if script < 0.40:
-            cps = rng.integers(0x61, 0x7B, size=wl)
-        elif script < 0.60:
-            cps = rng.integers(0x0410, 0x0450, size=wl)
-        elif script < 0.90:
-            cps = rng.integers(0x4E00, 0x4E00 + 2000, size=wl)
-        else:
-            cps = rng.integers(0x1F300, 0x1F600, size=wl)
-        w = ("".join(map(chr, cps.tolist())) + " ").encode("utf-8")
-        out.append(w)
-        size += len(w)
-    b = b"".join(out)[:n]
-    while True:                      # trim to a code-point boundary
-        try:
-            b.decode("utf-8")
-            break
-        except UnicodeDecodeError:
-            b = b[:-1]
-    return np.frombuffer(b, dtype=np.uint8)
+        W = max(1024, min(1 << 21, (n - size) // 6 + 1024))
+        sc = np.searchsorted(np.array([0.40, 0.60, 0.90]), rng.random(W), side="right")
+        wl = rng.integers(1, 9, size=W)
+        tot = int(wl.sum())
+        sc_c = np.repeat(sc, wl)
+        cp = lo[sc_c] + (rng.random(tot) * span[sc_c]).astype(np.int64)
+        # interleave a space after every word
+        ends = np.cumsum(wl)
+        cps = np.empty(tot + W, dtype=np.int64)
+        pos = np.arange(tot) + np.repeat(np.arange(W), wl)
+        cps[pos] = cp
+        cps[ends + np.arange(W)] = 0x20
+        nb = np.where(cps < 0x80, 1, np.where(cps < 0x800, 2, np.where(cps < 0x10000, 3, 4)))
+        off = np.cumsum(nb) - nb
+        buf = np.empty(int(nb.sum()), dtype=np.uint8)
+        m1, m2, m3, m4 = nb == 1, nb == 2, nb == 3, nb == 4
+        buf[off[m1]] = cps[m1]
+        buf[off[m2]] = 0xC0 | (cps[m2] >> 6)
+        buf[off[m2] + 1] = 0x80 | (cps[m2] & 0x3F)
+        buf[off[m3]] = 0xE0 | (cps[m3] >> 12)
+        buf[off[m3] + 1] = 0x80 | ((cps[m3] >> 6) & 0x3F)
+        buf[off[m3] + 2] = 0x80 | (cps[m3] & 0x3F)
+        buf[off[m4]] = 0xF0 | (cps[m4] >> 18)
+        buf[off[m4] + 1] = 0x80 | ((cps[m4] >> 12) & 0x3F)
+        buf[off[m4] + 2] = 0x80 | ((cps[m4] >> 6) & 0x3F)
+        buf[off[m4] + 3] = 0x80 | (cps[m4] & 0x3F)
+        parts.append(buf)
+        size += buf.size
+    b = np.concatenate(parts)[:n]
+    end = b.size
+    while end > 0 and (b[end - 1] & 0xC0) == 0x80:          # strip trailing continuation bytes
+        end -= 1
+    if end > 0 and b[end - 1] >= 0xC0:                       # and a dangling lead byte
+        end -= 1
+    elif end < b.size:                                       # continuation bytes followed a complete char?
+        lead = b[end - 1] if end else 0
+        need = 0 if lead < 0x80 else (2 if lead < 0xE0 else 3 if lead < 0xF0 else 4)
+        have = b.size - end + 1
+        end = b.size if have == need else end - 1
+    return np.ascontiguousarray(b[:end])
 
 
 def fibonacci_string(k):
