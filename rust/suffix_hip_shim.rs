@@ -1,0 +1,126 @@
+//! rust/suffix_hip_shim.rs -- the Rust side of the drop-in boundary.
+//!
+//! NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no rustc/cargo
+//!.  This is the binding a maintainer of BurntSushi/suffix
+//! adds to `src/table.rs` (v1.3.0) to route the hot path through
+//! `libsuffix_hip.so`; every signature below is exactly what
+//! `include/suffix_hip.h` exports, and the ctypes binding in
+//! `suffix_amd/_lib.py` exercises the same symbols with the same argument
+//! meaning on the GPU box.
+//!
+//! What changes in the crate (nothing in `:140-312` or `lib.rs` changes):
+//!   * `sais_table`  (src/table.rs:378-386)  body after `vec![0u32; n]`
+//!   * `lcp_lens`    (src/table.rs:130-138)  body
+//!   * new additive  `SuffixTable::positions_batch` / `contains_batch`
+//! `sais()`, `Bins`, `SuffixTypes` stay in the crate as the reference CPU path.
+//!
+//! build.rs:   println!("cargo:rustc-link-lib=dylib=suffix_hip");
+//!             println!("cargo:rustc-link-search=native={}", env!("SUFFIX_HIP_LIB_DIR"));
+
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct SfxIndex {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    fn sfx_strerror(status: c_int) -> *const c_char;
+    fn sfx_last_hip_error() -> *const c_char;
+    fn sfx_device_count() -> c_int;
+    // SuffixTable::new -> sais_table
+    fn sfx_build_sa_u32(text: *const u8, n: u64, sa_out: *mut u32) -> c_int;
+    // lcp_lens
+    fn sfx_build_lcp_u32(text: *const u8, n: u64, sa: *const u32, lcp_out: *mut u32) -> c_int;
+    // device-resident index for batched queries
+    fn sfx_index_create(text: *const u8, n: u64, sa: *const u32, out: *mut *mut SfxIndex) -> c_int;
+    fn sfx_index_destroy(ix: *mut SfxIndex);
+    fn sfx_positions_batch(ix: *const SfxIndex, qbytes: *const u8, qoff: *const u64, nq: u64,
+                           start_out: *mut u32, end_out: *mut u32) -> c_int;
+    fn sfx_contains_batch(ix: *const SfxIndex, qbytes: *const u8, qoff: *const u64, nq: u64,
+                          found_out: *mut u8, any_out: *mut u32) -> c_int;
+    // device-pointer variants (`*_dev`) take a hipStream_t as *mut c_void; omitted here.
+    #[allow(dead_code)]
+    fn sfx_build_sa_u32_dev(d_text: *const u8, n: u64, d_sa: *mut u32, ws: *mut c_void,
+                            ws_bytes: u64, stream: *mut c_void) -> c_int;
+}
+
+fn check(status: c_int, what: &str) {
+    if status != 0 {
+        let msg = unsafe { std::ffi::CStr::from_ptr(sfx_strerror(status)) }.to_string_lossy();
+        let hip = unsafe { std::ffi::CStr::from_ptr(sfx_last_hip_error()) }.to_string_lossy();
+        // the reference's error convention is panic (assert! at :380, assert_eq! at :117)
+        panic!("{}: {} {}", what, msg, hip);
+    }
+}
+
+/// Replacement for `fn sais_table(text: &str) -> Vec<u32>` (src/table.rs:378-386).
+pub fn sais_table(text: &str) -> Vec<u32> {
+    let text = text.as_bytes();
+    assert!(text.len() <= u32::MAX as usize);              // :380, unchanged
+    let mut sa = vec![0u32; text.len()];                   // :381, unchanged: caller allocates
+    if unsafe { sfx_device_count() } <= 0 {
+        panic!("suffix: no HIP device (build without the `hip` feature for the CPU path)");
+    }
+    check(unsafe { sfx_build_sa_u32(text.as_ptr(), text.len() as u64, sa.as_mut_ptr()) },
+          "sfx_build_sa_u32");
+    sa
+}
+
+/// Replacement for the body of `SuffixTable::lcp_lens` (src/table.rs:130-138).
+pub fn lcp_lens(text: &str, table: &[u32]) -> Vec<u32> {
+    let mut lcp = vec![0u32; table.len()];
+    check(unsafe {
+        sfx_build_lcp_u32(text.as_ptr(), text.len() as u64, table.as_ptr(), lcp.as_mut_ptr())
+    }, "sfx_build_lcp_u32");
+    lcp
+}
+
+/// Additive API: many `positions()` at once.  Returns (start, end) pairs;
+/// `positions(q_k) == &table[start_k as usize .. end_k as usize]` exactly as :244-258.
+pub struct DeviceIndex(*mut SfxIndex);
+unsafe impl Send for DeviceIndex {}
+unsafe impl Sync for DeviceIndex {}          // queries only read the index
+
+impl DeviceIndex {
+    pub fn new(text: &str, table: &[u32]) -> DeviceIndex {
+        let mut h: *mut SfxIndex = std::ptr::null_mut();
+        check(unsafe { sfx_index_create(text.as_ptr(), text.len() as u64, table.as_ptr(), &mut h) },
+              "sfx_index_create");
+        DeviceIndex(h)
+    }
+    pub fn positions_batch(&self, queries: &[&str]) -> Vec<(u32, u32)> {
+        let mut off = Vec::with_capacity(queries.len() + 1);
+        let mut blob = Vec::new();
+        off.push(0u64);
+        for q in queries {
+            blob.extend_from_slice(q.as_bytes());
+            off.push(blob.len() as u64);
+        }
+        let (mut s, mut e) = (vec![0u32; queries.len()], vec![0u32; queries.len()]);
+        check(unsafe {
+            sfx_positions_batch(self.0, blob.as_ptr(), off.as_ptr(), queries.len() as u64,
+                                s.as_mut_ptr(), e.as_mut_ptr())
+        }, "sfx_positions_batch");
+        s.into_iter().zip(e).collect()
+    }
+    pub fn contains_batch(&self, queries: &[&str]) -> Vec<bool> {
+        let mut off = vec![0u64];
+        let mut blob = Vec::new();
+        for q in queries {
+            blob.extend_from_slice(q.as_bytes());
+            off.push(blob.len() as u64);
+        }
+        let mut f = vec![0u8; queries.len()];
+        check(unsafe {
+            sfx_contains_batch(self.0, blob.as_ptr(), off.as_ptr(), queries.len() as u64,
+                               f.as_mut_ptr(), std::ptr::null_mut())
+        }, "sfx_contains_batch");
+        f.into_iter().map(|b| b != 0).collect()
+    }
+}
+impl Drop for DeviceIndex {
+    fn drop(&mut self) {
+        unsafe { sfx_index_destroy(self.0) }
+    }
+}
