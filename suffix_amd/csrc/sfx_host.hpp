@@ -93,16 +93,22 @@ void profile_end(hipStream_t st);
 // ---- cross-TU entry points ----------------------------------------------------------
 struct BuildStats;   // = sfx_build_stats
 
-// radix sort of (key, value) pairs on bits [bit_lo, bit_hi) of the key.
-// Buffers ping-pong between (k0,v0) and (k1,v1); on return *result_in_1 tells
-// which pair holds the sorted data.  `hist` is 256 * kMaxGrid + 256 u32 of scratch.
-// With `src` the first pass reads nothing from (k0,v0): element i is
-// (packed_key<KeyT>(*src, i), i), i.e. the suffix keys come straight from the
-// packed text and are never materialised unsorted.
-template <class KeyT>
-int radix_sort_pairs(KeyT* k0, uint32_t* v0, KeyT* k1, uint32_t* v1, uint64_t m, int bit_lo,
-                     int bit_hi, uint32_t* hist, hipStream_t st, int* result_in_1,
-                     sfx_build_stats* stats, const PackedText* src = nullptr);
+// LSD radix sorts (sfx_radix.hip), 8 bits per pass over element bits [bit_lo, bit_hi).
+// `scratch` is radix_scratch_words(m) u32 of device memory.
+//  - E64: one 64-bit word per suffix, (32-bit key << 32) | suffix.  e0/e1 ping-pong.
+//    With `text` the first pass computes element i from the packed text (e0 holds nothing).
+//    With `split_v` the last pass writes the suffix halves to split_v and the key halves to
+//    a u32 array carved from whichever of e0/e1 it does not read (*split_k_out);
+//    otherwise *result_in_1 tells which buffer holds the sorted elements.
+//  - KV: u64 keys + u32 values, (k0,v0)/(k1,v1) ping-pong; with `text` the first pass
+//    reads (packed_key64(text, i), i) instead of (k0, v0).
+uint64_t radix_scratch_words(uint64_t m);
+int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, uint32_t* scratch,
+                   hipStream_t st, int* result_in_1, sfx_build_stats* stats, const PackedText* text,
+                   uint32_t* split_v, uint32_t** split_k_out);
+int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, int bit_lo,
+                    int bit_hi, uint32_t* scratch, hipStream_t st, int* result_in_1,
+                    sfx_build_stats* stats, const PackedText* text);
 inline int radix_pass_count(int bit_lo, int bit_hi) { return (bit_hi - bit_lo + 7) / 8; }
 
 uint64_t sa_workspace_bytes(uint64_t n);

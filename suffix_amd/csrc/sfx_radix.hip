@@ -1,63 +1,132 @@
-// sfx_radix.hip -- device-wide LSD radix sort of (key, u32 value) pairs.
+// sfx_radix.hip -- device-wide LSD radix sort, 8 key bits (256 buckets) per pass.
 //
 // This is the "bucket" engine of the suffix sorter: where the reference keeps
 // per-symbol bucket head/tail pointers in `Bins` (src/table.rs:671-750) and
 // scatters one suffix at a time (head_insert/tail_insert :723-736), the GPU
-// engine distributes whole arrays of suffixes 8 key bits (256 buckets) per pass:
+// engine distributes whole arrays of suffixes 256 buckets at a time.
 //
-//   k_radix_hist     each persistent workgroup histograms its contiguous chunk
-//                    of keys (16-byte loads) into LDS, one private histogram per
-//                    wave, and writes one column of the [256][blocks] matrix;
-//   k_radix_scan     one workgroup per digit turns its row into exclusive
-//                    offsets and records the digit total (bucket sizes, cf.
-//                    Bins::find_sizes :686-704);
-//   k_radix_scatter  the same chunking; bucket heads (cf. find_head_pointers
-//                    :706-712) live in LDS; every tile of 256*KPT keys is ranked
-//                    with wave64 ballots (8 ballots -> match mask -> popcount
-//                    rank), reordered through LDS so that each bucket's elements
-//                    leave as one contiguous run, then written out; heads advance
-//                    by the tile's bucket sizes.  Stable, so passes compose
-//                    LSD-first.  Keys and values are staged through the SAME LDS
-//                    buffer one after the other, which halves the footprint and
-//                    lets a tile hold 8192 keys (32 per bucket on average = 128-B
-//                    runs) at 4 workgroups per CU.
+// Element layouts
+//   E64   one 64-bit word per suffix: (32-bit key << 32) | suffix index.  Used
+//         whenever the key fits 32 bits (DNA: 16 symbols).  One 8-byte load, one
+//         8-byte LDS staging slot and one 8-byte store per element and pass; a
+//         bucket's share of a 4096-element tile leaves as one 128-byte run.
+//         The last pass may "split": keys -> a u32 array, suffixes -> the SA.
+//   KV    64-bit key array + 32-bit suffix array (composite keys of the
+//         refinement rounds, 2*spw-symbol keys of large alphabets).
+// The first pass of an initial sort is "text-fed": element i is computed from
+// the packed text, the unsorted key array is never materialised.
 //
-// HBM traffic per pass and element: read key (hist) + read key,value + write
-// key,value  =  3*sizeof(Key) + 8 bytes.  No MFMA anywhere: pure scan/scatter.
+// Two schedules for a pass (same tile engine):
+//   one-sweep  (default, m < 2^30)  digit totals of ALL passes come from one
+//         up-front histogram kernel; a pass is a single kernel in which tiles are
+//         handed out by an atomic ticket and each tile obtains its bucket offsets
+//         by decoupled look-back over a [tile][256] status array (agent-scope
+//         relaxed atomics; flag and value share one 32-bit word, so no fence is
+//         needed).  Traffic per pass and element: read + write, nothing else.
+//   chunked    every workgroup owns one contiguous chunk; per pass a histogram
+//         kernel counts the chunk's digits, a scan kernel turns the
+//         [256][workgroups] matrix into offsets, the scatter kernel walks the
+//         chunk.  No inter-workgroup communication inside a launch.
+//
+// Tile engine (k_radix_pass): wave w owns 64*KPT consecutive elements, 64 per
+// round, so (wave, round, lane) order is memory order and the ranking is stable:
+//   rank    each round, lanes with equal digits find each other through a 64-bit
+//           match mask in LDS (ds_or_b64 of the lane bit, read back, lowest lane
+//           of each digit clears the mask and advances the wave's digit count) --
+//           ~10 VALU + 5 LDS instructions per key instead of the ~50 VALU of an
+//           8-ballot match (the ballot form is kept as a variant);
+//   scan    thread d sums digit d over the 4 waves, block scan -> tile-local
+//           bucket starts; bucket heads from look-back (one-sweep) or from the
+//           running cursor kept in thread d's register (chunked);
+//   reorder elements go to their tile-local slot in LDS, are read back in slot
+//           order and leave as one contiguous run per bucket.
+// No MFMA anywhere: pure scan/scatter, HBM-bound by design.
 #include <stdlib.h>
 
 #include "sfx_host.hpp"
 
 namespace sfx {
 
-// --------------------------------------------------------------------------------------
-template <class KeyT, bool FROM_TEXT>
-__global__ void __launch_bounds__(kBlock)
-k_radix_hist(const KeyT* __restrict__ keys, PackedText src, uint64_t m, int shift, unsigned mask,
-             uint64_t chunk, uint32_t* __restrict__ hist)
+constexpr uint32_t kStatusAgg = 1u << 30;        // tile aggregate published
+constexpr uint32_t kStatusPrefix = 2u << 30;     // inclusive prefix published
+constexpr uint32_t kStatusValue = (1u << 30) - 1u;
+constexpr int kMaxPasses = 8;
+constexpr unsigned kHistAllGrid = 1024;          // workgroups of the up-front histogram
+
+// ---- element sources / sinks ---------------------------------------------------------
+struct SrcE64 {
+    static constexpr bool kHasVal = false;
+    const uint64_t* in;
+    __device__ __forceinline__ uint64_t key(uint64_t i) const { return in[i]; }
+    __device__ __forceinline__ uint32_t val(uint64_t) const { return 0u; }
+};
+struct SrcText32 {
+    static constexpr bool kHasVal = false;
+    PackedText t;
+    __device__ __forceinline__ uint64_t key(uint64_t i) const
+    {
+        return ((uint64_t)packed_key32(t, i) << 32) | (uint64_t)(uint32_t)i;
+    }
+    __device__ __forceinline__ uint32_t val(uint64_t) const { return 0u; }
+};
+struct SrcKV {
+    static constexpr bool kHasVal = true;
+    const uint64_t* k;
+    const uint32_t* v;
+    __device__ __forceinline__ uint64_t key(uint64_t i) const { return k[i]; }
+    __device__ __forceinline__ uint32_t val(uint64_t i) const { return v[i]; }
+};
+struct SrcText64 {
+    static constexpr bool kHasVal = true;
+    PackedText t;
+    __device__ __forceinline__ uint64_t key(uint64_t i) const { return packed_key64(t, i); }
+    __device__ __forceinline__ uint32_t val(uint64_t i) const { return (uint32_t)i; }
+};
+struct DstE64 {
+    uint64_t* out;
+    __device__ __forceinline__ void store(uint32_t d, uint64_t key, uint32_t) const { out[d] = key; }
+};
+struct DstSplit32 {
+    uint32_t* k;
+    uint32_t* v;
+    __device__ __forceinline__ void store(uint32_t d, uint64_t key, uint32_t) const
+    {
+        k[d] = (uint32_t)(key >> 32);
+        v[d] = (uint32_t)key;
+    }
+};
+struct DstKV {
+    uint64_t* k;
+    uint32_t* v;
+    __device__ __forceinline__ void store(uint32_t d, uint64_t key, uint32_t val) const
+    {
+        k[d] = key;
+        v[d] = val;
+    }
+};
+
+__device__ __forceinline__ unsigned digit_of(uint64_t key, int shift, unsigned mask)
 {
-    constexpr int kVec = 16 / sizeof(KeyT);                    // keys per 16-byte load
-    struct alignas(16) Vec { KeyT v[kVec]; };
+    return (unsigned)(key >> shift) & mask;
+}
+
+// ---- histograms ------------------------------------------------------------------------
+// chunked schedule: digit counts of one pass for this workgroup's chunk -> column of
+// the [256][workgroups] matrix.
+template <class Src>
+__global__ void __launch_bounds__(kBlock)
+k_radix_hist_chunk(Src src, uint64_t m, int shift, unsigned mask, uint64_t chunk,
+                   uint32_t* __restrict__ hist)
+{
     __shared__ uint32_t h[kWavesPerBlock][kRadix];
     const unsigned tid = threadIdx.x, w = wave_id();
     for (unsigned i = tid; i < kWavesPerBlock * kRadix; i += kBlock) (&h[0][0])[i] = 0;
     __syncthreads();
-    uint64_t begin = (uint64_t)blockIdx.x * chunk;             // chunk is a multiple of the tile
+    uint64_t begin = (uint64_t)blockIdx.x * chunk;
     uint64_t end = begin + chunk;
     if (end > m) end = m;
-    if (FROM_TEXT) {
-        for (uint64_t i = begin + tid; i < end; i += kBlock)
-            atomicAdd(&h[w][(unsigned)(packed_key<KeyT>(src, i) >> shift) & mask], 1u);
-    } else {
-        uint64_t vec_end = begin + ((end > begin ? end - begin : 0) / kVec) * kVec;
-        for (uint64_t i = begin + (uint64_t)tid * kVec; i < vec_end; i += (uint64_t)kBlock * kVec) {
-            Vec q = *reinterpret_cast<const Vec*>(keys + i);
-#pragma unroll
-            for (int j = 0; j < kVec; j++) atomicAdd(&h[w][(unsigned)(q.v[j] >> shift) & mask], 1u);
-        }
-        for (uint64_t i = vec_end + tid; i < end; i += kBlock)
-            atomicAdd(&h[w][(unsigned)(keys[i] >> shift) & mask], 1u);
-    }
+    for (uint64_t i = begin + tid; i < end; i += kBlock)
+        atomicAdd(&h[w][digit_of(src.key(i), shift, mask)], 1u);
     __syncthreads();
     uint32_t c = 0;
 #pragma unroll
@@ -65,9 +134,40 @@ k_radix_hist(const KeyT* __restrict__ keys, PackedText src, uint64_t m, int shif
     hist[(uint64_t)tid * gridDim.x + blockIdx.x] = c;
 }
 
-// grid = 256 workgroups, one per digit: exclusive scan of that digit's row.
+// one-sweep schedule: digit counts of ALL passes in one read of the keys.
+// partial[(pass*256 + digit) * workgroups + workgroup]
+template <class Src>
 __global__ void __launch_bounds__(kBlock)
-k_radix_scan(uint32_t* __restrict__ hist, unsigned nblocks, uint32_t* __restrict__ digit_total)
+k_radix_hist_all(Src src, uint64_t m, int bit_lo, int bit_hi, int npass, uint64_t chunk,
+                 uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[kWavesPerBlock][kMaxPasses][kRadix];     // 32 KiB
+    const unsigned tid = threadIdx.x, w = wave_id();
+    for (unsigned i = tid; i < kWavesPerBlock * kMaxPasses * kRadix; i += kBlock) (&h[0][0][0])[i] = 0;
+    __syncthreads();
+    uint64_t begin = (uint64_t)blockIdx.x * chunk;
+    uint64_t end = begin + chunk;
+    if (end > m) end = m;
+    for (uint64_t i = begin + tid; i < end; i += kBlock) {
+        const uint64_t key = src.key(i);
+        for (int p = 0; p < npass; p++) {
+            const int shift = bit_lo + p * kRadixBits;
+            const int nb = bit_hi - shift < kRadixBits ? bit_hi - shift : kRadixBits;
+            atomicAdd(&h[w][p][digit_of(key, shift, (1u << nb) - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < npass; p++) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < kWavesPerBlock; k++) c += h[k][p][tid];
+        partial[((uint64_t)p * kRadix + tid) * gridDim.x + blockIdx.x] = c;
+    }
+}
+
+// one workgroup per row: exclusive scan of the row in place, row total -> row_total.
+__global__ void __launch_bounds__(kBlock)
+k_radix_scan(uint32_t* __restrict__ hist, unsigned nblocks, uint32_t* __restrict__ row_total)
 {
     __shared__ uint32_t part[kWavesPerBlock];
     uint32_t* row = hist + (uint64_t)blockIdx.x * nblocks;
@@ -80,180 +180,383 @@ k_radix_scan(uint32_t* __restrict__ hist, unsigned nblocks, uint32_t* __restrict
         if (i < nblocks) row[i] = carry + ex;
         carry += total;
     }
-    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
+    if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
 }
 
-// --------------------------------------------------------------------------------------
-template <class KeyT, int KPT, int WPS, bool FROM_TEXT>   // WPS: waves/SIMD the registers must allow
-__global__ void __launch_bounds__(kBlock, WPS)
-k_radix_scatter(const KeyT* __restrict__ kin, const uint32_t* __restrict__ vin, PackedText src,
-                KeyT* __restrict__ kout, uint32_t* __restrict__ vout, uint64_t m, int shift,
-                unsigned mask, uint64_t chunk, const uint32_t* __restrict__ hist,
-                const uint32_t* __restrict__ digit_total)
+// ---- tile engine ---------------------------------------------------------------------
+template <int KPT, bool HAS_VAL>
+struct RadixSmem {
+    unsigned long long flags[kWavesPerBlock][kRadix];   // match mask of the round in flight, per wave
+    uint32_t cnt[kWavesPerBlock][kRadix];               // per-wave digit counts, then tile-local bases
+    uint32_t off[kRadix];                               // global bucket head minus tile-local bucket start
+    uint32_t part[2][kWavesPerBlock];
+    uint32_t ticket;
+    uint64_t stage[kBlock * KPT];
+    uint32_t stage_v[HAS_VAL ? kBlock * KPT : 1];
+};
+
+// exclusive prefix of one value per thread; ONE barrier (callers alternate `par`)
+__device__ __forceinline__ uint32_t block_scan_excl_1b(uint32_t v, uint32_t (*part)[kWavesPerBlock], unsigned& par)
 {
-    constexpr int kTile = kBlock * KPT;
-    __shared__ uint32_t cnt[kWavesPerBlock][kRadix];   // per-wave bucket counts, then bases
-    __shared__ uint32_t dstart[kRadix];                // tile-local first slot of each bucket
-    __shared__ uint32_t cursor[kRadix];                // this workgroup's global bucket heads
-    __shared__ uint32_t part[kWavesPerBlock];
-    __shared__ KeyT stage[kTile];                      // keys, then (as u32) values
-    uint32_t* stage32 = reinterpret_cast<uint32_t*>(stage);
+    const uint32_t incl = wave_scan_add(v);
+    if (lane_id() == 63) part[par][wave_id()] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (unsigned k = 0; k < (unsigned)kWavesPerBlock; k++)
+        if (k < wave_id()) base += part[par][k];
+    par ^= 1u;
+    return base + incl - v;
+}
 
-    const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    const uint64_t lane_lt = (1ull << lane) - 1ull;
+__device__ __forceinline__ unsigned lanes_below(unsigned long long peers)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
+}
 
-    {   // bucket heads: exclusive scan of the digit totals + this workgroup's row offset
-        uint32_t total;
-        uint32_t ex = block_scan_add_excl(digit_total[tid], part, total);
-        cursor[tid] = ex + hist[(uint64_t)tid * gridDim.x + blockIdx.x];
+// rank of this lane's key among the keys with the same digit that its wave has seen so
+// far in this tile (earlier rounds, then lower lanes of this round)
+template <bool RANK_ATOMIC>
+__device__ __forceinline__ uint32_t rank_round(unsigned d, unsigned long long* flags_w, uint32_t* cnt_w,
+                                               unsigned long long mybit)
+{
+    unsigned long long peers;
+    if (RANK_ATOMIC) {
+        atomicOr(&flags_w[d], mybit);
+        wave_sync();
+        peers = flags_w[d];
+    } else {
+        peers = ~0ull;
+#pragma unroll
+        for (int b = 0; b < kRadixBits; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long vote = __ballot(bit);
+            peers &= bit ? vote : ~vote;
+        }
     }
+    const uint32_t pre = cnt_w[d];
+    wave_sync();
+    const unsigned below = lanes_below(peers);
+    if (below == 0) {
+        if (RANK_ATOMIC) flags_w[d] = 0ull;
+        cnt_w[d] = pre + (uint32_t)__popcll(peers);
+    }
+    wave_sync();
+    return pre + below;
+}
+
+// decoupled look-back for digit `tid` of tile `tile_no`: publishes the tile's count,
+// returns the number of elements with this digit in all earlier tiles.
+__device__ __forceinline__ uint32_t lookback(uint32_t* status, uint32_t tile_no, unsigned tid, uint32_t agg)
+{
+    uint32_t* mine = status + (uint64_t)tile_no * kRadix + tid;
+    if (tile_no == 0) {
+        __hip_atomic_store(mine, kStatusPrefix | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0u;
+    }
+    __hip_atomic_store(mine, kStatusAgg | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0;
+    const uint32_t* p = mine;
+    for (uint32_t j = tile_no; j > 0; j--) {
+        p -= kRadix;
+        uint32_t sv = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((sv >> 30) == 0u) {
+            __builtin_amdgcn_s_sleep(1);
+            sv = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        excl += sv & kStatusValue;
+        if ((sv >> 30) == 2u) break;
+    }
+    __hip_atomic_store(mine, kStatusPrefix | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+template <class Src, class Dst, int KPT, bool ONESWEEP, bool RANK_ATOMIC>
+__global__ void __launch_bounds__(kBlock)
+k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t chunk,
+             const uint32_t* __restrict__ hist, const uint32_t* __restrict__ digit_total,
+             uint32_t* __restrict__ status, uint32_t* __restrict__ ticket)
+{
+    constexpr bool HAS_VAL = Src::kHasVal;
+    constexpr int kTile = kBlock * KPT;
+    __shared__ RadixSmem<KPT, HAS_VAL> s;
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const unsigned long long mybit = 1ull << lane;
+    unsigned par = 0;
+
+#pragma unroll
+    for (int k = 0; k < kWavesPerBlock; k++) { s.flags[k][tid] = 0ull; s.cnt[k][tid] = 0u; }
+    // one-sweep: global start of bucket `tid`; chunked: this workgroup's running head of bucket `tid`
+    uint32_t my_head = block_scan_excl_1b(digit_total[tid], s.part, par);
+    if (!ONESWEEP) my_head += hist[(uint64_t)tid * gridDim.x + blockIdx.x];
+
+    uint64_t next = (uint64_t)blockIdx.x * chunk;
+    uint64_t limit = m;
+    if (!ONESWEEP) limit = dmin<uint64_t>(m, next + chunk);
     __syncthreads();
 
-    uint64_t begin = (uint64_t)blockIdx.x * chunk;
-    uint64_t end = begin + chunk;
-    if (end > m) end = m;
+    for (;;) {
+        uint64_t tile;
+        uint32_t tile_no = 0;
+        if (ONESWEEP) {
+            if (tid == 0) s.ticket = atomicAdd(ticket, 1u);
+            __syncthreads();
+            tile_no = s.ticket;
+            tile = (uint64_t)tile_no * kTile;
+        } else {
+            tile = next;
+            next += kTile;
+        }
+        if (tile >= limit) break;
+        const unsigned nvalid = (unsigned)dmin<uint64_t>(kTile, limit - tile);
 
-    for (uint64_t tile = begin; tile < end; tile += kTile) {
-        const unsigned nvalid = (unsigned)dmin<uint64_t>(kTile, end - tile);
-        for (unsigned i = tid; i < kWavesPerBlock * kRadix; i += kBlock) (&cnt[0][0])[i] = 0;
-        __syncthreads();
-
-        KeyT key[KPT];
-        uint32_t pos[KPT];          // rank within (wave, bucket), then tile-local slot
-        // wave-striped: wave w owns tile slots [w*64*KPT, (w+1)*64*KPT), 64 consecutive per round
+        // load: wave-striped, 64 consecutive elements per round; padding sorts last in the tile
+        uint64_t key[KPT];
+        uint32_t val[HAS_VAL ? KPT : 1];
+        uint32_t pos[KPT];
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
-            unsigned idx = w * (kWave * KPT) + r * kWave + lane;
-            if (FROM_TEXT) key[r] = (idx < nvalid) ? packed_key<KeyT>(src, tile + idx) : ~KeyT(0);
-            else key[r] = (idx < nvalid) ? kin[tile + idx] : ~KeyT(0);   // padding sorts last in the tile
+            const unsigned idx = w * (kWave * KPT) + r * kWave + lane;
+            key[r] = (idx < nvalid) ? src.key(tile + idx) : ~0ull;
+            if (HAS_VAL) val[r] = (idx < nvalid) ? src.val(tile + idx) : 0u;
         }
 #pragma unroll
-        for (int r = 0; r < KPT; r++) {
-            unsigned d = (unsigned)(key[r] >> shift) & mask;
-            uint64_t peers = ~0ull;                         // lanes holding the same digit
-#pragma unroll
-            for (int b = 0; b < kRadixBits; b++) {
-                bool bit = (d >> b) & 1u;
-                uint64_t vote = __ballot(bit);
-                peers &= bit ? vote : ~vote;
+        for (int r = 0; r < KPT; r++)
+            pos[r] = rank_round<RANK_ATOMIC>(digit_of(key[r], shift, mask), s.flags[w], s.cnt[w], mybit);
+        __syncthreads();
+
+        // thread d: bucket d's size in this tile -> tile-local start, per-wave bases, global head
+        {
+            const uint32_t c0 = s.cnt[0][tid], c1 = s.cnt[1][tid], c2 = s.cnt[2][tid], c3 = s.cnt[3][tid];
+            const uint32_t tile_count = c0 + c1 + c2 + c3;
+            const uint32_t ex = block_scan_excl_1b(tile_count, s.part, par);
+            s.cnt[0][tid] = ex;
+            s.cnt[1][tid] = ex + c0;
+            s.cnt[2][tid] = ex + c0 + c1;
+            s.cnt[3][tid] = ex + c0 + c1 + c2;
+            // padding elements all carry the largest digit (== mask)
+            const uint32_t real_count = tile_count - ((tid == mask) ? (uint32_t)(kTile - nvalid) : 0u);
+            if (ONESWEEP) {
+                s.off[tid] = my_head + lookback(status, tile_no, tid, real_count) - ex;
+            } else {
+                s.off[tid] = my_head - ex;
+                my_head += real_count;
             }
-            uint32_t pre = cnt[w][d];
-            wave_sync();
-            unsigned below = (unsigned)__popcll(peers & lane_lt);
-            if (below == 0) cnt[w][d] = pre + (uint32_t)__popcll(peers);
-            wave_sync();
-            pos[r] = pre + below;
-        }
-        // values: issued now, consumed after the key phase
-        uint32_t val[KPT];
-#pragma unroll
-        for (int r = 0; r < KPT; r++) {
-            unsigned idx = w * (kWave * KPT) + r * kWave + lane;
-            if (FROM_TEXT) val[r] = (uint32_t)(tile + idx);
-            else val[r] = (idx < nvalid) ? vin[tile + idx] : 0u;
         }
         __syncthreads();
 
-        // bucket sizes of this tile -> tile-local bucket starts and per-wave bases
-        uint32_t c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
-        uint32_t tile_count = c0 + c1 + c2 + c3, total;
-        uint32_t ex = block_scan_add_excl(tile_count, part, total);
-        dstart[tid] = ex;
-        cnt[0][tid] = ex;
-        cnt[1][tid] = ex + c0;
-        cnt[2][tid] = ex + c0 + c1;
-        cnt[3][tid] = ex + c0 + c1 + c2;
-        __syncthreads();
-
-        // key phase: LDS reorder, then each bucket's keys leave as one contiguous run
+        // reorder through LDS: every bucket's elements become one contiguous run
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
-            unsigned d = (unsigned)(key[r] >> shift) & mask;
-            pos[r] += cnt[w][d];
-            stage[pos[r]] = key[r];
+            const unsigned p = pos[r] + s.cnt[w][digit_of(key[r], shift, mask)];
+            s.stage[p] = key[r];
+            if (HAS_VAL) s.stage_v[p] = val[r];
         }
         __syncthreads();
-        uint32_t dest[KPT];
+        // (three separate loops: all LDS reads of a kind are in flight together)
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
-            unsigned p = r * kBlock + tid;
-            KeyT k = stage[p];
-            unsigned d = (unsigned)(k >> shift) & mask;
-            dest[r] = cursor[d] + (p - dstart[d]);
-            if (p < nvalid) kout[dest[r]] = k;
+            key[r] = s.stage[r * kBlock + tid];
+            if (HAS_VAL) val[r] = s.stage_v[r * kBlock + tid];
         }
-        __syncthreads();
-        // value phase through the same buffer
 #pragma unroll
-        for (int r = 0; r < KPT; r++) stage32[pos[r]] = val[r];
-        __syncthreads();
+        for (int r = 0; r < KPT; r++) pos[r] = s.off[digit_of(key[r], shift, mask)] + (r * kBlock + tid);
 #pragma unroll
-        for (int r = 0; r < KPT; r++) {
-            unsigned p = r * kBlock + tid;
-            if (p < nvalid) vout[dest[r]] = stage32[p];
-        }
+        for (int r = 0; r < KPT; r++)
+            if ((unsigned)(r * kBlock) + tid < nvalid) dst.store(pos[r], key[r], HAS_VAL ? val[r] : 0u);
+#pragma unroll
+        for (int k = 0; k < kWavesPerBlock; k++) s.cnt[k][tid] = 0u;
         __syncthreads();
-        cursor[tid] += tile_count;
-        // the next iteration's first barrier (after zeroing cnt) orders this update
     }
 }
 
-// --------------------------------------------------------------------------------------
-// Tuning knob (development only): SFX_RADIX_VARIANT picks the scatter geometry.
-//   0 (default)  = 3
-//   1  8 keys/thread, 6 waves/SIMD     2  16 keys/thread, 4 waves/SIMD
-//   3  16 keys/thread, 3 waves/SIMD    4  32 keys/thread, 2 waves/SIMD
-static int radix_variant(size_t key_bytes, uint64_t m)
+// ---- host side -------------------------------------------------------------------------
+// Tuning knobs (development only; read once per process):
+//   SFX_RADIX_SWEEP  1 = one-sweep (default), 0 = chunked
+//   SFX_RADIX_KPT    elements per thread and tile: 8 (default) or 16
+//   SFX_RADIX_RANK   1 = LDS match masks (default), 0 = 8-ballot match
+struct RadixTuning { int sweep, kpt, rank; };
+static RadixTuning radix_tuning()
 {
-    const char* e = getenv("SFX_RADIX_VARIANT");
-    int forced = e ? atoi(e) : 0;
-    if (forced >= 1 && forced <= 4) return forced;
-    (void)key_bytes; (void)m;
-    return 3;
+    static const RadixTuning t = [] {
+        RadixTuning r = {1, 8, 1};
+        if (const char* e = getenv("SFX_RADIX_SWEEP")) r.sweep = atoi(e) ? 1 : 0;
+        if (const char* e = getenv("SFX_RADIX_KPT")) r.kpt = atoi(e) == 16 ? 16 : 8;
+        if (const char* e = getenv("SFX_RADIX_RANK")) r.rank = atoi(e) ? 1 : 0;
+        return r;
+    }();
+    return t;
 }
 
-template <class KeyT, int KPT, int WPS>
-static int radix_sort_impl(KeyT* k0, uint32_t* v0, KeyT* k1, uint32_t* v1, uint64_t m, int bit_lo,
-                           int bit_hi, uint32_t* hist, hipStream_t st, int* result_in_1,
-                           sfx_build_stats* stats, const PackedText* src)
+uint64_t radix_scratch_words(uint64_t m)
+{
+    // [0, partial): max(one-sweep partials 8*256*1024, chunked matrix 256*2048)
+    // totals 8*256, tickets 64, status m/8 + 256 (tiles of >= 2048 elements)
+    return (uint64_t)kMaxPasses * kRadix * kHistAllGrid + (uint64_t)kMaxPasses * kRadix + 64 + m / 8 + 2 * kRadix;
+}
+
+struct RadixScratch {
+    uint32_t* partial;      // one-sweep: [npass*256][grid] ; chunked: [256][grid]
+    uint32_t* totals;       // [npass][256]
+    uint32_t* tickets;      // [kMaxPasses]
+    uint32_t* status;       // [tiles][256]
+    RadixScratch(uint32_t* base, uint64_t)
+    {
+        partial = base;
+        totals = partial + (uint64_t)kMaxPasses * kRadix * kHistAllGrid;
+        tickets = totals + (uint64_t)kMaxPasses * kRadix;
+        status = tickets + 64;
+    }
+};
+
+template <class Src, class Dst, int KPT, bool ONESWEEP, bool RANK_ATOMIC>
+static int launch_pass(const char* name, double algo_bytes, const Src& src, const Dst& dst, uint64_t m, int shift,
+                       unsigned mask, const RadixScratch& scr, int pass, hipStream_t st)
 {
     constexpr int kTile = kBlock * KPT;
-    PackedText none = {nullptr, 0, 0, 1, 0, 1.0};
-    Chunking ch = make_chunking(m, kTile);
-    const uint64_t chunk = ch.tiles_per_block * kTile;
-    uint32_t* digit_total = hist + (uint64_t)kRadix * kMaxGrid;
-    KeyT* kin = k0; uint32_t* vin = v0;
-    KeyT* kout = k1; uint32_t* vout = v1;
+    if (ONESWEEP) {
+        const uint64_t tiles = (m + kTile - 1) / kTile;
+        const unsigned grid = (unsigned)dmin<uint64_t>(tiles, kMaxGrid);
+        SFX_HIP(hipMemsetAsync(scr.status, 0, tiles * kRadix * sizeof(uint32_t), st));
+        SFX_LAUNCH(name, algo_bytes, (k_radix_pass<Src, Dst, KPT, true, RANK_ATOMIC>), grid, kBlock, st, src, dst, m,
+                   shift, mask, (uint64_t)0, (const uint32_t*)nullptr, (const uint32_t*)(scr.totals + pass * kRadix),
+                   scr.status, scr.tickets + pass);
+    } else {
+        Chunking ch = make_chunking(m, kTile);
+        const uint64_t chunk = ch.tiles_per_block * kTile;
+        SFX_LAUNCH("radix_hist", (double)m * 8.0, (k_radix_hist_chunk<Src>), ch.blocks, kBlock, st, src, m, shift,
+                   mask, chunk, scr.partial);
+        SFX_LAUNCH("radix_scan", (double)kRadix * ch.blocks * 8, k_radix_scan, kRadix, kBlock, st, scr.partial,
+                   ch.blocks, scr.totals);
+        SFX_LAUNCH(name, algo_bytes, (k_radix_pass<Src, Dst, KPT, false, RANK_ATOMIC>), ch.blocks, kBlock, st, src,
+                   dst, m, shift, mask, chunk, (const uint32_t*)scr.partial, (const uint32_t*)scr.totals,
+                   (uint32_t*)nullptr, (uint32_t*)nullptr);
+    }
+    return SFX_OK;
+}
+
+template <class Src, class Dst>
+static int run_pass(const char* name, double algo_bytes, const Src& src, const Dst& dst, uint64_t m, int shift,
+                    unsigned mask, const RadixScratch& scr, int pass, bool sweep, hipStream_t st)
+{
+    const RadixTuning t = radix_tuning();
+#define SFX_PASS(KPT, SW, RK) launch_pass<Src, Dst, KPT, SW, RK>(name, algo_bytes, src, dst, m, shift, mask, scr, pass, st)
+    if (t.kpt == 16) {
+        if (sweep) return t.rank ? SFX_PASS(16, true, true) : SFX_PASS(16, true, false);
+        return t.rank ? SFX_PASS(16, false, true) : SFX_PASS(16, false, false);
+    }
+    if (sweep) return t.rank ? SFX_PASS(8, true, true) : SFX_PASS(8, true, false);
+    return t.rank ? SFX_PASS(8, false, true) : SFX_PASS(8, false, false);
+#undef SFX_PASS
+}
+
+// one-sweep preparation: digit totals of every pass + zeroed tickets
+template <class Src>
+static int prepare_sweep(const char* name, double algo_bytes, const Src& src, uint64_t m, int bit_lo, int bit_hi,
+                         int npass, const RadixScratch& scr, hipStream_t st)
+{
+    Chunking ch = make_chunking(m, kBlock * 8, kHistAllGrid);
+    const uint64_t chunk = ch.tiles_per_block * kBlock * 8;
+    SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
+    SFX_LAUNCH(name, algo_bytes, (k_radix_hist_all<Src>), ch.blocks, kBlock, st, src, m, bit_lo, bit_hi, npass, chunk,
+               scr.partial);
+    SFX_LAUNCH("radix_scan", (double)npass * kRadix * ch.blocks * 8, k_radix_scan, npass * kRadix, kBlock, st,
+               scr.partial, ch.blocks, scr.totals);
+    return SFX_OK;
+}
+
+static bool use_sweep(uint64_t m, int npass)
+{
+    return radix_tuning().sweep && m < (1ull << 30) && npass <= kMaxPasses;
+}
+
+// E64 sort on element bits [bit_lo, bit_hi).  With `text` the first pass computes element i
+// from the packed text (e0 need not hold anything).  With `split_v` the last pass writes
+// the suffix halves to split_v and the key halves to a u32 array carved from whichever of
+// e0/e1 it does not read (returned in *split_k_out); otherwise *result_in_1 tells which
+// buffer holds the sorted elements.
+int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, uint32_t* scratch, hipStream_t st,
+                   int* result_in_1, sfx_build_stats* stats, const PackedText* text, uint32_t* split_v,
+                   uint32_t** split_k_out)
+{
+    *result_in_1 = 0;
+    if (split_k_out) *split_k_out = (uint32_t*)e1;
+    if (m == 0) return SFX_OK;
+    if (bit_hi <= bit_lo) return (text || split_v) ? SFX_ERR_INTERNAL : SFX_OK;
+    if (m > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    const int npass = radix_pass_count(bit_lo, bit_hi);
+    const bool sweep = use_sweep(m, npass);
+    RadixScratch scr(scratch, m);
+    SrcText32 tsrc = {text ? *text : PackedText{nullptr, 0, 0, 1, 0, 1.0}};
+    if (sweep) {
+        if (text) SFX_TRY(prepare_sweep("radix_hist_all_text_u32", (double)m * text->bits / 8.0, tsrc, m, bit_lo, bit_hi, npass, scr, st));
+        else SFX_TRY(prepare_sweep("radix_hist_all_u32", (double)m * 8.0, SrcE64{e0}, m, bit_lo, bit_hi, npass, scr, st));
+    }
+    uint64_t* cur = text ? nullptr : e0;        // the text-fed pass reads no element buffer
+    uint64_t* nxt = text ? e0 : e1;
+    for (int p = 0; p < npass; p++) {
+        const int shift = bit_lo + p * kRadixBits;
+        const int nb = bit_hi - shift < kRadixBits ? bit_hi - shift : kRadixBits;
+        const unsigned mask = (1u << nb) - 1u;
+        const bool first_text = text && p == 0;
+        const bool last_split = split_v && p == npass - 1;
+        const double in_bytes = first_text ? text->bits / 8.0 : 8.0;
+        const char* name = first_text ? "radix_scatter_text_u32" : "radix_scatter_u32";
+        const double algo = (double)m * (in_bytes + 8.0);
+        uint32_t* split_k = (uint32_t*)nxt;
+        if (first_text && last_split) {
+            SFX_TRY(run_pass(name, algo, tsrc, DstSplit32{split_k, split_v}, m, shift, mask, scr, p, sweep, st));
+        } else if (first_text) {
+            SFX_TRY(run_pass(name, algo, tsrc, DstE64{nxt}, m, shift, mask, scr, p, sweep, st));
+        } else if (last_split) {
+            SFX_TRY(run_pass(name, algo, SrcE64{cur}, DstSplit32{split_k, split_v}, m, shift, mask, scr, p, sweep, st));
+        } else {
+            SFX_TRY(run_pass(name, algo, SrcE64{cur}, DstE64{nxt}, m, shift, mask, scr, p, sweep, st));
+        }
+        if (last_split) {
+            if (split_k_out) *split_k_out = split_k;
+        } else {
+            uint64_t* other = (nxt == e0) ? e1 : e0;
+            cur = nxt;
+            nxt = other;
+        }
+        if (stats) { stats->radix_passes++; stats->elements_sorted += m; }
+    }
+    *result_in_1 = (cur == e1) ? 1 : 0;
+    return SFX_OK;
+}
+
+int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, int bit_lo, int bit_hi,
+                    uint32_t* scratch, hipStream_t st, int* result_in_1, sfx_build_stats* stats,
+                    const PackedText* text)
+{
+    *result_in_1 = 0;
+    if (m == 0 || bit_hi <= bit_lo) return SFX_OK;
+    if (m > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    const int npass = radix_pass_count(bit_lo, bit_hi);
+    const bool sweep = use_sweep(m, npass);
+    RadixScratch scr(scratch, m);
+    SrcText64 tsrc = {text ? *text : PackedText{nullptr, 0, 0, 1, 0, 1.0}};
+    if (sweep) {
+        if (text) SFX_TRY(prepare_sweep("radix_hist_all_text_u64", (double)m * text->bits / 8.0, tsrc, m, bit_lo, bit_hi, npass, scr, st));
+        else SFX_TRY(prepare_sweep("radix_hist_all_u64", (double)m * 8.0, SrcKV{k0, v0}, m, bit_lo, bit_hi, npass, scr, st));
+    }
+    uint64_t* kin = k0; uint32_t* vin = v0;
+    uint64_t* kout = k1; uint32_t* vout = v1;
     int flips = 0;
-    for (int shift = bit_lo; shift < bit_hi; shift += kRadixBits) {
-        int nb = bit_hi - shift < kRadixBits ? bit_hi - shift : kRadixBits;
-        unsigned mask = (1u << nb) - 1u;
-        const bool from_text = src && shift == bit_lo;
-        // algorithmic bytes: a text-fed pass reads bits/8 bytes per element instead of key (+value)
-        const double in_key = from_text ? src->bits / 8.0 : (double)sizeof(KeyT);
-        if (from_text) {
-            SFX_LAUNCH(sizeof(KeyT) == 4 ? "radix_hist_text_u32" : "radix_hist_text_u64", (double)m * in_key,
-                       (k_radix_hist<KeyT, true>), ch.blocks, kBlock, st, kin, *src, m, shift, mask,
-                       chunk, hist);
+    for (int p = 0; p < npass; p++) {
+        const int shift = bit_lo + p * kRadixBits;
+        const int nb = bit_hi - shift < kRadixBits ? bit_hi - shift : kRadixBits;
+        const unsigned mask = (1u << nb) - 1u;
+        const bool first_text = text && p == 0;
+        const double in_bytes = first_text ? text->bits / 8.0 : 12.0;
+        const double algo = (double)m * (in_bytes + 12.0);
+        if (first_text) {
+            SFX_TRY(run_pass("radix_scatter_text_u64", algo, tsrc, DstKV{kout, vout}, m, shift, mask, scr, p, sweep, st));
         } else {
-            SFX_LAUNCH(sizeof(KeyT) == 4 ? "radix_hist_u32" : "radix_hist_u64", (double)m * in_key,
-                       (k_radix_hist<KeyT, false>), ch.blocks, kBlock, st, kin, none, m, shift, mask,
-                       chunk, hist);
+            SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKV{kin, vin}, DstKV{kout, vout}, m, shift, mask, scr, p, sweep, st));
         }
-        SFX_LAUNCH("radix_scan", (double)kRadix * ch.blocks * 8, k_radix_scan, kRadix, kBlock, st,
-                   hist, ch.blocks, digit_total);
-        if (from_text) {
-            SFX_LAUNCH(sizeof(KeyT) == 4 ? "radix_scatter_text_u32" : "radix_scatter_text_u64",
-                       (double)m * (in_key + sizeof(KeyT) + 4), (k_radix_scatter<KeyT, KPT, WPS, true>),
-                       ch.blocks, kBlock, st, kin, vin, *src, kout, vout, m, shift, mask, chunk, hist,
-                       digit_total);
-        } else {
-            SFX_LAUNCH(sizeof(KeyT) == 4 ? "radix_scatter_u32" : "radix_scatter_u64",
-                       2.0 * (double)m * (sizeof(KeyT) + 4), (k_radix_scatter<KeyT, KPT, WPS, false>),
-                       ch.blocks, kBlock, st, kin, vin, none, kout, vout, m, shift, mask, chunk, hist,
-                       digit_total);
-        }
-        KeyT* tk = kin; kin = kout; kout = tk;
+        uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
         flips ^= 1;
         if (stats) { stats->radix_passes++; stats->elements_sorted += m; }
@@ -261,28 +564,5 @@ static int radix_sort_impl(KeyT* k0, uint32_t* v0, KeyT* k1, uint32_t* v1, uint6
     *result_in_1 = flips;
     return SFX_OK;
 }
-
-template <class KeyT>
-int radix_sort_pairs(KeyT* k0, uint32_t* v0, KeyT* k1, uint32_t* v1, uint64_t m, int bit_lo,
-                     int bit_hi, uint32_t* hist, hipStream_t st, int* result_in_1,
-                     sfx_build_stats* stats, const PackedText* src)
-{
-    *result_in_1 = 0;
-    if (m == 0 || bit_hi <= bit_lo) return SFX_OK;
-    if (m > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
-    switch (radix_variant(sizeof(KeyT), m)) {
-    case 1: return radix_sort_impl<KeyT, 8, 6>(k0, v0, k1, v1, m, bit_lo, bit_hi, hist, st, result_in_1, stats, src);
-    case 2: return radix_sort_impl<KeyT, 16, 4>(k0, v0, k1, v1, m, bit_lo, bit_hi, hist, st, result_in_1, stats, src);
-    case 4: return radix_sort_impl<KeyT, 32, 2>(k0, v0, k1, v1, m, bit_lo, bit_hi, hist, st, result_in_1, stats, src);
-    default: return radix_sort_impl<KeyT, 16, 3>(k0, v0, k1, v1, m, bit_lo, bit_hi, hist, st, result_in_1, stats, src);
-    }
-}
-
-template int radix_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint64_t, int,
-                                        int, uint32_t*, hipStream_t, int*, sfx_build_stats*,
-                                        const PackedText*);
-template int radix_sort_pairs<uint64_t>(uint64_t*, uint32_t*, uint64_t*, uint32_t*, uint64_t, int,
-                                        int, uint32_t*, hipStream_t, int*, sfx_build_stats*,
-                                        const PackedText*);
 
 }  // namespace sfx

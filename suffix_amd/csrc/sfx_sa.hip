@@ -134,7 +134,8 @@ k_key_hist(PackedText src, uint64_t begin, uint64_t end, int key_bits_used, int 
         if (h[i]) atomicAdd(&bins[i], (unsigned long long)h[i]);
 }
 
-// Emit (key, suffix) for the suffixes whose top key bits fall in [bin_lo, bin_hi).
+// Emit (key, suffix) for the suffixes whose top key bits fall in [bin_lo, bin_hi)
+// (32-bit keys: as E64 elements in kout, vout unused).
 // phase 0 counts per workgroup, phase 1 writes at the scanned offsets (stream
 // compaction; order = text order).
 template <class KeyT>
@@ -162,8 +163,12 @@ k_range_filter(PackedText src, int key_bits_used, int top_bits, uint32_t bin_lo,
         uint32_t total;
         uint32_t ex = block_scan_add_excl<uint32_t>(keep ? 1u : 0u, part, total);
         if (phase == 1 && keep && running + ex < capacity) {
-            kout[running + ex] = key;
-            vout[running + ex] = (uint32_t)i;
+            if (sizeof(KeyT) == 4) {            // E64 element: (key << 32) | suffix
+                reinterpret_cast<uint64_t*>(kout)[running + ex] = ((uint64_t)key << 32) | (uint64_t)(uint32_t)i;
+            } else {
+                kout[running + ex] = key;
+                vout[running + ex] = (uint32_t)i;
+            }
         }
         running += total;
     }
@@ -330,7 +335,9 @@ k_groups_scan(uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep
 }
 
 // K,V: sorted keys / suffixes of the m active elements; S: their SA slots in
-// ascending order (nullptr = identity).  Writes SA[slot] = suffix; if isa:
+// ascending order (nullptr = identity).  Writes SA[slot] = suffix (skipped when
+// sa_in_place: V IS the SA and slots are the identity -- the last radix pass of the
+// initial sort already put every suffix in its slot); if isa:
 // ISA[suffix] = slot of its bucket head; and compacts the elements of
 // non-singleton buckets into (S_next, V_next, G_next = dense bucket id, and, if
 // R_next, R_next = slot of the bucket head).
@@ -342,7 +349,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                const uint32_t* __restrict__ part_ghead, uint32_t* __restrict__ sa,
                uint32_t* __restrict__ isa, uint32_t* __restrict__ S_next,
                uint32_t* __restrict__ V_next, uint32_t* __restrict__ G_next,
-               uint32_t* __restrict__ R_next)
+               uint32_t* __restrict__ R_next, int sa_in_place)
 {
     __shared__ uint32_t part[kWavesPerBlock];
     const unsigned tid = threadIdx.x;
@@ -378,8 +385,8 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                 if (head[j] && keep) run_ghead++;
                 uint32_t my_head = run_head - 1u;
                 uint32_t slot = S ? S[i] : (uint32_t)i;
-                uint32_t suffix = V[i];
-                sa[slot] = suffix;
+                uint32_t suffix = (!sa_in_place || keep || isa) ? V[i] : 0u;
+                if (!sa_in_place) sa[slot] = suffix;
                 if (isa || (keep && R_next)) {
                     uint32_t head_slot = S ? S[my_head] : my_head;
                     if (isa) isa[suffix] = head_slot;
@@ -473,7 +480,7 @@ struct SaBuffers {
     uint32_t* R;                                        // bucket-head slots (text rounds of a full build)
     uint32_t* isa;
     uint32_t* packed;                                   // PackedText words
-    uint32_t* hist;                                     // 256*kMaxGrid + 256
+    uint32_t* hist;                                     // radix_scratch_words(cap)
     uint32_t* part_head; uint32_t* part_keep; uint32_t* part_ghead;   // kMaxGrid each
     uint32_t* totals;
     unsigned long long* bins;                           // 256
@@ -497,7 +504,7 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint32_t* R = ar.template take<uint32_t>(isa_len ? cap / kTextFirstDivisor + 1024 : 0);
     uint32_t* isa = ar.template take<uint32_t>(isa_len);
     uint32_t* packed = ar.template take<uint32_t>(packed_words(n, nullptr));
-    uint32_t* hist = ar.template take<uint32_t>((uint64_t)kRadix * kMaxGrid + kRadix);
+    uint32_t* hist = ar.template take<uint32_t>(radix_scratch_words(cap));
     uint32_t* ph = ar.template take<uint32_t>(kMaxGrid);
     uint32_t* pk = ar.template take<uint32_t>(kMaxGrid);
     uint32_t* pg = ar.template take<uint32_t>(kMaxGrid);
@@ -547,13 +554,14 @@ static int round_totals(const KeyT* K, uint64_t m, SaBuffers& b, hipStream_t st,
 template <class KeyT>
 static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint64_t m, SaBuffers& b,
                        uint32_t* sa, uint32_t* isa, uint32_t* S_next, uint32_t* V_next,
-                       uint32_t* R_next, hipStream_t st)
+                       uint32_t* R_next, hipStream_t st, bool sa_in_place = false)
 {
     Chunking ch = make_chunking(m, kGroupTile);
     SFX_LAUNCH(sizeof(KeyT) == 4 ? "groups_apply_u32" : "groups_apply_u64",
-               (double)m * (sizeof(KeyT) + 4 + 4 + (isa ? 4 : 0) + (S ? 4 : 0)),
+               (double)m * (sizeof(KeyT) + (sa_in_place ? 0 : 8) + (isa ? 4 : 0) + (S ? 4 : 0)),
                (k_groups_apply<KeyT>), ch.blocks, kBlock, st, K, V, S, m, ch.tiles_per_block,
-               b.part_head, b.part_keep, b.part_ghead, sa, isa, S_next, V_next, b.G, R_next);
+               b.part_head, b.part_keep, b.part_ghead, sa, isa, S_next, V_next, b.G, R_next,
+               sa_in_place ? 1 : 0);
     return SFX_OK;
 }
 
@@ -624,8 +632,8 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         }
         uint32_t* V_other = (V_cur == b.VA) ? b.VB : b.VA;
         int in1 = 0;
-        SFX_TRY(radix_sort_pairs<uint64_t>(b.K0, V_cur, b.K1, V_other, m, 0, key2_bits + gid_bits,
-                                           b.hist, st, &in1, &stats));
+        SFX_TRY(radix_sort_kv64(b.K0, V_cur, b.K1, V_other, m, 0, key2_bits + gid_bits, b.hist, st, &in1,
+                                &stats, nullptr));
         const uint64_t* Kr = in1 ? b.K1 : b.K0;
         uint32_t* Vr = in1 ? V_other : V_cur;
         uint32_t* V_next = in1 ? V_cur : V_other;
@@ -660,20 +668,35 @@ template <class KeyT>
 static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool from_text, SaBuffers& b,
                            uint32_t* sa, uint32_t* isa, hipStream_t st, sfx_build_stats& stats)
 {
-    KeyT* k0 = (KeyT*)b.K0;
-    KeyT* k1 = (KeyT*)b.K1;
+    const KeyT* Kr;
+    const uint32_t* Vr;
+    uint32_t* V_next;
+    bool in_place = false;
     int in1 = 0;
-    SFX_TRY(radix_sort_pairs<KeyT>(k0, b.VA, k1, b.VB, count, 0, pt.bits * cpk, b.hist, st, &in1, &stats,
-                                   from_text ? &pt : nullptr));
-    const KeyT* Kr = in1 ? k1 : k0;
+    if (sizeof(KeyT) == 4) {
+        // E64 elements; the last pass drops every suffix straight into its SA slot and
+        // leaves the sorted 32-bit keys in the element buffer it did not read
+        uint32_t* k32 = nullptr;
+        SFX_TRY(radix_sort_e64(b.K0, b.K1, count, 32, 32 + pt.bits * cpk, b.hist, st, &in1, &stats,
+                               from_text ? &pt : nullptr, sa, &k32));
+        Kr = (const KeyT*)k32;
+        Vr = sa;
+        V_next = b.VA;
+        in_place = true;
+    } else {
+        SFX_TRY(radix_sort_kv64(b.K0, b.VA, b.K1, b.VB, count, 0, pt.bits * cpk, b.hist, st, &in1, &stats,
+                                from_text ? &pt : nullptr));
+        Kr = (const KeyT*)(in1 ? b.K1 : b.K0);
+        Vr = in1 ? b.VB : b.VA;
+        V_next = in1 ? b.VA : b.VB;
+    }
     uint64_t kept = 0, groups = 0;
     SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups));
     stats.active_after_initial = kept;
     // few unresolved suffixes: one text round first, ISA only if that does not finish the job
     const int text_rounds = (isa && kept * kTextFirstDivisor <= count && pt.spw >= 8) ? 1 : 0;
-    uint32_t* V_next = in1 ? b.VA : b.VB;
-    SFX_TRY(round_apply<KeyT>(Kr, in1 ? b.VB : b.VA, nullptr, count, b, sa,
-                              (isa && !text_rounds) ? isa : nullptr, b.S0, V_next, nullptr, st));
+    SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, (isa && !text_rounds) ? isa : nullptr, b.S0, V_next,
+                              nullptr, st, in_place));
     return refine(pt, cpk, b, sa, isa, text_rounds, b.S0, V_next, kept, groups, st, stats);
 }
 

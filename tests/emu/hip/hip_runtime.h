@@ -147,5 +147,25 @@ template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; ret
 template <class T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
 static inline unsigned atomicAdd(unsigned* p, int v) { unsigned o = *p; *p = o + (unsigned)v; return o; }
 
+// agent-scope atomics: one workgroup runs at a time, so plain accesses are exact
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <class T, class U> static inline void __hip_atomic_store(T* p, U v, int, int) { *p = (T)v; }
+// v_mbcnt: bits of `mask` below this lane (+ add)
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned add)
+{
+    unsigned lane = threadIdx.x & 63u;
+    unsigned lt = lane >= 32 ? 0xFFFFFFFFu : ((1u << lane) - 1u);
+    return add + (unsigned)__builtin_popcount(mask & lt);
+}
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned add)
+{
+    unsigned lane = threadIdx.x & 63u;
+    unsigned lt = lane <= 32 ? 0u : ((1u << (lane - 32)) - 1u);
+    return add + (unsigned)__builtin_popcount(mask & lt);
+}
+
 template <class T> static inline T min(T a, T b) { return a < b ? a : b; }
 template <class T> static inline T max(T a, T b) { return a > b ? a : b; }
