@@ -109,6 +109,21 @@ int sfx_build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n,
                                uint32_t* d_sa_part, uint64_t* count_out, void* d_workspace,
                                uint64_t workspace_bytes, void* stream);
 
+/* ---- memory-system micro-benchmarks (the scatter/gather roofline
+ * must be measured) -------------------------------------------------------------
+ * Allocates its own device buffers of about `bytes`, runs `reps` timed launches
+ * (after one warm-up) and reports algorithmic GB/s (10^9 B/s) in *gbps_out.
+ *   SFX_MB_COPY        streaming 16-byte copy (read + write counted)
+ *   SFX_MB_SCATTER4    random 4-byte writes into a `bytes`-sized array
+ *                      (head_insert/tail_insert :723-736, ISA[suffix] = rank)
+ *   SFX_MB_GATHER1     random 1-byte reads (T[s-1] in induce, :429)
+ *   SFX_MB_GATHER4     random 4-byte reads (ISA[suffix + h])
+ *   SFX_MB_RUNSCATTER  runs of `param` bytes (power of two >= 8) copied to
+ *                      pseudo-random places, run-aligned if param2 != 0, else
+ *                      offset by 8 bytes: the write side of a radix pass        */
+enum { SFX_MB_COPY = 0, SFX_MB_SCATTER4 = 1, SFX_MB_GATHER1 = 2, SFX_MB_GATHER4 = 3, SFX_MB_RUNSCATTER = 4 };
+int sfx_microbench(int kind, uint64_t bytes, int param, int param2, int reps, double* gbps_out);
+
 /* ---- profiling (per-kernel HIP-event timing; off by default) ---------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on its stream.
  * sfx_profile_report writes up to `cap` records and returns how many exist. */

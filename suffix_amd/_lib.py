@@ -60,6 +60,7 @@ ABI = [
     ("sfx_sa_range_workspace_bytes", _u64, [_u64, _u64]),
     ("sfx_build_sa_range_u32_dev", _int, [_vp, _u64, _vp, _int, _u32, _u32, _u64, _vp,
                                           ctypes.POINTER(_u64), _vp, _u64, _vp]),
+    ("sfx_microbench", _int, [_int, _u64, _int, _int, _int, ctypes.POINTER(ctypes.c_double)]),
     ("sfx_profile_enable", None, [_int]),
     ("sfx_profile_reset", None, []),
     ("sfx_profile_report", _int, [ctypes.POINTER(KernelStat), _int]),
@@ -117,6 +118,14 @@ class Engine:
         s = BuildStats()
         self.lib.sfx_last_build_stats(ctypes.byref(s))
         return s.as_dict()
+
+    MB_COPY, MB_SCATTER4, MB_GATHER1, MB_GATHER4, MB_RUNSCATTER = range(5)
+
+    def microbench(self, kind, nbytes, param=0, param2=0, reps=5):
+        """GB/s (algorithmic bytes) of one memory-system micro-benchmark (sfx_microbench)."""
+        g = ctypes.c_double(0.0)
+        self.check(self.lib.sfx_microbench(kind, nbytes, param, param2, reps, ctypes.byref(g)), "sfx_microbench")
+        return float(g.value)
 
     def profile(self, on):
         self.lib.sfx_profile_enable(1 if on else 0)

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/suffix_hip.h"
 #include "sfx_device.hpp"
@@ -66,9 +67,21 @@ struct Chunking {
     uint64_t tiles;         // total tiles
     uint64_t tiles_per_block;
 };
+// test hook: SFX_MAX_GRID=<k> caps the persistent grid so that small inputs still give
+// every workgroup a multi-tile chunk (carries across tiles get exercised on the emulator)
+inline unsigned grid_cap()
+{
+    static const unsigned cap = [] {
+        const char* e = getenv("SFX_MAX_GRID");
+        int v = e ? atoi(e) : 0;
+        return (v >= 1 && v <= (int)kMaxGrid) ? (unsigned)v : kMaxGrid;
+    }();
+    return cap;
+}
 inline Chunking make_chunking(uint64_t items, uint64_t tile, unsigned max_blocks = kMaxGrid)
 {
     Chunking c;
+    if (max_blocks > grid_cap()) max_blocks = grid_cap();
     c.tiles = (items + tile - 1) / tile;
     if (c.tiles == 0) c.tiles = 1;
     c.tiles_per_block = (c.tiles + max_blocks - 1) / max_blocks;

@@ -24,9 +24,37 @@ constexpr int kPlcpTile = kBlock * kRun;         // 8192 positions per workgroup
 __global__ void __launch_bounds__(kBlock)
 k_phi_scatter(const uint32_t* __restrict__ sa, uint64_t n, uint32_t* __restrict__ phi)
 {
+    constexpr int U = 4;                     // independent scatters in flight per thread
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride)
-        phi[sa[r]] = r ? sa[r - 1] : kNoPhi;
+    for (uint64_t r0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r0 < n; r0 += U * stride) {
+        uint32_t cur[U], prev[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t r = r0 + u * stride;
+            cur[u] = r < n ? sa[r] : 0u;
+            prev[u] = (r < n && r) ? sa[r - 1] : kNoPhi;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (r0 + u * stride < n) phi[cur[u]] = prev[u];
+    }
+}
+
+// length of the common prefix of text[a..] and text[b..] beyond the first h bytes, 8 bytes
+// per step where both windows are inside the text (unaligned 8-byte loads), bytes at the end
+__device__ __forceinline__ uint64_t extend_match(const uint8_t* __restrict__ text, uint64_t n, uint64_t a,
+                                                 uint64_t b, uint64_t h)
+{
+    while (a + h + 8 <= n && b + h + 8 <= n) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, text + a + h, 8);
+        __builtin_memcpy(&y, text + b + h, 8);
+        const uint64_t d = x ^ y;
+        if (d) return h + (uint64_t)(__ffsll((long long)d) - 1) / 8;      // little-endian: lowest differing byte
+        h += 8;
+    }
+    while (a + h < n && b + h < n && text[a + h] == text[b + h]) h++;
+    return h;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -52,7 +80,7 @@ k_plcp(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ phi_
             if (j == kNoPhi) {
                 h = 0;
             } else {
-                while (i + h < n && (uint64_t)j + h < n && text[i + h] == text[(uint64_t)j + h]) h++;
+                h = extend_match(text, n, i, (uint64_t)j, h);
             }
             s[tid * (kRun + 1) + k] = (uint32_t)h;
             if (h) h--;
@@ -70,9 +98,18 @@ __global__ void __launch_bounds__(kBlock)
 k_lcp_gather(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ plcp, uint64_t n,
              uint32_t* __restrict__ lcp)
 {
+    constexpr int U = 4;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride)
-        lcp[r] = plcp[sa[r]];
+    for (uint64_t r0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r0 < n; r0 += U * stride) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = (r0 + u * stride < n) ? sa[r0 + u * stride] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = (r0 + u * stride < n) ? plcp[v[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (r0 + u * stride < n) lcp[r0 + u * stride] = v[u];
+    }
 }
 
 uint64_t lcp_workspace_bytes(uint64_t n)

@@ -125,8 +125,16 @@ k_radix_hist_chunk(Src src, uint64_t m, int shift, unsigned mask, uint64_t chunk
     uint64_t begin = (uint64_t)blockIdx.x * chunk;
     uint64_t end = begin + chunk;
     if (end > m) end = m;
-    for (uint64_t i = begin + tid; i < end; i += kBlock)
-        atomicAdd(&h[w][digit_of(src.key(i), shift, mask)], 1u);
+    // 8 independent loads per thread in flight before the first histogram update
+    uint64_t i = begin + tid;
+    for (; i + 7 * kBlock < end; i += 8 * kBlock) {
+        uint64_t k[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) k[j] = src.key(i + (uint64_t)j * kBlock);
+#pragma unroll
+        for (int j = 0; j < 8; j++) atomicAdd(&h[w][digit_of(k[j], shift, mask)], 1u);
+    }
+    for (; i < end; i += kBlock) atomicAdd(&h[w][digit_of(src.key(i), shift, mask)], 1u);
     __syncthreads();
     uint32_t c = 0;
 #pragma unroll
@@ -148,7 +156,19 @@ k_radix_hist_all(Src src, uint64_t m, int bit_lo, int bit_hi, int npass, uint64_
     uint64_t begin = (uint64_t)blockIdx.x * chunk;
     uint64_t end = begin + chunk;
     if (end > m) end = m;
-    for (uint64_t i = begin + tid; i < end; i += kBlock) {
+    uint64_t i = begin + tid;
+    for (; i + 3 * kBlock < end; i += 4 * kBlock) {
+        uint64_t k[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) k[j] = src.key(i + (uint64_t)j * kBlock);
+        for (int p = 0; p < npass; p++) {
+            const int shift = bit_lo + p * kRadixBits;
+            const int nb = bit_hi - shift < kRadixBits ? bit_hi - shift : kRadixBits;
+#pragma unroll
+            for (int j = 0; j < 4; j++) atomicAdd(&h[w][p][digit_of(k[j], shift, (1u << nb) - 1u)], 1u);
+        }
+    }
+    for (; i < end; i += kBlock) {
         const uint64_t key = src.key(i);
         for (int p = 0; p < npass; p++) {
             const int shift = bit_lo + p * kRadixBits;
@@ -295,6 +315,22 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
     if (!ONESWEEP) limit = dmin<uint64_t>(m, next + chunk);
     __syncthreads();
 
+    // load: wave-striped, 64 consecutive elements per round; padding sorts last in the tile.
+    // Chunked schedule: the NEXT tile's loads are issued before this tile is processed, so a
+    // workgroup always has a tile of HBM reads in flight (bandwidth = bytes in flight / latency).
+    uint64_t nkey[KPT];
+    uint32_t nval[HAS_VAL ? KPT : 1];
+    auto load_tile = [&](uint64_t tile) {
+        const unsigned nv = (unsigned)dmin<uint64_t>(kTile, limit - tile);
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            const unsigned idx = w * (kWave * KPT) + r * kWave + lane;
+            nkey[r] = (idx < nv) ? src.key(tile + idx) : ~0ull;
+            if (HAS_VAL) nval[r] = (idx < nv) ? src.val(tile + idx) : 0u;
+        }
+    };
+    if (!ONESWEEP && next < limit) load_tile(next);
+
     for (;;) {
         uint64_t tile;
         uint32_t tile_no = 0;
@@ -309,17 +345,17 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
         }
         if (tile >= limit) break;
         const unsigned nvalid = (unsigned)dmin<uint64_t>(kTile, limit - tile);
+        if (ONESWEEP) load_tile(tile);
 
-        // load: wave-striped, 64 consecutive elements per round; padding sorts last in the tile
         uint64_t key[KPT];
         uint32_t val[HAS_VAL ? KPT : 1];
         uint32_t pos[KPT];
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
-            const unsigned idx = w * (kWave * KPT) + r * kWave + lane;
-            key[r] = (idx < nvalid) ? src.key(tile + idx) : ~0ull;
-            if (HAS_VAL) val[r] = (idx < nvalid) ? src.val(tile + idx) : 0u;
+            key[r] = nkey[r];
+            if (HAS_VAL) val[r] = nval[r];
         }
+        if (!ONESWEEP && next < limit) load_tile(next);
 #pragma unroll
         for (int r = 0; r < KPT; r++)
             pos[r] = rank_round<RANK_ATOMIC>(digit_of(key[r], shift, mask), s.flags[w], s.cnt[w], mybit);
@@ -370,18 +406,162 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
     }
 }
 
+// ---- chunked pass with software write combining ------------------------------------------
+// A bucket's share of a tile starts wherever the previous tile's share ended, so with
+// plain run-per-tile output nearly every 128-byte line of the destination is written in
+// two pieces, tens of microseconds apart, and reaches HBM as two partial writes (measured:
+// 128-byte runs land at 2.3 TB/s when offset by 8 bytes, 5.1 TB/s when line-aligned --
+// sfx_microbench SFX_MB_RUNSCATTER).  In the chunked schedule a workgroup owns, per
+// bucket, one contiguous piece of the output for its whole chunk, so it can hold back the
+// elements that do not yet complete a line: `carry[d]` keeps < LINE elements of bucket d
+// in LDS, and a tile writes only whole aligned lines (its carried elements first, then
+// the new ones), except for the first and last line of the workgroup's piece.
+template <int KPT, int LINE, bool HAS_VAL>
+struct RadixWcSmem {
+    struct Info { uint32_t off; int32_t thr; int32_t cb; uint32_t pad; };
+    uint32_t cnt[kWavesPerBlock][kRadix];       // per-wave digit counts, then tile-local bases
+    Info info[kRadix];                           // new element at stage slot p of bucket d:
+                                                 //   p < thr -> global[off + p], else carry[d][cb + p]
+    uint32_t cur[kRadix];                        // global position of carry slot 0
+    uint32_t cfl[kRadix];                        // carried elements leaving with this tile
+    uint32_t part[2][kWavesPerBlock];
+    uint64_t carry[kRadix][LINE];
+    uint32_t carry_v[HAS_VAL ? kRadix : 1][HAS_VAL ? LINE : 1];
+    uint64_t stage[kBlock * KPT];
+    uint32_t stage_v[HAS_VAL ? kBlock * KPT : 1];
+};
+
+template <class Src, class Dst, int KPT, int LINE>
+__global__ void __launch_bounds__(kBlock)
+k_radix_pass_wc(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t chunk,
+                const uint32_t* __restrict__ hist, const uint32_t* __restrict__ digit_total)
+{
+    constexpr bool HAS_VAL = Src::kHasVal;
+    constexpr int kTile = kBlock * KPT;
+    constexpr unsigned kLog = LINE == 16 ? 4u : 3u;
+    static_assert(LINE == 8 || LINE == 16, "line = 8 or 16 elements");
+    __shared__ RadixWcSmem<KPT, LINE, HAS_VAL> s;
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    unsigned par = 0;
+
+#pragma unroll
+    for (int k = 0; k < kWavesPerBlock; k++) s.cnt[k][tid] = 0u;
+    // thread d: first unwritten global position of bucket d, and how many elements of it wait in LDS
+    uint32_t cursor = block_scan_excl_1b(digit_total[tid], s.part, par) + hist[(uint64_t)tid * gridDim.x + blockIdx.x];
+    uint32_t carried = 0;
+    const uint64_t begin = (uint64_t)blockIdx.x * chunk;
+    const uint64_t limit = dmin<uint64_t>(m, begin + chunk);
+    __syncthreads();
+
+    uint64_t nkey[KPT];
+    uint32_t nval[HAS_VAL ? KPT : 1];
+    auto load_tile = [&](uint64_t tile) {           // (next tile in flight while this one is processed)
+        const unsigned nv = (unsigned)dmin<uint64_t>(kTile, limit - tile);
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            const unsigned idx = w * (kWave * KPT) + r * kWave + lane;
+            nkey[r] = (idx < nv) ? src.key(tile + idx) : ~0ull;
+            if (HAS_VAL) nval[r] = (idx < nv) ? src.val(tile + idx) : 0u;
+        }
+    };
+    if (begin < limit) load_tile(begin);
+
+    for (uint64_t tile = begin; tile < limit; tile += kTile) {
+        const unsigned nvalid = (unsigned)dmin<uint64_t>(kTile, limit - tile);
+        const bool last = tile + kTile >= limit;
+        uint64_t key[KPT];
+        uint32_t val[HAS_VAL ? KPT : 1];
+        uint32_t pos[KPT];
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            key[r] = nkey[r];
+            if (HAS_VAL) val[r] = nval[r];
+        }
+        if (!last) load_tile(tile + kTile);
+#pragma unroll
+        for (int r = 0; r < KPT; r++)
+            pos[r] = rank_round<false>(digit_of(key[r], shift, mask), nullptr, s.cnt[w], 0ull);
+        __syncthreads();
+
+        {
+            const uint32_t c0 = s.cnt[0][tid], c1 = s.cnt[1][tid], c2 = s.cnt[2][tid], c3 = s.cnt[3][tid];
+            const uint32_t tile_count = c0 + c1 + c2 + c3;
+            const uint32_t ex = block_scan_excl_1b(tile_count, s.part, par);
+            s.cnt[0][tid] = ex;
+            s.cnt[1][tid] = ex + c0;
+            s.cnt[2][tid] = ex + c0 + c1;
+            s.cnt[3][tid] = ex + c0 + c1 + c2;
+            const uint32_t real_count = tile_count - ((tid == mask) ? (uint32_t)(kTile - nvalid) : 0u);
+            const uint32_t avail = carried + real_count;
+            const uint32_t line_end = (cursor + avail) & ~(uint32_t)(LINE - 1);
+            const uint32_t nfl = last ? avail : (line_end > cursor ? line_end - cursor : 0u);
+            typename RadixWcSmem<KPT, LINE, HAS_VAL>::Info in;
+            in.off = cursor + carried - ex;
+            in.thr = (int32_t)ex + (int32_t)nfl - (int32_t)carried;
+            in.cb = (int32_t)carried - (int32_t)ex - (int32_t)nfl;
+            in.pad = 0;
+            s.info[tid] = in;
+            s.cur[tid] = cursor;
+            s.cfl[tid] = nfl > 0 ? carried : 0u;
+            cursor += nfl;
+            carried = avail - nfl;
+        }
+        __syncthreads();
+
+        // new elements to their tile-local slots ...
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            const unsigned p = pos[r] + s.cnt[w][digit_of(key[r], shift, mask)];
+            s.stage[p] = key[r];
+            if (HAS_VAL) s.stage_v[p] = val[r];
+        }
+        // ... while the carried elements of every line this tile completes leave
+#pragma unroll
+        for (int it = 0; it < LINE; it++) {
+            const unsigned x = it * kBlock + tid, d = x >> kLog, i = x & (LINE - 1);
+            if (i < s.cfl[d]) dst.store(s.cur[d] + i, s.carry[d][i], HAS_VAL ? s.carry_v[d][i] : 0u);
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            key[r] = s.stage[r * kBlock + tid];
+            if (HAS_VAL) val[r] = s.stage_v[r * kBlock + tid];
+        }
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            const unsigned p = r * kBlock + tid, d = digit_of(key[r], shift, mask);
+            const typename RadixWcSmem<KPT, LINE, HAS_VAL>::Info in = s.info[d];
+            if (p < nvalid) {
+                if ((int32_t)p < in.thr) {
+                    dst.store(in.off + p, key[r], HAS_VAL ? val[r] : 0u);
+                } else {
+                    s.carry[d][in.cb + (int32_t)p] = key[r];
+                    if (HAS_VAL) s.carry_v[d][in.cb + (int32_t)p] = val[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kWavesPerBlock; k++) s.cnt[k][tid] = 0u;
+        __syncthreads();
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------
 // Tuning knobs (development only; read once per process):
 //   SFX_RADIX_SWEEP  1 = one-sweep (default), 0 = chunked
-//   SFX_RADIX_KPT    elements per thread and tile: 8 (default) or 16
+//   SFX_RADIX_KPT    elements per thread and tile: 16 (default), 12 (write-combining only) or 8
 //   SFX_RADIX_RANK   1 = LDS match masks (default), 0 = 8-ballot match
-struct RadixTuning { int sweep, kpt, rank; };
+//   SFX_RADIX_WC     chunked schedule, E64 elements: write-combining line of 8 or 16
+//                    elements (0 = plain run-per-tile output); with KPT 8, 12 or 16
+struct RadixTuning { int sweep, kpt, rank, wc; };
 static RadixTuning radix_tuning()
 {
     static const RadixTuning t = [] {
-        RadixTuning r = {1, 8, 1};
+        RadixTuning r = {1, 16, 1, 0};          // measured best on MI355X (profiles/r1c_radix_variants.txt)
         if (const char* e = getenv("SFX_RADIX_SWEEP")) r.sweep = atoi(e) ? 1 : 0;
-        if (const char* e = getenv("SFX_RADIX_KPT")) r.kpt = atoi(e) == 16 ? 16 : 8;
+        if (const char* e = getenv("SFX_RADIX_KPT")) r.kpt = atoi(e) == 16 ? 16 : (atoi(e) == 12 ? 12 : 8);
+        if (const char* e = getenv("SFX_RADIX_WC")) r.wc = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 0);
         if (const char* e = getenv("SFX_RADIX_RANK")) r.rank = atoi(e) ? 1 : 0;
         return r;
     }();
@@ -435,11 +615,36 @@ static int launch_pass(const char* name, double algo_bytes, const Src& src, cons
     return SFX_OK;
 }
 
+template <class Src, class Dst, int KPT, int LINE>
+static int launch_pass_wc(const char* name, double algo_bytes, const Src& src, const Dst& dst, uint64_t m, int shift,
+                          unsigned mask, const RadixScratch& scr, hipStream_t st)
+{
+    constexpr int kTile = kBlock * KPT;
+    Chunking ch = make_chunking(m, kTile);
+    const uint64_t chunk = ch.tiles_per_block * kTile;
+    SFX_LAUNCH("radix_hist", (double)m * 8.0, (k_radix_hist_chunk<Src>), ch.blocks, kBlock, st, src, m, shift, mask,
+               chunk, scr.partial);
+    SFX_LAUNCH("radix_scan", (double)kRadix * ch.blocks * 8, k_radix_scan, kRadix, kBlock, st, scr.partial, ch.blocks,
+               scr.totals);
+    SFX_LAUNCH(name, algo_bytes, (k_radix_pass_wc<Src, Dst, KPT, LINE>), ch.blocks, kBlock, st, src, dst, m, shift,
+               mask, chunk, (const uint32_t*)scr.partial, (const uint32_t*)scr.totals);
+    return SFX_OK;
+}
+
 template <class Src, class Dst>
 static int run_pass(const char* name, double algo_bytes, const Src& src, const Dst& dst, uint64_t m, int shift,
                     unsigned mask, const RadixScratch& scr, int pass, bool sweep, hipStream_t st)
 {
     const RadixTuning t = radix_tuning();
+    if constexpr (!Src::kHasVal) {
+        // (instantiated for E64 elements only: the carry doubles the LDS footprint)
+        if (!sweep && t.wc) {
+#define SFX_WC(KPT, LINE) launch_pass_wc<Src, Dst, KPT, LINE>(name, algo_bytes, src, dst, m, shift, mask, scr, st)
+            if (t.wc == 16) return t.kpt == 16 ? SFX_WC(16, 16) : (t.kpt == 12 ? SFX_WC(12, 16) : SFX_WC(8, 16));
+            return t.kpt == 16 ? SFX_WC(16, 8) : (t.kpt == 12 ? SFX_WC(12, 8) : SFX_WC(8, 8));
+#undef SFX_WC
+        }
+    }
 #define SFX_PASS(KPT, SW, RK) launch_pass<Src, Dst, KPT, SW, RK>(name, algo_bytes, src, dst, m, shift, mask, scr, pass, st)
     if (t.kpt == 16) {
         if (sweep) return t.rank ? SFX_PASS(16, true, true) : SFX_PASS(16, true, false);

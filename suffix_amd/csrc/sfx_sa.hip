@@ -66,6 +66,40 @@ k_byte_hist(const uint8_t* __restrict__ text, uint64_t begin, uint64_t end,
     if (c) atomicAdd(&bins[tid], (unsigned long long)c);
 }
 
+// Which byte values occur?  The single-GPU build only needs the alphabet, not the counts
+// (the sorted `alphas` of Bins::find_sizes :700): plain LDS stores of a flag, 16 bytes of
+// text per thread and step -- no atomics, so 4-symbol DNA does not serialise on 4 counters.
+// bins[c] = 1 for every byte value c that occurs (bins zeroed by the caller).
+__global__ void __launch_bounds__(kBlock)
+k_byte_presence(const uint8_t* __restrict__ text, uint64_t n, unsigned long long* __restrict__ bins)
+{
+    __shared__ uint32_t present[256];
+    const unsigned tid = threadIdx.x;
+    present[tid] = 0;
+    __syncthreads();
+    const uint64_t n16 = n / 16;
+    const uint4* t16 = reinterpret_cast<const uint4*>(text);        // text comes 16-byte aligned or is handled below
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    if ((reinterpret_cast<uintptr_t>(text) & 15u) == 0) {
+        for (uint64_t i = (uint64_t)blockIdx.x * kBlock + tid; i < n16; i += stride) {
+            const uint4 v = t16[i];
+            const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                present[wds[k] & 255u] = 1u;
+                present[(wds[k] >> 8) & 255u] = 1u;
+                present[(wds[k] >> 16) & 255u] = 1u;
+                present[wds[k] >> 24] = 1u;
+            }
+        }
+        for (uint64_t i = n16 * 16 + (uint64_t)blockIdx.x * kBlock + tid; i < n; i += stride) present[text[i]] = 1u;
+    } else {
+        for (uint64_t i = (uint64_t)blockIdx.x * kBlock + tid; i < n; i += stride) present[text[i]] = 1u;
+    }
+    __syncthreads();
+    if (present[tid]) bins[tid] = 1ull;
+}
+
 // dense symbol codes from the 256 global byte counts (one workgroup, thread = byte value)
 __global__ void __launch_bounds__(kBlock)
 k_make_lut(const unsigned long long* __restrict__ bins, uint8_t* __restrict__ lut)
@@ -200,12 +234,29 @@ k_compose_rank_keys(const uint32_t* __restrict__ suf, const uint32_t* __restrict
                     const uint32_t* __restrict__ isa, uint64_t n, uint64_t h, int key2_bits,
                     uint64_t* __restrict__ keys)
 {
+    // 4 elements per thread and step: the dependent gathers (suffix -> rank) of all four
+    // are in flight together instead of one memory round trip after the other
+    constexpr int U = 4;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < m; q += stride) {
-        uint64_t i = suf[q];
-        uint64_t p = i + h;
-        uint64_t key2 = (p < n) ? (uint64_t)isa[p] + h : (n - 1 - i);
-        keys[q] = ((uint64_t)gid[q] << key2_bits) | key2;
+    for (uint64_t q0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q0 < m; q0 += U * stride) {
+        uint64_t i[U];
+        uint32_t g[U], rk[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t q = q0 + u * stride;
+            i[u] = q < m ? suf[q] : 0;
+            g[u] = q < m ? gid[q] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) rk[u] = (q0 + u * stride < m && i[u] + h < n) ? isa[i[u] + h] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t q = q0 + u * stride;
+            if (q < m) {
+                const uint64_t key2 = (i[u] + h < n) ? (uint64_t)rk[u] + h : (n - 1 - i[u]);
+                keys[q] = ((uint64_t)g[u] << key2_bits) | key2;
+            }
+        }
     }
 }
 
@@ -216,51 +267,82 @@ k_compose_text_keys(const uint32_t* __restrict__ suf, const uint32_t* __restrict
                     PackedText src, uint64_t h, int flag_shift, int key2_bits,
                     uint64_t* __restrict__ keys)
 {
+    constexpr int U = 4;                                   // see k_compose_rank_keys
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < m; q += stride) {
-        uint64_t i = suf[q];
-        uint64_t p = i + h;
-        uint64_t key2 = (p < src.n) ? ((1ull << flag_shift) | (uint64_t)packed_key32(src, p))
-                                    : (src.n - 1 - i);
-        keys[q] = ((uint64_t)gid[q] << key2_bits) | key2;
+    for (uint64_t q0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q0 < m; q0 += U * stride) {
+        uint64_t i[U];
+        uint32_t g[U], tk[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t q = q0 + u * stride;
+            i[u] = q < m ? suf[q] : 0;
+            g[u] = q < m ? gid[q] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) tk[u] = (q0 + u * stride < m && i[u] + h < src.n) ? packed_key32(src, i[u] + h) : 0u;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t q = q0 + u * stride;
+            if (q < m) {
+                const uint64_t key2 = (i[u] + h < src.n) ? ((1ull << flag_shift) | (uint64_t)tk[u]) : (src.n - 1 - i[u]);
+                keys[q] = ((uint64_t)g[u] << key2_bits) | key2;
+            }
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------
 // 3./4b. bucket boundaries, ranks, singleton removal  (reduce -> scan -> apply)
 // ---------------------------------------------------------------------------------
-constexpr int kGroupItems = 4;                       // consecutive elements per thread
-constexpr int kGroupTile = kBlock * kGroupItems;     // 1024 elements per workgroup step
+constexpr int kGroupItems = 8;                       // consecutive elements per thread
+constexpr int kGroupTile = kBlock * kGroupItems;     // 2048 elements per workgroup step
 
-// Loads the thread's 4 consecutive keys plus both neighbours and derives, per item,
-// "first of its bucket" (head) and "bucket of size one" (single).  K is a workspace
-// array (256-B aligned) and tile bases are multiples of 1024, so the 4-key group is
-// 16-B (u32) / 32-B (u64) aligned and fetched with wide loads.
+// A thread's 8 consecutive keys plus both neighbours, fetched with 16-byte loads (K is a
+// workspace array, 256-B aligned, and tile bases are multiples of 2048).  Loading is split
+// from flag computation so the NEXT tile's keys can be in flight while this one is scanned.
 template <class KeyT>
-__device__ __forceinline__ void group_flags4(const KeyT* __restrict__ K, uint64_t i0, uint64_t m,
-                                             bool (&head)[kGroupItems], bool (&single)[kGroupItems])
-{
+struct GroupKeys {
     KeyT k[kGroupItems + 2];
+};
+template <class KeyT>
+__device__ __forceinline__ void group_load(const KeyT* __restrict__ K, uint64_t i0, uint64_t m, GroupKeys<KeyT>& g)
+{
+    constexpr int kVec = 16 / sizeof(KeyT);
+    struct alignas(16) Vec { KeyT v[kVec]; };
     if (i0 + kGroupItems <= m) {
-        struct alignas(sizeof(KeyT) * kGroupItems) Vec { KeyT v[kGroupItems]; };
-        Vec q = *reinterpret_cast<const Vec*>(K + i0);
 #pragma unroll
-        for (int j = 0; j < kGroupItems; j++) k[j + 1] = q.v[j];
+        for (int q = 0; q < kGroupItems / kVec; q++) {
+            Vec v = *reinterpret_cast<const Vec*>(K + i0 + q * kVec);
+#pragma unroll
+            for (int j = 0; j < kVec; j++) g.k[1 + q * kVec + j] = v.v[j];
+        }
     } else {
 #pragma unroll
-        for (int j = 0; j < kGroupItems; j++) k[j + 1] = (i0 + j < m) ? K[i0 + j] : KeyT(0);
+        for (int j = 0; j < kGroupItems; j++) g.k[j + 1] = (i0 + j < m) ? K[i0 + j] : KeyT(0);
     }
-    k[0] = (i0 > 0 && i0 <= m) ? K[i0 - 1] : KeyT(0);
-    k[kGroupItems + 1] = (i0 + kGroupItems < m) ? K[i0 + kGroupItems] : KeyT(0);
+    g.k[0] = (i0 > 0 && i0 <= m) ? K[i0 - 1] : KeyT(0);
+    g.k[kGroupItems + 1] = (i0 + kGroupItems < m) ? K[i0 + kGroupItems] : KeyT(0);
+}
+// bit j of head: item j is the first of its bucket; bit j of single: bucket of size one
+template <class KeyT>
+__device__ __forceinline__ void group_flags(const GroupKeys<KeyT>& g, uint64_t i0, uint64_t m, unsigned& head,
+                                            unsigned& single)
+{
+    head = 0;
+    single = 0;
 #pragma unroll
     for (int j = 0; j < kGroupItems; j++) {
-        uint64_t i = i0 + j;
-        bool valid = i < m;
-        bool h = valid && ((i == 0) || (k[j] != k[j + 1]));
-        bool nh = (i + 1 >= m) || (k[j + 2] != k[j + 1]);
-        head[j] = h;
-        single[j] = h && nh;
+        const uint64_t i = i0 + j;
+        const bool h = (i < m) && ((i == 0) || (g.k[j] != g.k[j + 1]));
+        const bool nh = (i + 1 >= m) || (g.k[j + 2] != g.k[j + 1]);
+        head |= (h ? 1u : 0u) << j;
+        single |= ((h && nh) ? 1u : 0u) << j;
     }
+}
+__device__ __forceinline__ unsigned valid_mask(uint64_t i0, uint64_t m)
+{
+    if (i0 + kGroupItems <= m) return (1u << kGroupItems) - 1u;
+    return i0 >= m ? 0u : ((1u << (unsigned)(m - i0)) - 1u);
 }
 
 // per-workgroup partials: last bucket-head index (+1) in the chunk, #kept, #kept bucket heads
@@ -276,16 +358,18 @@ k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t tiles_per_block
     uint64_t end = begin + tiles_per_block * kGroupTile;
     if (end > m) end = m;
     uint32_t last_head = 0, keep = 0, ghead = 0;
-    for (uint64_t i0 = begin + (uint64_t)tid * kGroupItems; i0 < end; i0 += kGroupTile) {
-        bool head[kGroupItems], single[kGroupItems];
-        group_flags4(K, i0, m, head, single);
-#pragma unroll
-        for (int j = 0; j < kGroupItems; j++) {
-            bool valid = i0 + j < m;
-            if (head[j]) last_head = (uint32_t)(i0 + j) + 1u;       // ascending per thread
-            keep += (valid && !single[j]) ? 1u : 0u;
-            ghead += (head[j] && !single[j]) ? 1u : 0u;
-        }
+    GroupKeys<KeyT> nxt;
+    uint64_t i0 = begin + (uint64_t)tid * kGroupItems;
+    if (i0 < end) group_load(K, i0, m, nxt);
+    for (; i0 < end; i0 += kGroupTile) {
+        const GroupKeys<KeyT> cur = nxt;
+        if (i0 + kGroupTile < end) group_load(K, i0 + kGroupTile, m, nxt);
+        unsigned head, single;
+        group_flags(cur, i0, m, head, single);
+        const unsigned valid = valid_mask(i0, m);
+        if (head) last_head = (uint32_t)i0 + (32u - (unsigned)__clz((int)head));   // index+1 of the highest head bit
+        keep += (uint32_t)__popc(valid & ~single);
+        ghead += (uint32_t)__popc(head & ~single);
     }
     for (int d = 32; d >= 1; d >>= 1) {
         last_head = dmax(last_head, __shfl_xor(last_head, d));
@@ -351,58 +435,79 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                uint32_t* __restrict__ V_next, uint32_t* __restrict__ G_next,
                uint32_t* __restrict__ R_next, int sa_in_place)
 {
-    __shared__ uint32_t part[kWavesPerBlock];
-    const unsigned tid = threadIdx.x;
+    __shared__ uint32_t part_m[2][kWavesPerBlock], part_a[2][kWavesPerBlock];
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
     uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kGroupTile;
     uint64_t end = begin + tiles_per_block * kGroupTile;
     if (end > m) end = m;
     uint32_t c_head = part_head[blockIdx.x];     // index+1 of the last head before the chunk
     uint32_t c_keep = part_keep[blockIdx.x];
     uint32_t c_ghead = part_ghead[blockIdx.x];
+    unsigned par = 0;
+    GroupKeys<KeyT> nxt;
+    if (begin < end) group_load(K, begin + (uint64_t)tid * kGroupItems, m, nxt);
     for (uint64_t tile = begin; tile < end; tile += kGroupTile) {
         const uint64_t i0 = tile + (uint64_t)tid * kGroupItems;
-        bool head[kGroupItems], single[kGroupItems];
-        group_flags4(K, i0, m, head, single);
-        uint32_t hmax = 0, cnt = 0;                     // thread aggregates
+        const GroupKeys<KeyT> cur = nxt;
+        if (tile + kGroupTile < end) group_load(K, i0 + kGroupTile, m, nxt);      // next tile in flight
+        unsigned head, single;
+        group_flags(cur, i0, m, head, single);
+        const unsigned valid = valid_mask(i0, m);
+        const unsigned keepm = valid & ~single;
+        const uint32_t hmax = head ? (uint32_t)i0 + (32u - (unsigned)__clz((int)head)) : 0u;
+        const uint32_t cnt = (uint32_t)__popc(keepm) | ((uint32_t)__popc(head & ~single) << 16);
+        // one barrier for both scans: exclusive max of hmax, exclusive sum of cnt
+        uint32_t im = wave_scan_max(hmax), ia = wave_scan_add(cnt);
+        uint32_t pm = __shfl_up(im, 1u);
+        if (lane == 0) pm = 0;
+        if (lane == 63) { part_m[par][w] = im; part_a[par][w] = ia; }
+        __syncthreads();
+        uint32_t bm = 0, ba = 0, tot_m = 0, tot_a = 0;
 #pragma unroll
-        for (int j = 0; j < kGroupItems; j++) {
-            bool valid = i0 + j < m;
-            if (head[j]) hmax = (uint32_t)(i0 + j) + 1u;
-            cnt += ((valid && !single[j]) ? 1u : 0u) | ((head[j] && !single[j]) ? 0x10000u : 0u);
+        for (unsigned k = 0; k < (unsigned)kWavesPerBlock; k++) {
+            const uint32_t qm = part_m[par][k], qa = part_a[par][k];
+            if (k < w) { bm = dmax(bm, qm); ba += qa; }
+            tot_m = dmax(tot_m, qm);
+            tot_a += qa;
         }
-        uint32_t tot_h, tot_c;
-        uint32_t eh = block_scan_max_excl(hmax, part, tot_h);
-        uint32_t ec = block_scan_add_excl(cnt, part, tot_c);
-        uint32_t run_head = dmax(c_head, eh);           // index+1 of the last head before item 0
+        par ^= 1u;
+        const uint32_t ec = ba + ia - cnt;
+        uint32_t run_head = dmax(c_head, dmax(bm, pm));          // index+1 of the last head before item 0
         uint32_t run_keep = c_keep + (ec & 0xFFFFu);
         uint32_t run_ghead = c_ghead + (ec >> 16);
+        if (keepm || isa || !sa_in_place) {                      // (all-singleton threads have nothing to write in place)
+            // gathers first (all in flight together), stores after: one memory round trip per tile
+            uint32_t slot[kGroupItems], suffix[kGroupItems], head_slot[kGroupItems];
 #pragma unroll
-        for (int j = 0; j < kGroupItems; j++) {
-            uint64_t i = i0 + j;
-            if (i < m) {
-                if (head[j]) run_head = (uint32_t)i + 1u;
-                bool keep = !single[j];
-                if (head[j] && keep) run_ghead++;
-                uint32_t my_head = run_head - 1u;
-                uint32_t slot = S ? S[i] : (uint32_t)i;
-                uint32_t suffix = (!sa_in_place || keep || isa) ? V[i] : 0u;
-                if (!sa_in_place) sa[slot] = suffix;
-                if (isa || (keep && R_next)) {
-                    uint32_t head_slot = S ? S[my_head] : my_head;
-                    if (isa) isa[suffix] = head_slot;
-                    if (keep && R_next) R_next[run_keep] = head_slot;
-                }
-                if (keep) {
-                    S_next[run_keep] = slot;
-                    V_next[run_keep] = suffix;
-                    G_next[run_keep] = run_ghead - 1u;
-                    run_keep++;
+            for (int j = 0; j < kGroupItems; j++) {
+                const uint64_t i = i0 + j;
+                const bool v = (valid >> j) & 1u, keep = (keepm >> j) & 1u;
+                if ((head >> j) & 1u) run_head = (uint32_t)i + 1u;
+                const uint32_t my_head = run_head - 1u;
+                slot[j] = (v && S) ? S[i] : (uint32_t)i;
+                suffix[j] = (v && (!sa_in_place || keep || isa)) ? V[i] : 0u;
+                head_slot[j] = (v && S && (isa || (keep && R_next))) ? S[my_head] : my_head;
+            }
+#pragma unroll
+            for (int j = 0; j < kGroupItems; j++) {
+                if ((valid >> j) & 1u) {
+                    const bool keep = (keepm >> j) & 1u;
+                    if (((head >> j) & 1u) && keep) run_ghead++;
+                    if (!sa_in_place) sa[slot[j]] = suffix[j];
+                    if (isa) isa[suffix[j]] = head_slot[j];
+                    if (keep) {
+                        if (R_next) R_next[run_keep] = head_slot[j];
+                        S_next[run_keep] = slot[j];
+                        V_next[run_keep] = suffix[j];
+                        G_next[run_keep] = run_ghead - 1u;
+                        run_keep++;
+                    }
                 }
             }
         }
-        c_head = dmax(c_head, tot_h);
-        c_keep += tot_c & 0xFFFFu;
-        c_ghead += tot_c >> 16;
+        c_head = dmax(c_head, tot_m);
+        c_keep += tot_a & 0xFFFFu;
+        c_ghead += tot_a >> 16;
     }
 }
 
@@ -411,18 +516,36 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
 __global__ void __launch_bounds__(kBlock)
 k_isa_from_sa(const uint32_t* __restrict__ sa, uint64_t n, uint32_t* __restrict__ isa)
 {
+    constexpr int U = 4;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < n; s += stride)
-        isa[sa[s]] = (uint32_t)s;
+    for (uint64_t s0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s0 < n; s0 += U * stride) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = (s0 + u * stride < n) ? sa[s0 + u * stride] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (s0 + u * stride < n) isa[v[u]] = (uint32_t)(s0 + u * stride);
+    }
 }
 // ... except the members of still-unresolved buckets, which share their head's slot.
 __global__ void __launch_bounds__(kBlock)
 k_isa_fix_active(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ head_slot,
                  uint64_t m, uint32_t* __restrict__ isa)
 {
+    constexpr int U = 4;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < m; q += stride)
-        isa[suf[q]] = head_slot[q];
+    for (uint64_t q0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q0 < m; q0 += U * stride) {
+        uint32_t a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t q = q0 + u * stride;
+            a[u] = q < m ? suf[q] : 0u;
+            b[u] = q < m ? head_slot[q] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (q0 + u * stride < m) isa[a[u]] = b[u];
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -720,7 +843,11 @@ int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws
     carve_sa(ar, n, n, n, &b);
     if (ar.overflow) return SFX_ERR_WORKSPACE;
 
-    SFX_TRY(byte_histogram_dev(d_text, 0, n, (uint64_t*)b.bins, st));
+    SFX_HIP(hipMemsetAsync(b.bins, 0, 256 * sizeof(unsigned long long), st));
+    {
+        const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock * 64 - 1) / (kBlock * 64), kMaxGrid);
+        SFX_LAUNCH("byte_presence", (double)n, k_byte_presence, grid, kBlock, st, d_text, n, b.bins);
+    }
     Alphabet alpha;
     PackedText pt;
     SFX_TRY(prepare_text(d_text, n, b.bins, b.lut, b.packed, st, &alpha, &pt));

@@ -32,6 +32,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
+struct alignas(16) uint4 { unsigned x, y, z, w; };
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
