@@ -148,6 +148,7 @@ typedef struct {
     uint64_t active_after_initial;
     uint64_t radix_passes;
     uint64_t elements_sorted; /* sum over passes of elements moved             */
+    uint64_t small_bucket_resolved; /* suffixes placed by direct comparison of small buckets */
 } sfx_build_stats;
 void sfx_last_build_stats(sfx_build_stats* out);
 

@@ -511,6 +511,110 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     }
 }
 
+// ---------------------------------------------------------------------------------
+// 4c. direct ordering of small buckets
+// ---------------------------------------------------------------------------------
+// After the initial sort of low-entropy-free text (DNA) almost every unresolved bucket
+// holds 2-3 suffixes.  Sending those through another composite-key radix sort costs seven
+// passes; comparing the handful of suffixes directly on the packed text costs a few word
+// loads.  One thread per active element: find the bucket's extent in the active list
+// (<= kSmallCap members, else the bucket is left to the radix path), compare against every
+// other member from offset h on (all members share their first h symbols), and take
+// position = #smaller members (+ #undecided members before it).  A comparison is
+// undecided when kSmallDepthWords packed words are equal; such members stay unresolved,
+// in place, and go on to the next radix round together.
+constexpr int kSmallCap = 32;
+constexpr int kSmallDepthWords = 16;
+
+// -1: suffix a < suffix b, +1: a > b, 0: equal for kSmallDepthWords words beyond offset h.
+// "Shorter sorts first" (the reference's virtual sentinel, :422-425): when one suffix ends
+// inside the window only the symbols both still have are compared, then the shorter wins.
+__device__ __forceinline__ int direct_compare(const PackedText& t, uint64_t a, uint64_t b, uint64_t h)
+{
+    for (int wd = 0; wd < kSmallDepthWords; wd++) {
+        const int64_t la = (int64_t)t.n - (int64_t)(a + h), lb = (int64_t)t.n - (int64_t)(b + h);
+        const int64_t lim = la < lb ? la : lb;
+        if (lim <= 0) return la < lb ? -1 : 1;
+        uint32_t wa = packed_key32(t, a + h), wb = packed_key32(t, b + h);
+        if (lim < (int64_t)t.spw) {
+            const unsigned sh = (unsigned)(t.spw - (int)lim) * (unsigned)t.bits;
+            wa >>= sh;
+            wb >>= sh;
+            if (wa != wb) return wa < wb ? -1 : 1;
+            return la < lb ? -1 : 1;
+        }
+        if (wa != wb) return wa < wb ? -1 : 1;
+        h += (uint64_t)t.spw;
+    }
+    return 0;
+}
+
+// V/S/G: the active list (suffix, SA slot, bucket id per position; buckets contiguous).
+// V2: suffixes re-ordered inside every small bucket; flag[p] = 1 where position p is still
+// unresolved.  sa (and isa, if given) are updated for every member of a small bucket.
+__global__ void __launch_bounds__(kBlock)
+k_small_groups(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, const uint32_t* __restrict__ G,
+               uint64_t m, PackedText t, uint64_t h, uint32_t* __restrict__ sa, uint32_t* __restrict__ isa,
+               uint32_t* __restrict__ V2, uint32_t* __restrict__ flag)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < m; q += stride) {
+        const uint32_t g = G[q];
+        uint64_t lo = q, hi = q;
+        while (lo > 0 && q - lo < (uint64_t)kSmallCap && G[lo - 1] == g) lo--;
+        while (hi + 1 < m && hi - q < (uint64_t)kSmallCap && G[hi + 1] == g) hi++;
+        const bool cut = (lo > 0 && G[lo - 1] == g) || (hi + 1 < m && G[hi + 1] == g);
+        const uint32_t my = V[q];
+        if (cut || hi - lo + 1 > (uint64_t)kSmallCap) {          // large bucket: untouched
+            V2[q] = my;
+            flag[q] = 1u;
+            continue;
+        }
+        uint32_t smaller = 0, ties = 0, ties_before = 0;
+        for (uint64_t f = lo; f <= hi; f++) {
+            if (f == q) continue;
+            const int c = direct_compare(t, (uint64_t)my, (uint64_t)V[f], h);
+            if (c > 0) smaller++;
+            else if (c == 0) { ties++; if (f < q) ties_before++; }
+        }
+        const uint64_t pos = lo + smaller + ties_before;
+        const uint32_t slot = S[pos];
+        V2[pos] = my;
+        sa[slot] = my;                                           // keeps sa a permutation even where unresolved
+        flag[pos] = ties ? 1u : 0u;
+        if (isa && !ties) isa[my] = slot;
+    }
+}
+
+// stream compaction of the positions with flag != 0 (order kept): two-phase, per-workgroup
+// counts scanned by k_scan_block_counts
+__global__ void __launch_bounds__(kBlock)
+k_flag_compact(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ S, const uint32_t* __restrict__ V2,
+               const uint32_t* __restrict__ G, uint64_t m, uint64_t chunk, int phase,
+               uint32_t* __restrict__ block_counts, uint32_t* __restrict__ S_next, uint32_t* __restrict__ V_next,
+               uint32_t* __restrict__ G_next)
+{
+    __shared__ uint32_t part[kWavesPerBlock];
+    const unsigned tid = threadIdx.x;
+    uint64_t begin = (uint64_t)blockIdx.x * chunk;
+    uint64_t end = begin + chunk;
+    if (end > m) end = m;
+    uint64_t running = (phase == 1) ? (uint64_t)block_counts[blockIdx.x] : 0ull;
+    for (uint64_t base = begin; base < end; base += kBlock) {
+        const uint64_t p = base + tid;
+        const bool keep = p < end && flag[p] != 0u;
+        uint32_t total;
+        const uint32_t ex = block_scan_add_excl<uint32_t>(keep ? 1u : 0u, part, total);
+        if (phase == 1 && keep) {
+            S_next[running + ex] = S[p];
+            V_next[running + ex] = V2[p];
+            G_next[running + ex] = G[p];
+        }
+        running += total;
+    }
+    if (phase == 0 && tid == 0) block_counts[blockIdx.x] = (uint32_t)running;
+}
+
 // (Re)build the rank array when refinement switches from text symbols to ranks:
 // every slot is its own rank ...
 __global__ void __launch_bounds__(kBlock)
@@ -599,7 +703,9 @@ struct SaBuffers {
     uint64_t* K0; uint64_t* K1;                         // key ping-pong (8 B per element)
     uint32_t* VA; uint32_t* VB;                         // suffix ping-pong
     uint32_t* S0; uint32_t* S1;                         // slot lists
-    uint32_t* G;                                        // dense bucket ids
+    uint32_t* G;                                        // bucket ids of the active list (G/G1 ping-pong)
+    uint32_t* G1;
+    uint32_t* block_counts;                             // kMaxGrid
     uint32_t* R;                                        // bucket-head slots (text rounds of a full build)
     uint32_t* isa;
     uint32_t* packed;                                   // PackedText words
@@ -624,6 +730,8 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint32_t* S0 = ar.template take<uint32_t>(cap);
     uint32_t* S1 = ar.template take<uint32_t>(cap);
     uint32_t* G = ar.template take<uint32_t>(cap);
+    uint32_t* G1 = ar.template take<uint32_t>(cap);
+    uint32_t* bc = ar.template take<uint32_t>(kMaxGrid);
     uint32_t* R = ar.template take<uint32_t>(isa_len ? cap / kTextFirstDivisor + 1024 : 0);
     uint32_t* isa = ar.template take<uint32_t>(isa_len);
     uint32_t* packed = ar.template take<uint32_t>(packed_words(n, nullptr));
@@ -635,7 +743,7 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     unsigned long long* bins = ar.template take<unsigned long long>(256);
     uint8_t* lut = ar.template take<uint8_t>(256);
     if (b) {
-        b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->R = R;
+        b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->G1 = G1; b->block_counts = bc; b->R = R;
         b->isa = isa; b->packed = packed; b->hist = hist; b->part_head = ph; b->part_keep = pk;
         b->part_ghead = pg; b->totals = totals; b->bins = bins; b->lut = lut;
     }
@@ -724,6 +832,41 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
     return SFX_OK;
 }
 
+// Direct ordering of the small buckets of the active list (S_cur, *V_cur, b.G; m elements
+// sharing their first h symbols inside each bucket), followed by compaction of what is
+// still unresolved.  On return the active list is (*S_cur, *V_cur, b.G) with *m elements.
+static int small_groups_pass(const PackedText& pt, uint64_t h, SaBuffers& b, uint32_t* sa, uint32_t* isa,
+                             uint32_t** S_cur, uint32_t** V_cur, uint64_t* m, hipStream_t st,
+                             sfx_build_stats& stats)
+{
+    const uint64_t cnt = *m;
+    uint32_t* V_other = (*V_cur == b.VA) ? b.VB : b.VA;
+    uint32_t* S_next = (*S_cur == b.S0) ? b.S1 : b.S0;
+    uint32_t* flag = (uint32_t*)b.K0;                       // free between rounds
+    unsigned grid = (unsigned)dmin<uint64_t>((cnt + kBlock - 1) / kBlock, kMaxGrid);
+    SFX_LAUNCH("small_groups", (double)cnt * 28, k_small_groups, grid, kBlock, st, *V_cur, *S_cur, b.G, cnt, pt, h,
+               sa, isa, V_other, flag);
+    Chunking ch = make_chunking(cnt, 1024);
+    const uint64_t chunk = ch.tiles_per_block * 1024;
+    SFX_LAUNCH("flag_count", (double)cnt * 4, k_flag_compact, ch.blocks, kBlock, st, flag, *S_cur, V_other, b.G, cnt,
+               chunk, 0, b.block_counts, S_next, *V_cur, b.G1);
+    SFX_LAUNCH("flag_scan", 0.0, k_scan_block_counts, 1, kBlock, st, b.block_counts, ch.blocks, b.totals);
+    uint32_t left = 0;
+    SFX_HIP(hipMemcpyAsync(&left, b.totals, sizeof(left), hipMemcpyDeviceToHost, st));
+    SFX_HIP(hipStreamSynchronize(st));
+    if (left > 0) {
+        SFX_LAUNCH("flag_compact", (double)cnt * 4 + (double)left * 24, k_flag_compact, ch.blocks, kBlock, st, flag,
+                   *S_cur, V_other, b.G, cnt, chunk, 1, b.block_counts, S_next, *V_cur, b.G1);
+        uint32_t* t = b.G; b.G = b.G1; b.G1 = t;
+        *S_cur = S_next;                                    // V stays in *V_cur (compacted from V_other)
+    }
+    stats.small_bucket_resolved += cnt - left;
+    *m = left;
+    return SFX_OK;
+}
+// worth it when the average unresolved bucket is small
+static bool small_groups_pay(uint64_t m, uint64_t groups) { return m > 0 && groups * 4 >= m; }
+
 // refinement rounds shared by the full and the partitioned build.
 //   rank round: key2 = rank of the suffix h symbols on (needs ISA), h doubles
 //   text round: key2 = the next spw symbols (needs only the packed text), h += spw
@@ -780,6 +923,11 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         m = kept;
         groups = kept_groups;
         stats.rounds++;
+        if (small_groups_pay(m, groups)) {
+            // the rank array is in use from here on iff the next round is a rank round
+            uint32_t* live_isa = (isa && text_rounds <= 0) ? isa : nullptr;
+            SFX_TRY(small_groups_pass(pt, h, b, sa, live_isa, &S_cur, &V_cur, &m, st, stats));
+        }
     }
     return SFX_OK;
 }
@@ -820,7 +968,13 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     const int text_rounds = (isa && kept * kTextFirstDivisor <= count && pt.spw >= 8) ? 1 : 0;
     SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, (isa && !text_rounds) ? isa : nullptr, b.S0, V_next,
                               nullptr, st, in_place));
-    return refine(pt, cpk, b, sa, isa, text_rounds, b.S0, V_next, kept, groups, st, stats);
+    uint32_t* S_cur = b.S0;
+    if (small_groups_pay(kept, groups)) {
+        // (buckets keep their ids; `groups` stays an upper bound for the id width)
+        SFX_TRY(small_groups_pass(pt, (uint64_t)cpk, b, sa, (isa && !text_rounds) ? isa : nullptr, &S_cur, &V_next,
+                                  &kept, st, stats));
+    }
+    return refine(pt, cpk, b, sa, isa, text_rounds, S_cur, V_next, kept, groups, st, stats);
 }
 
 int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,

@@ -157,3 +157,38 @@ def generated(eng, orc, n_dna, n_text):
                queries=["日".encode(), b" ", "я".encode(), b"\xf0\x9f"])
     check_text(eng, orc, _gen.uniform_bytes(n_text, 256, 11).tobytes(), queries=[b"\x00", b"\xff\xff"])
     check_text(eng, orc, _gen.uniform_bytes(n_text, 2, 12, base=ord("a")).tobytes(), queries=[b"abab", b"bbbbbbbbb"])
+
+
+def small_buckets(eng, orc, scale=1):
+    """Planted short repeats: after the initial sort almost every unresolved bucket has
+    2-3 members, which the engine orders by direct comparison (k_small_groups); very long
+    repeats exceed its comparison depth and must fall through to the radix rounds; a
+    repeat that runs into the end of the text exercises "shorter sorts first"."""
+    rng = np.random.default_rng(5)
+
+    def planted(base, nrep, lo, hi, copies=1):
+        t = bytearray(base)
+        for _ in range(nrep):
+            length = int(rng.integers(lo, hi))
+            p = int(rng.integers(0, len(base) - length))
+            for _c in range(copies):
+                t += base[p:p + length] + bytes([base[int(rng.integers(0, len(base)))]])
+        return bytes(t)
+
+    dna = _gen.dna(6000 * scale).tobytes()
+    cases = {
+        "dna pairs": (planted(dna, 80 * scale, 18, 40), True),
+        "dna triples": (planted(dna, 40 * scale, 18, 60, 2), True),
+        "dna deep": (planted(dna, 6, 300, 400), True),
+        "bytes pairs": (planted(_gen.uniform_bytes(5000 * scale, 200, 3).tobytes(), 80 * scale, 10, 30), True),
+        "ascii": (planted(_gen.uniform_bytes(5000 * scale, 20, 4).tobytes(), 120 * scale, 12, 50, 2), True),
+        "runs into the end": (dna[:3000] + dna[:40], True),
+    }
+    for name, (text, expect_direct) in cases.items():
+        check_text(eng, orc, text)
+        st = eng.build_stats()
+        if expect_direct:
+            assert st["small_bucket_resolved"] > 0, (name, st)
+    # the deep repeats cannot all be settled within the comparison depth
+    check_text(eng, orc, cases["dna deep"][0], lcp=False)
+    assert eng.build_stats()["rounds"] > 0

@@ -55,6 +55,10 @@ def test_planted_repeats_switch_text_to_rank_rounds(emu, oracle):
     _cases.planted_repeats(emu, oracle, 7000)
 
 
+def test_small_buckets_direct_ordering(emu, oracle):
+    _cases.small_buckets(emu, oracle)
+
+
 def test_multi_tile_and_multi_block(emu, oracle):
     # > 4096-key radix tiles, several persistent workgroups, u32 and u64 initial keys
     import _gen

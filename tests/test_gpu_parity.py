@@ -58,6 +58,10 @@ def test_planted_repeats_switch_text_to_rank_rounds(eng, oracle):
     _cases.planted_repeats(eng, oracle, 2_000_000)
 
 
+def test_small_buckets_direct_ordering(eng, oracle):
+    _cases.small_buckets(eng, oracle, scale=20)
+
+
 def test_long_runs_and_repeats(eng, oracle):
     # worst cases for prefix doubling / PLCP: every round keeps every suffix active
     _cases.check_text(eng, oracle, b"a" * 50_000)   # (the oracle's LCP is quadratic here)
