@@ -423,7 +423,8 @@ k_groups_scan(uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep
 // sa_in_place: V IS the SA and slots are the identity -- the last radix pass of the
 // initial sort already put every suffix in its slot); if isa:
 // ISA[suffix] = slot of its bucket head; and compacts the elements of
-// non-singleton buckets into (S_next, V_next, G_next = dense bucket id, and, if
+// non-singleton buckets into (S_next, V_next, G_next = bucket id = position of the
+// bucket's head in the compacted list: unique and increasing along the list; and, if
 // R_next, R_next = slot of the bucket head).
 template <class KeyT>
 __global__ void __launch_bounds__(kBlock)
@@ -442,7 +443,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     if (end > m) end = m;
     uint32_t c_head = part_head[blockIdx.x];     // index+1 of the last head before the chunk
     uint32_t c_keep = part_keep[blockIdx.x];
-    uint32_t c_ghead = part_ghead[blockIdx.x];
+    (void)part_ghead;
     unsigned par = 0;
     GroupKeys<KeyT> nxt;
     if (begin < end) group_load(K, begin + (uint64_t)tid * kGroupItems, m, nxt);
@@ -455,7 +456,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         const unsigned valid = valid_mask(i0, m);
         const unsigned keepm = valid & ~single;
         const uint32_t hmax = head ? (uint32_t)i0 + (32u - (unsigned)__clz((int)head)) : 0u;
-        const uint32_t cnt = (uint32_t)__popc(keepm) | ((uint32_t)__popc(head & ~single) << 16);
+        const uint32_t cnt = (uint32_t)__popc(keepm);
         // one barrier for both scans: exclusive max of hmax, exclusive sum of cnt
         uint32_t im = wave_scan_max(hmax), ia = wave_scan_add(cnt);
         uint32_t pm = __shfl_up(im, 1u);
@@ -473,17 +474,17 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         par ^= 1u;
         const uint32_t ec = ba + ia - cnt;
         uint32_t run_head = dmax(c_head, dmax(bm, pm));          // index+1 of the last head before item 0
-        uint32_t run_keep = c_keep + (ec & 0xFFFFu);
-        uint32_t run_ghead = c_ghead + (ec >> 16);
+        uint32_t run_keep = c_keep + ec;
         if (keepm || isa || !sa_in_place) {                      // (all-singleton threads have nothing to write in place)
             // gathers first (all in flight together), stores after: one memory round trip per tile
-            uint32_t slot[kGroupItems], suffix[kGroupItems], head_slot[kGroupItems];
+            uint32_t slot[kGroupItems], suffix[kGroupItems], head_slot[kGroupItems], back[kGroupItems];
 #pragma unroll
             for (int j = 0; j < kGroupItems; j++) {
                 const uint64_t i = i0 + j;
                 const bool v = (valid >> j) & 1u, keep = (keepm >> j) & 1u;
                 if ((head >> j) & 1u) run_head = (uint32_t)i + 1u;
                 const uint32_t my_head = run_head - 1u;
+                back[j] = (uint32_t)i - my_head;                 // distance to the bucket head (all kept in between)
                 slot[j] = (v && S) ? S[i] : (uint32_t)i;
                 suffix[j] = (v && (!sa_in_place || keep || isa)) ? V[i] : 0u;
                 head_slot[j] = (v && S && (isa || (keep && R_next))) ? S[my_head] : my_head;
@@ -492,22 +493,20 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
             for (int j = 0; j < kGroupItems; j++) {
                 if ((valid >> j) & 1u) {
                     const bool keep = (keepm >> j) & 1u;
-                    if (((head >> j) & 1u) && keep) run_ghead++;
                     if (!sa_in_place) sa[slot[j]] = suffix[j];
                     if (isa) isa[suffix[j]] = head_slot[j];
                     if (keep) {
                         if (R_next) R_next[run_keep] = head_slot[j];
                         S_next[run_keep] = slot[j];
                         V_next[run_keep] = suffix[j];
-                        G_next[run_keep] = run_ghead - 1u;
+                        G_next[run_keep] = run_keep - back[j];   // bucket id = position of its head in the new list
                         run_keep++;
                     }
                 }
             }
         }
         c_head = dmax(c_head, tot_m);
-        c_keep += tot_a & 0xFFFFu;
-        c_ghead += tot_a >> 16;
+        c_keep += tot_a;
     }
 }
 
@@ -549,24 +548,29 @@ __device__ __forceinline__ int direct_compare(const PackedText& t, uint64_t a, u
     return 0;
 }
 
-// V/S/G: the active list (suffix, SA slot, bucket id per position; buckets contiguous).
-// V2: suffixes re-ordered inside every small bucket; flag[p] = 1 where position p is still
-// unresolved.  sa (and isa, if given) are updated for every member of a small bucket.
+// V/S/G: the active list (suffix, SA slot, bucket id per position; buckets contiguous,
+// id = position of the bucket's head).  V2/G2: suffixes re-ordered inside every small
+// bucket and the ids of what is left of it -- members that tie with each other form a new
+// bucket (id = position of its first member) which must not share an id, or a rank, with
+// the rest of the old bucket: a suffix resolved BETWEEN two tie classes would otherwise
+// outrank members that are in fact larger.  flag[p] = 1 where position p is still
+// unresolved.  sa (and the rank array, if in use) are updated for every member of a small
+// bucket.
 __global__ void __launch_bounds__(kBlock)
 k_small_groups(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, const uint32_t* __restrict__ G,
                uint64_t m, PackedText t, uint64_t h, uint32_t* __restrict__ sa, uint32_t* __restrict__ isa,
-               uint32_t* __restrict__ V2, uint32_t* __restrict__ flag)
+               uint32_t* __restrict__ V2, uint32_t* __restrict__ G2, uint32_t* __restrict__ flag)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < m; q += stride) {
         const uint32_t g = G[q];
-        uint64_t lo = q, hi = q;
-        while (lo > 0 && q - lo < (uint64_t)kSmallCap && G[lo - 1] == g) lo--;
-        while (hi + 1 < m && hi - q < (uint64_t)kSmallCap && G[hi + 1] == g) hi++;
-        const bool cut = (lo > 0 && G[lo - 1] == g) || (hi + 1 < m && G[hi + 1] == g);
+        const uint64_t lo = g;                                   // bucket id = position of its head
         const uint32_t my = V[q];
-        if (cut || hi - lo + 1 > (uint64_t)kSmallCap) {          // large bucket: untouched
+        uint64_t hi = q;
+        while (hi + 1 < m && hi + 1 - lo < (uint64_t)kSmallCap && G[hi + 1] == g) hi++;
+        if (q - lo >= (uint64_t)kSmallCap || (hi + 1 < m && G[hi + 1] == g)) {   // large bucket: untouched
             V2[q] = my;
+            G2[q] = g;
             flag[q] = 1u;
             continue;
         }
@@ -577,12 +581,13 @@ k_small_groups(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, c
             if (c > 0) smaller++;
             else if (c == 0) { ties++; if (f < q) ties_before++; }
         }
-        const uint64_t pos = lo + smaller + ties_before;
-        const uint32_t slot = S[pos];
+        const uint64_t cls = lo + smaller;                       // first position of my tie class
+        const uint64_t pos = cls + ties_before;
         V2[pos] = my;
-        sa[slot] = my;                                           // keeps sa a permutation even where unresolved
+        G2[pos] = (uint32_t)cls;
         flag[pos] = ties ? 1u : 0u;
-        if (isa && !ties) isa[my] = slot;
+        sa[S[pos]] = my;                                         // keeps sa a permutation even where unresolved
+        if (isa) isa[my] = S[cls];                               // final slot, or the tie class's head slot
     }
 }
 
@@ -844,21 +849,20 @@ static int small_groups_pass(const PackedText& pt, uint64_t h, SaBuffers& b, uin
     uint32_t* S_next = (*S_cur == b.S0) ? b.S1 : b.S0;
     uint32_t* flag = (uint32_t*)b.K0;                       // free between rounds
     unsigned grid = (unsigned)dmin<uint64_t>((cnt + kBlock - 1) / kBlock, kMaxGrid);
-    SFX_LAUNCH("small_groups", (double)cnt * 28, k_small_groups, grid, kBlock, st, *V_cur, *S_cur, b.G, cnt, pt, h,
-               sa, isa, V_other, flag);
+    SFX_LAUNCH("small_groups", (double)cnt * 32, k_small_groups, grid, kBlock, st, *V_cur, *S_cur, b.G, cnt, pt, h,
+               sa, isa, V_other, b.G1, flag);
     Chunking ch = make_chunking(cnt, 1024);
     const uint64_t chunk = ch.tiles_per_block * 1024;
-    SFX_LAUNCH("flag_count", (double)cnt * 4, k_flag_compact, ch.blocks, kBlock, st, flag, *S_cur, V_other, b.G, cnt,
-               chunk, 0, b.block_counts, S_next, *V_cur, b.G1);
+    SFX_LAUNCH("flag_count", (double)cnt * 4, k_flag_compact, ch.blocks, kBlock, st, flag, *S_cur, V_other, b.G1, cnt,
+               chunk, 0, b.block_counts, S_next, *V_cur, b.G);
     SFX_LAUNCH("flag_scan", 0.0, k_scan_block_counts, 1, kBlock, st, b.block_counts, ch.blocks, b.totals);
     uint32_t left = 0;
     SFX_HIP(hipMemcpyAsync(&left, b.totals, sizeof(left), hipMemcpyDeviceToHost, st));
     SFX_HIP(hipStreamSynchronize(st));
     if (left > 0) {
         SFX_LAUNCH("flag_compact", (double)cnt * 4 + (double)left * 24, k_flag_compact, ch.blocks, kBlock, st, flag,
-                   *S_cur, V_other, b.G, cnt, chunk, 1, b.block_counts, S_next, *V_cur, b.G1);
-        uint32_t* t = b.G; b.G = b.G1; b.G1 = t;
-        *S_cur = S_next;                                    // V stays in *V_cur (compacted from V_other)
+                   *S_cur, V_other, b.G1, cnt, chunk, 1, b.block_counts, S_next, *V_cur, b.G);
+        *S_cur = S_next;                                    // V stays in *V_cur (compacted from V_other), ids in b.G
     }
     stats.small_bucket_resolved += cnt - left;
     *m = left;
@@ -873,9 +877,11 @@ static bool small_groups_pay(uint64_t m, uint64_t groups) { return m > 0 && grou
 // The partitioned build (isa == nullptr) only has text rounds.  A full build runs
 // `text_rounds` text rounds first (0 or 1, see kTextFirstDivisor) and rank rounds after.
 static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uint32_t* isa,
-                  int text_rounds, uint32_t* S_cur, uint32_t* V_cur, uint64_t m, uint64_t groups,
+                  int text_rounds, uint32_t* S_cur, uint32_t* V_cur, uint64_t m, uint64_t id_bound,
                   hipStream_t st, sfx_build_stats& stats)
 {
+    // bucket ids are positions in the active list as it was when they were assigned
+    // (< id_bound); the direct pass and its compaction shrink the list but keep the ids
     const uint64_t n = pt.n;
     uint64_t h = (uint64_t)cpk;
     const int spw = pt.spw;
@@ -886,7 +892,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         if (++rounds > (isa ? 80 : 1 << 20)) return SFX_ERR_INTERNAL;
         const bool text_round = !isa || text_rounds > 0;
         int key2_bits = text_round ? flag_shift + 1 : bits_for(n - 1 + h);
-        int gid_bits = bits_for(groups > 0 ? groups - 1 : 0);
+        int gid_bits = bits_for(id_bound > 0 ? id_bound - 1 : 0);
         if (key2_bits + gid_bits > 64) return SFX_ERR_INTERNAL;
         unsigned grid = (unsigned)dmin<uint64_t>((m + kBlock - 1) / kBlock, kMaxGrid);
         if (text_round) {
@@ -921,9 +927,9 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         S_cur = S_next;
         V_cur = V_next;
         m = kept;
-        groups = kept_groups;
+        id_bound = kept;
         stats.rounds++;
-        if (small_groups_pay(m, groups)) {
+        if (small_groups_pay(m, kept_groups)) {
             // the rank array is in use from here on iff the next round is a rank round
             uint32_t* live_isa = (isa && text_rounds <= 0) ? isa : nullptr;
             SFX_TRY(small_groups_pass(pt, h, b, sa, live_isa, &S_cur, &V_cur, &m, st, stats));
@@ -969,12 +975,12 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, (isa && !text_rounds) ? isa : nullptr, b.S0, V_next,
                               nullptr, st, in_place));
     uint32_t* S_cur = b.S0;
+    const uint64_t id_bound = kept;
     if (small_groups_pay(kept, groups)) {
-        // (buckets keep their ids; `groups` stays an upper bound for the id width)
         SFX_TRY(small_groups_pass(pt, (uint64_t)cpk, b, sa, (isa && !text_rounds) ? isa : nullptr, &S_cur, &V_next,
                                   &kept, st, stats));
     }
-    return refine(pt, cpk, b, sa, isa, text_rounds, S_cur, V_next, kept, groups, st, stats);
+    return refine(pt, cpk, b, sa, isa, text_rounds, S_cur, V_next, kept, id_bound, st, stats);
 }
 
 int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,

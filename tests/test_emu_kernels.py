@@ -47,6 +47,15 @@ def test_structured(emu, oracle):
     _cases.structured(emu, oracle, scale=3)
 
 
+def test_structured_deep_ties(emu, oracle):
+    # overlap-free / Fibonacci words: many small buckets whose members tie beyond the direct
+    # comparison depth, next to members that resolve between them (rank consistency)
+    import _gen
+    _cases.check_text(emu, oracle, _gen.thue_morse(4000).tobytes())
+    _cases.check_text(emu, oracle, _gen.fibonacci_string(17))
+    _cases.check_text(emu, oracle, (b"ab" * 700 + b"c") * 3)
+
+
 def test_generated(emu, oracle):
     _cases.generated(emu, oracle, n_dna=9000, n_text=6000)
 
