@@ -97,9 +97,9 @@ k_lab_pass(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t
                     const unsigned d0 = (MODE & 1) ? (p / KPT) : digit_of(key[2 * r], shift, mask);
                     const unsigned d1 = (MODE & 1) ? ((p + 1) / KPT) : digit_of(key[2 * r + 1], shift, mask);
                     const uint32_t a0 = s.off[d0] + p, a1 = s.off[d1] + p + 1;
-                    if (d0 == d1) {
-                        struct alignas(8) P2 { uint64_t a, b; };
-                        *reinterpret_cast<P2*>(out + a0) = P2{key[2 * r], key[2 * r + 1]};
+                    if ((MODE & 64) || d0 == d1) {
+                        struct alignas(16) P2 { uint64_t a, b; };
+                        *reinterpret_cast<P2*>(out + ((MODE & 64) ? (a0 & ~1u) : a0)) = P2{key[2 * r], key[2 * r + 1]};
                     } else {
                         out[a0] = key[2 * r];
                         out[a1] = key[2 * r + 1];
@@ -218,6 +218,11 @@ int main()
     RUN(16, 48, true, "full, aligned + pair stores");
     RUN(16, 49, true, "no ranking, aligned + pair stores");
     RUN(16, 48, false, "full, aligned + pair, no prefetch");
+    RUN(16, 113, true, "no ranking, aligned, dwordx4 stores");
+    RUN(16, 112, true, "full, forced-aligned dwordx4 stores");
+    RUN(16, 97, true, "no ranking, unaligned heads, dwordx4");
+    RUN(8, 113, true, "no ranking, aligned, dwordx4 stores");
+    RUN(8, 17, true, "no ranking, line-aligned heads");
     RUN(8, 48, true, "full, aligned + pair stores");
     RUN(8, 0, true, "full");
     RUN(8, 1, true, "no ranking");

@@ -4,7 +4,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/sweep2; mkdir -p "$OUT"; export TMPDIR=/tmp
 S="$OUT/summary.txt"; : > "$S"
-for cfg in "0 0 16 1" "0 0 16 0" "0 0 8 1" "0 16 16 0" "0 16 12 0" "0 16 8 0" "0 8 16 0" "0 8 12 0" "0 8 8 0" "1 0 16 1" "1 0 8 1"; do
+for cfg in "1 0 16 1" "1 0 8 1" "0 0 16 1" "0 0 8 1" "0 0 16 0" "0 1 16 0"; do
   set -- $cfg
   tag="sw$1_wc$2_kpt$3_rk$4"
   echo "== $tag" | tee -a "$S"
