@@ -76,6 +76,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=50_000_000,
                     help="bytes of the same text the CPU baseline is timed on (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="also launch the known-byte-count copy / run-scatter micro-benchmarks once, so a "
+                         "rocprofv3 --pmc pass of this command can calibrate FETCH_SIZE / WRITE_SIZE")
+    ap.add_argument("--no-microbench", action="store_true", help="skip the scatter/gather roofline probes")
     args = ap.parse_args()
 
     import torch
@@ -164,6 +168,39 @@ def main():
                        "achieved": round(65.0 * value / 1e3, 1), "unit": "GB/s",
                        "frac": round(65.0 * value / 1e3 / HBM_PEAK_GBS, 4)},
     }
+
+    # ---- HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes
+    # (MI355X_MICROARCH.md, HBM section), so the per-launch figure comes from the committed
+    # summary of those passes over this same command (scripts/gpu_pmc.sh -> profiles/) ----
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            ent = pmc.get("kernels", {}).get(dom["name"])
+            if ent:
+                roofline["traffic"] = round(ent["hbm_bytes_per_launch"])
+                roofline["traffic_detail"] = {k: ent[k] for k in ("fetch_bytes", "write_bytes", "launches")}
+                roofline["traffic_source"] = pmc.get("source", "profiles/pmc_latest.json")
+        except (ValueError, KeyError, OSError):
+            pass
+
+    # ---- what the memory system sustains for the engine's access shapes ----
+    if rank == 0 and world == 1 and not args.no_microbench:
+        E = eng
+        roofline["scatter_bw"] = {
+            "unit": "GB/s",
+            "copy_16B": round(E.microbench(E.MB_COPY, 1 << 30), 1),
+            "random_4B_scatter_into_4n": round(E.microbench(E.MB_SCATTER4, 4 * n_local), 1),
+            "random_4B_gather_from_4n": round(E.microbench(E.MB_GATHER4, 4 * n_local), 1),
+            "random_1B_gather_from_n": round(E.microbench(E.MB_GATHER1, n_local), 1),
+            "runs_128B_unaligned_copy": round(E.microbench(E.MB_RUNSCATTER, 8 * n_local, 128, 0), 1),
+            "runs_128B_aligned_copy": round(E.microbench(E.MB_RUNSCATTER, 8 * n_local, 128, 1), 1),
+        }
+        # the radix pass is a read + run-scatter; its practical ceiling is the unaligned-run rate
+        roofline["frac_of_run_scatter"] = round(achieved / max(roofline["scatter_bw"]["runs_128B_unaligned_copy"], 1e-9), 4)
+    if args.calibrate and world == 1:
+        eng.microbench(eng.MB_COPY, 1 << 30, 0, 0, 1)
+        eng.microbench(eng.MB_RUNSCATTER, 8 * n_local, 128, 0, 1)
 
     # ---- correctness gates ----
     verified, how = None, "skipped"

@@ -1,14 +1,33 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc CSV output: per (kernel, counter) mean value per dispatch.
-usage: pmc_summary.py <dir-with-*counter_collection.csv> [...]   -> CSV on stdout"""
+usage: pmc_summary.py <dir-with-*counter_collection.csv> [...]   -> CSV on stdout
+       pmc_summary.py --json OUT.json <dirs...>                   also writes the per-kernel
+           HBM-traffic JSON bench.py reads (profiles/pmc_latest.json): FETCH_SIZE / WRITE_SIZE
+           are reported in KiB; they are calibrated on the known byte counts of the
+           sfx::k_mb_copy launch of the same run (bench.py --calibrate), as
+           MI355X_MICROARCH.md's HBM section prescribes (FETCH_SIZE reads half of a wide
+           streaming read on gfx950; WRITE_SIZE is uncalibrated)."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
+args = sys.argv[1:]
+json_out = None
+if args and args[0] == "--json":
+    json_out, args = args[1], args[2:]
+
+# profile name of the engine (sfx_kernel_stat.name) for each kernel symbol
+NAMES = [("k_radix_pass<sfx::SrcE64", "radix_scatter_u32"), ("k_radix_pass<sfx::SrcText32", "radix_scatter_text_u32"),
+         ("k_radix_pass<sfx::SrcKV", "radix_scatter_u64"), ("k_radix_pass<sfx::SrcText64", "radix_scatter_text_u64"),
+         ("k_groups_apply<unsigned int>", "groups_apply_u32"), ("k_groups_apply<unsigned long>", "groups_apply_u64"),
+         ("k_groups_reduce", "groups_reduce"), ("k_radix_hist_all<sfx::SrcText32", "radix_hist_all_text_u32"),
+         ("k_pack_text", "pack_text"), ("k_small_groups", "small_groups"), ("k_byte_presence", "byte_presence")]
+
 acc = defaultdict(lambda: [0.0, 0])
-for d in sys.argv[1:]:
+for d in args:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
@@ -21,3 +40,31 @@ w = csv.writer(sys.stdout)
 w.writerow(["Kernel", "Counter", "Dispatches", "MeanPerDispatch"])
 for (k, c), (tot, cnt) in sorted(acc.items()):
     w.writerow([k, c, cnt, f"{tot / max(cnt, 1):.1f}"])
+
+if json_out:
+    def mean(kernel_prefix, counter):
+        tot = cnt = 0
+        for (k, c), (t, n) in acc.items():
+            if c == counter and kernel_prefix in k:
+                tot += t
+                cnt += n
+        return (tot / cnt, cnt) if cnt else (None, 0)
+
+    # calibration on the 1 GiB streaming copy: 2^30 bytes read, 2^30 bytes written per launch
+    f_copy, _ = mean("k_mb_copy", "FETCH_SIZE")
+    w_copy, _ = mean("k_mb_copy", "WRITE_SIZE")
+    known = float(1 << 30)
+    f_cal = known / (f_copy * 1024.0) if f_copy else 2.0
+    w_cal = known / (w_copy * 1024.0) if w_copy else 1.0
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps 1 --calibrate` "
+                     "(scripts/gpu_pmc.sh); counters in KiB x calibration factor from sfx::k_mb_copy (1 GiB in, 1 GiB out)",
+           "fetch_calibration": round(f_cal, 4), "write_calibration": round(w_cal, 4), "kernels": {}}
+    for sym, prof in NAMES:
+        f, nf = mean(sym, "FETCH_SIZE")
+        wr, _ = mean(sym, "WRITE_SIZE")
+        if f is None or wr is None:
+            continue
+        fb, wb = f * 1024.0 * f_cal, wr * 1024.0 * w_cal
+        out["kernels"][prof] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "hbm_bytes_per_launch": round(fb + wb),
+                                "launches": nf, "symbol": sym}
+    json.dump(out, open(json_out, "w"), indent=1)
