@@ -49,6 +49,12 @@ uint64_t sfx_sa_workspace_bytes(uint64_t n);
 int sfx_build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa,
                          void* d_workspace, uint64_t workspace_bytes, void* stream);
 
+/* u64 index array (BASELINE config 4: "u64 indices").  SuffixTable itself is u32-only
+ * (`Cow<[u32]>` :57, assert :380), so positions fit 32 bits: the u32 engine runs and the
+ * array is widened on the device.  n > u32::MAX is SFX_ERR_TOO_LARGE as on the u32 entry. */
+int sfx_build_sa_u64(const uint8_t* text, uint64_t n, uint64_t* sa_out);
+int sfx_widen_u32_to_u64_dev(const uint32_t* d_in, uint64_t count, uint64_t* d_out, void* stream);
+
 /* ---- lcp_lens (:130-138 -> lcp_lens_quadratic :348-361): LCP array ---------- */
 /* lcp_out[0] = 0, lcp_out[r] = |lcp(text[sa[r-1]..], text[sa[r]..])| in bytes. */
 int sfx_build_lcp_u32(const uint8_t* text, uint64_t n, const uint32_t* sa, uint32_t* lcp_out);
@@ -108,6 +114,21 @@ int sfx_build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n,
                                uint32_t bin_lo, uint32_t bin_hi, uint64_t capacity,
                                uint32_t* d_sa_part, uint64_t* count_out, void* d_workspace,
                                uint64_t workspace_bytes, void* stream);
+
+/* Per-rank pieces of the partitioned index (every rank holds the text and ONE contiguous
+ * slice d_sa_part[0..count) of the suffix array):
+ *  - LCP of the slice: lcp_part[r] = |lcp(text[sa_part[r-1]..], text[sa_part[r]..])|, with
+ *    prev_suffix = the last suffix of the previous rank's slice for r == 0 (UINT32_MAX for
+ *    the first slice, giving 0 as :352 does).  Direct comparison, exactly :348-361.
+ *  - queries against the slice: start/end are positions INSIDE the slice (0/0 if the
+ *    slice holds no match); the global interval is the concatenation over ranks.        */
+int sfx_build_lcp_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa_part,
+                                uint64_t count, uint32_t prev_suffix, uint32_t* d_lcp_part,
+                                void* stream);
+int sfx_query_batch_range_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa_part,
+                              uint64_t count, const uint8_t* d_qbytes, const uint64_t* d_qoff,
+                              uint64_t nq, uint32_t* d_start, uint32_t* d_end, uint8_t* d_found,
+                              uint32_t* d_any, void* stream);
 
 /* ---- memory-system micro-benchmarks (the scatter/gather roofline
  * must be measured) -------------------------------------------------------------

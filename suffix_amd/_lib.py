@@ -43,6 +43,8 @@ ABI = [
     ("sfx_device_count", _int, []),
     ("sfx_last_hip_error", ctypes.c_char_p, []),
     ("sfx_build_sa_u32", _int, [_vp, _u64, _vp]),
+    ("sfx_build_sa_u64", _int, [_vp, _u64, _vp]),
+    ("sfx_widen_u32_to_u64_dev", _int, [_vp, _u64, _vp, _vp]),
     ("sfx_sa_workspace_bytes", _u64, [_u64]),
     ("sfx_build_sa_u32_dev", _int, [_vp, _u64, _vp, _vp, _u64, _vp]),
     ("sfx_build_lcp_u32", _int, [_vp, _u64, _vp, _vp]),
@@ -60,6 +62,8 @@ ABI = [
     ("sfx_sa_range_workspace_bytes", _u64, [_u64, _u64]),
     ("sfx_build_sa_range_u32_dev", _int, [_vp, _u64, _vp, _int, _u32, _u32, _u64, _vp,
                                           ctypes.POINTER(_u64), _vp, _u64, _vp]),
+    ("sfx_build_lcp_range_u32_dev", _int, [_vp, _u64, _vp, _u64, _u32, _vp, _vp]),
+    ("sfx_query_batch_range_dev", _int, [_vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     ("sfx_microbench", _int, [_int, _u64, _int, _int, _int, ctypes.POINTER(ctypes.c_double)]),
     ("sfx_profile_enable", None, [_int]),
     ("sfx_profile_reset", None, []),

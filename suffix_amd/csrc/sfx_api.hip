@@ -85,6 +85,7 @@ struct DevBuf {
         if (e != hipSuccess) { note_hip_error(e, "hipMalloc", __FILE__, __LINE__); p = nullptr; return SFX_ERR_HIP; }
         return SFX_OK;
     }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
 };
 
 static int check_device()
@@ -153,6 +154,31 @@ int sfx_build_sa_u32(const uint8_t* text, uint64_t n, uint32_t* sa_out)
     SFX_HIP(hipMemcpyAsync(dt.p, text, n, hipMemcpyHostToDevice, st));
     SFX_TRY(build_sa_u32_dev((const uint8_t*)dt.p, n, (uint32_t*)ds.p, dw.p, wsb, st));
     SFX_HIP(hipMemcpyAsync(sa_out, ds.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SFX_HIP(hipStreamSynchronize(st));
+    return SFX_OK;
+}
+
+// u64 index array (BASELINE config 4).  Positions fit u32 (n <= u32::MAX, :380), so the u32
+// engine runs and the result is widened on the device before the copy back.
+int sfx_build_sa_u64(const uint8_t* text, uint64_t n, uint64_t* sa_out)
+{
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    if (n == 0) return SFX_OK;
+    if (!text || !sa_out) return SFX_ERR_ARG;
+    SFX_TRY(check_device());
+    DevBuf dt, ds, dw, d64;
+    uint64_t wsb = sa_workspace_bytes(n);
+    SFX_TRY(dt.alloc(n));
+    SFX_TRY(ds.alloc(n * sizeof(uint32_t)));
+    SFX_TRY(dw.alloc(wsb));
+    hipStream_t st = nullptr;
+    SFX_HIP(hipMemcpyAsync(dt.p, text, n, hipMemcpyHostToDevice, st));
+    SFX_TRY(build_sa_u32_dev((const uint8_t*)dt.p, n, (uint32_t*)ds.p, dw.p, wsb, st));
+    SFX_HIP(hipStreamSynchronize(st));
+    dw.release();                                      // the workspace is larger than the u64 array
+    SFX_TRY(d64.alloc(n * sizeof(uint64_t)));
+    SFX_TRY(widen_u32_to_u64_dev((const uint32_t*)ds.p, n, (uint64_t*)d64.p, st));
+    SFX_HIP(hipMemcpyAsync(sa_out, d64.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     SFX_HIP(hipStreamSynchronize(st));
     return SFX_OK;
 }
@@ -246,8 +272,25 @@ int sfx_query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa,
                         uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any,
                         void* stream)
 {
-    return query_batch_dev(d_text, n, d_sa, d_qbytes, d_qoff, nq, d_start, d_end, d_found, d_any,
+    return query_batch_dev(d_text, n, d_sa, n, d_qbytes, d_qoff, nq, d_start, d_end, d_found, d_any,
                            (hipStream_t)stream);
+}
+int sfx_query_batch_range_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa_part, uint64_t count,
+                              const uint8_t* d_qbytes, const uint64_t* d_qoff, uint64_t nq,
+                              uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any,
+                              void* stream)
+{
+    return query_batch_dev(d_text, n, d_sa_part, count, d_qbytes, d_qoff, nq, d_start, d_end, d_found, d_any,
+                           (hipStream_t)stream);
+}
+int sfx_build_lcp_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa_part, uint64_t count,
+                                uint32_t prev_suffix, uint32_t* d_lcp_part, void* stream)
+{
+    return build_lcp_range_u32_dev(d_text, n, d_sa_part, count, prev_suffix, d_lcp_part, (hipStream_t)stream);
+}
+int sfx_widen_u32_to_u64_dev(const uint32_t* d_in, uint64_t count, uint64_t* d_out, void* stream)
+{
+    return widen_u32_to_u64_dev(d_in, count, d_out, (hipStream_t)stream);
 }
 
 static int query_host(const sfx_index* ix, const uint8_t* qbytes, const uint64_t* qoff, uint64_t nq,
@@ -268,7 +311,7 @@ static int query_host(const sfx_index* ix, const uint8_t* qbytes, const uint64_t
     hipStream_t st = nullptr;
     if (qtotal) SFX_HIP(hipMemcpyAsync(dq.p, qbytes, qtotal, hipMemcpyHostToDevice, st));
     SFX_HIP(hipMemcpyAsync(doff.p, qoff, (nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    SFX_TRY(query_batch_dev(ix->d_text, ix->n, ix->d_sa, (const uint8_t*)dq.p, (const uint64_t*)doff.p,
+    SFX_TRY(query_batch_dev(ix->d_text, ix->n, ix->d_sa, ix->n, (const uint8_t*)dq.p, (const uint64_t*)doff.p,
                             nq, (uint32_t*)ds.p, (uint32_t*)de.p, (uint8_t*)df.p, (uint32_t*)da.p, st));
     if (start_out) SFX_HIP(hipMemcpyAsync(start_out, ds.p, nq * 4, hipMemcpyDeviceToHost, st));
     if (end_out) SFX_HIP(hipMemcpyAsync(end_out, de.p, nq * 4, hipMemcpyDeviceToHost, st));

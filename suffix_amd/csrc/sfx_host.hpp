@@ -130,9 +130,12 @@ int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws
 uint64_t lcp_workspace_bytes(uint64_t n);
 int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint32_t* d_lcp,
                       void* ws, uint64_t ws_bytes, hipStream_t st);
-int query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint8_t* d_q,
-                    const uint64_t* d_qoff, uint64_t nq, uint32_t* d_start, uint32_t* d_end,
-                    uint8_t* d_found, uint32_t* d_any, hipStream_t st);
+int query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint64_t sa_len,
+                    const uint8_t* d_q, const uint64_t* d_qoff, uint64_t nq, uint32_t* d_start,
+                    uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st);
+int build_lcp_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa_part, uint64_t count,
+                            uint32_t prev_suffix, uint32_t* d_lcp_part, hipStream_t st);
+int widen_u32_to_u64_dev(const uint32_t* d_in, uint64_t count, uint64_t* d_out, hipStream_t st);
 int byte_histogram_dev(const uint8_t* d_text, uint64_t begin, uint64_t end, uint64_t* d_bins,
                        hipStream_t st);
 int key_histogram_dev(const uint8_t* d_text, uint64_t n, uint64_t begin, uint64_t end,

@@ -112,6 +112,51 @@ k_lcp_gather(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ plcp,
     }
 }
 
+// LCP of one contiguous SLICE of the suffix array (range-partitioned index): every rank
+// compares each suffix of its slice with its predecessor directly, 8 bytes per step --
+// the reference's own formulation (lcp_lens_quadratic :348-361), which is the right one
+// for the low-LCP texts the partitioned build is meant for, needs no inverse permutation
+// and no data from other ranks except the last suffix of the previous slice.
+__global__ void __launch_bounds__(kBlock)
+k_lcp_direct(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint64_t count,
+             uint32_t prev_suffix, uint32_t* __restrict__ lcp)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < count; r += stride) {
+        const uint32_t cur = sa[r];
+        const uint32_t prev = r ? sa[r - 1] : prev_suffix;
+        lcp[r] = (prev == kNoPhi) ? 0u : (uint32_t)extend_match(text, n, (uint64_t)prev, (uint64_t)cur, 0);
+    }
+}
+
+int build_lcp_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa_part, uint64_t count,
+                            uint32_t prev_suffix, uint32_t* d_lcp_part, hipStream_t st)
+{
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    if (count == 0) return SFX_OK;
+    if (!d_text || !d_sa_part || !d_lcp_part || count > n) return SFX_ERR_ARG;
+    unsigned grid = (unsigned)dmin<uint64_t>((count + kBlock - 1) / kBlock, kMaxGrid);
+    SFX_LAUNCH("lcp_direct", (double)count * 12, k_lcp_direct, grid, kBlock, st, d_text, n, d_sa_part, count,
+               prev_suffix, d_lcp_part);
+    return SFX_OK;
+}
+
+// u32 -> u64 index arrays (BASELINE config 4 asks for u64 indices; positions fit u32, :380)
+__global__ void __launch_bounds__(kBlock)
+k_widen(const uint32_t* __restrict__ in, uint64_t count, uint64_t* __restrict__ out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) out[i] = in[i];
+}
+int widen_u32_to_u64_dev(const uint32_t* d_in, uint64_t count, uint64_t* d_out, hipStream_t st)
+{
+    if (count == 0) return SFX_OK;
+    if (!d_in || !d_out) return SFX_ERR_ARG;
+    unsigned grid = (unsigned)dmin<uint64_t>((count + kBlock - 1) / kBlock, kMaxGrid);
+    SFX_LAUNCH("widen_u64", (double)count * 12, k_widen, grid, kBlock, st, d_in, count, d_out);
+    return SFX_OK;
+}
+
 uint64_t lcp_workspace_bytes(uint64_t n)
 {
     return ((n * sizeof(uint32_t) + 255) & ~uint64_t(255)) + 256;

@@ -37,7 +37,7 @@ __device__ __forceinline__ bool suffix_starts_with(const uint8_t* __restrict__ q
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_query_batch(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa,
+k_query_batch(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint64_t sa_len,
               const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, uint64_t nq,
               uint32_t* __restrict__ start_out, uint32_t* __restrict__ end_out,
               uint8_t* __restrict__ found_out, uint32_t* __restrict__ any_out)
@@ -47,14 +47,14 @@ k_query_batch(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __re
         const uint8_t* q = qbytes + qoff[k];
         uint64_t m = qoff[k + 1] - qoff[k];
         uint64_t start = 0, end = 0;
-        if (n != 0 && m != 0) {                                     // :228-229
-            uint64_t lo = 0, hi = n;                                // :244-246, :900-914
+        if (sa_len != 0 && m != 0) {                                // :228-229
+            uint64_t lo = 0, hi = sa_len;                           // :244-246, :900-914
             while (lo < hi) {
                 uint64_t mid = (lo + hi) >> 1;
                 if (query_le_suffix(q, m, text, n, sa[mid])) hi = mid; else lo = mid + 1;
             }
             start = lo;
-            lo = 0; hi = n - start;                                 // :247-250
+            lo = 0; hi = sa_len - start;                            // :247-250
             while (lo < hi) {
                 uint64_t mid = (lo + hi) >> 1;
                 if (!suffix_starts_with(q, m, text, n, sa[start + mid])) hi = mid; else lo = mid + 1;
@@ -70,17 +70,20 @@ k_query_batch(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __re
     }
 }
 
-int query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint8_t* d_q,
+// sa_len == n: the whole suffix array.  sa_len < n: a contiguous SLICE of it (one rank of
+// the range-partitioned index); start/end are then positions inside the slice.
+int query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint64_t sa_len, const uint8_t* d_q,
                     const uint64_t* d_qoff, uint64_t nq, uint32_t* d_start, uint32_t* d_end,
                     uint8_t* d_found, uint32_t* d_any, hipStream_t st)
 {
     if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    if (sa_len > n) return SFX_ERR_ARG;
     if (nq == 0) return SFX_OK;
-    if (!d_qoff || (n && (!d_text || !d_sa))) return SFX_ERR_ARG;
+    if (!d_qoff || (sa_len && (!d_text || !d_sa))) return SFX_ERR_ARG;
     unsigned grid = (unsigned)dmin<uint64_t>((nq + kBlock - 1) / kBlock, kMaxGrid);
-    double probes = 2.0 * bits_for(n ? n : 1);
+    double probes = 2.0 * bits_for(sa_len ? sa_len : 1);
     SFX_LAUNCH("query_batch", (double)nq * probes * 12.0, k_query_batch, grid, kBlock, st, d_text, n,
-               d_sa, d_q, d_qoff, nq, d_start, d_end, d_found, d_any);
+               d_sa, sa_len, d_q, d_qoff, nq, d_start, d_end, d_found, d_any);
     return SFX_OK;
 }
 

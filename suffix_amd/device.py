@@ -82,3 +82,39 @@ def query_batch(text, sa, qbytes, qoff, engine=None):
                                           _p(start), _p(end), _p(found), _p(anyp), _stream_ptr(text)),
               "sfx_query_batch_dev")
     return start, end, found, anyp
+
+
+def widen_u64(sa32, engine=None):
+    """u32 index tensor (int32 storage) -> int64 tensor holding the same indices (config 4)."""
+    eng = engine or default_engine()
+    out = torch.empty(sa32.numel(), dtype=torch.int64, device=sa32.device)
+    eng.check(eng.lib.sfx_widen_u32_to_u64_dev(_p(sa32), sa32.numel(), _p(out), _stream_ptr(sa32)),
+              "sfx_widen_u32_to_u64_dev")
+    return out
+
+
+def build_lcp_range(text, sa_part, prev_suffix=None, engine=None):
+    """LCP of one contiguous slice of the suffix array (direct comparison with the predecessor;
+    prev_suffix = last suffix of the previous slice, None for the first slice)."""
+    eng = engine or default_engine()
+    _check_u8(text)
+    out = torch.empty(sa_part.numel(), dtype=torch.int32, device=text.device)
+    prev = 0xFFFFFFFF if prev_suffix is None else int(prev_suffix) & 0xFFFFFFFF
+    eng.check(eng.lib.sfx_build_lcp_range_u32_dev(_p(text), text.numel(), _p(sa_part), sa_part.numel(), prev,
+                                                  _p(out), _stream_ptr(text)), "sfx_build_lcp_range_u32_dev")
+    return out
+
+
+def query_batch_range(text, sa_part, qbytes, qoff, engine=None):
+    """Like query_batch, against one contiguous slice of the suffix array: start/end index the slice."""
+    eng = engine or default_engine()
+    nq = qoff.numel() - 1
+    dev = text.device
+    start = torch.empty(nq, dtype=torch.int32, device=dev)
+    end = torch.empty(nq, dtype=torch.int32, device=dev)
+    found = torch.empty(nq, dtype=torch.uint8, device=dev)
+    anyp = torch.empty(nq, dtype=torch.int32, device=dev)
+    eng.check(eng.lib.sfx_query_batch_range_dev(_p(text), text.numel(), _p(sa_part), sa_part.numel(), _p(qbytes),
+                                                _p(qoff), nq, _p(start), _p(end), _p(found), _p(anyp),
+                                                _stream_ptr(text)), "sfx_query_batch_range_dev")
+    return start, end, found, anyp

@@ -52,11 +52,14 @@ def plan_ranges(bins, world):
     return out
 
 
-def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS):
+def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, return_text=False,
+                         index_dtype=torch.int32):
     """shard: this rank's contiguous uint8 piece of the text (all ranks the same
     length), on this rank's device.  Returns (sa_part, offset, n): sa_part is an
     int32-storage tensor holding u32 suffix indices, the slice
-    SA[offset : offset + sa_part.numel()] of the global suffix array."""
+    SA[offset : offset + sa_part.numel()] of the global suffix array.
+    index_dtype=torch.int64 widens the slice to u64 indices (BASELINE config 4);
+    return_text=True appends the all-gathered text (needed for LCP / queries)."""
     eng = engine or default_engine()
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -99,4 +102,46 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS):
                                                  stream), "sfx_build_sa_range_u32_dev")
     if int(got.value) != count:
         raise RuntimeError(f"rank {rank}: range build produced {got.value} suffixes, plan said {count}")
-    return sa_part[:count], offset, n
+    part = sa_part[:count]
+    if index_dtype == torch.int64:
+        from .device import widen_u64
+        part = widen_u64(part, engine=eng)
+    return (part, offset, n, text) if return_text else (part, offset, n)
+
+
+def build_lcp_partitioned(text, sa_part, group=None, engine=None):
+    """LCP of this rank's slice of the partitioned suffix array.  The only exchange is one
+    suffix index per rank (the last element of every slice, all-gathered): rank r needs the
+    last suffix of the nearest non-empty slice before it.  text = the all-gathered text."""
+    from .device import build_lcp_range
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = text.device
+    mine = torch.tensor([int(sa_part[-1]) & 0xFFFFFFFF if sa_part.numel() else -1], dtype=torch.int64, device=dev)
+    lasts = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(lasts, mine, group=group)
+    prev = None
+    for r in range(rank - 1, -1, -1):
+        if int(lasts[r]) >= 0:
+            prev = int(lasts[r])
+            break
+    return build_lcp_range(text, sa_part, prev, engine=engine)
+
+
+def positions_partitioned(text, sa_part, offset, qbytes, qoff, group=None, engine=None):
+    """positions()/contains() against the partitioned index: every rank searches its own
+    slice for ALL queries, then one all-reduce (SUM of match counts, MIN of global starts)
+    assembles the global SA intervals -- matches are contiguous in the suffix array, so the
+    slices that hold some of them are adjacent.  -> (start, end) int64 tensors, global SA
+    positions, start == end == 0 for no match (as sfx_positions_batch)."""
+    from .device import query_batch_range
+    s, e, _found, _any = query_batch_range(text, sa_part, qbytes, qoff, engine=engine)
+    s64 = s.to(torch.int64) & 0xFFFFFFFF
+    e64 = e.to(torch.int64) & 0xFFFFFFFF
+    cnt = e64 - s64
+    big = torch.iinfo(torch.int64).max
+    gstart = torch.where(cnt > 0, s64 + int(offset), torch.full_like(s64, big))
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(gstart, op=dist.ReduceOp.MIN, group=group)
+    gstart = torch.where(cnt > 0, gstart, torch.zeros_like(gstart))
+    return gstart, gstart + cnt

@@ -30,9 +30,22 @@ elif kind == "text":
 else:
     full = np.frombuffer((b"ab" * (m * world // 2)), dtype=np.uint8)
 shard = torch.from_numpy(np.ascontiguousarray(full[rank * m:(rank + 1) * m]).copy())
-part, offset, n = sdist.build_sa_partitioned(shard, engine=eng, top_bits=10)
+part, offset, n, text = sdist.build_sa_partitioned(shard, engine=eng, top_bits=10, return_text=True)
 np.save(os.path.join(os.environ["SFX_OUT"], f"part{{rank}}.npy"), part.numpy().view(np.uint32))
 np.save(os.path.join(os.environ["SFX_OUT"], f"off{{rank}}.npy"), np.array([offset, n]))
+# the partitioned index in use: per-slice LCP (one suffix index exchanged per rank) and
+# queries answered by every rank on its slice + one all-reduce
+lcp = sdist.build_lcp_partitioned(text, part, engine=eng)
+np.save(os.path.join(os.environ["SFX_OUT"], f"lcp{{rank}}.npy"), lcp.numpy().view(np.uint32))
+fb = full.tobytes()
+qs = [fb[100:106], fb[-7:], b"zzzz", fb[3000:3002], fb[m - 2:m + 3], fb[5:6]]
+qb = torch.from_numpy(np.frombuffer(b"".join(qs), dtype=np.uint8).copy())
+qoff = torch.tensor(np.concatenate([[0], np.cumsum([len(q) for q in qs])]), dtype=torch.int64)
+gs, ge = sdist.positions_partitioned(text, part, offset, qb, qoff, engine=eng)
+np.save(os.path.join(os.environ["SFX_OUT"], f"q{{rank}}.npy"), np.stack([gs.numpy(), ge.numpy()]))
+# u64 indices (BASELINE config 4)
+p64, o64, _n = sdist.build_sa_partitioned(shard, engine=eng, top_bits=10, index_dtype=torch.int64)
+assert p64.dtype == torch.int64 and o64 == offset and np.array_equal(p64.numpy().astype(np.uint32), part.numpy().view(np.uint32))
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -62,3 +75,12 @@ def test_partitioned_build_two_ranks(tmp_path, oracle, case):
     assert int(offs[0][0]) == 0 and int(offs[1][0]) == parts[0].size
     assert int(offs[0][1]) == m * world
     assert np.array_equal(np.concatenate(parts), exp)
+    text = full.tobytes()
+    lcps = [np.load(tmp_path / f"lcp{r}.npy") for r in range(world)]
+    assert np.array_equal(np.concatenate(lcps), oracle.lcp_quadratic(text, exp))
+    qs = [text[100:106], text[-7:], b"zzzz", text[3000:3002], text[m - 2:m + 3], text[5:6]]
+    for r in range(world):                                   # every rank holds the same global answer
+        q = np.load(tmp_path / f"q{r}.npy")
+        for k, query in enumerate(qs):
+            es, ee = oracle.positions(text, exp, query)
+            assert (int(q[0][k]), int(q[1][k])) == (es, ee), (case, r, query)

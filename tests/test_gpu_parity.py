@@ -151,3 +151,29 @@ def test_partitioned_build_single_rank_slices(eng, oracle):
             assert int(got.value) == cnt
             pieces.append(part[:cnt].cpu().numpy().view(np.uint32))
         assert np.array_equal(np.concatenate(pieces), exp)
+        # per-slice LCP (direct comparison, :348-361) and per-slice queries, then the u64 widening
+        from suffix_amd import device as sdev
+        exp_lcp = oracle.lcp_quadratic(text, exp)
+        qs = [text[1000:1007], text[-9:], b"zzzz", text[77:79], text[5:6]]
+        qb = torch.frombuffer(bytearray(b"".join(qs)), dtype=torch.uint8).cuda()
+        qoff = torch.tensor(np.concatenate([[0], np.cumsum([len(q) for q in qs])]), dtype=torch.int64).cuda()
+        off, prev, total, gstart = 0, None, np.zeros(len(qs), dtype=np.int64), np.full(len(qs), -1, dtype=np.int64)
+        for piece in pieces:
+            part = torch.from_numpy(piece.view(np.int32)).cuda()
+            lcp = sdev.build_lcp_range(t, part, prev, engine=eng).cpu().numpy().view(np.uint32)
+            assert np.array_equal(lcp, exp_lcp[off:off + piece.size])
+            s_, e_, _f, _a = sdev.query_batch_range(t, part, qb, qoff, engine=eng)
+            s_, e_ = s_.cpu().numpy().astype(np.int64), e_.cpu().numpy().astype(np.int64)
+            for k in range(len(qs)):
+                if e_[k] > s_[k]:
+                    if gstart[k] < 0:
+                        gstart[k] = off + s_[k]
+                    total[k] += e_[k] - s_[k]
+            w64 = sdev.widen_u64(part, engine=eng).cpu().numpy()
+            assert w64.dtype == np.int64 and np.array_equal(w64.astype(np.uint32), piece)
+            if piece.size:
+                prev = int(piece[-1])
+            off += piece.size
+        for k, q in enumerate(qs):
+            es, ee = oracle.positions(text, exp, q)
+            assert (int(total[k]) == ee - es) and (total[k] == 0 or int(gstart[k]) == es), (q, gstart[k], total[k], es, ee)
