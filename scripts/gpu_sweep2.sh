@@ -1,14 +1,14 @@
 #!/bin/bash
-# radix-pass variant sweep: "<sweep> <wc> <kpt> <rank>" per line
+# radix-pass variant sweep: "<sweep> <nw> <kpt> <rank>" per line
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/sweep2; mkdir -p "$OUT"; export TMPDIR=/tmp
 S="$OUT/summary.txt"; : > "$S"
-for cfg in "1 0 16 1" "1 0 8 1" "0 0 16 1" "0 0 8 1" "0 0 16 0" "0 1 16 0"; do
+for cfg in "1 8 16 1" "1 8 8 1" "1 16 8 1" "1 16 8 0" "0 16 8 1"; do
   set -- $cfg
-  tag="sw$1_wc$2_kpt$3_rk$4"
+  tag="sw$1_nw$2_kpt$3_rk$4"
   echo "== $tag" | tee -a "$S"
-  SFX_RADIX_SWEEP=$1 SFX_RADIX_WC=$2 SFX_RADIX_KPT=$3 SFX_RADIX_RANK=$4 timeout 200 python bench.py --steps 5 --warmup 1 --cpu-sample 0 > "$OUT/$tag.json" 2> "$OUT/$tag.err"
+  SFX_RADIX_SWEEP=$1 SFX_RADIX_NW=$2 SFX_RADIX_KPT=$3 SFX_RADIX_RANK=$4 timeout 200 python bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-microbench > "$OUT/$tag.json" 2> "$OUT/$tag.err"
   echo "rc=$?" | tee -a "$S"
   python - "$OUT/$tag.json" <<'PY' | tee -a "$S"
 import json, sys

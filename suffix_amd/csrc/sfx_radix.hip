@@ -204,26 +204,27 @@ k_radix_scan(uint32_t* __restrict__ hist, unsigned nblocks, uint32_t* __restrict
 }
 
 // ---- tile engine ---------------------------------------------------------------------
-template <int KPT, bool HAS_VAL>
+template <int KPT, bool HAS_VAL, int NW, bool RANK_ATOMIC>
 struct RadixSmem {
-    unsigned long long flags[kWavesPerBlock][kRadix];   // match mask of the round in flight, per wave
-    uint32_t cnt[kWavesPerBlock][kRadix];               // per-wave digit counts, then tile-local bases
+    unsigned long long flags[RANK_ATOMIC ? NW : 1][RANK_ATOMIC ? kRadix : 1];   // match mask of the round in flight, per wave
+    uint32_t cnt[NW][kRadix];                           // per-wave digit counts, then tile-local bases
     uint32_t off[kRadix];                               // global bucket head minus tile-local bucket start
-    uint32_t part[2][kWavesPerBlock];
+    uint32_t part[2][NW];
     uint32_t ticket;
-    uint64_t stage[kBlock * KPT];
-    uint32_t stage_v[HAS_VAL ? kBlock * KPT : 1];
+    uint64_t stage[NW * kWave * KPT];
+    uint32_t stage_v[HAS_VAL ? NW * kWave * KPT : 1];
 };
 
 // exclusive prefix of one value per thread; ONE barrier (callers alternate `par`)
-__device__ __forceinline__ uint32_t block_scan_excl_1b(uint32_t v, uint32_t (*part)[kWavesPerBlock], unsigned& par)
+template <int NW>
+__device__ __forceinline__ uint32_t block_scan_excl_1b(uint32_t v, uint32_t (*part)[NW], unsigned& par)
 {
     const uint32_t incl = wave_scan_add(v);
     if (lane_id() == 63) part[par][wave_id()] = incl;
     __syncthreads();
     uint32_t base = 0;
 #pragma unroll
-    for (unsigned k = 0; k < (unsigned)kWavesPerBlock; k++)
+    for (unsigned k = 0; k < (unsigned)NW; k++)
         if (k < wave_id()) base += part[par][k];
     par ^= 1u;
     return base + incl - v;
@@ -291,24 +292,33 @@ __device__ __forceinline__ uint32_t lookback(uint32_t* status, uint32_t tile_no,
     return excl;
 }
 
-template <class Src, class Dst, int KPT, bool ONESWEEP, bool RANK_ATOMIC>
-__global__ void __launch_bounds__(kBlock)
+// NW = waves per workgroup (4 or 8): thread d < 256 owns bucket d; a 512-thread workgroup
+// sorts 8192-element tiles, i.e. 256-byte runs per bucket.
+template <class Src, class Dst, int KPT, bool ONESWEEP, bool RANK_ATOMIC, int NW>
+__global__ void __launch_bounds__(NW * kWave)
 k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t chunk,
              const uint32_t* __restrict__ hist, const uint32_t* __restrict__ digit_total,
              uint32_t* __restrict__ status, uint32_t* __restrict__ ticket)
 {
     constexpr bool HAS_VAL = Src::kHasVal;
-    constexpr int kTile = kBlock * KPT;
-    __shared__ RadixSmem<KPT, HAS_VAL> s;
+    constexpr int kThreads = NW * kWave;
+    constexpr int kTile = kThreads * KPT;
+    __shared__ RadixSmem<KPT, HAS_VAL, NW, RANK_ATOMIC> s;
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const unsigned long long mybit = 1ull << lane;
+    const bool owner = tid < (unsigned)kRadix;                   // thread d owns bucket d
     unsigned par = 0;
 
+    if (owner) {
 #pragma unroll
-    for (int k = 0; k < kWavesPerBlock; k++) { s.flags[k][tid] = 0ull; s.cnt[k][tid] = 0u; }
+        for (int k = 0; k < NW; k++) {
+            if (RANK_ATOMIC) s.flags[k][tid] = 0ull;
+            s.cnt[k][tid] = 0u;
+        }
+    }
     // one-sweep: global start of bucket `tid`; chunked: this workgroup's running head of bucket `tid`
-    uint32_t my_head = block_scan_excl_1b(digit_total[tid], s.part, par);
-    if (!ONESWEEP) my_head += hist[(uint64_t)tid * gridDim.x + blockIdx.x];
+    uint32_t my_head = block_scan_excl_1b<NW>(owner ? digit_total[tid] : 0u, s.part, par);
+    if (!ONESWEEP && owner) my_head += hist[(uint64_t)tid * gridDim.x + blockIdx.x];
 
     uint64_t next = (uint64_t)blockIdx.x * chunk;
     uint64_t limit = m;
@@ -358,25 +368,33 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
         if (!ONESWEEP && next < limit) load_tile(next);
 #pragma unroll
         for (int r = 0; r < KPT; r++)
-            pos[r] = rank_round<RANK_ATOMIC>(digit_of(key[r], shift, mask), s.flags[w], s.cnt[w], mybit);
+            pos[r] = rank_round<RANK_ATOMIC>(digit_of(key[r], shift, mask), s.flags[RANK_ATOMIC ? w : 0], s.cnt[w], mybit);
         __syncthreads();
 
         // thread d: bucket d's size in this tile -> tile-local start, per-wave bases, global head
         {
-            const uint32_t c0 = s.cnt[0][tid], c1 = s.cnt[1][tid], c2 = s.cnt[2][tid], c3 = s.cnt[3][tid];
-            const uint32_t tile_count = c0 + c1 + c2 + c3;
-            const uint32_t ex = block_scan_excl_1b(tile_count, s.part, par);
-            s.cnt[0][tid] = ex;
-            s.cnt[1][tid] = ex + c0;
-            s.cnt[2][tid] = ex + c0 + c1;
-            s.cnt[3][tid] = ex + c0 + c1 + c2;
-            // padding elements all carry the largest digit (== mask)
-            const uint32_t real_count = tile_count - ((tid == mask) ? (uint32_t)(kTile - nvalid) : 0u);
-            if (ONESWEEP) {
-                s.off[tid] = my_head + lookback(status, tile_no, tid, real_count) - ex;
-            } else {
-                s.off[tid] = my_head - ex;
-                my_head += real_count;
+            uint32_t c[NW], tile_count = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                c[k] = owner ? s.cnt[k][tid] : 0u;
+                tile_count += c[k];
+            }
+            const uint32_t ex = block_scan_excl_1b<NW>(tile_count, s.part, par);
+            if (owner) {
+                uint32_t run = ex;
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    s.cnt[k][tid] = run;
+                    run += c[k];
+                }
+                // padding elements all carry the largest digit (== mask)
+                const uint32_t real_count = tile_count - ((tid == mask) ? (uint32_t)(kTile - nvalid) : 0u);
+                if (ONESWEEP) {
+                    s.off[tid] = my_head + lookback(status, tile_no, tid, real_count) - ex;
+                } else {
+                    s.off[tid] = my_head - ex;
+                    my_head += real_count;
+                }
             }
         }
         __syncthreads();
@@ -392,16 +410,18 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
         // (three separate loops: all LDS reads of a kind are in flight together)
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
-            key[r] = s.stage[r * kBlock + tid];
-            if (HAS_VAL) val[r] = s.stage_v[r * kBlock + tid];
+            key[r] = s.stage[r * kThreads + tid];
+            if (HAS_VAL) val[r] = s.stage_v[r * kThreads + tid];
         }
 #pragma unroll
-        for (int r = 0; r < KPT; r++) pos[r] = s.off[digit_of(key[r], shift, mask)] + (r * kBlock + tid);
+        for (int r = 0; r < KPT; r++) pos[r] = s.off[digit_of(key[r], shift, mask)] + (r * kThreads + tid);
 #pragma unroll
         for (int r = 0; r < KPT; r++)
-            if ((unsigned)(r * kBlock) + tid < nvalid) dst.store(pos[r], key[r], HAS_VAL ? val[r] : 0u);
+            if ((unsigned)(r * kThreads) + tid < nvalid) dst.store(pos[r], key[r], HAS_VAL ? val[r] : 0u);
+        if (owner) {
 #pragma unroll
-        for (int k = 0; k < kWavesPerBlock; k++) s.cnt[k][tid] = 0u;
+            for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0u;
+        }
         __syncthreads();
     }
 }
@@ -409,16 +429,19 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
 // ---- host side -------------------------------------------------------------------------
 // Tuning knobs (development only; read once per process):
 //   SFX_RADIX_SWEEP  1 = one-sweep (default), 0 = chunked
-//   SFX_RADIX_KPT    elements per thread and tile: 16 (default) or 8
+//   SFX_RADIX_KPT    elements per thread and tile: 8 (default) or 16
 //   SFX_RADIX_RANK   1 = LDS match masks (default), 0 = 8-ballot match
-struct RadixTuning { int sweep, kpt, rank; };
+//   SFX_RADIX_NW     waves per workgroup: 4, 8 or 16 (default); tile = 64 * NW * KPT elements
+struct RadixTuning { int sweep, kpt, rank, nw; };
 static RadixTuning radix_tuning()
 {
     static const RadixTuning t = [] {
-        RadixTuning r = {1, 16, 1};             // measured best on MI355X (profiles/r1c_radix_variants.txt)
+        RadixTuning r = {1, 8, 1, 16};          // measured best on MI355X (profiles/r1c_radix_variants.txt):
+                                                // 1024-thread workgroups, 8192-element tiles = 256-byte runs
         if (const char* e = getenv("SFX_RADIX_SWEEP")) r.sweep = atoi(e) ? 1 : 0;
         if (const char* e = getenv("SFX_RADIX_KPT")) r.kpt = atoi(e) == 16 ? 16 : 8;
         if (const char* e = getenv("SFX_RADIX_RANK")) r.rank = atoi(e) ? 1 : 0;
+        if (const char* e = getenv("SFX_RADIX_NW")) r.nw = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 4);
         return r;
     }();
     return t;
@@ -445,16 +468,17 @@ struct RadixScratch {
     }
 };
 
-template <class Src, class Dst, int KPT, bool ONESWEEP, bool RANK_ATOMIC>
+template <class Src, class Dst, int KPT, bool ONESWEEP, bool RANK_ATOMIC, int NW>
 static int launch_pass(const char* name, double algo_bytes, const Src& src, const Dst& dst, uint64_t m, int shift,
                        unsigned mask, const RadixScratch& scr, int pass, hipStream_t st)
 {
-    constexpr int kTile = kBlock * KPT;
+    constexpr int kThreads = NW * kWave;
+    constexpr int kTile = kThreads * KPT;
     if (ONESWEEP) {
         const uint64_t tiles = (m + kTile - 1) / kTile;
         const unsigned grid = (unsigned)dmin<uint64_t>(tiles, kMaxGrid);
         SFX_HIP(hipMemsetAsync(scr.status, 0, tiles * kRadix * sizeof(uint32_t), st));
-        SFX_LAUNCH(name, algo_bytes, (k_radix_pass<Src, Dst, KPT, true, RANK_ATOMIC>), grid, kBlock, st, src, dst, m,
+        SFX_LAUNCH(name, algo_bytes, (k_radix_pass<Src, Dst, KPT, true, RANK_ATOMIC, NW>), grid, kThreads, st, src, dst, m,
                    shift, mask, (uint64_t)0, (const uint32_t*)nullptr, (const uint32_t*)(scr.totals + pass * kRadix),
                    scr.status, scr.tickets + pass);
     } else {
@@ -464,7 +488,7 @@ static int launch_pass(const char* name, double algo_bytes, const Src& src, cons
                    mask, chunk, scr.partial);
         SFX_LAUNCH("radix_scan", (double)kRadix * ch.blocks * 8, k_radix_scan, kRadix, kBlock, st, scr.partial,
                    ch.blocks, scr.totals);
-        SFX_LAUNCH(name, algo_bytes, (k_radix_pass<Src, Dst, KPT, false, RANK_ATOMIC>), ch.blocks, kBlock, st, src,
+        SFX_LAUNCH(name, algo_bytes, (k_radix_pass<Src, Dst, KPT, false, RANK_ATOMIC, NW>), ch.blocks, kThreads, st, src,
                    dst, m, shift, mask, chunk, (const uint32_t*)scr.partial, (const uint32_t*)scr.totals,
                    (uint32_t*)nullptr, (uint32_t*)nullptr);
     }
@@ -476,13 +500,17 @@ static int run_pass(const char* name, double algo_bytes, const Src& src, const D
                     unsigned mask, const RadixScratch& scr, int pass, bool sweep, hipStream_t st)
 {
     const RadixTuning t = radix_tuning();
-#define SFX_PASS(KPT, SW, RK) launch_pass<Src, Dst, KPT, SW, RK>(name, algo_bytes, src, dst, m, shift, mask, scr, pass, st)
-    if (t.kpt == 16) {
-        if (sweep) return t.rank ? SFX_PASS(16, true, true) : SFX_PASS(16, true, false);
-        return t.rank ? SFX_PASS(16, false, true) : SFX_PASS(16, false, false);
-    }
-    if (sweep) return t.rank ? SFX_PASS(8, true, true) : SFX_PASS(8, true, false);
-    return t.rank ? SFX_PASS(8, false, true) : SFX_PASS(8, false, false);
+#define SFX_PASS(KPT, SW, RK, NW) launch_pass<Src, Dst, KPT, SW, RK, NW>(name, algo_bytes, src, dst, m, shift, mask, scr, pass, st)
+#define SFX_PASS_NW(KPT, NW)                                                                     \
+    do {                                                                                         \
+        if (sweep) return t.rank ? SFX_PASS(KPT, true, true, NW) : SFX_PASS(KPT, true, false, NW);  \
+        return t.rank ? SFX_PASS(KPT, false, true, NW) : SFX_PASS(KPT, false, false, NW);           \
+    } while (0)
+    if (t.nw == 16) SFX_PASS_NW(8, 16);                          // (16 x 16 would not fit the 160 KiB of LDS)
+    if (t.nw == 8) { if (t.kpt == 16) SFX_PASS_NW(16, 8); SFX_PASS_NW(8, 8); }
+    if (t.kpt == 16) SFX_PASS_NW(16, 4);
+    SFX_PASS_NW(8, 4);
+#undef SFX_PASS_NW
 #undef SFX_PASS
 }
 
