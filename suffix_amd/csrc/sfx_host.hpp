@@ -122,6 +122,21 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
 int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, int bit_lo,
                     int bit_hi, uint32_t* scratch, hipStream_t st, int* result_in_1,
                     sfx_build_stats* stats, const PackedText* text);
+// target[idx] = val for m (idx << 32 | val) pairs, idx < n: one partitioning pass on the top
+// bits of idx, then a scatter whose writes stay inside a cache-sized window of `target`.
+// `tmp` is m u64 of scratch, `radix_scratch` as for the sorts.  Pays for 4n >> Infinity Cache.
+int scatter_pairs_u32(uint64_t* pairs, uint64_t* tmp, uint64_t m, uint64_t n, uint32_t* target,
+                      uint32_t* radix_scratch, hipStream_t st, sfx_build_stats* stats);
+// from 2^27 entries (a 512 MB target) up; SFX_PARTITION_MIN=<entries> is a test hook
+inline uint64_t partitioned_scatter_min()
+{
+    static const uint64_t v = [] {
+        const char* e = getenv("SFX_PARTITION_MIN");
+        long long x = e ? atoll(e) : 0;
+        return x > 0 ? (uint64_t)x : (1ull << 27);
+    }();
+    return v;
+}
 inline int radix_pass_count(int bit_lo, int bit_hi) { return (bit_hi - bit_lo + 7) / 8; }
 
 uint64_t sa_workspace_bytes(uint64_t n);

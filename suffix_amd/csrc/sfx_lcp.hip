@@ -40,6 +40,15 @@ k_phi_scatter(const uint32_t* __restrict__ sa, uint64_t n, uint32_t* __restrict_
     }
 }
 
+// large texts: (position, predecessor) pairs in SA order for scatter_pairs_u32
+__global__ void __launch_bounds__(kBlock)
+k_phi_pairs(const uint32_t* __restrict__ sa, uint64_t n, uint64_t* __restrict__ pairs)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride)
+        pairs[r] = ((uint64_t)sa[r] << 32) | (uint64_t)(r ? sa[r - 1] : kNoPhi);
+}
+
 // length of the common prefix of text[a..] and text[b..] beyond the first h bytes, 8 bytes
 // per step where both windows are inside the text (unaligned 8-byte loads), bytes at the end
 __device__ __forceinline__ uint64_t extend_match(const uint8_t* __restrict__ text, uint64_t n, uint64_t a,
@@ -157,9 +166,18 @@ int widen_u32_to_u64_dev(const uint32_t* d_in, uint64_t count, uint64_t* d_out, 
     return SFX_OK;
 }
 
+// phi / PLCP (4n); for large texts also the pair buffers and radix scratch of the
+// partitioned Phi scatter
 uint64_t lcp_workspace_bytes(uint64_t n)
 {
-    return ((n * sizeof(uint32_t) + 255) & ~uint64_t(255)) + 256;
+    ArenaSizer a;
+    a.take<uint32_t>(n);
+    if (n >= partitioned_scatter_min()) {
+        a.take<uint64_t>(n);
+        a.take<uint64_t>(n);
+        a.take<uint32_t>(radix_scratch_words(n));
+    }
+    return a.used + 256;
 }
 
 int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint32_t* d_lcp,
@@ -173,7 +191,16 @@ int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, u
     uint32_t* phi = ar.take<uint32_t>(n);
     if (ar.overflow) return SFX_ERR_WORKSPACE;
     unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
-    SFX_LAUNCH("phi_scatter", (double)n * 8, k_phi_scatter, grid, kBlock, st, d_sa, n, phi);
+    if (n >= partitioned_scatter_min()) {
+        uint64_t* pairs = ar.take<uint64_t>(n);
+        uint64_t* tmp = ar.take<uint64_t>(n);
+        uint32_t* scratch = ar.take<uint32_t>(radix_scratch_words(n));
+        if (ar.overflow) return SFX_ERR_WORKSPACE;
+        SFX_LAUNCH("phi_pairs", (double)n * 12, k_phi_pairs, grid, kBlock, st, d_sa, n, pairs);
+        SFX_TRY(scatter_pairs_u32(pairs, tmp, n, n, phi, scratch, st, nullptr));
+    } else {
+        SFX_LAUNCH("phi_scatter", (double)n * 8, k_phi_scatter, grid, kBlock, st, d_sa, n, phi);
+    }
     Chunking ch = make_chunking(n, kPlcpTile);
     SFX_LAUNCH("plcp", (double)n * 10, k_plcp, ch.blocks, kBlock, st, d_text, n, phi,
                ch.tiles_per_block);

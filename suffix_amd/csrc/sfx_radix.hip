@@ -629,4 +629,42 @@ int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
     return SFX_OK;
 }
 
+// ---- cache-confined scatter ------------------------------------------------------------
+// target[idx] = val for m (idx << 32 | val) pairs whose idx values are spread over [0, n).
+// A random 4-byte write into a multi-GB array costs a 128-byte read-modify-write in HBM
+// (22-25 G writes/s measured on the rank and Phi scatters at n = 4*10^8 ... 10^9, whatever the
+// array size beyond the L2).  Radix passes on the top 20 bits of idx first confine each
+// stretch of the stream to a few KB of the target, which the L2 absorbs; the passes cost
+// less than the scatter saves (34 vs 44 ms per 10^9 pairs), a full sort would not.
+__global__ void __launch_bounds__(kBlock)
+k_scatter_pairs(const uint64_t* __restrict__ pairs, uint64_t m, uint32_t* __restrict__ target)
+{
+    constexpr int U = 4;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i0 < m; i0 += U * stride) {
+        uint64_t e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) e[u] = (i0 + u * stride < m) ? pairs[i0 + u * stride] : 0ull;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (i0 + u * stride < m) target[e[u] >> 32] = (uint32_t)e[u];
+    }
+}
+
+int scatter_pairs_u32(uint64_t* pairs, uint64_t* tmp, uint64_t m, uint64_t n, uint32_t* target,
+                      uint32_t* radix_scratch, hipStream_t st, sfx_build_stats* stats)
+{
+    if (m == 0) return SFX_OK;
+    const int nb = bits_for(n > 1 ? n - 1 : 1);
+    // measured at n = 10^9 (ms): direct scatter 44; 8 bits 50; 12 bits 52; 16 bits 37; 20 bits 34
+    static const int part_bits = [] { const char* e = getenv("SFX_PARTITION_BITS"); int v = e ? atoi(e) : 20; return v >= 8 && v <= 24 ? v : 20; }();
+    const int lo = nb > part_bits ? nb - part_bits : 0;
+    int in1 = 0;
+    SFX_TRY(radix_sort_e64(pairs, tmp, m, 32 + lo, 32 + nb, radix_scratch, st, &in1, stats, nullptr, nullptr, nullptr));
+    const uint64_t* src = in1 ? tmp : pairs;
+    unsigned grid = (unsigned)dmin<uint64_t>((m + kBlock - 1) / kBlock, kMaxGrid);
+    SFX_LAUNCH("scatter_pairs", (double)m * 12, k_scatter_pairs, grid, kBlock, st, src, m, target);
+    return SFX_OK;
+}
+
 }  // namespace sfx

@@ -481,7 +481,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                const uint32_t* __restrict__ part_ghead, uint32_t* __restrict__ sa,
                uint32_t* __restrict__ isa, uint32_t* __restrict__ S_next,
                uint32_t* __restrict__ V_next, uint32_t* __restrict__ G_next,
-               uint32_t* __restrict__ R_next, int sa_in_place)
+               uint32_t* __restrict__ R_next, int sa_in_place, uint64_t* __restrict__ rank_pairs)
 {
     __shared__ uint32_t part_m[2][kWavesPerBlock], part_a[2][kWavesPerBlock];
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -541,7 +541,12 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                 if ((valid >> j) & 1u) {
                     const bool keep = (keepm >> j) & 1u;
                     if (!sa_in_place) sa[slot[j]] = suffix[j];
-                    if (isa) isa[suffix[j]] = head_slot[j];
+                    if (isa) {
+                        // large texts: (suffix, rank) pairs out in stream order, scattered afterwards
+                        // through a partitioning pass (scatter_pairs_u32) instead of n random writes
+                        if (rank_pairs) rank_pairs[i0 + j] = ((uint64_t)suffix[j] << 32) | (uint64_t)head_slot[j];
+                        else isa[suffix[j]] = head_slot[j];
+                    }
                     if (keep) {
                         if (R_next) R_next[run_keep] = head_slot[j];
                         S_next[run_keep] = slot[j];
@@ -837,14 +842,24 @@ static int round_totals(const KeyT* K, uint64_t m, SaBuffers& b, hipStream_t st,
 template <class KeyT>
 static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint64_t m, SaBuffers& b,
                        uint32_t* sa, uint32_t* isa, uint32_t* S_next, uint32_t* V_next,
-                       uint32_t* R_next, hipStream_t st, bool sa_in_place = false)
+                       uint32_t* R_next, hipStream_t st, bool sa_in_place, uint64_t n, sfx_build_stats& stats)
 {
+    // the sorted keys K sit in one of K0/K1 (for 32-bit keys: in its first half); the other
+    // one is free for the (suffix, rank) pairs, and K's own buffer is free once this kernel is done
+    uint64_t* pairs = nullptr;
+    uint64_t* pairs_tmp = nullptr;
+    if (isa && n >= partitioned_scatter_min()) {
+        const bool k_in_0 = (const void*)K >= (const void*)b.K0 && (const void*)K < (const void*)(b.K0 + m);
+        pairs = k_in_0 ? b.K1 : b.K0;
+        pairs_tmp = k_in_0 ? b.K0 : b.K1;
+    }
     Chunking ch = make_chunking(m, kGroupTile);
     SFX_LAUNCH(sizeof(KeyT) == 4 ? "groups_apply_u32" : "groups_apply_u64",
                (double)m * (sizeof(KeyT) + (sa_in_place ? 0 : 8) + (isa ? 4 : 0) + (S ? 4 : 0)),
                (k_groups_apply<KeyT>), ch.blocks, kBlock, st, K, V, S, m, ch.tiles_per_block,
                b.part_head, b.part_keep, b.part_ghead, sa, isa, S_next, V_next, b.G, R_next,
-               sa_in_place ? 1 : 0);
+               sa_in_place ? 1 : 0, pairs);
+    if (pairs) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, m, n, isa, b.hist, st, &stats));
     return SFX_OK;
 }
 
@@ -961,7 +976,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         SFX_TRY(round_totals<uint64_t>(Kr, m, b, st, &kept, &kept_groups));
         const bool full_text_round = isa && text_round;
         SFX_TRY(round_apply<uint64_t>(Kr, Vr, S_cur, m, b, sa, (isa && !text_round) ? isa : nullptr,
-                                      S_next, V_next, full_text_round ? b.R : nullptr, st));
+                                      S_next, V_next, full_text_round ? b.R : nullptr, st, false, n, stats));
         h = text_round ? h + (uint64_t)spw : h * 2;
         if (full_text_round && --text_rounds == 0 && kept > 0) {
             // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
@@ -1020,7 +1035,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     // few unresolved suffixes: one text round first, ISA only if that does not finish the job
     const int text_rounds = (isa && kept * kTextFirstDivisor <= count && pt.spw >= 8) ? 1 : 0;
     SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, (isa && !text_rounds) ? isa : nullptr, b.S0, V_next,
-                              nullptr, st, in_place));
+                              nullptr, st, in_place, pt.n, stats));
     uint32_t* S_cur = b.S0;
     const uint64_t id_bound = kept;
     if (small_groups_pay(kept, groups)) {
