@@ -185,6 +185,61 @@ k_radix_hist_all(Src src, uint64_t m, int bit_lo, int bit_hi, int npass, uint64_
     }
 }
 
+// Text-fed initial sort with 8 % bits == 0 and 32-bit keys: digit p of the key of suffix i is
+// the 8-bit window of the packed symbol stream at symbol (i + shift_p), shift_p = (3 - p) *
+// (8 / bits).  So all four digit histograms are ONE histogram W of the 8-bit windows at
+// symbols [0, n + 3 * 8/bits), shifted: H_p = W minus the <= 3*8/bits windows before
+// shift_p and the same number past n + shift_p (k_window_fix).  One LDS atomic per position
+// instead of four, and 16 windows come out of two packed words.
+__global__ void __launch_bounds__(kBlock)
+k_window_hist(PackedText t, uint64_t npos, uint64_t words_per_block, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[kWavesPerBlock][kRadix];
+    const unsigned tid = threadIdx.x, w = wave_id();
+    for (unsigned i = tid; i < kWavesPerBlock * kRadix; i += kBlock) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t nwords = (npos + (uint64_t)t.spw - 1) / (uint64_t)t.spw;
+    const uint64_t qb = (uint64_t)blockIdx.x * words_per_block;
+    const uint64_t qe = dmin<uint64_t>(nwords, qb + words_per_block);
+    for (uint64_t q = qb + tid; q < qe; q += kBlock) {
+        const uint64_t comb = ((uint64_t)t.words[q] << 32) | (uint64_t)t.words[q + 1];
+        const uint64_t j0 = q * (uint64_t)t.spw;
+        for (int o = 0; o < t.spw; o++)
+            if (j0 + (uint64_t)o < npos) atomicAdd(&h[w][(unsigned)(comb >> (56 - o * t.bits)) & 255u], 1u);
+    }
+    __syncthreads();
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kWavesPerBlock; k++) c += h[k][tid];
+    partial[(uint64_t)tid * gridDim.x + blockIdx.x] = c;
+}
+// totals[0..256) = W on entry; totals[p*256 + d] = H_p[d] on exit (p = 0 is the lowest digit)
+__global__ void __launch_bounds__(kBlock)
+k_window_fix(PackedText t, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t sub[4][kRadix];
+    const unsigned tid = threadIdx.x;
+    const uint32_t wcount = totals[tid];
+    for (int p = 0; p < 4; p++) sub[p][tid] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        const int spd = 8 / t.bits;
+        auto window = [&](uint64_t j) -> unsigned {
+            const uint64_t q = j / (uint64_t)t.spw;
+            const int o = (int)(j - q * (uint64_t)t.spw);
+            const uint64_t comb = ((uint64_t)t.words[q] << 32) | (uint64_t)t.words[q + 1];
+            return (unsigned)(comb >> (56 - o * t.bits)) & 255u;
+        };
+        for (int p = 0; p < 4; p++) {
+            const uint64_t shift = (uint64_t)(3 - p) * spd;
+            for (uint64_t j = 0; j < shift; j++) sub[p][window(j)]++;
+            for (uint64_t j = t.n + shift; j < t.n + 3ull * spd; j++) sub[p][window(j)]++;
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < 4; p++) totals[p * kRadix + tid] = wcount - sub[p][tid];
+}
+
 // one workgroup per row: exclusive scan of the row in place, row total -> row_total.
 __global__ void __launch_bounds__(kBlock)
 k_radix_scan(uint32_t* __restrict__ hist, unsigned nblocks, uint32_t* __restrict__ row_total)
@@ -529,6 +584,26 @@ static int prepare_sweep(const char* name, double algo_bytes, const Src& src, ui
     return SFX_OK;
 }
 
+// the window form applies to a full text-fed build whose digits are whole symbols
+static bool window_hist_applies(const PackedText* text, uint64_t m, int bit_lo, int bit_hi)
+{
+    return text && m == text->n && text->kbits == 32 && (8 % text->bits) == 0 && bit_lo == 32 && bit_hi == 64;
+}
+static int prepare_sweep_windows(const PackedText& t, const RadixScratch& scr, hipStream_t st)
+{
+    const uint64_t npos = t.n + 3ull * (8 / t.bits);
+    const uint64_t nwords = (npos + t.spw - 1) / t.spw;
+    Chunking ch = make_chunking(nwords, kBlock * 4, kHistAllGrid);
+    const uint64_t wpb = ch.tiles_per_block * kBlock * 4;
+    SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
+    SFX_LAUNCH("radix_hist_all_text_u32", (double)t.n * t.bits / 8.0, k_window_hist, ch.blocks, kBlock, st, t, npos, wpb,
+               scr.partial);
+    SFX_LAUNCH("radix_scan", (double)kRadix * ch.blocks * 8, k_radix_scan, kRadix, kBlock, st, scr.partial, ch.blocks,
+               scr.totals);
+    SFX_LAUNCH("radix_window_fix", 0.0, k_window_fix, 1, kBlock, st, t, scr.totals);
+    return SFX_OK;
+}
+
 static bool use_sweep(uint64_t m, int npass)
 {
     return radix_tuning().sweep && m < (1ull << 30) && npass <= kMaxPasses;
@@ -553,7 +628,8 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
     RadixScratch scr(scratch, m);
     SrcText32 tsrc = {text ? *text : PackedText{nullptr, 0, 0, 1, 0, 1.0}};
     if (sweep) {
-        if (text) SFX_TRY(prepare_sweep("radix_hist_all_text_u32", (double)m * text->bits / 8.0, tsrc, m, bit_lo, bit_hi, npass, scr, st));
+        if (window_hist_applies(text, m, bit_lo, bit_hi)) SFX_TRY(prepare_sweep_windows(*text, scr, st));
+        else if (text) SFX_TRY(prepare_sweep("radix_hist_all_text_u32", (double)m * text->bits / 8.0, tsrc, m, bit_lo, bit_hi, npass, scr, st));
         else SFX_TRY(prepare_sweep("radix_hist_all_u32", (double)m * 8.0, SrcE64{e0}, m, bit_lo, bit_hi, npass, scr, st));
     }
     uint64_t* cur = text ? nullptr : e0;        // the text-fed pass reads no element buffer

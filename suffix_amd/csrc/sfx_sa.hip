@@ -143,6 +143,43 @@ k_pack_text(const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restr
     }
 }
 
+// Fast path of the above for bits in {8, 4, 2, 1} (spw = 32/bits exactly) and a 16-byte aligned
+// text: a thread makes one word from spw consecutive bytes fetched with one or two wide
+// loads -- consecutive threads read consecutive bytes, no LDS staging, only the LUT lives
+// in LDS.  The last word (< spw bytes left) and the zero tail take the guarded path.
+template <int SPW>
+__global__ void __launch_bounds__(kBlock)
+k_pack_text_pow2(const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ lut,
+                 uint64_t n_words_total, uint32_t* __restrict__ words)
+{
+    constexpr int BITS = 32 / SPW;
+    __shared__ uint8_t s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < n_words_total; q += stride) {
+        const uint64_t p0 = q * SPW;
+        uint32_t w = 0;
+        if (p0 + SPW <= n) {
+            uint8_t raw[SPW];
+            if (SPW == 4) {
+                *reinterpret_cast<uint32_t*>(raw) = *reinterpret_cast<const uint32_t*>(text + p0);
+            } else if (SPW == 8) {
+                *reinterpret_cast<uint2*>(raw) = *reinterpret_cast<const uint2*>(text + p0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < SPW / 16; k++)
+                    *reinterpret_cast<uint4*>(raw + 16 * k) = *reinterpret_cast<const uint4*>(text + p0 + 16 * k);
+            }
+#pragma unroll
+            for (int k = 0; k < SPW; k++) w = (w << BITS) | s_lut[raw[k]];
+        } else {
+            for (int k = 0; k < SPW; k++) w = (w << BITS) | (p0 + k < n ? (uint32_t)s_lut[text[p0 + k]] : 0u);
+        }
+        words[q] = w;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // 2. partitioned build: bucket-boundary histogram and range filter
 // ---------------------------------------------------------------------------------
@@ -887,9 +924,25 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
     SFX_HIP(hipStreamSynchronize(st));
     *alpha = make_alphabet(host_bins);
     uint64_t nw = packed_words(n, alpha);
-    Chunking ch = make_chunking(nw, kPackWords);
-    SFX_LAUNCH("pack_text", (double)n * (1.0 + alpha->bits / 8.0), k_pack_text, ch.blocks, kBlock, st,
-               d_text, n, d_lut, alpha->bits, alpha->spw, ch.tiles_per_block, nw, d_packed);
+    const double pack_bytes = (double)n * (1.0 + alpha->bits / 8.0);
+    const bool pow2 = alpha->bits * alpha->spw == 32 &&          // bits in {1, 2, 4, 8}
+                      (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0;
+    if (pow2) {
+        const unsigned grid = (unsigned)dmin<uint64_t>((nw + kBlock - 1) / kBlock, 4 * kMaxGrid);
+        if (alpha->spw == 4) {
+            SFX_LAUNCH("pack_text", pack_bytes, (k_pack_text_pow2<4>), grid, kBlock, st, d_text, n, d_lut, nw, d_packed);
+        } else if (alpha->spw == 8) {
+            SFX_LAUNCH("pack_text", pack_bytes, (k_pack_text_pow2<8>), grid, kBlock, st, d_text, n, d_lut, nw, d_packed);
+        } else if (alpha->spw == 16) {
+            SFX_LAUNCH("pack_text", pack_bytes, (k_pack_text_pow2<16>), grid, kBlock, st, d_text, n, d_lut, nw, d_packed);
+        } else {
+            SFX_LAUNCH("pack_text", pack_bytes, (k_pack_text_pow2<32>), grid, kBlock, st, d_text, n, d_lut, nw, d_packed);
+        }
+    } else {
+        Chunking ch = make_chunking(nw, kPackWords);
+        SFX_LAUNCH("pack_text", pack_bytes, k_pack_text, ch.blocks, kBlock, st, d_text, n, d_lut, alpha->bits,
+                   alpha->spw, ch.tiles_per_block, nw, d_packed);
+    }
     pt->words = d_packed;
     pt->n = n;
     pt->bits = alpha->bits;

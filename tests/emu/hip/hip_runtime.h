@@ -33,6 +33,7 @@ struct dim3 {
 };
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
