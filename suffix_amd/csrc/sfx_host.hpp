@@ -116,7 +116,6 @@ struct BuildStats;   // = sfx_build_stats
 //  - KV: u64 keys + u32 values, (k0,v0)/(k1,v1) ping-pong; with `text` the first pass
 //    reads (packed_key64(text, i), i) instead of (k0, v0).
 uint64_t radix_scratch_words(uint64_t m);
-void radix_scratch_regions(uint32_t* base, uint32_t** tickets, uint32_t** status);   // 64 u32 / m/8 + 512 u32
 int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, uint32_t* scratch,
                    hipStream_t st, int* result_in_1, sfx_build_stats* stats, const PackedText* text,
                    uint32_t* split_v, uint32_t** split_k_out);

@@ -705,15 +705,6 @@ int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
     return SFX_OK;
 }
 
-// the ticket and status regions of a radix scratch block, for other single-pass kernels that
-// run while no sort is in flight (k_groups_apply<., true>)
-void radix_scratch_regions(uint32_t* base, uint32_t** tickets, uint32_t** status)
-{
-    RadixScratch scr(base, 0);
-    *tickets = scr.tickets;
-    *status = scr.status;
-}
-
 // ---- cache-confined scatter ------------------------------------------------------------
 // target[idx] = val for m (idx << 32 | val) pairs whose idx values are spread over [0, n).
 // A random 4-byte write into a multi-GB array costs a 128-byte read-modify-write in HBM

@@ -510,16 +510,7 @@ k_groups_scan(uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep
 // non-singleton buckets into (S_next, V_next, G_next = bucket id = position of the
 // bucket's head in the compacted list: unique and increasing along the list; and, if
 // R_next, R_next = slot of the bucket head).
-//
-// Two schedules.  SWEEP = false: chunked, the carries of every workgroup's chunk come from
-// k_groups_reduce + k_groups_scan (the totals are known BEFORE this kernel runs, which the
-// rank-round decision needs).  SWEEP = true: single pass -- 2048-element tiles handed out
-// by an atomic ticket, the carries (last bucket head so far, #kept so far, #kept buckets so
-// far) obtained by decoupled look-back over two self-validating 64-bit status words per
-// tile, the totals written by the last tile.  Used where the decision can wait (32-bit-key
-// builds): it saves the second read of the sorted keys.
-constexpr unsigned long long kGsAgg = 1ull << 62, kGsPrefix = 2ull << 62;
-template <class KeyT, bool SWEEP>
+template <class KeyT>
 __global__ void __launch_bounds__(kBlock)
 k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                const uint32_t* __restrict__ S, uint64_t m, uint64_t tiles_per_block,
@@ -527,42 +518,29 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                const uint32_t* __restrict__ part_ghead, uint32_t* __restrict__ sa,
                uint32_t* __restrict__ isa, uint32_t* __restrict__ S_next,
                uint32_t* __restrict__ V_next, uint32_t* __restrict__ G_next,
-               uint32_t* __restrict__ R_next, int sa_in_place, uint64_t* __restrict__ rank_pairs,
-               unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket,
-               uint32_t* __restrict__ totals)
+               uint32_t* __restrict__ R_next, int sa_in_place, uint64_t* __restrict__ rank_pairs)
 {
     __shared__ uint32_t part_m[2][kWavesPerBlock], part_a[2][kWavesPerBlock];
-    __shared__ uint32_t s_ticket, s_carry[2];
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    uint64_t begin = SWEEP ? 0 : (uint64_t)blockIdx.x * tiles_per_block * kGroupTile;
-    uint64_t end = SWEEP ? m : begin + tiles_per_block * kGroupTile;
+    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kGroupTile;
+    uint64_t end = begin + tiles_per_block * kGroupTile;
     if (end > m) end = m;
-    uint32_t c_head = SWEEP ? 0u : part_head[blockIdx.x];     // index+1 of the last head before the chunk / tile
-    uint32_t c_keep = SWEEP ? 0u : part_keep[blockIdx.x];
+    uint32_t c_head = part_head[blockIdx.x];     // index+1 of the last head before the chunk
+    uint32_t c_keep = part_keep[blockIdx.x];
     (void)part_ghead;
     unsigned par = 0;
     GroupKeys<KeyT> nxt;
-    if (!SWEEP && begin < end) group_load(K, begin + (uint64_t)tid * kGroupItems, m, nxt);
-    const uint64_t ntiles = (m + kGroupTile - 1) / kGroupTile;
+    if (begin < end) group_load(K, begin + (uint64_t)tid * kGroupItems, m, nxt);
     for (uint64_t tile = begin; tile < end; tile += kGroupTile) {
-        uint32_t tile_no = 0;
-        if (SWEEP) {
-            if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
-            __syncthreads();
-            tile_no = s_ticket;
-            if (tile_no >= ntiles) break;
-            tile = (uint64_t)tile_no * kGroupTile;
-            group_load(K, tile + (uint64_t)tid * kGroupItems, m, nxt);
-        }
         const uint64_t i0 = tile + (uint64_t)tid * kGroupItems;
         const GroupKeys<KeyT> cur = nxt;
-        if (!SWEEP && tile + kGroupTile < end) group_load(K, i0 + kGroupTile, m, nxt);      // next tile in flight
+        if (tile + kGroupTile < end) group_load(K, i0 + kGroupTile, m, nxt);      // next tile in flight
         unsigned head, single;
         group_flags(cur, i0, m, head, single);
         const unsigned valid = valid_mask(i0, m);
         const unsigned keepm = valid & ~single;
         const uint32_t hmax = head ? (uint32_t)i0 + (32u - (unsigned)__clz((int)head)) : 0u;
-        const uint32_t cnt = (uint32_t)__popc(keepm) | (SWEEP ? (uint32_t)__popc(head & ~single) << 16 : 0u);
+        const uint32_t cnt = (uint32_t)__popc(keepm);
         // one barrier for both scans: exclusive max of hmax, exclusive sum of cnt
         uint32_t im = wave_scan_max(hmax), ia = wave_scan_add(cnt);
         uint32_t pm = __shfl_up(im, 1u);
@@ -578,41 +556,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
             tot_a += qa;
         }
         par ^= 1u;
-        if (SWEEP) {
-            // thread 0: publish this tile's aggregate, look back for the carries, publish the prefix
-            if (tid == 0) {
-                const unsigned long long a_head = tot_m, a_keep = tot_a & 0xFFFFu, a_gh = tot_a >> 16;
-                unsigned long long* mine = status + 2ull * tile_no;
-                unsigned long long p_head = 0, p_keep = 0, p_gh = 0;
-                if (tile_no > 0) {
-                    __hip_atomic_store(mine, kGsAgg | (a_head << 31) | a_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(mine + 1, kGsAgg | a_gh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (uint32_t j = tile_no; j > 0; j--) {
-                        const unsigned long long* q = status + 2ull * (j - 1);
-                        unsigned long long v0, v1;
-                        do { v0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(v0 >> 62)) __builtin_amdgcn_s_sleep(1); } while (!(v0 >> 62));
-                        do { v1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(v1 >> 62)) __builtin_amdgcn_s_sleep(1); } while (!(v1 >> 62));
-                        // (both words of a tile are written with the same flag; a prefix word may
-                        //  already have replaced an aggregate word -- wait until the flags agree)
-                        if ((v0 >> 62) != (v1 >> 62)) { j++; continue; }
-                        p_head = dmax<unsigned long long>(p_head, (v0 >> 31) & 0x7FFFFFFFull);
-                        p_keep += v0 & 0x7FFFFFFFull;
-                        p_gh += v1 & 0xFFFFFFFFull;
-                        if ((v0 >> 62) == 2ull) break;
-                    }
-                }
-                const unsigned long long i_head = dmax<unsigned long long>(p_head, a_head);
-                __hip_atomic_store(mine, kGsPrefix | (i_head << 31) | (p_keep + a_keep), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(mine + 1, kGsPrefix | (p_gh + a_gh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_carry[0] = (uint32_t)p_head;
-                s_carry[1] = (uint32_t)p_keep;
-                if (tile_no == ntiles - 1) { totals[0] = (uint32_t)(p_keep + a_keep); totals[1] = (uint32_t)(p_gh + a_gh); }
-            }
-            __syncthreads();
-            c_head = s_carry[0];
-            c_keep = s_carry[1];
-        }
-        const uint32_t ec = (ba + ia - cnt) & 0xFFFFu;
+        const uint32_t ec = ba + ia - cnt;
         uint32_t run_head = dmax(c_head, dmax(bm, pm));          // index+1 of the last head before item 0
         uint32_t run_keep = c_keep + ec;
         if (keepm || isa || !sa_in_place) {                      // (all-singleton threads have nothing to write in place)
@@ -651,7 +595,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
             }
         }
         c_head = dmax(c_head, tot_m);
-        c_keep += tot_a & 0xFFFFu;
+        c_keep += tot_a;
     }
 }
 
@@ -949,10 +893,9 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
     Chunking ch = make_chunking(m, kGroupTile);
     SFX_LAUNCH(sizeof(KeyT) == 4 ? "groups_apply_u32" : "groups_apply_u64",
                (double)m * (sizeof(KeyT) + (sa_in_place ? 0 : 8) + (isa ? 4 : 0) + (S ? 4 : 0)),
-               (k_groups_apply<KeyT, false>), ch.blocks, kBlock, st, K, V, S, m, ch.tiles_per_block,
-               b.part_head, b.part_keep, b.part_ghead, sa_in_place ? (uint32_t*)nullptr : sa, isa, S_next, V_next,
-               b.G, R_next, sa_in_place ? 1 : 0, pairs, (unsigned long long*)nullptr, (uint32_t*)nullptr,
-               (uint32_t*)nullptr);
+               (k_groups_apply<KeyT>), ch.blocks, kBlock, st, K, V, S, m, ch.tiles_per_block,
+               b.part_head, b.part_keep, b.part_ghead, sa_in_place ? (uint32_t*)nullptr /* V is the SA */ : sa, isa,
+               S_next, V_next, b.G, R_next, sa_in_place ? 1 : 0, pairs);
     if (pairs) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, m, n, isa, b.hist, st, &stats));
     return SFX_OK;
 }
@@ -1009,55 +952,6 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
     return SFX_OK;
 }
 
-// rank array of the active list straight from its bucket ids: the id is the position of the
-// bucket's head in the list, so the head's slot is S[G[q]]
-__global__ void __launch_bounds__(kBlock)
-k_isa_fix_from_heads(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, const uint32_t* __restrict__ G,
-                     uint64_t m, uint32_t* __restrict__ isa)
-{
-    constexpr int U = 4;
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t q0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q0 < m; q0 += U * stride) {
-        uint32_t v[U], g[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint64_t q = q0 + u * stride;
-            v[u] = q < m ? V[q] : 0u;
-            g[u] = q < m ? G[q] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) g[u] = (q0 + u * stride < m) ? S[g[u]] : 0u;
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if (q0 + u * stride < m) isa[v[u]] = g[u];
-    }
-}
-
-// Single-pass bucket pass over sorted 32-bit keys whose suffixes already sit in their SA
-// slots (k_groups_apply<., true>): no reduce / scan kernels, totals come back afterwards.
-static int bucket_pass_sweep(const uint32_t* K, uint64_t m, SaBuffers& b, uint32_t* sa, uint32_t* S_next,
-                             uint32_t* V_next, hipStream_t st, uint64_t* kept, uint64_t* kept_groups)
-{
-    uint32_t* tickets;
-    uint32_t* status;
-    radix_scratch_regions(b.hist, &tickets, &status);
-    const uint64_t tiles = (m + kGroupTile - 1) / kGroupTile;
-    SFX_HIP(hipMemsetAsync(tickets, 0, sizeof(uint32_t), st));
-    SFX_HIP(hipMemsetAsync(status, 0, tiles * 2 * sizeof(unsigned long long), st));
-    const unsigned grid = (unsigned)dmin<uint64_t>(tiles, kMaxGrid);
-    SFX_LAUNCH("groups_apply_u32", (double)m * 4, (k_groups_apply<uint32_t, true>), grid, kBlock, st, K,
-               (const uint32_t*)sa, (const uint32_t*)nullptr, m, (uint64_t)0, (const uint32_t*)nullptr,
-               (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr /* in place: V is the SA */,
-               (uint32_t*)nullptr, S_next, V_next, b.G,
-               (uint32_t*)nullptr, 1, (uint64_t*)nullptr, (unsigned long long*)status, tickets, b.totals);
-    uint32_t host_totals[2] = {0, 0};
-    SFX_HIP(hipMemcpyAsync(host_totals, b.totals, sizeof(host_totals), hipMemcpyDeviceToHost, st));
-    SFX_HIP(hipStreamSynchronize(st));
-    *kept = host_totals[0];
-    *kept_groups = host_totals[1];
-    return SFX_OK;
-}
-
 // Direct ordering of the small buckets of the active list (S_cur, *V_cur, b.G; m elements
 // sharing their first h symbols inside each bucket), followed by compaction of what is
 // still unresolved.  On return the active list is (*S_cur, *V_cur, b.G) with *m elements.
@@ -1088,12 +982,6 @@ static int small_groups_pass(const PackedText& pt, uint64_t h, SaBuffers& b, uin
     stats.small_bucket_resolved += cnt - left;
     *m = left;
     return SFX_OK;
-}
-// test hook: SFX_GROUPS_SWEEP=0 keeps the reduce + scan + apply schedule everywhere
-static bool groups_sweep_enabled()
-{
-    static const bool on = [] { const char* e = getenv("SFX_GROUPS_SWEEP"); return !e || atoi(e) != 0; }();
-    return on;
 }
 // worth it when the average unresolved bucket is small
 static bool small_groups_pay(uint64_t m, uint64_t groups) { return m > 0 && groups * 4 >= m; }
@@ -1195,27 +1083,12 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         V_next = in1 ? b.VA : b.VB;
     }
     uint64_t kept = 0, groups = 0;
-    int text_rounds = 0;
-    if (in_place && count < (1ull << 31) && groups_sweep_enabled()) {
-        // 32-bit keys: one pass over the sorted keys; the rank-round decision is taken afterwards
-        // and, if rank rounds are needed right away, the rank array is built from the SA
-        SFX_TRY(bucket_pass_sweep((const uint32_t*)Kr, count, b, sa, b.S0, V_next, st, &kept, &groups));
-        stats.active_after_initial = kept;
-        text_rounds = (isa && kept * kTextFirstDivisor <= count && pt.spw >= 8) ? 1 : 0;
-        if (isa && !text_rounds && kept > 0) {
-            unsigned g1 = (unsigned)dmin<uint64_t>((pt.n + kBlock - 1) / kBlock, kMaxGrid);
-            unsigned g2 = (unsigned)dmin<uint64_t>((kept + kBlock - 1) / kBlock, kMaxGrid);
-            SFX_LAUNCH("isa_from_sa", (double)pt.n * 8, k_isa_from_sa, g1, kBlock, st, sa, pt.n, isa);
-            SFX_LAUNCH("isa_fix_active", (double)kept * 16, k_isa_fix_from_heads, g2, kBlock, st, V_next, b.S0, b.G, kept, isa);
-        }
-    } else {
-        SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups));
-        stats.active_after_initial = kept;
-        // few unresolved suffixes: one text round first, ISA only if that does not finish the job
-        text_rounds = (isa && kept * kTextFirstDivisor <= count && pt.spw >= 8) ? 1 : 0;
-        SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, (isa && !text_rounds) ? isa : nullptr, b.S0, V_next,
-                                  nullptr, st, in_place, pt.n, stats));
-    }
+    SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups));
+    stats.active_after_initial = kept;
+    // few unresolved suffixes: one text round first, ISA only if that does not finish the job
+    const int text_rounds = (isa && kept * kTextFirstDivisor <= count && pt.spw >= 8) ? 1 : 0;
+    SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, (isa && !text_rounds) ? isa : nullptr, b.S0, V_next,
+                              nullptr, st, in_place, pt.n, stats));
     uint32_t* S_cur = b.S0;
     const uint64_t id_bound = kept;
     if (small_groups_pay(kept, groups)) {
