@@ -80,7 +80,7 @@ class Engine:
     """One loaded copy of the C ABI."""
 
     def __init__(self, lib_path=None):
-        path = lib_path or DEFAULT_LIB
+        path = lib_path or os.environ.get("SFX_LIB") or DEFAULT_LIB      # SFX_LIB: development builds (lab/)
         if not os.path.exists(path):
             raise SuffixHipError(
                 f"{path} not found: the HIP extension is not built (run "

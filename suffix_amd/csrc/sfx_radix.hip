@@ -331,20 +331,37 @@ __device__ __forceinline__ uint32_t lookback(uint32_t* status, uint32_t tile_no,
         return 0u;
     }
     __hip_atomic_store(mine, kStatusAgg | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // walk back kLookAhead tiles per step: the status words of the next few predecessors are
+    // fetched together (independent uncached loads) instead of one dependent round trip each
+    #ifndef SFX_LOOKAHEAD
+#define SFX_LOOKAHEAD 4
+#endif
+    constexpr int kLookAhead = SFX_LOOKAHEAD;
     uint32_t excl = 0;
-    const uint32_t* p = mine;
-    for (uint32_t j = tile_no; j > 0; j--) {
-        p -= kRadix;
-        uint32_t sv = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((sv >> 30) == 0u) {
-            __builtin_amdgcn_s_sleep(1);
-            sv = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int64_t j = (int64_t)tile_no - 1;
+    for (;;) {
+        uint32_t sv[kLookAhead];
+#pragma unroll
+        for (int u = 0; u < kLookAhead; u++) {
+            const int64_t t = j - u;
+            sv[u] = t >= 0 ? __hip_atomic_load(status + (uint64_t)t * kRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                           : kStatusPrefix;                                   // before tile 0: empty prefix
         }
-        excl += sv & kStatusValue;
-        if ((sv >> 30) == 2u) break;
+#pragma unroll
+        for (int u = 0; u < kLookAhead; u++) {
+            const int64_t t = j - u;
+            while ((sv[u] >> 30) == 0u) {
+                __builtin_amdgcn_s_sleep(1);
+                sv[u] = __hip_atomic_load(status + (uint64_t)t * kRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            excl += sv[u] & kStatusValue;
+            if ((sv[u] >> 30) == 2u) {
+                __hip_atomic_store(mine, kStatusPrefix | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return excl;
+            }
+        }
+        j -= kLookAhead;
     }
-    __hip_atomic_store(mine, kStatusPrefix | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return excl;
 }
 
 // NW = waves per workgroup (4 or 8): thread d < 256 owns bucket d; a 512-thread workgroup
