@@ -323,44 +323,55 @@ __device__ __forceinline__ uint32_t rank_round(unsigned d, unsigned long long* f
 
 // decoupled look-back for digit `tid` of tile `tile_no`: publishes the tile's count,
 // returns the number of elements with this digit in all earlier tiles.
-__device__ __forceinline__ uint32_t lookback(uint32_t* status, uint32_t tile_no, unsigned tid, uint32_t agg)
-{
-    uint32_t* mine = status + (uint64_t)tile_no * kRadix + tid;
-    if (tile_no == 0) {
-        __hip_atomic_store(mine, kStatusPrefix | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0u;
-    }
-    __hip_atomic_store(mine, kStatusAgg | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // walk back kLookAhead tiles per step: the status words of the next few predecessors are
-    // fetched together (independent uncached loads) instead of one dependent round trip each
-    #ifndef SFX_LOOKAHEAD
+#ifndef SFX_LOOKAHEAD
 #define SFX_LOOKAHEAD 4
 #endif
-    constexpr int kLookAhead = SFX_LOOKAHEAD;
+constexpr int kLookAhead = SFX_LOOKAHEAD;
+struct LookBack {
+    uint32_t sv[kLookAhead];     // status words of the kLookAhead nearest predecessors, in flight
+};
+// Publish this tile's count for digit `tid` and START the look-back: the status words of the
+// next kLookAhead predecessors are fetched together (independent uncached loads) and not
+// waited for -- the caller does its LDS staging in between.
+__device__ __forceinline__ void lookback_begin(uint32_t* status, uint32_t tile_no, unsigned tid, uint32_t agg, LookBack& lb)
+{
+    uint32_t* mine = status + (uint64_t)tile_no * kRadix + tid;
+    __hip_atomic_store(mine, (tile_no == 0 ? kStatusPrefix : kStatusAgg) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int u = 0; u < kLookAhead; u++) {
+        const int64_t t = (int64_t)tile_no - 1 - u;
+        lb.sv[u] = t >= 0 ? __hip_atomic_load(status + (uint64_t)t * kRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                          : kStatusPrefix;                                    // before tile 0: empty prefix
+    }
+}
+// Finish: number of elements with this digit in all earlier tiles; publishes the inclusive prefix.
+__device__ __forceinline__ uint32_t lookback_finish(uint32_t* status, uint32_t tile_no, unsigned tid, uint32_t agg, LookBack& lb)
+{
+    if (tile_no == 0) return 0u;
+    uint32_t* mine = status + (uint64_t)tile_no * kRadix + tid;
     uint32_t excl = 0;
     int64_t j = (int64_t)tile_no - 1;
     for (;;) {
-        uint32_t sv[kLookAhead];
 #pragma unroll
         for (int u = 0; u < kLookAhead; u++) {
             const int64_t t = j - u;
-            sv[u] = t >= 0 ? __hip_atomic_load(status + (uint64_t)t * kRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                           : kStatusPrefix;                                   // before tile 0: empty prefix
-        }
-#pragma unroll
-        for (int u = 0; u < kLookAhead; u++) {
-            const int64_t t = j - u;
-            while ((sv[u] >> 30) == 0u) {
+            while ((lb.sv[u] >> 30) == 0u) {
                 __builtin_amdgcn_s_sleep(1);
-                sv[u] = __hip_atomic_load(status + (uint64_t)t * kRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lb.sv[u] = __hip_atomic_load(status + (uint64_t)t * kRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            excl += sv[u] & kStatusValue;
-            if ((sv[u] >> 30) == 2u) {
+            excl += lb.sv[u] & kStatusValue;
+            if ((lb.sv[u] >> 30) == 2u) {
                 __hip_atomic_store(mine, kStatusPrefix | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return excl;
             }
         }
         j -= kLookAhead;
+#pragma unroll
+        for (int u = 0; u < kLookAhead; u++) {
+            const int64_t t = j - u;
+            lb.sv[u] = t >= 0 ? __hip_atomic_load(status + (uint64_t)t * kRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              : kStatusPrefix;
+        }
     }
 }
 
@@ -444,6 +455,8 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
         __syncthreads();
 
         // thread d: bucket d's size in this tile -> tile-local start, per-wave bases, global head
+        LookBack lb;
+        uint32_t real_count = 0, tile_ex = 0;
         {
             uint32_t c[NW], tile_count = 0;
 #pragma unroll
@@ -460,9 +473,10 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
                     run += c[k];
                 }
                 // padding elements all carry the largest digit (== mask)
-                const uint32_t real_count = tile_count - ((tid == mask) ? (uint32_t)(kTile - nvalid) : 0u);
+                real_count = tile_count - ((tid == mask) ? (uint32_t)(kTile - nvalid) : 0u);
+                tile_ex = ex;
                 if (ONESWEEP) {
-                    s.off[tid] = my_head + lookback(status, tile_no, tid, real_count) - ex;
+                    lookback_begin(status, tile_no, tid, real_count, lb);     // loads in flight during the staging
                 } else {
                     s.off[tid] = my_head - ex;
                     my_head += real_count;
@@ -478,6 +492,7 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
             s.stage[p] = key[r];
             if (HAS_VAL) s.stage_v[p] = val[r];
         }
+        if (ONESWEEP && owner) s.off[tid] = my_head + lookback_finish(status, tile_no, tid, real_count, lb) - tile_ex;
         __syncthreads();
         // (three separate loops: all LDS reads of a kind are in flight together)
 #pragma unroll
