@@ -72,7 +72,10 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
 
     # 1. whole text on every GPU
     text = torch.empty(n, dtype=torch.uint8, device=dev)
-    dist.all_gather(list(text.split(m)), shard.contiguous(), group=group)
+    try:
+        dist.all_gather_into_tensor(text, shard.contiguous(), group=group)     # one flat receive buffer (RCCL)
+    except (RuntimeError, NotImplementedError, AttributeError):
+        dist.all_gather(list(text.split(m)), shard.contiguous(), group=group)  # backends without the flat form
 
     # 2. global alphabet
     byte_bins = torch.zeros(256, dtype=torch.int64, device=dev)
