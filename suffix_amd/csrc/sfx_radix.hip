@@ -56,12 +56,14 @@ constexpr unsigned kHistAllGrid = 1024;          // workgroups of the up-front h
 // ---- element sources / sinks ---------------------------------------------------------
 struct SrcE64 {
     static constexpr bool kHasVal = false;
+    static constexpr bool kFromText = false;
     const uint64_t* in;
     __device__ __forceinline__ uint64_t key(uint64_t i) const { return in[i]; }
     __device__ __forceinline__ uint32_t val(uint64_t) const { return 0u; }
 };
 struct SrcText32 {
     static constexpr bool kHasVal = false;
+    static constexpr bool kFromText = true;
     PackedText t;
     __device__ __forceinline__ uint64_t key(uint64_t i) const
     {
@@ -71,6 +73,7 @@ struct SrcText32 {
 };
 struct SrcKV {
     static constexpr bool kHasVal = true;
+    static constexpr bool kFromText = false;
     const uint64_t* k;
     const uint32_t* v;
     __device__ __forceinline__ uint64_t key(uint64_t i) const { return k[i]; }
@@ -78,6 +81,7 @@ struct SrcKV {
 };
 struct SrcText64 {
     static constexpr bool kHasVal = true;
+    static constexpr bool kFromText = true;
     PackedText t;
     __device__ __forceinline__ uint64_t key(uint64_t i) const { return packed_key64(t, i); }
     __device__ __forceinline__ uint32_t val(uint64_t i) const { return (uint32_t)i; }
@@ -259,9 +263,10 @@ k_radix_scan(uint32_t* __restrict__ hist, unsigned nblocks, uint32_t* __restrict
 }
 
 // ---- tile engine ---------------------------------------------------------------------
+// The match masks of the ranking (NW x 256 u64) live in the first 2 KiB x NW of `stage`:
+// ranking is over before anything is staged, and every wave clears its own row before it ranks.
 template <int KPT, bool HAS_VAL, int NW, bool RANK_ATOMIC>
 struct RadixSmem {
-    unsigned long long flags[RANK_ATOMIC ? NW : 1][RANK_ATOMIC ? kRadix : 1];   // match mask of the round in flight, per wave
     uint32_t cnt[NW][kRadix];                           // per-wave digit counts, then tile-local bases
     uint32_t off[kRadix];                               // global bucket head minus tile-local bucket start
     uint32_t part[2][NW];
@@ -377,8 +382,11 @@ __device__ __forceinline__ uint32_t lookback_finish(uint32_t* status, uint32_t t
 
 // NW = waves per workgroup (4 or 8): thread d < 256 owns bucket d; a 512-thread workgroup
 // sorts 8192-element tiles, i.e. 256-byte runs per bucket.
+#ifndef SFX_RADIX_MIN_WAVES
+#define SFX_RADIX_MIN_WAVES 1
+#endif
 template <class Src, class Dst, int KPT, bool ONESWEEP, bool RANK_ATOMIC, int NW>
-__global__ void __launch_bounds__(NW * kWave)
+__global__ void __launch_bounds__(NW * kWave, SFX_RADIX_MIN_WAVES)
 k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t chunk,
              const uint32_t* __restrict__ hist, const uint32_t* __restrict__ digit_total,
              uint32_t* __restrict__ status, uint32_t* __restrict__ ticket)
@@ -392,12 +400,11 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
     const bool owner = tid < (unsigned)kRadix;                   // thread d owns bucket d
     unsigned par = 0;
 
+    static_assert(kWave * KPT >= kRadix, "the match masks must fit the staging buffer");
+    unsigned long long* const my_flags = reinterpret_cast<unsigned long long*>(s.stage) + w * kRadix;
     if (owner) {
 #pragma unroll
-        for (int k = 0; k < NW; k++) {
-            if (RANK_ATOMIC) s.flags[k][tid] = 0ull;
-            s.cnt[k][tid] = 0u;
-        }
+        for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0u;
     }
     // one-sweep: global start of bucket `tid`; chunked: this workgroup's running head of bucket `tid`
     uint32_t my_head = block_scan_excl_1b<NW>(owner ? digit_total[tid] : 0u, s.part, par);
@@ -449,9 +456,14 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
             if (HAS_VAL) val[r] = nval[r];
         }
         if (!ONESWEEP && next < limit) load_tile(next);
+        if (RANK_ATOMIC) {                                  // this wave's match masks (aliased onto the stage)
+#pragma unroll
+            for (int k = 0; k < kRadix / kWave; k++) my_flags[k * kWave + lane] = 0ull;
+            wave_sync();
+        }
 #pragma unroll
         for (int r = 0; r < KPT; r++)
-            pos[r] = rank_round<RANK_ATOMIC>(digit_of(key[r], shift, mask), s.flags[RANK_ATOMIC ? w : 0], s.cnt[w], mybit);
+            pos[r] = rank_round<RANK_ATOMIC>(digit_of(key[r], shift, mask), my_flags, s.cnt[w], mybit);
         __syncthreads();
 
         // thread d: bucket d's size in this tile -> tile-local start, per-wave bases, global head
@@ -593,7 +605,12 @@ static int run_pass(const char* name, double algo_bytes, const Src& src, const D
         if (sweep) return t.rank ? SFX_PASS(KPT, true, true, NW) : SFX_PASS(KPT, true, false, NW);  \
         return t.rank ? SFX_PASS(KPT, false, true, NW) : SFX_PASS(KPT, false, false, NW);           \
     } while (0)
-    if (t.nw == 16) SFX_PASS_NW(8, 16);                          // (16 x 16 would not fit the 160 KiB of LDS)
+    if (t.nw == 16) {
+        // 16384-element tiles (E64 only: LDS): measured faster for the text-fed pass (0.45 vs
+        // 0.535 ms, no element loads to hold in registers), slower for the others (0.57 vs 0.55)
+        if constexpr (!Src::kHasVal) { if (t.kpt == 16 || Src::kFromText) SFX_PASS_NW(16, 16); }
+        SFX_PASS_NW(8, 16);
+    }
     if (t.nw == 8) { if (t.kpt == 16) SFX_PASS_NW(16, 8); SFX_PASS_NW(8, 8); }
     if (t.kpt == 16) SFX_PASS_NW(16, 4);
     SFX_PASS_NW(8, 4);
