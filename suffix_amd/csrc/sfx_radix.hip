@@ -506,17 +506,22 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
         }
         if (ONESWEEP && owner) s.off[tid] = my_head + lookback_finish(status, tile_no, tid, real_count, lb) - tile_ex;
         __syncthreads();
-        // (three separate loops: all LDS reads of a kind are in flight together)
+        // batches of 8 slots: within a batch all LDS reads of a kind are in flight together;
+        // more than 8 at once only costs registers (16-element threads spilled)
+        constexpr int kOut = KPT < 8 ? KPT : 8;
 #pragma unroll
-        for (int r = 0; r < KPT; r++) {
-            key[r] = s.stage[r * kThreads + tid];
-            if (HAS_VAL) val[r] = s.stage_v[r * kThreads + tid];
+        for (int r0 = 0; r0 < KPT; r0 += kOut) {
+#pragma unroll
+            for (int r = r0; r < r0 + kOut; r++) {
+                key[r] = s.stage[r * kThreads + tid];
+                if (HAS_VAL) val[r] = s.stage_v[r * kThreads + tid];
+            }
+#pragma unroll
+            for (int r = r0; r < r0 + kOut; r++) pos[r] = s.off[digit_of(key[r], shift, mask)] + (r * kThreads + tid);
+#pragma unroll
+            for (int r = r0; r < r0 + kOut; r++)
+                if ((unsigned)(r * kThreads) + tid < nvalid) dst.store(pos[r], key[r], HAS_VAL ? val[r] : 0u);
         }
-#pragma unroll
-        for (int r = 0; r < KPT; r++) pos[r] = s.off[digit_of(key[r], shift, mask)] + (r * kThreads + tid);
-#pragma unroll
-        for (int r = 0; r < KPT; r++)
-            if ((unsigned)(r * kThreads) + tid < nvalid) dst.store(pos[r], key[r], HAS_VAL ? val[r] : 0u);
         if (owner) {
 #pragma unroll
             for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0u;
