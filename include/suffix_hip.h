@@ -115,6 +115,23 @@ int sfx_build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n,
                                uint32_t* d_sa_part, uint64_t* count_out, void* d_workspace,
                                uint64_t workspace_bytes, void* stream);
 
+/* Packed-text variant of steps 1 and 4 (saves xGMI volume: the all-gather moves
+ * bits/8 of the raw bytes, and no rank packs the whole text):
+ *   sfx_pack_text_dev   symbols of d_text[0..count) re-coded with the GLOBAL alphabet
+ *         (d_global_byte_bins256) and packed big-endian, floor(32/bits) per u32 word,
+ *         bits = ceil(log2 sigma); writes exactly n_words words (zeros past the text).
+ *         A shard whose length is a multiple of floor(32/bits) packs into count /
+ *         floor(32/bits) words that can be concatenated across ranks; the concatenation
+ *         must end in >= 3 zero words.  d_scratch256: 256 bytes of device scratch.
+ *   sfx_build_sa_range_packed_u32_dev   step 4 on that packed text (n = symbols). */
+int sfx_pack_text_dev(const uint8_t* d_text, uint64_t count, const uint64_t* d_global_byte_bins256,
+                      uint8_t* d_scratch256, uint32_t* d_words, uint64_t n_words, void* stream);
+int sfx_build_sa_range_packed_u32_dev(const uint32_t* d_packed, uint64_t n,
+                                      const uint64_t* d_global_byte_bins256, int top_bits,
+                                      uint32_t bin_lo, uint32_t bin_hi, uint64_t capacity,
+                                      uint32_t* d_sa_part, uint64_t* count_out, void* d_workspace,
+                                      uint64_t workspace_bytes, void* stream);
+
 /* Per-rank pieces of the partitioned index (every rank holds the text and ONE contiguous
  * slice d_sa_part[0..count) of the suffix array):
  *  - LCP of the slice: lcp_part[r] = |lcp(text[sa_part[r-1]..], text[sa_part[r]..])|, with

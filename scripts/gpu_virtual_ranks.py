@@ -48,16 +48,38 @@ for world in (1, 2, 4, 8):
         ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(n, cap)), dtype=torch.uint8, device=dev)
         got = ctypes.c_uint64(0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        eng.check(eng.lib.sfx_build_sa_range_u32_dev(_p(text), n, _p(bb), tb, lo, hi, cap, _p(part), ctypes.byref(got),
-                                                     _p(ws), ws.numel(), None), "range")
-        torch.cuda.synchronize(); t_rb = time.perf_counter() - t0
+        if packed_flow:
+            # what dist.py does when shards pack into whole words: every rank packs its own shard
+            # (here: rank 0's share of the work = one shard; the others' words are packed untimed)
+            wps = m // 16
+            eng.check(eng.lib.sfx_pack_text_dev(_p(text), m, _p(bb), _p(scratch), _p(packed), wps, None), "pack")
+            torch.cuda.synchronize(); t_pk = time.perf_counter() - t0
+            for r in range(1, world):
+                eng.check(eng.lib.sfx_pack_text_dev(_p(text[r * m:]), m, _p(bb), _p(scratch), _p(packed[r * wps:]), wps, None), "pack")
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            eng.check(eng.lib.sfx_build_sa_range_packed_u32_dev(_p(packed), n, _p(bb), tb, lo, hi, cap, _p(part),
+                                                                ctypes.byref(got), _p(ws), ws.numel(), None), "range")
+            torch.cuda.synchronize(); t_rb = time.perf_counter() - t0 + t_pk
+        else:
+            eng.check(eng.lib.sfx_build_sa_range_u32_dev(_p(text), n, _p(bb), tb, lo, hi, cap, _p(part), ctypes.byref(got),
+                                                         _p(ws), ws.numel(), None), "range")
+            torch.cuda.synchronize(); t_rb = time.perf_counter() - t0
+        results[packed_flow] = part[:int(got.value)].clone()
         return t_kh, t_rb, int(got.value)
 
+    results = {}
+    packed = torch.zeros(n // 16 + 4, dtype=torch.int32, device=dev)
+    scratch = torch.empty(256, dtype=torch.uint8, device=dev)
+    packed_flow = False
+    rank0()
+    t_kh, t_rb_raw, got = rank0()
+    packed_flow = True
     rank0()
     t_kh, t_rb, got = rank0()
+    assert torch.equal(results[True], results[False]), "packed and raw range builds differ"
     eng.profile(True); eng.profile_reset(); rank0(); torch.cuda.synchronize()
     rep = {r["name"]: round(r["total_ms"], 3) for r in eng.profile_report()}
     eng.profile(False)
     print(json.dumps({"world": world, "n": n, "rank0_suffixes": got, "key_hist_ms": round(t_kh * 1e3, 3),
-                      "range_build_ms": round(t_rb * 1e3, 3), "kernel_ms": rep}), flush=True)
+                      "range_build_ms": round(t_rb * 1e3, 3), "range_build_raw_text_ms": round(t_rb_raw * 1e3, 3), "kernel_ms": rep}), flush=True)
     del text

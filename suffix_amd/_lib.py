@@ -62,6 +62,9 @@ ABI = [
     ("sfx_sa_range_workspace_bytes", _u64, [_u64, _u64]),
     ("sfx_build_sa_range_u32_dev", _int, [_vp, _u64, _vp, _int, _u32, _u32, _u64, _vp,
                                           ctypes.POINTER(_u64), _vp, _u64, _vp]),
+    ("sfx_pack_text_dev", _int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp]),
+    ("sfx_build_sa_range_packed_u32_dev", _int, [_vp, _u64, _vp, _int, _u32, _u32, _u64, _vp,
+                                                 ctypes.POINTER(_u64), _vp, _u64, _vp]),
     ("sfx_build_lcp_range_u32_dev", _int, [_vp, _u64, _vp, _u64, _u32, _vp, _vp]),
     ("sfx_query_batch_range_dev", _int, [_vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     ("sfx_microbench", _int, [_int, _u64, _int, _int, _int, ctypes.POINTER(ctypes.c_double)]),

@@ -358,6 +358,22 @@ int sfx_build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n,
                                   (hipStream_t)stream);
 }
 
+int sfx_pack_text_dev(const uint8_t* d_text, uint64_t count, const uint64_t* d_global_byte_bins256,
+                      uint8_t* d_scratch256, uint32_t* d_words, uint64_t n_words, void* stream)
+{
+    return pack_text_dev(d_text, count, d_global_byte_bins256, d_scratch256, d_words, n_words, (hipStream_t)stream);
+}
+int sfx_build_sa_range_packed_u32_dev(const uint32_t* d_packed, uint64_t n,
+                                      const uint64_t* d_global_byte_bins256, int top_bits, uint32_t bin_lo,
+                                      uint32_t bin_hi, uint64_t capacity, uint32_t* d_sa_part,
+                                      uint64_t* count_out, void* d_workspace, uint64_t workspace_bytes,
+                                      void* stream)
+{
+    if (!d_packed) return SFX_ERR_ARG;
+    return build_sa_range_u32_dev(nullptr, n, d_global_byte_bins256, top_bits, bin_lo, bin_hi, capacity, d_sa_part,
+                                  count_out, d_workspace, workspace_bytes, (hipStream_t)stream, d_packed);
+}
+
 // ---- profiling --------------------------------------------------------------------------------
 void sfx_profile_enable(int on) { g_profile = on != 0; }
 void sfx_profile_reset(void)

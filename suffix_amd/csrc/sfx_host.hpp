@@ -159,7 +159,9 @@ uint64_t sa_range_workspace_bytes(uint64_t n, uint64_t max_count);
 int build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint64_t* d_byte_bins,
                            int top_bits, uint32_t bin_lo, uint32_t bin_hi, uint64_t capacity,
                            uint32_t* d_sa_part, uint64_t* count_out, void* ws, uint64_t ws_bytes,
-                           hipStream_t st);
+                           hipStream_t st, const uint32_t* d_packed_in = nullptr);
+int pack_text_dev(const uint8_t* d_text, uint64_t count, const uint64_t* d_byte_bins, uint8_t* d_lut256,
+                  uint32_t* d_words, uint64_t n_words, hipStream_t st);
 
 sfx_build_stats& tls_build_stats();
 

@@ -914,16 +914,28 @@ int byte_histogram_dev(const uint8_t* d_text, uint64_t begin, uint64_t end, uint
 }
 
 // alphabet (host) + LUT and packed text (device) from device-resident global byte counts
+// `n_words_out` > 0: write exactly that many words (zeros past the text) instead of the
+// default (n + spw - 1) / spw + 3; `packed_in`: the text is already packed (partitioned
+// build after an all-gather of packed shards) -- only the alphabet is derived.
 static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long long* d_bins,
                         uint8_t* d_lut, uint32_t* d_packed, hipStream_t st, Alphabet* alpha,
-                        PackedText* pt)
+                        PackedText* pt, uint64_t n_words_out = 0, const uint32_t* packed_in = nullptr)
 {
     unsigned long long host_bins[256];
     SFX_HIP(hipMemcpyAsync(host_bins, d_bins, sizeof(host_bins), hipMemcpyDeviceToHost, st));
-    SFX_LAUNCH("make_lut", 0.0, k_make_lut, 1, kBlock, st, d_bins, d_lut);
+    if (!packed_in) SFX_LAUNCH("make_lut", 0.0, k_make_lut, 1, kBlock, st, d_bins, d_lut);
     SFX_HIP(hipStreamSynchronize(st));
     *alpha = make_alphabet(host_bins);
-    uint64_t nw = packed_words(n, alpha);
+    if (packed_in) {
+        pt->words = packed_in;
+        pt->n = n;
+        pt->bits = alpha->bits;
+        pt->spw = alpha->spw;
+        pt->kbits = alpha->kbits;
+        pt->inv_spw = 1.0 / alpha->spw;
+        return SFX_OK;
+    }
+    uint64_t nw = n_words_out ? n_words_out : packed_words(n, alpha);
     const double pack_bytes = (double)n * (1.0 + alpha->bits / 8.0);
     const bool pow2 = alpha->bits * alpha->spw == 32 &&          // bits in {1, 2, 4, 8}
                       (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0;
@@ -1186,10 +1198,23 @@ static int range_build(const PackedText& pt, int cpk, int top_bits, uint32_t bin
     return sort_and_refine<KeyT>(pt, cpk, host_total, false, b, d_sa_part, nullptr, st, stats);
 }
 
+// packed-text plumbing of the partitioned build: a rank packs its own shard (global symbol
+// codes), the packed shards are all-gathered (bits/8 of the raw volume over xGMI), and the
+// range build runs on the packed text directly.
+int pack_text_dev(const uint8_t* d_text, uint64_t count, const uint64_t* d_byte_bins, uint8_t* d_lut256,
+                  uint32_t* d_words, uint64_t n_words, hipStream_t st)
+{
+    if (!d_byte_bins || !d_lut256 || !d_words || (count && !d_text)) return SFX_ERR_ARG;
+    Alphabet alpha;
+    PackedText pt;
+    return prepare_text(d_text, count, (const unsigned long long*)d_byte_bins, d_lut256, d_words, st, &alpha, &pt,
+                        n_words ? n_words : 1);
+}
+
 int build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint64_t* d_byte_bins,
                            int top_bits, uint32_t bin_lo, uint32_t bin_hi, uint64_t capacity,
                            uint32_t* d_sa_part, uint64_t* count_out, void* ws, uint64_t ws_bytes,
-                           hipStream_t st)
+                           hipStream_t st, const uint32_t* d_packed_in)
 {
     sfx_build_stats& stats = tls_build_stats();
     memset(&stats, 0, sizeof(stats));
@@ -1198,7 +1223,7 @@ int build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint64_t* d_
     *count_out = 0;
     if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
     if (n == 0 || bin_lo >= bin_hi) return SFX_OK;
-    if (!d_text || !d_byte_bins || !d_sa_part || capacity == 0) return SFX_ERR_ARG;
+    if ((!d_text && !d_packed_in) || !d_byte_bins || !d_sa_part || capacity == 0) return SFX_ERR_ARG;
     if (top_bits < 1 || top_bits > kMaxTopBits || bin_hi > (1u << top_bits)) return SFX_ERR_ARG;
     if (!ws || ws_bytes < sa_range_workspace_bytes(n, capacity)) return SFX_ERR_WORKSPACE;
 
@@ -1211,7 +1236,7 @@ int build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint64_t* d_
     Alphabet alpha;
     PackedText pt;
     SFX_TRY(prepare_text(d_text, n, (const unsigned long long*)d_byte_bins, b.lut, b.packed, st, &alpha,
-                         &pt));
+                         &pt, 0, d_packed_in));
     int key_bits, cpk;
     choose_key(alpha, n, &key_bits, &cpk);
     if (alpha.bits * cpk < top_bits) return SFX_ERR_ARG;

@@ -7,7 +7,8 @@ because it is unique: split the SA index space at bucket boundaries.
 
     1. every rank owns a contiguous shard of the byte stream; the shards are
        all-gathered so each GPU holds the whole text in HBM (the one bulk
-       exchange: n/G bytes per rank over xGMI);
+       exchange) -- as PACKED symbol codes (bits/8 of the raw bytes over xGMI)
+       whenever a shard packs into whole words, after step 2 has fixed the codes;
     2. each rank histograms the bytes of ITS shard; all-reduce(sum) of 256 bins
        -> the global alphabet (dense symbol codes), identical everywhere;
     3. each rank histograms the top `top_bits` key bits of the suffixes starting
@@ -70,25 +71,44 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
         raise OverflowError("text longer than u32::MAX bytes")     # src/table.rs:380
     stream = _stream_ptr(shard)
 
-    # 1. whole text on every GPU
-    text = torch.empty(n, dtype=torch.uint8, device=dev)
-    try:
-        dist.all_gather_into_tensor(text, shard.contiguous(), group=group)     # one flat receive buffer (RCCL)
-    except (RuntimeError, NotImplementedError, AttributeError):
-        dist.all_gather(list(text.split(m)), shard.contiguous(), group=group)  # backends without the flat form
+    def gather(dst, src):
+        try:
+            dist.all_gather_into_tensor(dst, src, group=group)                 # one flat receive buffer (RCCL)
+        except (RuntimeError, NotImplementedError, AttributeError):
+            dist.all_gather(list(dst.split(src.numel())), src, group=group)   # backends without the flat form
 
-    # 2. global alphabet
+    # 2. global alphabet: byte histogram of the own shard, all-reduced
+    shard = shard.contiguous()
     byte_bins = torch.zeros(256, dtype=torch.int64, device=dev)
-    eng.check(eng.lib.sfx_byte_histogram_dev(_p(text), rank * m, (rank + 1) * m, _p(byte_bins), stream),
-              "sfx_byte_histogram_dev")
+    eng.check(eng.lib.sfx_byte_histogram_dev(_p(shard), 0, m, _p(byte_bins), stream), "sfx_byte_histogram_dev")
     dist.all_reduce(byte_bins, op=dist.ReduceOp.SUM, group=group)
-
-    # 3. bucket-boundary histogram
     sigma = int((byte_bins > 0).sum())
     sym_bits = max(1, (max(sigma, 2) - 1).bit_length())
-    tb = min(top_bits, sym_bits * max(1, 32 // sym_bits))
+    spw = 32 // sym_bits
+    tb = min(top_bits, sym_bits * max(1, spw))
+
+    # 1. the text on every GPU -- packed when the shards pack into whole words (bits/8 of the
+    #    raw volume over xGMI, and no rank packs the whole text), raw otherwise or on request
+    packed_path = (m % spw == 0) and m >= 64
+    text = None
+    if packed_path:
+        # key bits near the end of a shard reach into the next shard: a 64-byte halo is enough
+        heads = torch.empty(64 * world, dtype=torch.uint8, device=dev)
+        gather(heads, shard[:64].contiguous())
+        if rank + 1 < world:
+            local = torch.cat([shard, heads[64 * (rank + 1):64 * (rank + 2)]])
+        else:
+            local = shard
+        hist_text, hist_n, hist_lo, hist_hi = local, local.numel(), 0, m
+    if not packed_path or return_text:
+        text = torch.empty(n, dtype=torch.uint8, device=dev)
+        gather(text, shard)
+    if not packed_path:
+        hist_text, hist_n, hist_lo, hist_hi = text, n, rank * m, (rank + 1) * m
+
+    # 3. bucket-boundary histogram
     key_bins = torch.zeros(1 << tb, dtype=torch.int64, device=dev)
-    eng.check(eng.lib.sfx_key_histogram_dev(_p(text), n, rank * m, (rank + 1) * m, _p(byte_bins), tb,
+    eng.check(eng.lib.sfx_key_histogram_dev(_p(hist_text), hist_n, hist_lo, hist_hi, _p(byte_bins), tb,
                                             _p(key_bins), stream), "sfx_key_histogram_dev")
     dist.all_reduce(key_bins, op=dist.ReduceOp.SUM, group=group)
 
@@ -100,9 +120,21 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
     sa_part = torch.empty(cap, dtype=torch.int32, device=dev)
     ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(n, cap)), dtype=torch.uint8, device=dev)
     got = ctypes.c_uint64(0)
-    eng.check(eng.lib.sfx_build_sa_range_u32_dev(_p(text), n, _p(byte_bins), tb, lo, hi, cap,
-                                                 _p(sa_part), ctypes.byref(got), _p(ws), ws.numel(),
-                                                 stream), "sfx_build_sa_range_u32_dev")
+    if packed_path:
+        wps = m // spw                                             # words per shard
+        packed = torch.zeros(wps * world + 4, dtype=torch.int32, device=dev)   # + the zero tail keys read into
+        mine = torch.empty(wps, dtype=torch.int32, device=dev)
+        scratch = torch.empty(256, dtype=torch.uint8, device=dev)
+        eng.check(eng.lib.sfx_pack_text_dev(_p(shard), m, _p(byte_bins), _p(scratch), _p(mine), wps, stream),
+                  "sfx_pack_text_dev")
+        gather(packed[:wps * world], mine)
+        eng.check(eng.lib.sfx_build_sa_range_packed_u32_dev(_p(packed), n, _p(byte_bins), tb, lo, hi, cap,
+                                                            _p(sa_part), ctypes.byref(got), _p(ws), ws.numel(),
+                                                            stream), "sfx_build_sa_range_packed_u32_dev")
+    else:
+        eng.check(eng.lib.sfx_build_sa_range_u32_dev(_p(text), n, _p(byte_bins), tb, lo, hi, cap,
+                                                     _p(sa_part), ctypes.byref(got), _p(ws), ws.numel(),
+                                                     stream), "sfx_build_sa_range_u32_dev")
     if int(got.value) != count:
         raise RuntimeError(f"rank {rank}: range build produced {got.value} suffixes, plan said {count}")
     part = sa_part[:count]
