@@ -116,3 +116,13 @@ if __name__ == "__main__":
     if "dna1g" in which:
         t0 = time.time(); h = _gen.dna(size, seed=0x5AF1C5 + 4); print("gen dna", round(time.time() - t0, 1), "s", flush=True)
         run("control: 1 GB uniform DNA, SA + LCP", h)
+    if "dna2g" in which:
+        # n >= 2^30: the one-sweep status words no longer fit, the chunked radix schedule takes over;
+        # also the largest single-GPU input tried (2 * 10^9 positions, ~93 GB of workspace)
+        big = int(os.environ.get("SFX_HUGE_N", "2000000000"))
+        t0 = time.time(); h = _gen.dna(big, seed=0x5AF1C5 + 5); print("gen dna", round(time.time() - t0, 1), "s", flush=True)
+        run(f"stress: {big} B uniform DNA (n >= 2^30: chunked radix schedule), SA + LCP", h, reps=1)
+    if "eng2g" in which:
+        big = int(os.environ.get("SFX_HUGE_N", "1500000000"))
+        t0 = time.time(); h = _gen.english_like(big); print("gen english", round(time.time() - t0, 1), "s", flush=True)
+        run(f"stress: {big} B English-like ASCII (n >= 2^30), SA + LCP", h, reps=1)

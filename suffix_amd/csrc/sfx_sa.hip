@@ -826,7 +826,7 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint32_t* G = ar.template take<uint32_t>(cap);
     uint32_t* G1 = ar.template take<uint32_t>(cap);
     uint32_t* bc = ar.template take<uint32_t>(kMaxGrid);
-    uint32_t* R = ar.template take<uint32_t>(isa_len ? cap / kTextFirstDivisor + 1024 : 0);
+    uint32_t* R = ar.template take<uint32_t>(isa_len ? cap + 1024 : 0);     // (a text round may keep up to cap elements)
     uint32_t* isa = ar.template take<uint32_t>(isa_len);
     uint32_t* packed = ar.template take<uint32_t>(packed_words(n, nullptr));
     uint32_t* hist = ar.template take<uint32_t>(radix_scratch_words(cap));
@@ -1097,8 +1097,10 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     uint64_t kept = 0, groups = 0;
     SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups));
     stats.active_after_initial = kept;
-    // few unresolved suffixes: one text round first, ISA only if that does not finish the job
-    const int text_rounds = (isa && kept * kTextFirstDivisor <= count && pt.spw >= 8) ? 1 : 0;
+    // few unresolved suffixes, or small buckets that the direct pass will order: no rank array
+    // yet (its n-element scatter is only paid if a rank round turns out to be needed)
+    const int text_rounds =
+        (isa && ((kept * kTextFirstDivisor <= count && pt.spw >= 8) || small_groups_pay(kept, groups))) ? 1 : 0;
     SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, (isa && !text_rounds) ? isa : nullptr, b.S0, V_next,
                               nullptr, st, in_place, pt.n, stats));
     uint32_t* S_cur = b.S0;
