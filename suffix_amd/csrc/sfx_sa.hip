@@ -655,6 +655,24 @@ k_small_groups(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, c
         const uint32_t g = G[q];
         const uint64_t lo = g;                                   // bucket id = position of its head
         const uint32_t my = V[q];
+        // buckets of exactly two (the common case): the head orders the pair alone -- one
+        // comparison and half the loads; the second member has nothing to do
+        if (q == lo + 1 && (q + 1 >= m || G[q + 1] != g)) continue;
+        if (q == lo && q + 1 < m && (q + 2 >= m || G[q + 2] != g)) {
+            const uint32_t other = V[q + 1];
+            const int c = direct_compare(t, (uint64_t)my, (uint64_t)other, h);
+            const uint32_t first = c > 0 ? other : my, second = c > 0 ? my : other;
+            const uint32_t s0 = S[lo], s1 = S[lo + 1];
+            V2[lo] = first;
+            V2[lo + 1] = second;
+            G2[lo] = (uint32_t)lo;
+            G2[lo + 1] = (uint32_t)(c == 0 ? lo : lo + 1);
+            flag[lo] = flag[lo + 1] = (c == 0) ? 1u : 0u;
+            sa[s0] = first;
+            sa[s1] = second;
+            if (isa) { isa[first] = s0; isa[second] = (c == 0) ? s0 : s1; }
+            continue;
+        }
         uint64_t hi = q;
         while (hi + 1 < m && hi + 1 - lo < (uint64_t)kSmallCap && G[hi + 1] == g) hi++;
         if (q - lo >= (uint64_t)kSmallCap || (hi + 1 < m && G[hi + 1] == g)) {   // large bucket: untouched
