@@ -434,7 +434,7 @@ template <class KeyT>
 __global__ void __launch_bounds__(kBlock)
 k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t tiles_per_block,
                 uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep,
-                uint32_t* __restrict__ part_ghead)
+                uint32_t* __restrict__ part_ghead, uint16_t* __restrict__ flags_out)
 {
     __shared__ uint32_t red[3][kWavesPerBlock];
     const unsigned tid = threadIdx.x;
@@ -450,6 +450,8 @@ k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t tiles_per_block
         if (i0 + kGroupTile < end) group_load(K, i0 + kGroupTile, m, nxt);
         unsigned head, single;
         group_flags(cur, i0, m, head, single);
+        // the apply kernel reads these 2 bits per element instead of the keys again
+        flags_out[i0 / kGroupItems] = (uint16_t)(head | (single << 8));
         const unsigned valid = valid_mask(i0, m);
         if (head) last_head = (uint32_t)i0 + (32u - (unsigned)__clz((int)head));   // index+1 of the highest head bit
         keep += (uint32_t)__popc(valid & ~single);
@@ -518,7 +520,8 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                const uint32_t* __restrict__ part_ghead, uint32_t* __restrict__ sa,
                uint32_t* __restrict__ isa, uint32_t* __restrict__ S_next,
                uint32_t* __restrict__ V_next, uint32_t* __restrict__ G_next,
-               uint32_t* __restrict__ R_next, int sa_in_place, uint64_t* __restrict__ rank_pairs)
+               uint32_t* __restrict__ R_next, int sa_in_place, uint64_t* __restrict__ rank_pairs,
+               const uint16_t* __restrict__ flags_in)
 {
     __shared__ uint32_t part_m[2][kWavesPerBlock], part_a[2][kWavesPerBlock];
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -529,15 +532,16 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     uint32_t c_keep = part_keep[blockIdx.x];
     (void)part_ghead;
     unsigned par = 0;
-    GroupKeys<KeyT> nxt;
-    if (begin < end) group_load(K, begin + (uint64_t)tid * kGroupItems, m, nxt);
+    (void)K;
+    // head / single bits of the thread's 8 elements, as k_groups_reduce left them (25 MB per
+    // 10^8 elements instead of reading the keys a second time); next tile's word in flight
+    uint32_t nf = (begin + (uint64_t)tid * kGroupItems < end) ? flags_in[(begin + (uint64_t)tid * kGroupItems) / kGroupItems] : 0u;
     for (uint64_t tile = begin; tile < end; tile += kGroupTile) {
         const uint64_t i0 = tile + (uint64_t)tid * kGroupItems;
-        const GroupKeys<KeyT> cur = nxt;
-        if (tile + kGroupTile < end) group_load(K, i0 + kGroupTile, m, nxt);      // next tile in flight
-        unsigned head, single;
-        group_flags(cur, i0, m, head, single);
+        const uint32_t f = nf;
+        if (i0 + kGroupTile < end) nf = flags_in[(i0 + kGroupTile) / kGroupItems];
         const unsigned valid = valid_mask(i0, m);
+        const unsigned head = (i0 < end) ? (f & 0xFFu) : 0u, single = (i0 < end) ? (f >> 8) : 0u;
         const unsigned keepm = valid & ~single;
         const uint32_t hmax = head ? (uint32_t)i0 + (32u - (unsigned)__clz((int)head)) : 0u;
         const uint32_t cnt = (uint32_t)__popc(keepm);
@@ -817,6 +821,7 @@ struct SaBuffers {
     uint32_t* S0; uint32_t* S1;                         // slot lists
     uint32_t* G;                                        // bucket ids of the active list (G/G1 ping-pong)
     uint32_t* G1;
+    uint16_t* F;                                        // head / single bits, 16 per 8 elements
     uint32_t* block_counts;                             // kMaxGrid
     uint32_t* R;                                        // bucket-head slots (text rounds of a full build)
     uint32_t* isa;
@@ -843,6 +848,7 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint32_t* S1 = ar.template take<uint32_t>(cap);
     uint32_t* G = ar.template take<uint32_t>(cap);
     uint32_t* G1 = ar.template take<uint32_t>(cap);
+    uint16_t* F = ar.template take<uint16_t>(cap / kGroupItems + kBlock);
     uint32_t* bc = ar.template take<uint32_t>(kMaxGrid);
     uint32_t* R = ar.template take<uint32_t>(isa_len ? cap + 1024 : 0);     // (a text round may keep up to cap elements)
     uint32_t* isa = ar.template take<uint32_t>(isa_len);
@@ -855,7 +861,7 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     unsigned long long* bins = ar.template take<unsigned long long>(256);
     uint8_t* lut = ar.template take<uint8_t>(256);
     if (b) {
-        b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->G1 = G1; b->block_counts = bc; b->R = R;
+        b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->G1 = G1; b->F = F; b->block_counts = bc; b->R = R;
         b->isa = isa; b->packed = packed; b->hist = hist; b->part_head = ph; b->part_keep = pk;
         b->part_ghead = pg; b->totals = totals; b->bins = bins; b->lut = lut;
     }
@@ -883,7 +889,7 @@ static int round_totals(const KeyT* K, uint64_t m, SaBuffers& b, hipStream_t st,
 {
     Chunking ch = make_chunking(m, kGroupTile);
     SFX_LAUNCH("groups_reduce", (double)m * sizeof(KeyT), (k_groups_reduce<KeyT>), ch.blocks, kBlock,
-               st, K, m, ch.tiles_per_block, b.part_head, b.part_keep, b.part_ghead);
+               st, K, m, ch.tiles_per_block, b.part_head, b.part_keep, b.part_ghead, b.F);
     SFX_LAUNCH("groups_scan", 0.0, k_groups_scan, 1, kBlock, st, b.part_head, b.part_keep,
                b.part_ghead, ch.blocks, b.totals);
     uint32_t host_totals[2] = {0, 0};
@@ -910,10 +916,10 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
     }
     Chunking ch = make_chunking(m, kGroupTile);
     SFX_LAUNCH(sizeof(KeyT) == 4 ? "groups_apply_u32" : "groups_apply_u64",
-               (double)m * (sizeof(KeyT) + (sa_in_place ? 0 : 8) + (isa ? 4 : 0) + (S ? 4 : 0)),
+               (double)m * (0.25 + (sa_in_place ? 0 : 8) + (isa ? 4 : 0) + (S ? 4 : 0)),
                (k_groups_apply<KeyT>), ch.blocks, kBlock, st, K, V, S, m, ch.tiles_per_block,
                b.part_head, b.part_keep, b.part_ghead, sa_in_place ? (uint32_t*)nullptr /* V is the SA */ : sa, isa,
-               S_next, V_next, b.G, R_next, sa_in_place ? 1 : 0, pairs);
+               S_next, V_next, b.G, R_next, sa_in_place ? 1 : 0, pairs, (const uint16_t*)b.F);
     if (pairs) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, m, n, isa, b.hist, st, &stats));
     return SFX_OK;
 }
