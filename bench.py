@@ -67,6 +67,43 @@ def verify_sa_on_device(torch, sdev, text, sa, n_samples=20000, seed=1):
     return True, "permutation + adjacent-order (all pairs) + sampled LCP bytes"
 
 
+def verify_sa_chunked(torch, sdev, text, sa, chunk=200_000_000):
+    """verify_sa_on_device for inputs whose int64 temporaries would not fit next to the data:
+    the permutation test counts in place, and the adjacent-order test walks the suffix array in
+    slices, taking each slice's LCP from the engine's per-slice routine (direct comparison,
+    src/table.rs:348-361) -- every adjacent pair is still checked."""
+    n = text.numel()
+    cnt = torch.zeros(n, dtype=torch.int8, device=text.device)
+    for lo in range(0, n, chunk):
+        idx = sa[lo:lo + chunk].to(torch.int64) & 0xFFFFFFFF
+        cnt.index_add_(0, idx, torch.ones(idx.numel(), dtype=torch.int8, device=text.device))
+        del idx
+    if not bool((cnt == 1).all()):
+        return False, "not a permutation"
+    del cnt
+    prev = None
+    for lo in range(0, n, chunk):
+        part = sa[lo:lo + chunk]
+        lcp = sdev.build_lcp_range(text, part, prev)
+        cur = part.to(torch.int64) & 0xFFFFFFFF
+        h = lcp.to(torch.int64) & 0xFFFFFFFF
+        before = torch.empty_like(cur)
+        before[1:] = cur[:-1]
+        before[0] = prev if prev is not None else 0
+        pa, pb = before + h, cur + h
+        skip_first = 1 if prev is None else 0
+        pa, pb = pa[skip_first:], pb[skip_first:]
+        if bool((pb >= n).any()):
+            return False, "right suffix exhausted before left one"
+        ca = text[torch.clamp(pa, max=n - 1)].to(torch.int32)
+        cb = text[pb].to(torch.int32)
+        if not bool(((pa >= n) | (ca < cb)).all()):
+            return False, "adjacent suffixes out of order"
+        prev = int(cur[-1])
+        del lcp, cur, h, before, pa, pb, ca, cb
+    return True, "permutation + adjacent-order (all pairs, in slices of %d)" % chunk
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

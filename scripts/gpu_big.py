@@ -126,3 +126,28 @@ if __name__ == "__main__":
         big = int(os.environ.get("SFX_HUGE_N", "1500000000"))
         t0 = time.time(); h = _gen.english_like(big); print("gen english", round(time.time() - t0, 1), "s", flush=True)
         run(f"stress: {big} B English-like ASCII (n >= 2^30), SA + LCP", h, reps=1)
+    if "c4single" in which:
+        # BASELINE config 4's input (4 * 10^9 B of DNA, u64 indices) on ONE GPU: positions still fit
+        # u32 (src/table.rs:380), so the u32 engine runs (~198 GB of workspace) and the array is widened
+        import hashlib
+        big = int(os.environ.get("SFX_HUGE_N", "4000000000"))
+        t0 = time.time(); h = _gen.dna(big, seed=0x5AF1C5 + 3); print("gen dna", round(time.time() - t0, 1), "s", flush=True)
+        rec = {"config": f"config 4 input on one GPU: {big} B uniform DNA, u32 engine + u64 widening", "n": int(big),
+               "sha256_text": hashlib.sha256(h.tobytes()).hexdigest()}
+        text = torch.from_numpy(h).to(dev)
+        ws = sdev.sa_workspace(big, dev)
+        sa = torch.empty(big, dtype=torch.int32, device=dev)
+        _, t_sa = timed(lambda: sdev.build_sa(text, out=sa, workspace=ws), 1)
+        rec["sa_ms"] = round(t_sa * 1e3, 2); rec["sa_MBps"] = round(big / t_sa / 1e6, 1); rec["build"] = eng.build_stats()
+        rec["workspace_GB"] = round(ws.numel() / 1e9, 1)
+        del ws
+        torch.cuda.empty_cache()
+        ok, how = bench.verify_sa_chunked(torch, sdev, text, sa)
+        rec["verified"], rec["verification"] = bool(ok), how
+        (sa64), t_w = timed(lambda: sdev.widen_u64(sa), 1)
+        rec["widen_u64_ms"] = round(t_w * 1e3, 2)
+        k = torch.randint(0, big, (1_000_000,), device=dev)
+        rec["u64_matches_u32_on_sample"] = bool(((sa[k].to(torch.int64) & 0xFFFFFFFF) == sa64[k]).all())
+        print(json.dumps(rec), flush=True)
+        with open(os.path.join(OUT, "results.jsonl"), "a") as fh:
+            fh.write(json.dumps(rec) + "\n")
