@@ -38,8 +38,9 @@ def timed(fn, reps=1):
 
 
 def run(name, host_text, with_lcp=True, queries=0, reps=2):
+    import hashlib
     n = host_text.size
-    rec = {"config": name, "n": int(n)}
+    rec = {"config": name, "n": int(n), "sha256_text": hashlib.sha256(host_text.tobytes()).hexdigest()}
     text = torch.from_numpy(host_text).to(dev)
     ws = sdev.sa_workspace(n, dev)
     sa = torch.empty(n, dtype=torch.int32, device=dev)
@@ -59,11 +60,14 @@ def run(name, host_text, with_lcp=True, queries=0, reps=2):
         rec["lcp_ms"] = round(t_lcp * 1e3, 2)
         rec["lcp_MBps"] = round(n / t_lcp / 1e6, 1)
         rec["sa_plus_lcp_MBps"] = round(n / (t_sa + t_lcp) / 1e6, 1)
+        rec["sha256_lcp"] = hashlib.sha256(lcp.cpu().numpy().tobytes()).hexdigest()
         rec["max_lcp"] = int((lcp.to(torch.int64) & 0xFFFFFFFF).max())
         rec["mean_lcp"] = float((lcp.to(torch.int64) & 0xFFFFFFFF).double().mean())
         del lcp, lws
-    ok, how = bench.verify_sa_on_device(torch, sdev, text, sa)
+    ok, how = bench.verify_sa_on_device(torch, sdev, text, sa) if n <= 1_000_000_000 else \
+        bench.verify_sa_chunked(torch, sdev, text, sa)
     rec["verified"], rec["verification"] = bool(ok), how
+    rec["sha256_sa"] = hashlib.sha256(sa.cpu().numpy().tobytes()).hexdigest()      # LE u32, as SURVEY.md 8c
     if queries:
         import oracle
         rng = np.random.default_rng(17)
