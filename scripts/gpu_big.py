@@ -37,7 +37,7 @@ def timed(fn, reps=1):
     return r, best
 
 
-def run(name, host_text, with_lcp=True, queries=0, reps=2):
+def run(name, host_text, with_lcp=True, queries=0, reps=2, cpu_sample=20_000_000):
     import hashlib
     n = host_text.size
     rec = {"config": name, "n": int(n), "sha256_text": hashlib.sha256(host_text.tobytes()).hexdigest()}
@@ -101,6 +101,25 @@ def run(name, host_text, with_lcp=True, queries=0, reps=2):
             if (int(s[k]), int(e[k])) != oracle.positions(tb, sa_h, q):
                 bad += 1
         rec["query_mismatches_vs_oracle_of_1500"] = bad
+    # CPU baseline beside it: the oracle = C restatement of the reference, 1 thread,
+    # on a bounded sample (first 20 MB) of the same text: SA (sais), LCP as the reference computes it
+    # (lcp_lens_quadratic) and Kasai; the same sample's GPU SA is compared bit-exactly
+    if cpu_sample:
+        import oracle
+        m = min(cpu_sample, n)
+        sample = host_text[:m]
+        t0 = time.perf_counter(); exp = oracle.sais(sample); t_sa_cpu = time.perf_counter() - t0
+        t0 = time.perf_counter(); lq = oracle.lcp_quadratic(sample, exp); t_lq = time.perf_counter() - t0
+        t0 = time.perf_counter(); lk = oracle.lcp_kasai(sample, exp); t_lk = time.perf_counter() - t0
+        sub = torch.from_numpy(np.ascontiguousarray(sample)).to(dev)
+        got = sdev.build_sa(sub)
+        got_lcp = sdev.build_lcp(sub, got).cpu().numpy().view(np.uint32)
+        rec["cpu_baseline"] = {"sample_bytes": int(m), "kind": "port", "cores": 1,
+                               "sa_MBps": round(m / t_sa_cpu / 1e6, 2), "lcp_quadratic_MBps": round(m / t_lq / 1e6, 2),
+                               "lcp_kasai_MBps": round(m / t_lk / 1e6, 2),
+                               "gpu_sa_bit_exact_on_sample": bool(np.array_equal(got.cpu().numpy().view(np.uint32), exp)),
+                               "gpu_lcp_bit_exact_on_sample": bool(np.array_equal(got_lcp, lq) and np.array_equal(lq, lk))}
+        del sub, got
     print(json.dumps(rec), flush=True)
     with open(os.path.join(OUT, "results.jsonl"), "a") as fh:
         fh.write(json.dumps(rec) + "\n")
