@@ -120,6 +120,22 @@ def run(name, host_text, with_lcp=True, queries=0, reps=2, cpu_sample=20_000_000
                                "gpu_sa_bit_exact_on_sample": bool(np.array_equal(got.cpu().numpy().view(np.uint32), exp)),
                                "gpu_lcp_bit_exact_on_sample": bool(np.array_equal(got_lcp, lq) and np.array_equal(lq, lk))}
         del sub, got
+    # SFX_FULL_ORACLE=1: the whole text through the oracle (one core, ~1 minute per GB) -- the
+    # full-size CPU baseline and a bit-exact comparison of the complete SA and LCP arrays
+    if os.environ.get("SFX_FULL_ORACLE") == "1":
+        import oracle
+        t0 = time.perf_counter(); exp = oracle.sais(host_text); t_cpu = time.perf_counter() - t0
+        full = {"sa_seconds": round(t_cpu, 1), "sa_MBps": round(n / t_cpu / 1e6, 2),
+                "sa_bit_exact": bool(np.array_equal(sa.cpu().numpy().view(np.uint32), exp))}
+        if with_lcp:
+            t0 = time.perf_counter(); lq = oracle.lcp_quadratic(host_text, exp); t_lq = time.perf_counter() - t0
+            lcp2 = sdev.build_lcp(text, sa)
+            full["lcp_quadratic_seconds"] = round(t_lq, 1)
+            full["lcp_quadratic_MBps"] = round(n / t_lq / 1e6, 2)
+            full["lcp_bit_exact"] = bool(np.array_equal(lcp2.cpu().numpy().view(np.uint32), lq))
+            del lcp2, lq
+        rec["full_oracle"] = full
+        del exp
     print(json.dumps(rec), flush=True)
     with open(os.path.join(OUT, "results.jsonl"), "a") as fh:
         fh.write(json.dumps(rec) + "\n")
