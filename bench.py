@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=100_000_000, help="bytes of text per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=50_000_000,
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000,
                     help="bytes of the same text the CPU baseline is timed on (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--calibrate", action="store_true",
@@ -283,9 +283,10 @@ def main():
         torch.cuda.synchronize()
         same = bool(np.array_equal(got, exp))
         verified = bool(verified) and same if verified is not None else same
-        how += "; SA of the CPU sample bit-exact vs oracle" if same else "; MISMATCH vs oracle on CPU sample"
+        how += ("; complete SA bit-exact vs oracle" if m == n_local else "; SA of the CPU sample bit-exact vs oracle") \
+            if same else "; MISMATCH vs oracle on CPU sample"
         cpu = {"value": round(m / cpu_s / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
-               "sample": f"first {m} bytes of the same DNA text, oracle.sais (C restatement of "
+               "sample": f"{'all' if m == n_local else 'first'} {m} bytes of the same DNA text, oracle.sais (C restatement of "
                          f"src/table.rs:388-574, gcc -O3 -march=native), pinned to one core, best of 3: {cpu_s:.1f} s",
                "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
 
