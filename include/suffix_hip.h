@@ -55,6 +55,10 @@ int sfx_build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa,
 int sfx_build_sa_u64(const uint8_t* text, uint64_t n, uint64_t* sa_out);
 int sfx_widen_u32_to_u64_dev(const uint32_t* d_in, uint64_t count, uint64_t* d_out, void* stream);
 
+/* The host-pointer entry points keep a few released device buffers in a mutex-guarded pool
+ * so that repeated calls on similar sizes skip hipMalloc/hipFree; this returns them. */
+void sfx_release_cached_buffers(void);
+
 /* ---- lcp_lens (:130-138 -> lcp_lens_quadratic :348-361): LCP array ---------- */
 /* lcp_out[0] = 0, lcp_out[r] = |lcp(text[sa[r-1]..], text[sa[r]..])| in bytes. */
 int sfx_build_lcp_u32(const uint8_t* text, uint64_t n, const uint32_t* sa, uint32_t* lcp_out);

@@ -43,6 +43,7 @@ ABI = [
     ("sfx_device_count", _int, []),
     ("sfx_last_hip_error", ctypes.c_char_p, []),
     ("sfx_build_sa_u32", _int, [_vp, _u64, _vp]),
+    ("sfx_release_cached_buffers", None, []),
     ("sfx_build_sa_u64", _int, [_vp, _u64, _vp]),
     ("sfx_widen_u32_to_u64_dev", _int, [_vp, _u64, _vp, _vp]),
     ("sfx_sa_workspace_bytes", _u64, [_u64]),
@@ -133,6 +134,10 @@ class Engine:
         g = ctypes.c_double(0.0)
         self.check(self.lib.sfx_microbench(kind, nbytes, param, param2, reps, ctypes.byref(g)), "sfx_microbench")
         return float(g.value)
+
+    def release_cached_buffers(self):
+        """Return the pooled device buffers of the host-pointer entry points to the driver."""
+        self.lib.sfx_release_cached_buffers()
 
     def profile(self, on):
         self.lib.sfx_profile_enable(1 if on else 0)

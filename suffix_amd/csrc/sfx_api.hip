@@ -75,17 +75,73 @@ static void profile_fold()
     g_prof_open.clear();
 }
 
-// ---- small RAII for the host-pointer entry points ------------------------------------
+// ---- device buffers of the host-pointer entry points ----------------------------------
+// A small mutex-guarded pool ("workspace from a mutex-guarded pool"): a buffer
+// released by one call is handed to the next call on the same device that asks for at most
+// that size and at least half of it, so a loop of SuffixTable::new over similar texts does
+// not pay hipMalloc/hipFree of ~50 n bytes every time.  At most kPoolMaxBuffers buffers
+// are kept; sfx_release_cached_buffers() returns them to the driver.
+struct PooledBuf { void* p; uint64_t bytes; int device; };
+static std::mutex g_pool_mu;
+static std::vector<PooledBuf> g_pool;
+constexpr size_t kPoolMaxBuffers = 8;
+
+static void* pool_take(uint64_t bytes, int device, uint64_t* got_bytes)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t best = g_pool.size();
+    for (size_t i = 0; i < g_pool.size(); i++) {
+        const PooledBuf& b = g_pool[i];
+        if (b.device == device && b.bytes >= bytes && b.bytes / 2 <= bytes &&
+            (best == g_pool.size() || b.bytes < g_pool[best].bytes))
+            best = i;
+    }
+    if (best == g_pool.size()) return nullptr;
+    void* p = g_pool[best].p;
+    *got_bytes = g_pool[best].bytes;
+    g_pool.erase(g_pool.begin() + (long)best);
+    return p;
+}
+static void pool_give(void* p, uint64_t bytes, int device)
+{
+    void* evict = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_pool.push_back(PooledBuf{p, bytes, device});
+        if (g_pool.size() > kPoolMaxBuffers) {                 // drop the oldest
+            evict = g_pool.front().p;
+            g_pool.erase(g_pool.begin());
+        }
+    }
+    if (evict) (void)hipFree(evict);
+}
+
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(uint64_t bytes)
+    uint64_t bytes = 0;
+    int device = 0;
+    ~DevBuf() { release(); }
+    int alloc(uint64_t want)
     {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (want == 0) want = 1;
+        (void)hipGetDevice(&device);
+        p = pool_take(want, device, &bytes);
+        if (p) return SFX_OK;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            // the pool may be what is in the way: give everything back and retry once
+            sfx_release_cached_buffers();
+            e = hipMalloc(&p, want);
+        }
         if (e != hipSuccess) { note_hip_error(e, "hipMalloc", __FILE__, __LINE__); p = nullptr; return SFX_ERR_HIP; }
+        bytes = want;
         return SFX_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; }
+    void release()
+    {
+        if (p) pool_give(p, bytes, device);
+        p = nullptr;
+    }
 };
 
 static int check_device()
@@ -372,6 +428,16 @@ int sfx_build_sa_range_packed_u32_dev(const uint32_t* d_packed, uint64_t n,
     if (!d_packed) return SFX_ERR_ARG;
     return build_sa_range_u32_dev(nullptr, n, d_global_byte_bins256, top_bits, bin_lo, bin_hi, capacity, d_sa_part,
                                   count_out, d_workspace, workspace_bytes, (hipStream_t)stream, d_packed);
+}
+
+void sfx_release_cached_buffers(void)
+{
+    std::vector<PooledBuf> take;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        take.swap(g_pool);
+    }
+    for (PooledBuf& b : take) (void)hipFree(b.p);
 }
 
 // ---- profiling --------------------------------------------------------------------------------
