@@ -13,27 +13,45 @@
 
 namespace sfx {
 
+// Three-way comparison of query q[0..m) with the first min(m, n - s) bytes of the suffix at s,
+// 8 bytes per step (unaligned 8-byte loads; little-endian, so the first differing byte is the
+// lowest non-zero byte of the XOR).  <0: q smaller, >0: q larger, 0: equal on those bytes.
+__device__ __forceinline__ int compare_query(const uint8_t* __restrict__ q, uint64_t m,
+                                             const uint8_t* __restrict__ text, uint64_t n, uint64_t s)
+{
+    const uint64_t len = n - s, lim = m < len ? m : len;
+    uint64_t k = 0;
+    while (k + 8 <= lim) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, q + k, 8);
+        __builtin_memcpy(&y, text + s + k, 8);
+        const uint64_t d = x ^ y;
+        if (d) {
+            const unsigned sh = (unsigned)(__ffsll((long long)d) - 1) & ~7u;
+            return (int)((x >> sh) & 0xFFu) - (int)((y >> sh) & 0xFFu);
+        }
+        k += 8;
+    }
+    while (k < lim) {
+        const int a = q[k], b = text[s + k];
+        if (a != b) return a - b;
+        k++;
+    }
+    return 0;
+}
 // query <= suffix ?  (Rust slice Ord: lexicographic, a proper prefix is smaller)
 __device__ __forceinline__ bool query_le_suffix(const uint8_t* __restrict__ q, uint64_t m,
                                                 const uint8_t* __restrict__ text, uint64_t n,
                                                 uint64_t s)
 {
-    uint64_t len = n - s, k = 0, lim = m < len ? m : len;
-    while (k < lim) {
-        uint8_t a = q[k], b = text[s + k];
-        if (a != b) return a < b;
-        k++;
-    }
-    return m <= len;
+    const int c = compare_query(q, m, text, n, s);
+    return c ? c < 0 : m <= n - s;
 }
 __device__ __forceinline__ bool suffix_starts_with(const uint8_t* __restrict__ q, uint64_t m,
                                                    const uint8_t* __restrict__ text, uint64_t n,
                                                    uint64_t s)
 {
-    if (n - s < m) return false;
-    for (uint64_t k = 0; k < m; k++)
-        if (q[k] != text[s + k]) return false;
-    return true;
+    return n - s >= m && compare_query(q, m, text, n, s) == 0;
 }
 
 __global__ void __launch_bounds__(kBlock)
