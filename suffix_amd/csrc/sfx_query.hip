@@ -72,12 +72,28 @@ k_query_batch(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __re
                 if (query_le_suffix(q, m, text, n, sa[mid])) hi = mid; else lo = mid + 1;
             }
             start = lo;
-            lo = 0; hi = sa_len - start;                            // :247-250
-            while (lo < hi) {
-                uint64_t mid = (lo + hi) >> 1;
-                if (!suffix_starts_with(q, m, text, n, sa[start + mid])) hi = mid; else lo = mid + 1;
+            // :247-250 is a binary search of "starts with q" over table[start..]; the predicate is
+            // monotone there (true on a prefix of it), so galloping from `start` finds the same end
+            // in ~2 log2(#matches) probes instead of log2(n) -- most queries match a few suffixes
+            uint64_t cnt = 0;                                       // matches known so far
+            if (start < sa_len && suffix_starts_with(q, m, text, n, sa[start])) {
+                cnt = 1;
+                uint64_t step = 1;
+                while (start + cnt - 1 + step < sa_len &&
+                       suffix_starts_with(q, m, text, n, sa[start + cnt - 1 + step])) {
+                    cnt += step;
+                    step <<= 1;
+                }
+                // the end lies in (start + cnt - 1, min(sa_len, start + cnt - 1 + step)]
+                lo = start + cnt;
+                hi = dmin<uint64_t>(sa_len, start + cnt - 1 + step);
+                while (lo < hi) {
+                    uint64_t mid = (lo + hi) >> 1;
+                    if (!suffix_starts_with(q, m, text, n, sa[mid])) hi = mid; else lo = mid + 1;
+                }
+                cnt = lo - start;
             }
-            end = start + lo;
+            end = start + cnt;
         }
         bool found = end > start;
         if (!found) start = end = 0;
