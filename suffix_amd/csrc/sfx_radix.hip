@@ -533,20 +533,20 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
 // ---- host side -------------------------------------------------------------------------
 // Tuning knobs (development only; read once per process):
 //   SFX_RADIX_SWEEP  1 = one-sweep (default), 0 = chunked
-//   SFX_RADIX_KPT    elements per thread and tile: 8 (default) or 16
+//   SFX_RADIX_KPT    elements per thread of the E64 passes: 11 (default), 16 or 8
+//   SFX_RADIX_KPT_TEXT  ... of the text-fed pass: 16 (default), 11 or 8
 //   SFX_RADIX_RANK   1 = LDS match masks (default), 0 = 8-ballot match
 //   SFX_RADIX_NW     waves per workgroup: 4, 8 or 16 (default); tile = 64 * NW * KPT elements
-struct RadixTuning { int sweep, kpt, rank, nw, kpt_text, kpt_kv; };
+struct RadixTuning { int sweep, kpt, rank, nw, kpt_text; };
 static RadixTuning radix_tuning()
 {
     static const RadixTuning t = [] {
-        RadixTuning r = {1, 11, 1, 16, 16, 8};          // measured best on MI355X (profiles/r1c_radix_variants.txt):
+        RadixTuning r = {1, 11, 1, 16, 16};          // measured best on MI355X (profiles/r1c_radix_variants.txt):
                                                 // 1024-thread workgroups, 8192-element tiles = 256-byte runs
         if (const char* e = getenv("SFX_RADIX_SWEEP")) r.sweep = atoi(e) ? 1 : 0;
         if (const char* e = getenv("SFX_RADIX_KPT")) r.kpt = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 8;
         if (const char* e = getenv("SFX_RADIX_RANK")) r.rank = atoi(e) ? 1 : 0;
         if (const char* e = getenv("SFX_RADIX_KPT_TEXT")) r.kpt_text = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 16;
-        if (const char* e = getenv("SFX_RADIX_KPT_KV")) r.kpt_kv = (atoi(e) >= 8 && atoi(e) <= 11) ? atoi(e) : 8;
         if (const char* e = getenv("SFX_RADIX_NW")) r.nw = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 4);
         return r;
     }();
@@ -613,21 +613,12 @@ static int run_pass(const char* name, double algo_bytes, const Src& src, const D
         return t.rank ? SFX_PASS(KPT, false, true, NW) : SFX_PASS(KPT, false, false, NW);           \
     } while (0)
     if (t.nw == 16) {
-        // 16384-element tiles (E64 only: LDS): measured faster for the text-fed pass (0.45 vs
-        // 0.535 ms, no element loads to hold in registers), slower for the others (0.57 vs 0.55)
-        if constexpr (!Src::kHasVal) {
+        if constexpr (!Src::kHasVal) {                           // (KV elements: 8 per thread, LDS)
+            // elements per thread swept from 8 to 16 on hardware (profiles/r1c_radix_variants.txt):
+            // 11 wins for the E64 passes, 16 for the text-fed pass; the other sizes are not built
             const int kk = Src::kFromText ? t.kpt_text : t.kpt;
             if (kk == 16) SFX_PASS_NW(16, 16);
-            if (kk == 15) SFX_PASS_NW(15, 16);
-            if (kk == 13) SFX_PASS_NW(13, 16);
-            if (kk == 12) SFX_PASS_NW(12, 16);
             if (kk == 11) SFX_PASS_NW(11, 16);
-            if (kk == 10) SFX_PASS_NW(10, 16);
-            if (kk == 9) SFX_PASS_NW(9, 16);
-        } else {
-            if (t.kpt_kv == 11) SFX_PASS_NW(11, 16);
-            if (t.kpt_kv == 10) SFX_PASS_NW(10, 16);
-            if (t.kpt_kv == 9) SFX_PASS_NW(9, 16);
         }
         SFX_PASS_NW(8, 16);
     }
