@@ -378,8 +378,11 @@ k_compose_text_keys(const uint32_t* __restrict__ suf, const uint32_t* __restrict
 // ---------------------------------------------------------------------------------
 // 3./4b. bucket boundaries, ranks, singleton removal  (reduce -> scan -> apply)
 // ---------------------------------------------------------------------------------
-constexpr int kGroupItems = 8;                       // consecutive elements per thread
-constexpr int kGroupTile = kBlock * kGroupItems;     // 2048 elements per workgroup step
+constexpr int kGroupItems = 8;                       // consecutive elements per thread (reduce kernel; one flag word)
+constexpr int kGroupTile = kBlock * kGroupItems;     // 2048 elements per workgroup step of the reduce kernel
+constexpr int kApplySub = 4;                         // the apply kernel takes 4 such groups per thread
+constexpr int kApplyItems = kGroupItems * kApplySub; // 32 consecutive elements per thread
+constexpr int kApplyTile = kBlock * kApplyItems;     // 8192 elements per workgroup step; chunks are multiples of it
 
 // A thread's 8 consecutive keys plus both neighbours, fetched with 16-byte loads (K is a
 // workspace array, 256-B aligned, and tile bases are multiples of 2048).  Loading is split
@@ -432,14 +435,14 @@ __device__ __forceinline__ unsigned valid_mask(uint64_t i0, uint64_t m)
 // per-workgroup partials: last bucket-head index (+1) in the chunk, #kept, #kept bucket heads
 template <class KeyT>
 __global__ void __launch_bounds__(kBlock)
-k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t tiles_per_block,
+k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t chunk,
                 uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep,
                 uint32_t* __restrict__ part_ghead, uint16_t* __restrict__ flags_out)
 {
     __shared__ uint32_t red[3][kWavesPerBlock];
     const unsigned tid = threadIdx.x;
-    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kGroupTile;
-    uint64_t end = begin + tiles_per_block * kGroupTile;
+    uint64_t begin = (uint64_t)blockIdx.x * chunk;               // chunk: a multiple of kApplyTile elements
+    uint64_t end = begin + chunk;
     if (end > m) end = m;
     uint32_t last_head = 0, keep = 0, ghead = 0;
     GroupKeys<KeyT> nxt;
@@ -515,7 +518,7 @@ k_groups_scan(uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep
 template <class KeyT>
 __global__ void __launch_bounds__(kBlock)
 k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
-               const uint32_t* __restrict__ S, uint64_t m, uint64_t tiles_per_block,
+               const uint32_t* __restrict__ S, uint64_t m, uint64_t chunk,
                const uint32_t* __restrict__ part_head, const uint32_t* __restrict__ part_keep,
                const uint32_t* __restrict__ part_ghead, uint32_t* __restrict__ sa,
                uint32_t* __restrict__ isa, uint32_t* __restrict__ S_next,
@@ -525,24 +528,38 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
 {
     __shared__ uint32_t part_m[2][kWavesPerBlock], part_a[2][kWavesPerBlock];
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kGroupTile;
-    uint64_t end = begin + tiles_per_block * kGroupTile;
+    uint64_t begin = (uint64_t)blockIdx.x * chunk;
+    uint64_t end = begin + chunk;
     if (end > m) end = m;
     uint32_t c_head = part_head[blockIdx.x];     // index+1 of the last head before the chunk
     uint32_t c_keep = part_keep[blockIdx.x];
     (void)part_ghead;
     unsigned par = 0;
     (void)K;
-    // head / single bits of the thread's 8 elements, as k_groups_reduce left them (25 MB per
-    // 10^8 elements instead of reading the keys a second time); next tile's word in flight
-    uint32_t nf = (begin + (uint64_t)tid * kGroupItems < end) ? flags_in[(begin + (uint64_t)tid * kGroupItems) / kGroupItems] : 0u;
-    for (uint64_t tile = begin; tile < end; tile += kGroupTile) {
-        const uint64_t i0 = tile + (uint64_t)tid * kGroupItems;
-        const uint32_t f = nf;
-        if (i0 + kGroupTile < end) nf = flags_in[(i0 + kGroupTile) / kGroupItems];
-        const unsigned valid = valid_mask(i0, m);
-        const unsigned head = (i0 < end) ? (f & 0xFFu) : 0u, single = (i0 < end) ? (f >> 8) : 0u;
-        const unsigned keepm = valid & ~single;
+    // head / single bits of the thread's 32 elements = 4 flag words of k_groups_reduce, one
+    // 8-byte load (25 MB per 10^8 elements instead of reading the keys a second time); the next
+    // tile's words are in flight while this tile is scanned
+    auto load_flags = [&](uint64_t i0) -> uint64_t {
+        return i0 < end ? *reinterpret_cast<const uint64_t*>(flags_in + i0 / kGroupItems) : 0ull;
+    };
+    uint64_t nf = load_flags(begin + (uint64_t)tid * kApplyItems);
+    for (uint64_t tile = begin; tile < end; tile += kApplyTile) {
+        const uint64_t i0 = tile + (uint64_t)tid * kApplyItems;
+        const uint64_t f = nf;
+        if (tile + kApplyTile < end) nf = load_flags(i0 + kApplyTile);
+        // 32-bit masks over the thread's elements (groups past `end` were never written: masked off)
+        uint32_t head = 0, single = 0, valid = 0;
+#pragma unroll
+        for (int b = 0; b < kApplySub; b++) {
+            const uint64_t ib = i0 + (uint64_t)b * kGroupItems;
+            if (ib < end) {
+                const uint32_t fw = (uint32_t)(f >> (16 * b)) & 0xFFFFu;
+                head |= (fw & 0xFFu) << (8 * b);
+                single |= (fw >> 8) << (8 * b);
+                valid |= valid_mask(ib, m) << (8 * b);
+            }
+        }
+        const uint32_t keepm = valid & ~single;
         const uint32_t hmax = head ? (uint32_t)i0 + (32u - (unsigned)__clz((int)head)) : 0u;
         const uint32_t cnt = (uint32_t)__popc(keepm);
         // one barrier for both scans: exclusive max of hmax, exclusive sum of cnt
@@ -563,39 +580,46 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         const uint32_t ec = ba + ia - cnt;
         uint32_t run_head = dmax(c_head, dmax(bm, pm));          // index+1 of the last head before item 0
         uint32_t run_keep = c_keep + ec;
-        if (keepm || isa || !sa_in_place) {                      // (all-singleton threads have nothing to write in place)
-            // gathers first (all in flight together), stores after: one memory round trip per tile
-            uint32_t slot[kGroupItems], suffix[kGroupItems], head_slot[kGroupItems], back[kGroupItems];
 #pragma unroll
-            for (int j = 0; j < kGroupItems; j++) {
-                const uint64_t i = i0 + j;
-                const bool v = (valid >> j) & 1u, keep = (keepm >> j) & 1u;
-                if ((head >> j) & 1u) run_head = (uint32_t)i + 1u;
-                const uint32_t my_head = run_head - 1u;
-                back[j] = (uint32_t)i - my_head;                 // distance to the bucket head (all kept in between)
-                slot[j] = (v && S) ? S[i] : (uint32_t)i;
-                suffix[j] = (v && (!sa_in_place || keep || isa)) ? V[i] : 0u;
-                head_slot[j] = (v && S && (isa || (keep && R_next))) ? S[my_head] : my_head;
-            }
+        for (int b = 0; b < kApplySub; b++) {
+            const uint64_t ib = i0 + (uint64_t)b * kGroupItems;
+            const unsigned v8 = (valid >> (8 * b)) & 0xFFu, h8 = (head >> (8 * b)) & 0xFFu, k8 = (keepm >> (8 * b)) & 0xFFu;
+            if (k8 || ((isa || !sa_in_place) && v8)) {           // (all-singleton groups have nothing to write in place)
+                // gathers first (all in flight together), stores after: one memory round trip per group
+                uint32_t slot[kGroupItems], suffix[kGroupItems], head_slot[kGroupItems], back[kGroupItems];
 #pragma unroll
-            for (int j = 0; j < kGroupItems; j++) {
-                if ((valid >> j) & 1u) {
-                    const bool keep = (keepm >> j) & 1u;
-                    if (!sa_in_place) sa[slot[j]] = suffix[j];
-                    if (isa) {
-                        // large texts: (suffix, rank) pairs out in stream order, scattered afterwards
-                        // through a partitioning pass (scatter_pairs_u32) instead of n random writes
-                        if (rank_pairs) rank_pairs[i0 + j] = ((uint64_t)suffix[j] << 32) | (uint64_t)head_slot[j];
-                        else isa[suffix[j]] = head_slot[j];
-                    }
-                    if (keep) {
-                        if (R_next) R_next[run_keep] = head_slot[j];
-                        S_next[run_keep] = slot[j];
-                        V_next[run_keep] = suffix[j];
-                        G_next[run_keep] = run_keep - back[j];   // bucket id = position of its head in the new list
-                        run_keep++;
+                for (int j = 0; j < kGroupItems; j++) {
+                    const uint64_t i = ib + j;
+                    const bool v = (v8 >> j) & 1u, keep = (k8 >> j) & 1u;
+                    if ((h8 >> j) & 1u) run_head = (uint32_t)i + 1u;
+                    const uint32_t my_head = run_head - 1u;
+                    back[j] = (uint32_t)i - my_head;             // distance to the bucket head (all kept in between)
+                    slot[j] = (v && S) ? S[i] : (uint32_t)i;
+                    suffix[j] = (v && (!sa_in_place || keep || isa)) ? V[i] : 0u;
+                    head_slot[j] = (v && S && (isa || (keep && R_next))) ? S[my_head] : my_head;
+                }
+#pragma unroll
+                for (int j = 0; j < kGroupItems; j++) {
+                    if ((v8 >> j) & 1u) {
+                        const bool keep = (k8 >> j) & 1u;
+                        if (!sa_in_place) sa[slot[j]] = suffix[j];
+                        if (isa) {
+                            // large texts: (suffix, rank) pairs out in stream order, scattered afterwards
+                            // through a partitioning pass (scatter_pairs_u32) instead of n random writes
+                            if (rank_pairs) rank_pairs[ib + j] = ((uint64_t)suffix[j] << 32) | (uint64_t)head_slot[j];
+                            else isa[suffix[j]] = head_slot[j];
+                        }
+                        if (keep) {
+                            if (R_next) R_next[run_keep] = head_slot[j];
+                            S_next[run_keep] = slot[j];
+                            V_next[run_keep] = suffix[j];
+                            G_next[run_keep] = run_keep - back[j];   // bucket id = position of its head in the new list
+                            run_keep++;
+                        }
                     }
                 }
+            } else if (h8) {
+                run_head = (uint32_t)ib + (32u - (unsigned)__clz((int)h8));      // heads of skipped groups still count
             }
         }
         c_head = dmax(c_head, tot_m);
@@ -848,7 +872,7 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint32_t* S1 = ar.template take<uint32_t>(cap);
     uint32_t* G = ar.template take<uint32_t>(cap);
     uint32_t* G1 = ar.template take<uint32_t>(cap);
-    uint16_t* F = ar.template take<uint16_t>(cap / kGroupItems + kBlock);
+    uint16_t* F = ar.template take<uint16_t>(cap / kGroupItems + kBlock * kApplySub);
     uint32_t* bc = ar.template take<uint32_t>(kMaxGrid);
     uint32_t* R = ar.template take<uint32_t>(isa_len ? cap + 1024 : 0);     // (a text round may keep up to cap elements)
     uint32_t* isa = ar.template take<uint32_t>(isa_len);
@@ -887,9 +911,9 @@ template <class KeyT>
 static int round_totals(const KeyT* K, uint64_t m, SaBuffers& b, hipStream_t st, uint64_t* kept,
                         uint64_t* kept_groups)
 {
-    Chunking ch = make_chunking(m, kGroupTile);
+    Chunking ch = make_chunking(m, kApplyTile);
     SFX_LAUNCH("groups_reduce", (double)m * sizeof(KeyT), (k_groups_reduce<KeyT>), ch.blocks, kBlock,
-               st, K, m, ch.tiles_per_block, b.part_head, b.part_keep, b.part_ghead, b.F);
+               st, K, m, ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, b.F);
     SFX_LAUNCH("groups_scan", 0.0, k_groups_scan, 1, kBlock, st, b.part_head, b.part_keep,
                b.part_ghead, ch.blocks, b.totals);
     uint32_t host_totals[2] = {0, 0};
@@ -914,10 +938,10 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
         pairs = k_in_0 ? b.K1 : b.K0;
         pairs_tmp = k_in_0 ? b.K0 : b.K1;
     }
-    Chunking ch = make_chunking(m, kGroupTile);
+    Chunking ch = make_chunking(m, kApplyTile);
     SFX_LAUNCH(sizeof(KeyT) == 4 ? "groups_apply_u32" : "groups_apply_u64",
                (double)m * (0.25 + (sa_in_place ? 0 : 8) + (isa ? 4 : 0) + (S ? 4 : 0)),
-               (k_groups_apply<KeyT>), ch.blocks, kBlock, st, K, V, S, m, ch.tiles_per_block,
+               (k_groups_apply<KeyT>), ch.blocks, kBlock, st, K, V, S, m, ch.tiles_per_block * kApplyTile,
                b.part_head, b.part_keep, b.part_ghead, sa_in_place ? (uint32_t*)nullptr /* V is the SA */ : sa, isa,
                S_next, V_next, b.G, R_next, sa_in_place ? 1 : 0, pairs, (const uint16_t*)b.F);
     if (pairs) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, m, n, isa, b.hist, st, &stats));
