@@ -135,11 +135,19 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     eng = suffix_amd.default_engine()
     eng.require_device()                       # no CPU fallback: fail loudly without a GPU
+    # test hook for 1-GPU boxes: SFX_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and swaps RCCL
+    # (which refuses two ranks on one device) for gloo, so the N>1 code path can be rehearsed
+    share_gpu = os.environ.get("SFX_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n_local = args.size
     seed = 0x5AF1C5 + 1 + rank                 # seed = 0x5AF1C5 + config index

@@ -136,6 +136,47 @@ __device__ __forceinline__ uint64_t packed_key64(const PackedText& t, uint64_t p
     const uint64_t b = (((w1 << t.kbits) | w2) >> sh) & mask;
     return (a << t.kbits) | b;
 }
+// Keys of consecutive positions: one word-index computation, then a step per position
+// (the next word is fetched only when the window crosses a word boundary).
+template <class KeyT>
+struct PackedWalk {
+    uint64_t q = 0;
+    unsigned off = 0;
+    uint64_t w0 = 0, w1 = 0, w2 = 0;
+    __device__ __forceinline__ void init(const PackedText& t, uint64_t p)
+    {
+        q = packed_word_index(t, p);
+        off = (unsigned)(p - q * (uint64_t)t.spw);
+        w0 = t.words[q];
+        w1 = t.words[q + 1];
+        w2 = sizeof(KeyT) == 8 ? t.words[q + 2] : 0u;
+    }
+    __device__ __forceinline__ KeyT key(const PackedText& t) const
+    {
+        const uint64_t mask = (1ull << t.kbits) - 1ull;
+        const unsigned sh = ((unsigned)t.spw - off) * (unsigned)t.bits;
+        const uint64_t a = (((w0 << t.kbits) | w1) >> sh) & mask;
+        if (sizeof(KeyT) == 4) return (KeyT)a;
+        const uint64_t b = (((w1 << t.kbits) | w2) >> sh) & mask;
+        return (KeyT)((a << t.kbits) | b);
+    }
+    // only while the next position is still < n (the array carries 3 zero words past the end)
+    __device__ __forceinline__ void step(const PackedText& t)
+    {
+        if (++off == (unsigned)t.spw) {
+            off = 0;
+            q++;
+            w0 = w1;
+            if (sizeof(KeyT) == 8) {
+                w1 = w2;
+                w2 = t.words[q + 2];
+            } else {
+                w1 = t.words[q + 1];
+            }
+        }
+    }
+};
+
 template <class KeyT> __device__ __forceinline__ KeyT packed_key(const PackedText& t, uint64_t p);
 template <> __device__ __forceinline__ uint32_t packed_key<uint32_t>(const PackedText& t, uint64_t p)
 {

@@ -54,15 +54,38 @@ __global__ void __launch_bounds__(kBlock)
 k_byte_hist(const uint8_t* __restrict__ text, uint64_t begin, uint64_t end,
             unsigned long long* __restrict__ bins)
 {
-    __shared__ uint32_t h[kWavesPerBlock][256];
-    const unsigned tid = threadIdx.x, w = wave_id();
-    for (unsigned i = tid; i < kWavesPerBlock * 256; i += kBlock) (&h[0][0])[i] = 0;
+    // 16 sub-counters per byte value, picked by lane: small alphabets (DNA: 4 values) would
+    // otherwise serialise a whole wave on 4 LDS addresses
+    constexpr unsigned kCols = 16;
+    __shared__ uint32_t h[256 * kCols];
+    const unsigned tid = threadIdx.x, col = tid & (kCols - 1u);
+    for (unsigned i = tid; i < 256 * kCols; i += kBlock) h[i] = 0;
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = begin + (uint64_t)blockIdx.x * kBlock + tid; i < end; i += stride)
-        atomicAdd(&h[w][text[i]], 1u);
+    // head up to the first 16-byte boundary, 16-byte vectors, tail
+    uint64_t vb = begin + ((16u - (unsigned)((reinterpret_cast<uintptr_t>(text) + begin) & 15u)) & 15u);
+    if (vb > end) vb = end;
+    const uint64_t nvec = (end - vb) / 16;
+    const uint4* t16 = reinterpret_cast<const uint4*>(text + vb);
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + tid; i < nvec; i += stride) {
+        const uint4 v = t16[i];
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            atomicAdd(&h[(wds[k] & 255u) * kCols + col], 1u);
+            atomicAdd(&h[((wds[k] >> 8) & 255u) * kCols + col], 1u);
+            atomicAdd(&h[((wds[k] >> 16) & 255u) * kCols + col], 1u);
+            atomicAdd(&h[(wds[k] >> 24) * kCols + col], 1u);
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (uint64_t i = begin + tid; i < vb; i += kBlock) atomicAdd(&h[text[i] * kCols + col], 1u);
+        for (uint64_t i = vb + nvec * 16 + tid; i < end; i += kBlock) atomicAdd(&h[text[i] * kCols + col], 1u);
+    }
     __syncthreads();
-    uint32_t c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+    uint32_t c = 0;
+#pragma unroll
+    for (unsigned k = 0; k < kCols; k++) c += h[tid * kCols + ((k + tid) & (kCols - 1u))];
     if (c) atomicAdd(&bins[tid], (unsigned long long)c);
 }
 
@@ -210,8 +233,26 @@ k_key_hist_raw(const uint8_t* __restrict__ text, uint64_t n, uint64_t begin, uin
     const uint64_t ce = dmin<uint64_t>(cb + chunk, end);
     const uint32_t wmask = (1u << (nsym * bits)) - 1u;            // nsym*bits < top_bits + bits <= 22
     const int down = nsym * bits - top_bits;
+    // a thread's run and its overhang (nsym - 1 more bytes) as two 16-byte vectors when the
+    // chunk starts on a 16-byte boundary (chunks are multiples of kKeyHistRun = 16)
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(text) + cb) & 15u) == 0 && nsym - 1 <= 16;
     for (uint64_t i0 = cb + (uint64_t)tid * kKeyHistRun; i0 < ce; i0 += (uint64_t)kBlock * kKeyHistRun) {
         uint32_t wnd = 0;
+        if (vec_ok && i0 + 2 * kKeyHistRun <= n) {
+            const uint4 va = *reinterpret_cast<const uint4*>(text + i0);
+            const uint4 vb = *reinterpret_cast<const uint4*>(text + i0 + kKeyHistRun);
+            const uint32_t wds[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+            const int lim = kKeyHistRun + nsym - 1;
+#pragma unroll
+            for (int j = 0; j < 2 * kKeyHistRun; j++) {
+                if (j < lim) {
+                    const uint32_t c = (uint32_t)lut[(wds[j >> 2] >> (8 * (j & 3))) & 255u];
+                    wnd = ((wnd << bits) | c) & wmask;
+                    if (j >= nsym - 1 && i0 + (uint64_t)(j - (nsym - 1)) < ce) atomicAdd(&h[wnd >> down], 1u);
+                }
+            }
+            continue;
+        }
         for (int j = 0; j < kKeyHistRun + nsym - 1; j++) {
             const uint64_t p = i0 + (uint64_t)j;
             const uint32_t c = p < n ? (uint32_t)lut[text[p]] : 0u;
@@ -227,70 +268,145 @@ k_key_hist_raw(const uint8_t* __restrict__ text, uint64_t n, uint64_t begin, uin
 // Emit (key, suffix) for the suffixes whose top key bits fall in [bin_lo, bin_hi)
 // (32-bit keys: as E64 elements in kout, vout unused).
 // phase 0 counts per workgroup, phase 1 writes at the scanned offsets (stream
-// compaction; order = text order).  8 consecutive positions per thread and step: their
-// keys come out of the same few packed words, and one block scan serves 2048 positions.
+// compaction; order = text order).
 // (A one-pass variant that reserves output per tile with an atomic cursor was measured
 // 2x slower: the returning device-scope atomic sits on every tile's critical path.)
-constexpr int kFilterItems = 8;
-constexpr int kFilterTile = kBlock * kFilterItems;
-template <class KeyT>
+constexpr int kFilterMaxSpw = 32;                    // symbols per packed word: floor(32 / bits) <= 32
+constexpr int kFilterStageSpw = 16;                  // tiles of up to 256 x 16 positions are compacted in LDS
+// A thread takes one packed word = spw consecutive positions: their keys are windows of the
+// 2-3 words it loads (coalesced), no index arithmetic per position.  phase 0 counts the kept
+// positions per chunk, phase 1 (after the scan of the counts) emits them in position order.
+// BITS != 0: symbol width known at compile time (2 = DNA), every shift becomes a constant.
+template <class KeyT, int BITS>
 __global__ void __launch_bounds__(kBlock)
 k_range_filter(PackedText src, int key_bits_used, int top_bits, uint32_t bin_lo, uint32_t bin_hi,
-               uint64_t chunk, int phase, uint32_t* __restrict__ block_counts, uint64_t capacity,
+               uint64_t chunk_words, int phase, uint32_t* __restrict__ block_counts, uint64_t capacity,
                KeyT* __restrict__ kout, uint32_t* __restrict__ vout)
 {
     __shared__ uint32_t part[2][kWavesPerBlock];
+    __shared__ uint64_t stage_k[kBlock * kFilterStageSpw];                       // 32 KiB
+    __shared__ uint32_t stage_v[sizeof(KeyT) == 8 ? kBlock * kFilterStageSpw : 1];
     const unsigned tid = threadIdx.x;
     const int shift = key_bits_used - top_bits;
-    uint64_t begin = (uint64_t)blockIdx.x * chunk;                 // chunk is a multiple of kFilterTile
-    uint64_t end = begin + chunk;
-    if (end > src.n) end = src.n;
+    const unsigned bits = BITS ? (unsigned)BITS : (unsigned)src.bits;
+    const unsigned spw = BITS ? 32u / (unsigned)(BITS ? BITS : 1) : (unsigned)src.spw;
+    const unsigned kbits = BITS ? spw * bits : (unsigned)src.kbits;
+    const uint64_t n_words = (src.n + spw - 1) / spw;
+    const uint64_t mask = (1ull << kbits) - 1ull;
+    const KeyT key_lo = (KeyT)((uint64_t)bin_lo << shift);
+    const KeyT key_span = (KeyT)((((uint64_t)(bin_hi - bin_lo)) << shift) - 1ull);   // (2^64 wraps to all ones: right)
+    uint64_t wbegin = (uint64_t)blockIdx.x * chunk_words;          // chunk_words is a multiple of kBlock
+    uint64_t wend = wbegin + chunk_words;
+    if (wend > n_words) wend = n_words;
     uint64_t running = (phase == 1) ? (uint64_t)block_counts[blockIdx.x] : 0ull;
     unsigned par = 0;
-    for (uint64_t base = begin; base < end; base += kFilterTile) {
-        const uint64_t i0 = base + (uint64_t)tid * kFilterItems;
-        KeyT key[kFilterItems];
-        unsigned keep = 0;
+    uint32_t mine = 0;
+    for (uint64_t base = wbegin; base < wend; base += kBlock) {
+        const uint64_t q = base + tid;
+        const bool live = q < wend;
+        const uint64_t p0 = q * spw;
+        uint64_t x01 = 0, x12 = 0;                                 // the key windows: words (q, q+1) and (q+1, q+2)
+        if (live) {
+            const uint64_t w0 = src.words[q], w1 = src.words[q + 1];
+            x01 = (w0 << kbits) | w1;
+            if (sizeof(KeyT) == 8) x12 = (w1 << kbits) | (uint64_t)src.words[q + 2];
+        }
+        auto key_at = [&](unsigned j) -> KeyT {                    // key of position p0 + j, j < spw
+            const unsigned sh = (spw - j) * bits;
+            if (sizeof(KeyT) == 4 && kbits == 32u)                 // whole-word keys (DNA): one 32-bit funnel shift
+                return (KeyT)(j ? (uint32_t)(x01 >> (sh & 31u)) : (uint32_t)(x01 >> 32));
+            const uint64_t a = (x01 >> sh) & mask;
+            if (sizeof(KeyT) == 4) return (KeyT)a;
+            return (KeyT)((a << kbits) | ((x12 >> sh) & mask));
+        };
+        uint32_t keep = 0;
+        if (live) {
+            // bin in [bin_lo, bin_hi)  <=>  key - (bin_lo << shift) <= ((bin_hi - bin_lo) << shift) - 1
 #pragma unroll
-        for (int j = 0; j < kFilterItems; j++) {
-            key[j] = 0;
-            if (i0 + j < end) {
-                key[j] = packed_key<KeyT>(src, i0 + j);
-                const uint32_t bin = (uint32_t)(key[j] >> shift);
-                keep |= ((bin >= bin_lo && bin < bin_hi) ? 1u : 0u) << j;
+            for (unsigned j = 0; j < (unsigned)kFilterMaxSpw; j++) {
+                if (j < spw) keep |= ((KeyT)(key_at(j) - key_lo) <= key_span ? 1u : 0u) << j;
             }
+            const uint64_t left = src.n - p0;                      // positions past the end of the text: dropped
+            if (left < spw) keep &= (1u << (unsigned)left) - 1u;
+        }
+        const uint32_t cnt = (uint32_t)__popc(keep);
+        if (phase == 0) {                              // counting needs no order: per-thread sums, one reduction at the end
+            mine += cnt;
+            continue;
         }
         // exclusive prefix of the per-thread keep counts, one barrier (parity buffers)
-        const uint32_t cnt = (uint32_t)__popc(keep);
         const uint32_t incl = wave_scan_add(cnt);
         if (lane_id() == 63) part[par][wave_id()] = incl;
         __syncthreads();
         uint32_t before = 0, total = 0;
 #pragma unroll
         for (unsigned k = 0; k < (unsigned)kWavesPerBlock; k++) {
-            const uint32_t q = part[par][k];
-            if (k < wave_id()) before += q;
-            total += q;
+            const uint32_t qq = part[par][k];
+            if (k < wave_id()) before += qq;
+            total += qq;
         }
         par ^= 1u;
-        if (phase == 1 && keep) {
-            uint64_t dst = running + before + incl - cnt;
-#pragma unroll
-            for (int j = 0; j < kFilterItems; j++) {
-                if (((keep >> j) & 1u) && dst < capacity) {
-                    if (sizeof(KeyT) == 4) {            // E64 element: (key << 32) | suffix
-                        reinterpret_cast<uint64_t*>(kout)[dst] = ((uint64_t)key[j] << 32) | (uint64_t)(uint32_t)(i0 + j);
+        if (spw <= (unsigned)kFilterStageSpw && total * 6u >= kBlock * spw) {
+            // compact the tile in LDS, then write it out as one contiguous run (a thread's own
+            // elements are up to spw * 8 bytes apart from its neighbour's: direct stores would
+            // touch one line per lane)
+            uint32_t at = before + incl - cnt;
+            uint32_t k = keep;
+            while (k) {
+                const unsigned j = (unsigned)__ffs((int)k) - 1u;
+                k &= k - 1u;
+                const KeyT key = key_at(j);
+                if (sizeof(KeyT) == 4) {                // E64 element: (key << 32) | suffix
+                    stage_k[at] = ((uint64_t)key << 32) | (uint64_t)(uint32_t)(p0 + j);
+                } else {
+                    stage_k[at] = (uint64_t)key;
+                    stage_v[at] = (uint32_t)(p0 + j);
+                }
+                at++;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < total; i += kBlock) {
+                const uint64_t dst = running + i;
+                if (dst < capacity) {
+                    if (sizeof(KeyT) == 4) {
+                        reinterpret_cast<uint64_t*>(kout)[dst] = stage_k[i];
                     } else {
-                        kout[dst] = key[j];
-                        vout[dst] = (uint32_t)(i0 + j);
+                        kout[dst] = (KeyT)stage_k[i];
+                        vout[dst] = stage_v[i];
                     }
                 }
-                dst += (keep >> j) & 1u;
+            }
+            __syncthreads();
+        } else {                                       // sparse tile (a narrow range of a long text): direct stores
+            uint64_t dst = running + before + incl - cnt;
+            uint32_t k = keep;
+            while (k) {
+                const unsigned j = (unsigned)__ffs((int)k) - 1u;
+                k &= k - 1u;
+                if (dst < capacity) {
+                    const KeyT key = key_at(j);
+                    if (sizeof(KeyT) == 4) {
+                        reinterpret_cast<uint64_t*>(kout)[dst] = ((uint64_t)key << 32) | (uint64_t)(uint32_t)(p0 + j);
+                    } else {
+                        kout[dst] = key;
+                        vout[dst] = (uint32_t)(p0 + j);
+                    }
+                }
+                dst++;
             }
         }
         running += total;
     }
-    if (phase == 0 && tid == 0) block_counts[blockIdx.x] = (uint32_t)running;
+    if (phase == 0) {
+        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+        if (lane_id() == 0) part[0][wave_id()] = mine;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t c = 0;
+            for (int w = 0; w < kWavesPerBlock; w++) c += part[0][w];
+            block_counts[blockIdx.x] = c;
+        }
+    }
 }
 
 // exclusive scan of <= kMaxGrid per-workgroup counts (single workgroup); total -> out_total
@@ -432,6 +548,9 @@ __device__ __forceinline__ unsigned valid_mask(uint64_t i0, uint64_t m)
     return i0 >= m ? 0u : ((1u << (unsigned)(m - i0)) - 1u);
 }
 
+#ifndef SFX_REDUCE_DEPTH
+#define SFX_REDUCE_DEPTH 2
+#endif
 // per-workgroup partials: last bucket-head index (+1) in the chunk, #kept, #kept bucket heads
 template <class KeyT>
 __global__ void __launch_bounds__(kBlock)
@@ -445,20 +564,30 @@ k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t chunk,
     uint64_t end = begin + chunk;
     if (end > m) end = m;
     uint32_t last_head = 0, keep = 0, ghead = 0;
-    GroupKeys<KeyT> nxt;
+    // kReduceDepth tiles of keys in flight per thread (the kernel is a pure stream: what bounds
+    // it is bytes in flight per CU, not arithmetic)
+    constexpr int kReduceDepth = SFX_REDUCE_DEPTH;
+    GroupKeys<KeyT> nxt[kReduceDepth];
     uint64_t i0 = begin + (uint64_t)tid * kGroupItems;
-    if (i0 < end) group_load(K, i0, m, nxt);
-    for (; i0 < end; i0 += kGroupTile) {
-        const GroupKeys<KeyT> cur = nxt;
-        if (i0 + kGroupTile < end) group_load(K, i0 + kGroupTile, m, nxt);
-        unsigned head, single;
-        group_flags(cur, i0, m, head, single);
-        // the apply kernel reads these 2 bits per element instead of the keys again
-        flags_out[i0 / kGroupItems] = (uint16_t)(head | (single << 8));
-        const unsigned valid = valid_mask(i0, m);
-        if (head) last_head = (uint32_t)i0 + (32u - (unsigned)__clz((int)head));   // index+1 of the highest head bit
-        keep += (uint32_t)__popc(valid & ~single);
-        ghead += (uint32_t)__popc(head & ~single);
+#pragma unroll
+    for (int u = 0; u < kReduceDepth; u++)
+        if (i0 + (uint64_t)u * kGroupTile < end) group_load(K, i0 + (uint64_t)u * kGroupTile, m, nxt[u]);
+    for (; i0 < end; i0 += (uint64_t)kReduceDepth * kGroupTile) {
+#pragma unroll
+        for (int u = 0; u < kReduceDepth; u++) {
+            const uint64_t iu = i0 + (uint64_t)u * kGroupTile;
+            if (iu >= end) break;
+            const GroupKeys<KeyT> cur = nxt[u];
+            if (iu + (uint64_t)kReduceDepth * kGroupTile < end) group_load(K, iu + (uint64_t)kReduceDepth * kGroupTile, m, nxt[u]);
+            unsigned head, single;
+            group_flags(cur, iu, m, head, single);
+            // the apply kernel reads these 2 bits per element instead of the keys again
+            flags_out[iu / kGroupItems] = (uint16_t)(head | (single << 8));
+            const unsigned valid = valid_mask(iu, m);
+            if (head) last_head = (uint32_t)iu + (32u - (unsigned)__clz((int)head));   // index+1 of the highest head bit
+            keep += (uint32_t)__popc(valid & ~single);
+            ghead += (uint32_t)__popc(head & ~single);
+        }
     }
     for (int d = 32; d >= 1; d >>= 1) {
         last_head = dmax(last_head, __shfl_xor(last_head, d));
@@ -580,6 +709,25 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         const uint32_t ec = ba + ia - cnt;
         uint32_t run_head = dmax(c_head, dmax(bm, pm));          // index+1 of the last head before item 0
         uint32_t run_keep = c_keep + ec;
+        if (sa_in_place && !isa) {
+            // only the kept elements have anything to write (a few per cent of a first round):
+            // walk the set bits of the keep mask; every quantity is a bit trick on the two masks
+            uint32_t k = keepm;
+            while (k) {
+                const int j = __ffs((int)k) - 1;
+                k &= k - 1u;
+                const uint64_t i = i0 + (unsigned)j;
+                const uint32_t hb = head & ((2u << j) - 1u);     // heads at or before item j
+                const uint32_t my_head = hb ? (uint32_t)i0 + 31u - (unsigned)__clz((int)hb) : run_head - 1u;
+                const uint32_t pos = run_keep + (uint32_t)__popc(keepm & ((1u << j) - 1u));
+                const uint32_t slot = S ? S[i] : (uint32_t)i;
+                const uint32_t suffix = V[i];
+                if (R_next) R_next[pos] = S ? S[my_head] : my_head;
+                S_next[pos] = slot;
+                V_next[pos] = suffix;
+                G_next[pos] = pos - ((uint32_t)i - my_head);
+            }
+        } else
 #pragma unroll
         for (int b = 0; b < kApplySub; b++) {
             const uint64_t ib = i0 + (uint64_t)b * kGroupItems;
@@ -1230,11 +1378,16 @@ static int range_build(const PackedText& pt, int cpk, int top_bits, uint32_t bin
                        uint32_t* block_counts, hipStream_t st, sfx_build_stats& stats)
 {
     const uint64_t n = pt.n;
-    Chunking ch = make_chunking(n, kFilterTile);
-    const uint64_t chunk = ch.tiles_per_block * kFilterTile;
+    Chunking ch = make_chunking((n + (uint64_t)pt.spw - 1) / (uint64_t)pt.spw, kBlock);       // in packed words
+    const uint64_t chunk = ch.tiles_per_block * kBlock;
     KeyT* k0 = (KeyT*)b.K0;
-    SFX_LAUNCH("range_count", (double)n * pt.bits / 8.0, (k_range_filter<KeyT>), ch.blocks, kBlock, st, pt,
-               pt.bits * cpk, top_bits, bin_lo, bin_hi, chunk, 0, block_counts, capacity, k0, b.VA);
+    const bool dna = pt.bits == 2;                              // the compile-time-width instance
+    if (dna)
+        SFX_LAUNCH("range_count", (double)n * pt.bits / 8.0, (k_range_filter<KeyT, 2>), ch.blocks, kBlock, st, pt,
+                   pt.bits * cpk, top_bits, bin_lo, bin_hi, chunk, 0, block_counts, capacity, k0, b.VA);
+    else
+        SFX_LAUNCH("range_count", (double)n * pt.bits / 8.0, (k_range_filter<KeyT, 0>), ch.blocks, kBlock, st, pt,
+                   pt.bits * cpk, top_bits, bin_lo, bin_hi, chunk, 0, block_counts, capacity, k0, b.VA);
     SFX_LAUNCH("range_scan", 0.0, k_scan_block_counts, 1, kBlock, st, block_counts, ch.blocks, b.totals);
     uint32_t host_total = 0;
     SFX_HIP(hipMemcpyAsync(&host_total, b.totals, sizeof(host_total), hipMemcpyDeviceToHost, st));
@@ -1242,9 +1395,14 @@ static int range_build(const PackedText& pt, int cpk, int top_bits, uint32_t bin
     *count_out = host_total;
     if (host_total > capacity) return SFX_ERR_WORKSPACE;
     if (host_total == 0) return SFX_OK;
-    SFX_LAUNCH("range_emit", (double)n * pt.bits / 8.0 + (double)host_total * (sizeof(KeyT) + 4),
-               (k_range_filter<KeyT>), ch.blocks, kBlock, st, pt, pt.bits * cpk, top_bits, bin_lo, bin_hi,
-               chunk, 1, block_counts, capacity, k0, b.VA);
+    if (dna)
+        SFX_LAUNCH("range_emit", (double)n * pt.bits / 8.0 + (double)host_total * (sizeof(KeyT) + 4),
+                   (k_range_filter<KeyT, 2>), ch.blocks, kBlock, st, pt, pt.bits * cpk, top_bits, bin_lo, bin_hi,
+                   chunk, 1, block_counts, capacity, k0, b.VA);
+    else
+        SFX_LAUNCH("range_emit", (double)n * pt.bits / 8.0 + (double)host_total * (sizeof(KeyT) + 4),
+                   (k_range_filter<KeyT, 0>), ch.blocks, kBlock, st, pt, pt.bits * cpk, top_bits, bin_lo, bin_hi,
+                   chunk, 1, block_counts, capacity, k0, b.VA);
     return sort_and_refine<KeyT>(pt, cpk, host_total, false, b, d_sa_part, nullptr, st, stats);
 }
 

@@ -192,3 +192,55 @@ def small_buckets(eng, orc, scale=1):
     # the deep repeats cannot all be settled within the comparison depth
     check_text(eng, orc, cases["dna deep"][0], lcp=False)
     assert eng.build_stats()["rounds"] > 0
+
+
+def range_slices(eng, orc, text, nranges, device="cpu", packed=False, top_bits=14):
+    """The range-partitioned build driven for `nranges` virtual ranks in one process: every
+    range [lo, hi) of the planned key bins is built on its own and the slices must
+    concatenate to the oracle's suffix array.  Many ranges make sparse tiles in the filter
+    (direct stores), few make dense ones (LDS-compacted)."""
+    import ctypes
+
+    import torch
+
+    from suffix_amd import dist as sdist
+    from suffix_amd.device import _p
+    exp = orc.sais(text)
+    n = len(text)
+    t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(device)
+    bb = torch.zeros(256, dtype=torch.int64, device=device)
+    eng.check(eng.lib.sfx_byte_histogram_dev(_p(t), 0, n, _p(bb), None), "byte_hist")
+    assert np.array_equal(bb.cpu().numpy(), np.bincount(np.frombuffer(text, dtype=np.uint8), minlength=256))
+    sigma = int((bb > 0).sum())
+    sym_bits = max(1, (max(sigma, 2) - 1).bit_length())
+    spw = 32 // sym_bits
+    tb = min(top_bits, sym_bits * spw)
+    kb = torch.zeros(1 << tb, dtype=torch.int64, device=device)
+    # the histogram in two pieces with an odd split point: unaligned chunk starts take the byte path
+    cut = (n // 3) | 1
+    kb2 = torch.zeros_like(kb)
+    eng.check(eng.lib.sfx_key_histogram_dev(_p(t), n, 0, cut, _p(bb), tb, _p(kb), None), "key_hist")
+    eng.check(eng.lib.sfx_key_histogram_dev(_p(t), n, cut, n, _p(bb), tb, _p(kb2), None), "key_hist")
+    kb += kb2
+    assert int(kb.sum()) == n
+    d_packed = None
+    if packed:
+        nw = (n + spw - 1) // spw
+        d_packed = torch.zeros(nw + 4, dtype=torch.int32, device=device)
+        scratch = torch.empty(256, dtype=torch.uint8, device=device)
+        eng.check(eng.lib.sfx_pack_text_dev(_p(t), n, _p(bb), _p(scratch), _p(d_packed), nw, None), "pack")
+    pieces = []
+    for lo, hi, off, cnt in sdist.plan_ranges(kb.cpu(), nranges):
+        cap = max(cnt, 1)
+        part = torch.empty(cap, dtype=torch.int32, device=device)
+        ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(n, cap)), dtype=torch.uint8, device=device)
+        got = ctypes.c_uint64(0)
+        if packed:
+            eng.check(eng.lib.sfx_build_sa_range_packed_u32_dev(_p(d_packed), n, _p(bb), tb, lo, hi, cap, _p(part),
+                                                                ctypes.byref(got), _p(ws), ws.numel(), None), "range")
+        else:
+            eng.check(eng.lib.sfx_build_sa_range_u32_dev(_p(t), n, _p(bb), tb, lo, hi, cap, _p(part),
+                                                         ctypes.byref(got), _p(ws), ws.numel(), None), "range")
+        assert int(got.value) == cnt and off == sum(p.size for p in pieces)
+        pieces.append(part[:cnt].cpu().numpy().view(np.uint32))
+    assert np.array_equal(np.concatenate(pieces), exp)

@@ -105,3 +105,11 @@ def test_build_stats_and_profile(emu):
     emu.profile(False)
     assert rep["radix_scatter_text_u32"]["launches"] >= 1 and rep["radix_scatter_u32"]["launches"] >= 3
     assert rep["radix_scatter_u32"]["algo_bytes"] > 0 and "pack_text" in rep
+
+
+@pytest.mark.parametrize("nranges", [1, 3, 11])
+def test_range_build_virtual_ranks(emu, oracle, nranges):
+    import _gen
+    _cases.range_slices(emu, oracle, _gen.dna(7001, seed=8).tobytes(), nranges, packed=(nranges != 3))
+    _cases.range_slices(emu, oracle, _gen.english_like(5003).tobytes(), nranges, packed=(nranges == 3))
+    _cases.range_slices(emu, oracle, (b"ab" * 900 + b"b"), nranges)

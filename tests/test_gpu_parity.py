@@ -177,3 +177,11 @@ def test_partitioned_build_single_rank_slices(eng, oracle):
         for k, q in enumerate(qs):
             es, ee = oracle.positions(text, exp, q)
             assert (int(total[k]) == ee - es) and (total[k] == 0 or int(gstart[k]) == es), (q, gstart[k], total[k], es, ee)
+
+
+@pytest.mark.parametrize("nranges", [2, 9])
+def test_range_build_many_ranges(eng, oracle, nranges):
+    """Dense (LDS-compacted) and sparse (direct-store) tiles of the range filter, raw and packed input."""
+    _cases.range_slices(eng, oracle, _gen.dna(1_000_003, seed=8).tobytes(), nranges, device="cuda", packed=True)
+    _cases.range_slices(eng, oracle, _gen.dna(300_001, seed=9).tobytes(), nranges, device="cuda")
+    _cases.range_slices(eng, oracle, _gen.english_like(400_000).tobytes(), nranges, device="cuda", packed=(nranges == 9))
