@@ -116,9 +116,16 @@ struct BuildStats;   // = sfx_build_stats
 //  - KV: u64 keys + u32 values, (k0,v0)/(k1,v1) ping-pong; with `text` the first pass
 //    reads (packed_key64(text, i), i) instead of (k0, v0).
 uint64_t radix_scratch_words(uint64_t m);
+//    A producer that had the keys in registers anyway (the range filter) may have counted the
+//    digits itself: `hist_blocks` workgroups' counts at radix_partial(scratch)[(pass * 256 +
+//    digit) * hist_blocks + workgroup]; only honoured when radix_e64_presort_hist() said so.
 int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, uint32_t* scratch,
                    hipStream_t st, int* result_in_1, sfx_build_stats* stats, const PackedText* text,
-                   uint32_t* split_v, uint32_t** split_k_out);
+                   uint32_t* split_v, uint32_t** split_k_out, unsigned hist_blocks = 0);
+// > 0: an E64 sort of m elements on bits [bit_lo, bit_hi) takes digit counts from its producer,
+// from at most this many workgroups
+unsigned radix_e64_presort_hist(uint64_t m, int bit_lo, int bit_hi);
+inline uint32_t* radix_partial(uint32_t* scratch) { return scratch; }
 int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, int bit_lo,
                     int bit_hi, uint32_t* scratch, hipStream_t st, int* result_in_1,
                     sfx_build_stats* stats, const PackedText* text);

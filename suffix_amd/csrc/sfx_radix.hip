@@ -674,9 +674,15 @@ static bool use_sweep(uint64_t m, int npass)
 // the suffix halves to split_v and the key halves to a u32 array carved from whichever of
 // e0/e1 it does not read (returned in *split_k_out); otherwise *result_in_1 tells which
 // buffer holds the sorted elements.
+unsigned radix_e64_presort_hist(uint64_t m, int bit_lo, int bit_hi)
+{
+    if (m == 0 || bit_hi <= bit_lo || m > 0xFFFFFFFFull) return 0;
+    return use_sweep(m, radix_pass_count(bit_lo, bit_hi)) ? kHistAllGrid : 0u;
+}
+
 int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, uint32_t* scratch, hipStream_t st,
                    int* result_in_1, sfx_build_stats* stats, const PackedText* text, uint32_t* split_v,
-                   uint32_t** split_k_out)
+                   uint32_t** split_k_out, unsigned hist_blocks)
 {
     *result_in_1 = 0;
     if (split_k_out) *split_k_out = (uint32_t*)e1;
@@ -687,7 +693,13 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
     const bool sweep = use_sweep(m, npass);
     RadixScratch scr(scratch, m);
     SrcText32 tsrc = {text ? *text : PackedText{nullptr, 0, 0, 1, 0, 1.0}};
-    if (sweep) {
+    if (sweep && hist_blocks && !text) {
+        // the producer of e0 counted the digits (radix_e64_presort_hist): only the row sums are left
+        if (hist_blocks > kHistAllGrid) return SFX_ERR_INTERNAL;
+        SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
+        SFX_LAUNCH("radix_scan", (double)npass * kRadix * hist_blocks * 8, k_radix_scan, npass * kRadix, kBlock, st,
+                   scr.partial, hist_blocks, scr.totals);
+    } else if (sweep) {
         if (window_hist_applies(text, m, bit_lo, bit_hi)) SFX_TRY(prepare_sweep_windows(*text, scr, st));
         else if (text) SFX_TRY(prepare_sweep("radix_hist_all_text_u32", (double)m * text->bits / 8.0, tsrc, m, bit_lo, bit_hi, npass, scr, st));
         else SFX_TRY(prepare_sweep("radix_hist_all_u32", (double)m * 8.0, SrcE64{e0}, m, bit_lo, bit_hi, npass, scr, st));

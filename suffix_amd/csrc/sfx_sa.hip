@@ -281,8 +281,28 @@ template <class KeyT, int BITS>
 __global__ void __launch_bounds__(kBlock)
 k_range_filter(PackedText src, int key_bits_used, int top_bits, uint32_t bin_lo, uint32_t bin_hi,
                uint64_t chunk_words, int phase, uint32_t* __restrict__ block_counts, uint64_t capacity,
-               KeyT* __restrict__ kout, uint32_t* __restrict__ vout)
+               KeyT* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t* __restrict__ digit_partial)
 {
+    // digit_partial (32-bit keys, phase 1): the 8-bit digit counts of the emitted keys for the
+    // sort that follows, [(pass * 256 + digit) * gridDim.x + blockIdx.x] -- the keys are in
+    // registers here, the sort would read all its elements once more to count them
+    constexpr int kDigitPasses = 4;
+    __shared__ uint32_t dig[sizeof(KeyT) == 4 ? kDigitPasses * 256 : 1];
+    const bool count_digits = sizeof(KeyT) == 4 && phase == 1 && digit_partial != nullptr;
+    if (count_digits) {
+        for (unsigned i = threadIdx.x; i < kDigitPasses * 256; i += kBlock) dig[i] = 0;
+        __syncthreads();
+    }
+    const int digit_passes = (key_bits_used + 7) / 8;
+    auto count_key = [&](uint32_t key) {
+#pragma unroll
+        for (int p = 0; p < kDigitPasses; p++) {
+            if (p < digit_passes) {
+                const int nb = key_bits_used - 8 * p < 8 ? key_bits_used - 8 * p : 8;
+                atomicAdd(&dig[p * 256 + ((key >> (8 * p)) & ((1u << nb) - 1u))], 1u);
+            }
+        }
+    };
     __shared__ uint32_t part[2][kWavesPerBlock];
     __shared__ uint64_t stage_k[kBlock * kFilterStageSpw];                       // 32 KiB
     __shared__ uint32_t stage_v[sizeof(KeyT) == 8 ? kBlock * kFilterStageSpw : 1];
@@ -356,6 +376,7 @@ k_range_filter(PackedText src, int key_bits_used, int top_bits, uint32_t bin_lo,
                 const unsigned j = (unsigned)__ffs((int)k) - 1u;
                 k &= k - 1u;
                 const KeyT key = key_at(j);
+                if (count_digits) count_key((uint32_t)key);
                 if (sizeof(KeyT) == 4) {                // E64 element: (key << 32) | suffix
                     stage_k[at] = ((uint64_t)key << 32) | (uint64_t)(uint32_t)(p0 + j);
                 } else {
@@ -385,6 +406,7 @@ k_range_filter(PackedText src, int key_bits_used, int top_bits, uint32_t bin_lo,
                 k &= k - 1u;
                 if (dst < capacity) {
                     const KeyT key = key_at(j);
+                    if (count_digits) count_key((uint32_t)key);
                     if (sizeof(KeyT) == 4) {
                         reinterpret_cast<uint64_t*>(kout)[dst] = ((uint64_t)key << 32) | (uint64_t)(uint32_t)(p0 + j);
                     } else {
@@ -396,6 +418,11 @@ k_range_filter(PackedText src, int key_bits_used, int top_bits, uint32_t bin_lo,
             }
         }
         running += total;
+    }
+    if (count_digits) {
+        __syncthreads();
+        for (int p = 0; p < digit_passes; p++)
+            digit_partial[((uint64_t)p * 256 + tid) * gridDim.x + blockIdx.x] = dig[p * 256 + tid];
     }
     if (phase == 0) {
         for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
@@ -1266,7 +1293,8 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
 // otherwise `count` explicit (key, suffix) pairs already sit in (K0 as KeyT, VA).
 template <class KeyT>
 static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool from_text, SaBuffers& b,
-                           uint32_t* sa, uint32_t* isa, hipStream_t st, sfx_build_stats& stats)
+                           uint32_t* sa, uint32_t* isa, hipStream_t st, sfx_build_stats& stats,
+                           unsigned hist_blocks = 0)
 {
     const KeyT* Kr;
     const uint32_t* Vr;
@@ -1278,7 +1306,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         // leaves the sorted 32-bit keys in the element buffer it did not read
         uint32_t* k32 = nullptr;
         SFX_TRY(radix_sort_e64(b.K0, b.K1, count, 32, 32 + pt.bits * cpk, b.hist, st, &in1, &stats,
-                               from_text ? &pt : nullptr, sa, &k32));
+                               from_text ? &pt : nullptr, sa, &k32, hist_blocks));
         Kr = (const KeyT*)k32;
         Vr = sa;
         V_next = b.VA;
@@ -1378,16 +1406,17 @@ static int range_build(const PackedText& pt, int cpk, int top_bits, uint32_t bin
                        uint32_t* block_counts, hipStream_t st, sfx_build_stats& stats)
 {
     const uint64_t n = pt.n;
-    Chunking ch = make_chunking((n + (uint64_t)pt.spw - 1) / (uint64_t)pt.spw, kBlock);       // in packed words
+    // (at most as many workgroups as the sort accepts digit counts from)
+    Chunking ch = make_chunking((n + (uint64_t)pt.spw - 1) / (uint64_t)pt.spw, kBlock, 1024);  // in packed words
     const uint64_t chunk = ch.tiles_per_block * kBlock;
     KeyT* k0 = (KeyT*)b.K0;
     const bool dna = pt.bits == 2;                              // the compile-time-width instance
     if (dna)
         SFX_LAUNCH("range_count", (double)n * pt.bits / 8.0, (k_range_filter<KeyT, 2>), ch.blocks, kBlock, st, pt,
-                   pt.bits * cpk, top_bits, bin_lo, bin_hi, chunk, 0, block_counts, capacity, k0, b.VA);
+                   pt.bits * cpk, top_bits, bin_lo, bin_hi, chunk, 0, block_counts, capacity, k0, b.VA, (uint32_t*)nullptr);
     else
         SFX_LAUNCH("range_count", (double)n * pt.bits / 8.0, (k_range_filter<KeyT, 0>), ch.blocks, kBlock, st, pt,
-                   pt.bits * cpk, top_bits, bin_lo, bin_hi, chunk, 0, block_counts, capacity, k0, b.VA);
+                   pt.bits * cpk, top_bits, bin_lo, bin_hi, chunk, 0, block_counts, capacity, k0, b.VA, (uint32_t*)nullptr);
     SFX_LAUNCH("range_scan", 0.0, k_scan_block_counts, 1, kBlock, st, block_counts, ch.blocks, b.totals);
     uint32_t host_total = 0;
     SFX_HIP(hipMemcpyAsync(&host_total, b.totals, sizeof(host_total), hipMemcpyDeviceToHost, st));
@@ -1395,15 +1424,22 @@ static int range_build(const PackedText& pt, int cpk, int top_bits, uint32_t bin
     *count_out = host_total;
     if (host_total > capacity) return SFX_ERR_WORKSPACE;
     if (host_total == 0) return SFX_OK;
+    // 32-bit keys: the emit pass also counts the digits for the one-sweep sort of its output
+    unsigned hist_blocks = 0;
+    uint32_t* digit_partial = nullptr;
+    if (sizeof(KeyT) == 4 && ch.blocks <= radix_e64_presort_hist(host_total, 32, 32 + pt.bits * cpk)) {
+        hist_blocks = ch.blocks;
+        digit_partial = radix_partial(b.hist);
+    }
     if (dna)
         SFX_LAUNCH("range_emit", (double)n * pt.bits / 8.0 + (double)host_total * (sizeof(KeyT) + 4),
                    (k_range_filter<KeyT, 2>), ch.blocks, kBlock, st, pt, pt.bits * cpk, top_bits, bin_lo, bin_hi,
-                   chunk, 1, block_counts, capacity, k0, b.VA);
+                   chunk, 1, block_counts, capacity, k0, b.VA, digit_partial);
     else
         SFX_LAUNCH("range_emit", (double)n * pt.bits / 8.0 + (double)host_total * (sizeof(KeyT) + 4),
                    (k_range_filter<KeyT, 0>), ch.blocks, kBlock, st, pt, pt.bits * cpk, top_bits, bin_lo, bin_hi,
-                   chunk, 1, block_counts, capacity, k0, b.VA);
-    return sort_and_refine<KeyT>(pt, cpk, host_total, false, b, d_sa_part, nullptr, st, stats);
+                   chunk, 1, block_counts, capacity, k0, b.VA, digit_partial);
+    return sort_and_refine<KeyT>(pt, cpk, host_total, false, b, d_sa_part, nullptr, st, stats, hist_blocks);
 }
 
 // packed-text plumbing of the partitioned build: a rank packs its own shard (global symbol
