@@ -71,11 +71,11 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
         raise OverflowError("text longer than u32::MAX bytes")     # src/table.rs:380
     stream = _stream_ptr(shard)
 
-    def gather(dst, src):
+    def gather(dst, src, async_op=False):
         try:
-            dist.all_gather_into_tensor(dst, src, group=group)                 # one flat receive buffer (RCCL)
+            return dist.all_gather_into_tensor(dst, src, group=group, async_op=async_op)   # one flat receive buffer (RCCL)
         except (RuntimeError, NotImplementedError, AttributeError):
-            dist.all_gather(list(dst.split(src.numel())), src, group=group)   # backends without the flat form
+            return dist.all_gather(list(dst.split(src.numel())), src, group=group, async_op=async_op)
 
     # 2. global alphabet: byte histogram of the own shard, all-reduced
     shard = shard.contiguous()
@@ -106,10 +106,23 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
     if not packed_path:
         hist_text, hist_n, hist_lo, hist_hi = text, n, rank * m, (rank + 1) * m
 
+    # the big exchange (the packed shards) starts now and runs under the key histogram
+    packed = mine = packed_work = None
+    if packed_path:
+        wps = m // spw                                             # words per shard
+        packed = torch.zeros(wps * world + 4, dtype=torch.int32, device=dev)   # + the zero tail keys read into
+        mine = torch.empty(wps, dtype=torch.int32, device=dev)
+        scratch = torch.empty(256, dtype=torch.uint8, device=dev)
+        eng.check(eng.lib.sfx_pack_text_dev(_p(shard), m, _p(byte_bins), _p(scratch), _p(mine), wps, stream),
+                  "sfx_pack_text_dev")
+        packed_work = gather(packed[:wps * world], mine, async_op=True)
+
     # 3. bucket-boundary histogram
     key_bins = torch.zeros(1 << tb, dtype=torch.int64, device=dev)
     eng.check(eng.lib.sfx_key_histogram_dev(_p(hist_text), hist_n, hist_lo, hist_hi, _p(byte_bins), tb,
                                             _p(key_bins), stream), "sfx_key_histogram_dev")
+    if packed_work is not None:
+        packed_work.wait()
     dist.all_reduce(key_bins, op=dist.ReduceOp.SUM, group=group)
 
     # 4. plan (tiny, on the host; identical on every rank)
@@ -121,13 +134,6 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
     ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(n, cap)), dtype=torch.uint8, device=dev)
     got = ctypes.c_uint64(0)
     if packed_path:
-        wps = m // spw                                             # words per shard
-        packed = torch.zeros(wps * world + 4, dtype=torch.int32, device=dev)   # + the zero tail keys read into
-        mine = torch.empty(wps, dtype=torch.int32, device=dev)
-        scratch = torch.empty(256, dtype=torch.uint8, device=dev)
-        eng.check(eng.lib.sfx_pack_text_dev(_p(shard), m, _p(byte_bins), _p(scratch), _p(mine), wps, stream),
-                  "sfx_pack_text_dev")
-        gather(packed[:wps * world], mine)
         eng.check(eng.lib.sfx_build_sa_range_packed_u32_dev(_p(packed), n, _p(byte_bins), tb, lo, hi, cap,
                                                             _p(sa_part), ctypes.byref(got), _p(ws), ws.numel(),
                                                             stream), "sfx_build_sa_range_packed_u32_dev")
