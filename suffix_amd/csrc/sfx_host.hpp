@@ -149,6 +149,8 @@ inline int radix_pass_count(int bit_lo, int bit_hi) { return (bit_hi - bit_lo + 
 uint64_t sa_workspace_bytes(uint64_t n);
 int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,
                      hipStream_t st);
+int pack_small_alphabet(const uint8_t* d_text, uint64_t n, int max_bits, void* small, uint32_t* d_packed,
+                        hipStream_t st, PackedText* pt, bool* packed);
 uint64_t lcp_workspace_bytes(uint64_t n);
 int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint32_t* d_lcp,
                       void* ws, uint64_t ws_bytes, hipStream_t st);

@@ -13,6 +13,13 @@
 //                  staged through LDS so global traffic is coalesced
 //   k_lcp_gather   lcp[r] = PLCP[sa[r]]
 // Algorithmic bytes per text byte: 8 (phi) + 4+4+2 (plcp) + 4+4+4 (gather) = 30.
+//
+// Three n-sized random-access passes are the price of linearity.  Where the text does not
+// need it -- a sample of adjacent pairs says the mean LCP is a few dozen bytes -- the
+// reference's own formulation is cheaper on this machine: k_lcp_windows compares every
+// suffix with its predecessor directly (:348-361), one 16-byte gather per suffix (the
+// predecessor's window comes from the neighbouring lane), capped at kDirectCap bytes; if any
+// pair reaches the cap the Phi/PLCP path recomputes the array, so the worst case stays linear.
 #include "sfx_host.hpp"
 
 namespace sfx {
@@ -121,6 +128,153 @@ k_lcp_gather(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ plcp,
     }
 }
 
+// first 16 bytes of suffix s, zero-padded past the end of the text
+__device__ __forceinline__ void load_window(const uint8_t* __restrict__ text, uint64_t n, uint64_t s, uint64_t& w0,
+                                            uint64_t& w1)
+{
+    if (s + 16 <= n) {
+        __builtin_memcpy(&w0, text + s, 8);
+        __builtin_memcpy(&w1, text + s + 8, 8);
+    } else {
+        w0 = w1 = 0;
+        for (unsigned k = 0; k < 16 && s + k < n; k++) {
+            const uint64_t b = (uint64_t)text[s + k] << (8 * (k & 7u));
+            if (k < 8) w0 |= b; else w1 |= b;
+        }
+    }
+}
+__device__ __forceinline__ unsigned match_windows(uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1)
+{
+    const uint64_t d0 = a0 ^ b0, d1 = a1 ^ b1;
+    if (d0) return (unsigned)(__ffsll((long long)d0) - 1) / 8u;
+    if (d1) return 8u + (unsigned)(__ffsll((long long)d1) - 1) / 8u;
+    return 16u;
+}
+// extend_match that gives up at `cap` bytes (returns a value >= cap then)
+__device__ __forceinline__ uint64_t extend_match_capped(const uint8_t* __restrict__ text, uint64_t n, uint64_t a,
+                                                        uint64_t b, uint64_t h, uint64_t cap)
+{
+    while (h < cap && a + h + 8 <= n && b + h + 8 <= n) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, text + a + h, 8);
+        __builtin_memcpy(&y, text + b + h, 8);
+        const uint64_t d = x ^ y;
+        if (d) return h + (uint64_t)(__ffsll((long long)d) - 1) / 8;
+        h += 8;
+    }
+    while (h < cap && a + h < n && b + h < n && text[a + h] == text[b + h]) h++;
+    return h;
+}
+
+constexpr uint32_t kDirectCap = 1024;            // bytes compared directly before a pair is handed to Phi/PLCP
+constexpr uint32_t kSampleCap = 4096;
+constexpr uint32_t kSamples = 1u << 16;          // adjacent pairs sampled to choose the path
+constexpr uint64_t kSampleMeanMax = 64;          // direct path if the sampled mean LCP is at most this many bytes
+constexpr uint64_t kDirectMinN = 1ull << 20;     // below: the three launches of the Phi path, no host round trip
+
+// counters[0] += LCP of `samples` evenly spaced adjacent pairs (capped)
+__global__ void __launch_bounds__(kBlock)
+k_lcp_sample(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint32_t samples,
+             uint64_t every, unsigned long long* __restrict__ counters)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    uint64_t l = 0;
+    if (j < samples) {
+        const uint64_t r = 1 + j * every;
+        if (r < n) l = extend_match_capped(text, n, (uint64_t)sa[r - 1], (uint64_t)sa[r], 0, kSampleCap);
+    }
+    for (int d = 32; d >= 1; d >>= 1) l += __shfl_xor(l, d);
+    if (lane_id() == 0 && l) atomicAdd(&counters[0], (unsigned long long)l);
+}
+
+// lcp[r] for every r; counters[1] counts the pairs that reached the cap (their lcp[r] is not final)
+__global__ void __launch_bounds__(kBlock)
+k_lcp_windows(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa,
+              uint32_t* __restrict__ lcp, unsigned long long* __restrict__ counters)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const unsigned lane = lane_id();
+    uint32_t capped = 0;
+    // (whole waves stay in the loop: the predecessor's window is taken from the lane below)
+    for (uint64_t r0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); r0 < n; r0 += stride) {
+        const uint64_t r = r0 + lane;
+        const bool live = r < n;
+        const uint64_t cur = live ? (uint64_t)sa[r] : 0;
+        uint64_t c0 = 0, c1 = 0;
+        if (live) load_window(text, n, cur, c0, c1);
+        uint64_t prev = __shfl_up(cur, 1u), p0 = __shfl_up(c0, 1u), p1 = __shfl_up(c1, 1u);
+        if (lane == 0 && live && r > 0) {
+            prev = (uint64_t)sa[r - 1];
+            load_window(text, n, prev, p0, p1);
+        }
+        if (!live) continue;
+        uint64_t l = 0;
+        if (r > 0) {
+            const uint64_t room = n - (cur > prev ? cur : prev);          // bytes the shorter suffix has
+            l = match_windows(p0, p1, c0, c1);
+            if (l > room) l = room;
+            if (l == 16) l = extend_match_capped(text, n, prev, cur, 16, kDirectCap);
+            if (l >= kDirectCap) capped++;
+        }
+        lcp[r] = (uint32_t)l;
+    }
+    if (__any(capped != 0)) {
+        for (int d = 32; d >= 1; d >>= 1) capped += __shfl_xor(capped, d);
+        if (lane == 0) atomicAdd(&counters[1], (unsigned long long)capped);
+    }
+}
+
+// The same on packed symbol codes (alphabets of <= 4 bits: DNA packs 32 symbols into the 64-bit
+// window, and the packed text of a 1 GB genome is 250 MB -- Infinity-Cache sized -- where the raw
+// text makes every gather an HBM line fetch).  Lengths are symbols = bytes of the text.
+__global__ void __launch_bounds__(kBlock)
+k_lcp_windows_packed(PackedText t, const uint32_t* __restrict__ sa, uint32_t* __restrict__ lcp,
+                     unsigned long long* __restrict__ counters)
+{
+    const uint64_t n = t.n;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const unsigned lane = lane_id();
+    const unsigned W = 2u * (unsigned)t.spw;                       // symbols per window
+    const unsigned pad = 64u - 2u * (unsigned)t.kbits;             // unused high bits of a window
+    const unsigned inv_bits = (65536u + (unsigned)t.bits - 1u) / (unsigned)t.bits;   // x / bits for x < 64, bits <= 4
+    auto common = [&](uint64_t a, uint64_t b) -> unsigned {        // equal leading symbols of two windows
+        const uint64_t x = a ^ b;
+        return x ? (((unsigned)__clzll((long long)x) - pad) * inv_bits) >> 16 : W;
+    };
+    uint32_t capped = 0;
+    for (uint64_t r0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); r0 < n; r0 += stride) {
+        const uint64_t r = r0 + lane;
+        const bool live = r < n;
+        const uint64_t cur = live ? (uint64_t)sa[r] : 0;
+        const uint64_t kc = live ? packed_key64(t, cur) : 0;
+        uint64_t prev = __shfl_up(cur, 1u), kp = __shfl_up(kc, 1u);
+        if (lane == 0 && live && r > 0) {
+            prev = (uint64_t)sa[r - 1];
+            kp = packed_key64(t, prev);
+        }
+        if (!live) continue;
+        uint64_t l = 0;
+        if (r > 0) {
+            const uint64_t room = n - (cur > prev ? cur : prev);
+            l = common(kp, kc);
+            if (l == W) {
+                while (l < room && l < kDirectCap) {
+                    const unsigned m = common(packed_key64(t, prev + l), packed_key64(t, cur + l));
+                    l += m;
+                    if (m < W) break;
+                }
+            }
+            if (l > room) l = room;
+            if (l >= kDirectCap) capped++;
+        }
+        lcp[r] = (uint32_t)l;
+    }
+    if (__any(capped != 0)) {
+        for (int d = 32; d >= 1; d >>= 1) capped += __shfl_xor(capped, d);
+        if (lane == 0) atomicAdd(&counters[1], (unsigned long long)capped);
+    }
+}
+
 // LCP of one contiguous SLICE of the suffix array (range-partitioned index): every rank
 // compares each suffix of its slice with its predecessor directly, 8 bytes per step --
 // the reference's own formulation (lcp_lens_quadratic :348-361), which is the right one
@@ -166,12 +320,25 @@ int widen_u32_to_u64_dev(const uint32_t* d_in, uint64_t count, uint64_t* d_out, 
     return SFX_OK;
 }
 
+// SFX_LCP_DIRECT_MIN=<n> is a test hook (the direct path from n bytes up; default 2^20)
+static uint64_t direct_lcp_min()
+{
+    static const uint64_t v = [] {
+        const char* e = getenv("SFX_LCP_DIRECT_MIN");
+        long long x = e ? atoll(e) : 0;
+        return x >= 8 ? (uint64_t)x : kDirectMinN;              // (the counters borrow 16 bytes of the 4n Phi array)
+    }();
+    return v;
+}
+
 // phi / PLCP (4n); for large texts also the pair buffers and radix scratch of the
 // partitioned Phi scatter
 uint64_t lcp_workspace_bytes(uint64_t n)
 {
     ArenaSizer a;
     a.take<uint32_t>(n);
+    a.take<uint8_t>(4096);                       // direct path: alphabet scratch + packed text (sigma <= 16)
+    a.take<uint32_t>(n / 8 + 8);
     if (n >= partitioned_scatter_min()) {
         a.take<uint64_t>(n);
         a.take<uint64_t>(n);
@@ -189,8 +356,36 @@ int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, u
     if (!ws || ws_bytes < lcp_workspace_bytes(n)) return SFX_ERR_WORKSPACE;
     Arena ar(ws, ws_bytes);
     uint32_t* phi = ar.take<uint32_t>(n);
+    uint8_t* small = ar.take<uint8_t>(4096);
+    uint32_t* packed_words = ar.take<uint32_t>(n / 8 + 8);
     if (ar.overflow) return SFX_ERR_WORKSPACE;
     unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
+    if (n >= direct_lcp_min()) {
+        // low-LCP text (by a sample of adjacent pairs): compare directly, fall through to the
+        // linear path only if some pair reached the cap
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(phi);      // (phi is not in use yet)
+        unsigned long long host[2] = {0, 0};
+        SFX_HIP(hipMemsetAsync(counters, 0, sizeof(host), st));
+        const uint32_t samples = (uint32_t)dmin<uint64_t>(kSamples, n - 1);
+        const uint64_t every = (n - 1) / samples;
+        SFX_LAUNCH("lcp_sample", (double)samples * 24, k_lcp_sample, (samples + kBlock - 1) / kBlock, kBlock, st, d_text,
+                   n, d_sa, samples, every, counters);
+        SFX_HIP(hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, st));
+        SFX_HIP(hipStreamSynchronize(st));
+        if (host[0] <= kSampleMeanMax * samples) {
+            PackedText pt;
+            bool packed = false;
+            SFX_TRY(pack_small_alphabet(d_text, n, 4, small, packed_words, st, &pt, &packed));
+            if (packed)
+                SFX_LAUNCH("lcp_windows_packed", (double)n * 24, k_lcp_windows_packed, grid, kBlock, st, pt, d_sa, d_lcp,
+                           counters);
+            else
+                SFX_LAUNCH("lcp_windows", (double)n * 24, k_lcp_windows, grid, kBlock, st, d_text, n, d_sa, d_lcp, counters);
+            SFX_HIP(hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, st));
+            SFX_HIP(hipStreamSynchronize(st));
+            if (host[1] == 0) return SFX_OK;
+        }
+    }
     if (n >= partitioned_scatter_min()) {
         uint64_t* pairs = ar.take<uint64_t>(n);
         uint64_t* tmp = ar.take<uint64_t>(n);

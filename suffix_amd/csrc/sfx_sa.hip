@@ -1187,6 +1187,29 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
     return SFX_OK;
 }
 
+// For consumers outside the SA build (the direct LCP pass): pack the text if its alphabet needs
+// at most max_bits per symbol.  small = 4 KiB of device scratch, d_packed = n / 8 + 8 words.
+int pack_small_alphabet(const uint8_t* d_text, uint64_t n, int max_bits, void* small, uint32_t* d_packed,
+                        hipStream_t st, PackedText* pt, bool* packed)
+{
+    *packed = false;
+    unsigned long long* bins = reinterpret_cast<unsigned long long*>(small);
+    uint8_t* lut = reinterpret_cast<uint8_t*>(small) + 256 * sizeof(unsigned long long);
+    SFX_HIP(hipMemsetAsync(bins, 0, 256 * sizeof(unsigned long long), st));
+    const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock * 64 - 1) / (kBlock * 64), kMaxGrid);
+    SFX_LAUNCH("byte_presence", (double)n, k_byte_presence, grid, kBlock, st, d_text, n, bins);
+    unsigned long long host_bins[256];
+    SFX_HIP(hipMemcpyAsync(host_bins, bins, sizeof(host_bins), hipMemcpyDeviceToHost, st));
+    SFX_HIP(hipStreamSynchronize(st));
+    const Alphabet alpha = make_alphabet(host_bins);
+    if (alpha.bits > max_bits || packed_words(n, &alpha) > n / 8 + 8) return SFX_OK;
+    Alphabet a2;
+    SFX_TRY(prepare_text(d_text, n, bins, lut, d_packed, st, &a2, pt));
+    *packed = true;
+    return SFX_OK;
+}
+
+
 // Direct ordering of the small buckets of the active list (S_cur, *V_cur, b.G; m elements
 // sharing their first h symbols inside each bucket), followed by compaction of what is
 // still unresolved.  On return the active list is (*S_cur, *V_cur, b.G) with *m elements.

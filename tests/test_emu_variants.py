@@ -3,6 +3,7 @@ environment variables are read once per process, so every variant runs in a subp
   SFX_RADIX_SWEEP / _NW / _KPT / _RANK   radix schedules, tile geometries, ranking methods
   SFX_MAX_GRID                           multi-tile chunks per workgroup on small inputs
   SFX_PARTITION_MIN                      partitioned (cache-confined) rank / Phi scatters
+  SFX_LCP_DIRECT_MIN                     sampled choice between direct and Phi/PLCP LCP, cap + fallback
 Every run compares SA and LCP with the oracle on a few texts that exercise the path."""
 import os
 import subprocess
@@ -25,11 +26,39 @@ texts = [_gen.dna(40000, seed=9).tobytes(),                      # E64 path, sev
          _gen.english_like(15000, seed=3).tobytes(),             # 64-bit keys, rank rounds
          b"AAAAAAAAAAAAAAAAAAAAAAAC" * 600,                      # long repeats: many rounds
          _gen.dna(9000, seed=3).tobytes() + b"A" * 3000]
+if os.environ.get("SFX_LCP_DIRECT_MIN"):
+    # the sample says "low LCP", one run reaches the cap of the direct path -> Phi/PLCP redoes the array;
+    # then short texts whose last windows run off the end
+    texts.append(_gen.dna(50000, seed=11).tobytes() + b"A" * 1500 + _gen.dna(3000, seed=12).tobytes())
+    texts += [b"abcabcabcabcabcabcabx", b"a" * 40, _gen.utf8_mixed(5000).tobytes()]
+    # packed windows at 1, 3 and 4 bits per symbol, with repeats longer than one window
+    rng = np.random.default_rng(77)
+    for sigma in (2, 6, 12):
+        body = rng.integers(0, sigma, 12000, dtype=np.uint8) + 97
+        rep = body[1000:1000 + 90 + 40 * sigma].tobytes()
+        texts.append(body.tobytes() + rep + b"a" + rep)
 for t in texts:
     st = SuffixTable(t, engine=eng)
     exp = oracle.sais(t)
     assert np.array_equal(st.table(), exp), ("SA", len(t))
     assert np.array_equal(st.lcp_lens(), oracle.lcp_quadratic(t, exp)), ("LCP", len(t))
+if os.environ.get("SFX_LCP_DIRECT_MIN"):
+    def lcp_kernels(t):
+        st = SuffixTable(t, engine=eng)
+        st.table()
+        eng.profile(True); eng.profile_reset()
+        st.lcp_lens()
+        names = [r["name"] for r in eng.profile_report()]
+        eng.profile(False)
+        return names
+    k = lcp_kernels(texts[0])                          # DNA: direct, on packed symbols
+    assert "lcp_windows_packed" in k and "plcp" not in k, k
+    k = lcp_kernels(texts[1])                          # sigma > 16: direct, on the raw bytes
+    assert "lcp_windows" in k and "plcp" not in k, k
+    k = lcp_kernels(texts[2])                          # the sample says no
+    assert k == ["lcp_sample", "phi_scatter", "plcp", "lcp_gather"], k
+    k = lcp_kernels(texts[4])                          # cap reached: Phi/PLCP redoes the array
+    assert "lcp_windows_packed" in k and k[-3:] == ["phi_scatter", "plcp", "lcp_gather"], k
 print("OK")
 """
 
@@ -38,6 +67,7 @@ VARIANTS = {
     "one-sweep-4-waves-kpt16-ballot": {"SFX_RADIX_NW": "4", "SFX_RADIX_KPT": "16", "SFX_RADIX_RANK": "0"},
     "one-sweep-8-waves-kpt8": {"SFX_RADIX_NW": "8", "SFX_RADIX_KPT": "8", "SFX_MAX_GRID": "3"},
     "partitioned-scatter": {"SFX_PARTITION_MIN": "1"},
+    "direct-lcp": {"SFX_LCP_DIRECT_MIN": "8"},
 }
 
 
