@@ -188,6 +188,25 @@ def main():
     value = n_total * args.steps / elapsed / 1e6
     stats = eng.build_stats()
 
+    # ---- lcp_lens on the same text (reported next to the headline, never part of `value`:
+    # SuffixTable::new builds the suffix array only, src/table.rs:79-91; the LCP array is a
+    # separate call, :130-138) ----
+    lcp_info = None
+    if world == 1:
+        lcp_ws = sdev.lcp_workspace(n_local, dev)
+        lcp = torch.empty(n_local, dtype=torch.int32, device=dev)
+        sdev.build_lcp(text, sa, out=lcp, workspace=lcp_ws)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sdev.build_lcp(text, sa, out=lcp, workspace=lcp_ws)
+        barrier()
+        lcp_ms = (time.perf_counter() - t0) * 1e3 / max(args.steps, 1)
+        lcp_info = {"ms_per_step": round(lcp_ms, 3), "MB/s": round(n_local / lcp_ms / 1e3, 1),
+                    "sa_plus_lcp_MB/s": round(n_local / (lcp_ms + ms_per_step) / 1e3, 1),
+                    "note": "lcp_lens (src/table.rs:130-138) on the device-resident text and SA; not part of `value`"}
+        del lcp_ws
+
     # ---- per-kernel roofline: HIP events on the launch stream, separate untimed build ----
     eng.profile(True)
     eng.profile_reset()
@@ -256,7 +275,12 @@ def main():
             part, offset, n_all = result["part"]
             tot = torch.tensor([part.numel()], dtype=torch.int64, device=dev)
             dist.all_reduce(tot)
-            verified, how = bool(int(tot.item()) == n_all), "slice sizes sum to n (full parity: tests/)"
+            verified, how = bool(int(tot.item()) == n_all), "slice sizes sum to n"
+            if verified:
+                try:
+                    verified, how = sdist.verify_partitioned(text, part, n_all)
+                except Exception as exc:       # the gate must never cost the run its result line
+                    how += f"; full gate failed to run: {type(exc).__name__}: {exc}"
 
     # ---- CPU baseline: the oracle (C restatement of the reference's sais), 1 thread ----
     cpu = None
@@ -287,12 +311,24 @@ def main():
         except OSError:
             pass
         sub = torch.from_numpy(np.ascontiguousarray(sample)).to(dev)
-        got = sdev.build_sa(sub).cpu().numpy().view(np.uint32)
+        d_sub_sa = sdev.build_sa(sub)
+        got = d_sub_sa.cpu().numpy().view(np.uint32)
         torch.cuda.synchronize()
         same = bool(np.array_equal(got, exp))
+        if same and lcp_info is not None:
+            tc = time.perf_counter()
+            exp_lcp = oracle.lcp_kasai(sample, exp)
+            lcp_cpu_s = time.perf_counter() - tc
+            got_lcp = sdev.build_lcp(sub, d_sub_sa).cpu().numpy().view(np.uint32)
+            lcp_info["bit_exact_vs_oracle"] = bool(np.array_equal(got_lcp, exp_lcp))
+            lcp_info["cpu_kasai_MB/s"] = round(m / lcp_cpu_s / 1e6, 2)
+            same = same and lcp_info["bit_exact_vs_oracle"]
+            del exp_lcp, got_lcp
         verified = bool(verified) and same if verified is not None else same
         how += ("; complete SA bit-exact vs oracle" if m == n_local else "; SA of the CPU sample bit-exact vs oracle") \
             if same else "; MISMATCH vs oracle on CPU sample"
+        if lcp_info is not None and lcp_info.get("bit_exact_vs_oracle"):
+            how += "; LCP of the same bytes bit-exact vs oracle (Kasai)"
         cpu = {"value": round(m / cpu_s / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
                "sample": f"{'all' if m == n_local else 'first'} {m} bytes of the same DNA text, oracle.sais (C restatement of "
                          f"src/table.rs:388-574, gcc -O3 -march=native), pinned to one core, best of 3: {cpu_s:.1f} s",
@@ -309,7 +345,7 @@ def main():
                                    + ("" if world == 1 else f"; range-partitioned over {world} GPUs, "
                                       f"text {n_total} B"),
                        "text_bytes_total": n_total, "build": stats},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "lcp": lcp_info,
             "verified": verified, "verification": how,
         }
         print(json.dumps(out))

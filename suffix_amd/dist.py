@@ -150,23 +150,76 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
     return (part, offset, n, text) if return_text else (part, offset, n)
 
 
-def build_lcp_partitioned(text, sa_part, group=None, engine=None):
-    """LCP of this rank's slice of the partitioned suffix array.  The only exchange is one
-    suffix index per rank (the last element of every slice, all-gathered): rank r needs the
-    last suffix of the nearest non-empty slice before it.  text = the all-gathered text."""
-    from .device import build_lcp_range
+def previous_slice_last(sa_part, group=None):
+    """The suffix that precedes this rank's slice in the global suffix array: the last element of
+    the nearest non-empty slice before it (None for the first).  One index per rank, all-gathered."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    dev = text.device
+    dev = sa_part.device
     mine = torch.tensor([int(sa_part[-1]) & 0xFFFFFFFF if sa_part.numel() else -1], dtype=torch.int64, device=dev)
     lasts = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(lasts, mine, group=group)
-    prev = None
     for r in range(rank - 1, -1, -1):
         if int(lasts[r]) >= 0:
-            prev = int(lasts[r])
-            break
+            return int(lasts[r])
+    return None
+
+
+_FETCH = object()
+
+
+def build_lcp_partitioned(text, sa_part, group=None, engine=None, prev=_FETCH):
+    """LCP of this rank's slice of the partitioned suffix array.  The only exchange is one
+    suffix index per rank (previous_slice_last; pass prev= to reuse one already fetched).
+    text = the all-gathered text."""
+    from .device import build_lcp_range
+    if prev is _FETCH:
+        prev = previous_slice_last(sa_part, group)
     return build_lcp_range(text, sa_part, prev, engine=engine)
+
+
+def verify_partitioned(shard, sa_part, n, group=None, engine=None):
+    """Size-independent correctness gate for a partitioned suffix array (bench.py, N > 1; outside
+    any timed region): (1) the slices together are a permutation of 0..n-1 (per-rank marks,
+    all-reduced); (2) every adjacent pair -- inside the slices and across their boundaries -- is
+    in strictly increasing suffix order, with the engine's per-slice LCP giving the position of
+    the first difference.  -> (ok, description), identical on every rank."""
+    world = dist.get_world_size(group)
+    dev = shard.device
+    text = torch.empty(n, dtype=torch.uint8, device=dev)
+    try:
+        dist.all_gather_into_tensor(text, shard.contiguous(), group=group)
+    except (RuntimeError, NotImplementedError, AttributeError):
+        dist.all_gather(list(text.split(shard.numel())), shard.contiguous(), group=group)
+    cur = sa_part.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    marks = torch.zeros(n, dtype=torch.int32, device=dev)
+    marks.index_add_(0, cur, torch.ones(cur.numel(), dtype=torch.int32, device=dev))
+    dist.all_reduce(marks, op=dist.ReduceOp.SUM, group=group)
+    why = None
+    if not bool((marks == 1).all()):
+        why = "not a permutation"
+    del marks
+    prev = previous_slice_last(sa_part, group)
+    if why is None and cur.numel():
+        lcp = build_lcp_partitioned(text, sa_part, group, engine, prev=prev)
+        h = lcp.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        before = torch.empty_like(cur)
+        before[1:] = cur[:-1]
+        before[0] = prev if prev is not None else 0
+        skip = 1 if prev is None else 0
+        pa, pb = (before + h)[skip:], (cur + h)[skip:]
+        if bool((pb >= n).any()):
+            why = "right suffix exhausted before left one"
+        else:
+            ca = text[torch.clamp(pa, max=n - 1)].to(torch.int32)
+            cb = text[pb].to(torch.int32)
+            if not bool(((pa >= n) | (ca < cb)).all()):
+                why = "adjacent suffixes out of order"
+    bad = torch.tensor([0 if why is None else 1], dtype=torch.int64, device=dev)
+    dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=group)
+    if int(bad.item()):
+        return False, why or "another rank's slice failed"
+    return True, f"permutation (marks all-reduced over {world} ranks) + adjacent order of every pair, slice boundaries included"
 
 
 def positions_partitioned(text, sa_part, offset, qbytes, qoff, group=None, engine=None):

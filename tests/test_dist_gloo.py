@@ -46,6 +46,13 @@ np.save(os.path.join(os.environ["SFX_OUT"], f"q{{rank}}.npy"), np.stack([gs.nump
 # u64 indices (BASELINE config 4)
 p64, o64, _n = sdist.build_sa_partitioned(shard, engine=eng, top_bits=10, index_dtype=torch.int64)
 assert p64.dtype == torch.int64 and o64 == offset and np.array_equal(p64.numpy().astype(np.uint32), part.numpy().view(np.uint32))
+ok, how = sdist.verify_partitioned(shard, part, n, engine=eng)
+assert ok, how
+bad = part.clone(); 
+if bad.numel() > 1:
+    bad[0], bad[1] = part[1].clone(), part[0].clone()          # one swapped pair must be caught (on every rank)
+ok2, how2 = sdist.verify_partitioned(shard, bad, n, engine=eng)
+assert not ok2, how2
 dist.barrier()
 dist.destroy_process_group()
 """
