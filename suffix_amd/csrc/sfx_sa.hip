@@ -526,6 +526,7 @@ constexpr int kGroupTile = kBlock * kGroupItems;     // 2048 elements per workgr
 constexpr int kApplySub = 4;                         // the apply kernel takes 4 such groups per thread
 constexpr int kApplyItems = kGroupItems * kApplySub; // 32 consecutive elements per thread
 constexpr int kApplyTile = kBlock * kApplyItems;     // 8192 elements per workgroup step; chunks are multiples of it
+constexpr uint64_t kSparseApplyDivisor = 8;          // sparse form when at most 1/8 of the elements are kept
 
 // A thread's 8 consecutive keys plus both neighbours, fetched with 16-byte loads (K is a
 // workspace array, 256-B aligned, and tile bases are multiples of 2048).  Loading is split
@@ -671,7 +672,11 @@ k_groups_scan(uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep
 // non-singleton buckets into (S_next, V_next, G_next = bucket id = position of the
 // bucket's head in the compacted list: unique and increasing along the list; and, if
 // R_next, R_next = slot of the bucket head).
-template <class KeyT>
+// SUB = flag words (groups of 8 elements) per thread.  SUB = 4 is the sparse form: SA in place,
+// no rank array, few kept elements -- only the set bits of the keep mask are visited.  SUB = 1
+// is the dense form (every element writes its SA slot and / or rank): 8 elements per thread
+// keep 4x as many gathers in flight.
+template <class KeyT, int SUB>
 __global__ void __launch_bounds__(kBlock)
 k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                const uint32_t* __restrict__ S, uint64_t m, uint64_t chunk,
@@ -692,21 +697,26 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     (void)part_ghead;
     unsigned par = 0;
     (void)K;
-    // head / single bits of the thread's 32 elements = 4 flag words of k_groups_reduce, one
-    // 8-byte load (25 MB per 10^8 elements instead of reading the keys a second time); the next
-    // tile's words are in flight while this tile is scanned
+    // head / single bits of the thread's elements = SUB flag words of k_groups_reduce, one load
+    // (25 MB per 10^8 elements instead of reading the keys a second time); the next tile's
+    // words are in flight while this tile is scanned
+    constexpr int kItems = kGroupItems * SUB;
+    constexpr int kTile = kBlock * kItems;
+    static_assert(SUB == 1 || SUB == 4, "one 2-byte or one 8-byte flag load per thread");
     auto load_flags = [&](uint64_t i0) -> uint64_t {
-        return i0 < end ? *reinterpret_cast<const uint64_t*>(flags_in + i0 / kGroupItems) : 0ull;
+        if (i0 >= end) return 0ull;
+        if (SUB == 4) return *reinterpret_cast<const uint64_t*>(flags_in + i0 / kGroupItems);
+        return (uint64_t)flags_in[i0 / kGroupItems];
     };
-    uint64_t nf = load_flags(begin + (uint64_t)tid * kApplyItems);
-    for (uint64_t tile = begin; tile < end; tile += kApplyTile) {
-        const uint64_t i0 = tile + (uint64_t)tid * kApplyItems;
+    uint64_t nf = load_flags(begin + (uint64_t)tid * kItems);
+    for (uint64_t tile = begin; tile < end; tile += kTile) {
+        const uint64_t i0 = tile + (uint64_t)tid * kItems;
         const uint64_t f = nf;
-        if (tile + kApplyTile < end) nf = load_flags(i0 + kApplyTile);
+        if (tile + kTile < end) nf = load_flags(i0 + kTile);
         // 32-bit masks over the thread's elements (groups past `end` were never written: masked off)
         uint32_t head = 0, single = 0, valid = 0;
 #pragma unroll
-        for (int b = 0; b < kApplySub; b++) {
+        for (int b = 0; b < SUB; b++) {
             const uint64_t ib = i0 + (uint64_t)b * kGroupItems;
             if (ib < end) {
                 const uint32_t fw = (uint32_t)(f >> (16 * b)) & 0xFFFFu;
@@ -736,7 +746,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         const uint32_t ec = ba + ia - cnt;
         uint32_t run_head = dmax(c_head, dmax(bm, pm));          // index+1 of the last head before item 0
         uint32_t run_keep = c_keep + ec;
-        if (sa_in_place && !isa) {
+        if (SUB > 1) {                                   // (the host picks SUB = 4 only with sa_in_place && !isa)
             // only the kept elements have anything to write (a few per cent of a first round):
             // walk the set bits of the keep mask; every quantity is a bit trick on the two masks
             uint32_t k = keepm;
@@ -756,7 +766,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
             }
         } else
 #pragma unroll
-        for (int b = 0; b < kApplySub; b++) {
+        for (int b = 0; b < SUB; b++) {
             const uint64_t ib = i0 + (uint64_t)b * kGroupItems;
             const unsigned v8 = (valid >> (8 * b)) & 0xFFu, h8 = (head >> (8 * b)) & 0xFFu, k8 = (keepm >> (8 * b)) & 0xFFu;
             if (k8 || ((isa || !sa_in_place) && v8)) {           // (all-singleton groups have nothing to write in place)
@@ -1102,7 +1112,8 @@ static int round_totals(const KeyT* K, uint64_t m, SaBuffers& b, hipStream_t st,
 template <class KeyT>
 static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint64_t m, SaBuffers& b,
                        uint32_t* sa, uint32_t* isa, uint32_t* S_next, uint32_t* V_next,
-                       uint32_t* R_next, hipStream_t st, bool sa_in_place, uint64_t n, sfx_build_stats& stats)
+                       uint32_t* R_next, hipStream_t st, bool sa_in_place, uint64_t n, sfx_build_stats& stats,
+                       uint64_t kept)
 {
     // the sorted keys K sit in one of K0/K1 (for 32-bit keys: in its first half); the other
     // one is free for the (suffix, rank) pairs, and K's own buffer is free once this kernel is done
@@ -1114,11 +1125,17 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
         pairs_tmp = k_in_0 ? b.K0 : b.K1;
     }
     Chunking ch = make_chunking(m, kApplyTile);
-    SFX_LAUNCH(sizeof(KeyT) == 4 ? "groups_apply_u32" : "groups_apply_u64",
-               (double)m * (0.25 + (sa_in_place ? 0 : 8) + (isa ? 4 : 0) + (S ? 4 : 0)),
-               (k_groups_apply<KeyT>), ch.blocks, kBlock, st, K, V, S, m, ch.tiles_per_block * kApplyTile,
-               b.part_head, b.part_keep, b.part_ghead, sa_in_place ? (uint32_t*)nullptr /* V is the SA */ : sa, isa,
-               S_next, V_next, b.G, R_next, sa_in_place ? 1 : 0, pairs, (const uint16_t*)b.F);
+    const char* name = sizeof(KeyT) == 4 ? "groups_apply_u32" : "groups_apply_u64";
+    const double algo = (double)m * (0.25 + (sa_in_place ? 0 : 8) + (isa ? 4 : 0) + (S ? 4 : 0));
+    uint32_t* sa_arg = sa_in_place ? (uint32_t*)nullptr /* V is the SA */ : sa;
+    if (sa_in_place && !isa && kept * kSparseApplyDivisor <= m)
+        SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, kApplySub>), ch.blocks, kBlock, st, K, V, S, m,
+                   ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
+                   b.G, R_next, 1, pairs, (const uint16_t*)b.F);
+    else
+        SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, 1>), ch.blocks, kBlock, st, K, V, S, m,
+                   ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
+                   b.G, R_next, sa_in_place ? 1 : 0, pairs, (const uint16_t*)b.F);
     if (pairs) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, m, n, isa, b.hist, st, &stats));
     return SFX_OK;
 }
@@ -1287,7 +1304,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         SFX_TRY(round_totals<uint64_t>(Kr, m, b, st, &kept, &kept_groups));
         const bool full_text_round = isa && text_round;
         SFX_TRY(round_apply<uint64_t>(Kr, Vr, S_cur, m, b, sa, (isa && !text_round) ? isa : nullptr,
-                                      S_next, V_next, full_text_round ? b.R : nullptr, st, false, n, stats));
+                                      S_next, V_next, full_text_round ? b.R : nullptr, st, false, n, stats, kept));
         h = text_round ? h + (uint64_t)spw : h * 2;
         if (full_text_round && --text_rounds == 0 && kept > 0) {
             // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
@@ -1349,7 +1366,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     const int text_rounds =
         (isa && ((kept * kTextFirstDivisor <= count && pt.spw >= 8) || small_groups_pay(kept, groups))) ? 1 : 0;
     SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, (isa && !text_rounds) ? isa : nullptr, b.S0, V_next,
-                              nullptr, st, in_place, pt.n, stats));
+                              nullptr, st, in_place, pt.n, stats, kept));
     uint32_t* S_cur = b.S0;
     const uint64_t id_bound = kept;
     if (small_groups_pay(kept, groups)) {
