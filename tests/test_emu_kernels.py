@@ -5,6 +5,7 @@ small because every work-item is a fiber on one CPU core."""
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 import _cases
@@ -113,3 +114,6 @@ def test_range_build_virtual_ranks(emu, oracle, nranges):
     _cases.range_slices(emu, oracle, _gen.dna(7001, seed=8).tobytes(), nranges, packed=(nranges != 3))
     _cases.range_slices(emu, oracle, _gen.english_like(5003).tobytes(), nranges, packed=(nranges == 3))
     _cases.range_slices(emu, oracle, (b"ab" * 900 + b"b"), nranges)
+    rng = np.random.default_rng(5)
+    _cases.range_slices(emu, oracle, rng.integers(0, 256, 2500, dtype=np.uint8).tobytes(), nranges, packed=True)
+    _cases.range_slices(emu, oracle, (rng.integers(0, 11, 2500, dtype=np.uint8) + 65).tobytes(), nranges)
