@@ -161,7 +161,8 @@ k_radix_hist_all(Src src, uint64_t m, int bit_lo, int bit_hi, int npass, uint64_
     uint64_t end = begin + chunk;
     if (end > m) end = m;
     uint64_t i = begin + tid;
-    for (; i + 3 * kBlock < end; i += 4 * kBlock) {
+    // (whole waves only: the loop condition is the same for all 64 lanes, the wave-wide test below needs it)
+    for (; i - lane_id() + (kWave - 1) + 3 * kBlock < end; i += 4 * kBlock) {
         uint64_t k[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) k[j] = src.key(i + (uint64_t)j * kBlock);
@@ -169,7 +170,16 @@ k_radix_hist_all(Src src, uint64_t m, int bit_lo, int bit_hi, int npass, uint64_
             const int shift = bit_lo + p * kRadixBits;
             const int nb = bit_hi - shift < kRadixBits ? bit_hi - shift : kRadixBits;
 #pragma unroll
-            for (int j = 0; j < 4; j++) atomicAdd(&h[w][p][digit_of(k[j], shift, (1u << nb) - 1u)], 1u);
+            for (int j = 0; j < 4; j++) {
+                // the high digits of sorted or bucket-ordered keys are the same across a wave:
+                // one add of 64 instead of 64 atomics on one LDS address
+                const unsigned d = digit_of(k[j], shift, (1u << nb) - 1u);
+                if (!Src::kFromText && __all(d == __shfl(d, 0))) {        // (text-fed keys are not ordered: no test)
+                    if (lane_id() == 0) atomicAdd(&h[w][p][d], (uint32_t)kWave);
+                } else {
+                    atomicAdd(&h[w][p][d], 1u);
+                }
+            }
         }
     }
     for (; i < end; i += kBlock) {
