@@ -791,9 +791,10 @@ int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
 // target[idx] = val for m (idx << 32 | val) pairs whose idx values are spread over [0, n).
 // A random 4-byte write into a multi-GB array costs a 128-byte read-modify-write in HBM
 // (22-25 G writes/s measured on the rank and Phi scatters at n = 4*10^8 ... 10^9, whatever the
-// array size beyond the L2).  Radix passes on the top 20 bits of idx first confine each
-// stretch of the stream to a few KB of the target, which the L2 absorbs; the passes cost
-// less than the scatter saves (34 vs 44 ms per 10^9 pairs), a full sort would not.
+// array size beyond the L2).  Three radix passes on the top 24 bits of idx first confine each
+// stretch of the stream to a 256-byte window of the target, so the writes of a wave merge into
+// whole lines; the passes cost less than the scatter saves (26 vs 44 ms per 10^9 pairs), the
+// fourth pass of a full sort would not.
 __global__ void __launch_bounds__(kBlock)
 k_scatter_pairs(const uint64_t* __restrict__ pairs, uint64_t m, uint32_t* __restrict__ target)
 {
@@ -814,8 +815,10 @@ int scatter_pairs_u32(uint64_t* pairs, uint64_t* tmp, uint64_t m, uint64_t n, ui
 {
     if (m == 0) return SFX_OK;
     const int nb = bits_for(n > 1 ? n - 1 : 1);
-    // measured at n = 10^9 (ms): direct scatter 44; 8 bits 50; 12 bits 52; 16 bits 37; 20 bits 34
-    static const int part_bits = [] { const char* e = getenv("SFX_PARTITION_BITS"); int v = e ? atoi(e) : 20; return v >= 8 && v <= 24 ? v : 20; }();
+    // measured at n = 10^9 (ms, sort + scatter): direct scatter 44; 8 bits 50; 12 bits 52; 16 bits 37;
+    // 20 bits (3 passes, 4 KB windows) 34; 24 bits (still 3 passes, 256-byte windows: the writes
+    // coalesce into whole lines) 26
+    static const int part_bits = [] { const char* e = getenv("SFX_PARTITION_BITS"); int v = e ? atoi(e) : 24; return v >= 8 && v <= 24 ? v : 24; }();
     const int lo = nb > part_bits ? nb - part_bits : 0;
     int in1 = 0;
     SFX_TRY(radix_sort_e64(pairs, tmp, m, 32 + lo, 32 + nb, radix_scratch, st, &in1, stats, nullptr, nullptr, nullptr));
