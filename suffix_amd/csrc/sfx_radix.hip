@@ -547,16 +547,17 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
 //   SFX_RADIX_KPT_TEXT  ... of the text-fed pass: 16 (default), 11 or 8
 //   SFX_RADIX_RANK   1 = LDS match masks (default), 0 = 8-ballot match
 //   SFX_RADIX_NW     waves per workgroup: 4, 8 or 16 (default); tile = 64 * NW * KPT elements
-struct RadixTuning { int sweep, kpt, rank, nw, kpt_text; };
+struct RadixTuning { int sweep, kpt, rank, nw, kpt_text, kpt_kv; };
 static RadixTuning radix_tuning()
 {
     static const RadixTuning t = [] {
-        RadixTuning r = {1, 11, 1, 16, 16};          // measured best on MI355X (profiles/r1c_radix_variants.txt):
+        RadixTuning r = {1, 11, 1, 16, 16, 9};          // measured best on MI355X (profiles/r1c_radix_variants.txt):
                                                 // 1024-thread workgroups, 8192-element tiles = 256-byte runs
         if (const char* e = getenv("SFX_RADIX_SWEEP")) r.sweep = atoi(e) ? 1 : 0;
         if (const char* e = getenv("SFX_RADIX_KPT")) r.kpt = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 8;
         if (const char* e = getenv("SFX_RADIX_RANK")) r.rank = atoi(e) ? 1 : 0;
         if (const char* e = getenv("SFX_RADIX_KPT_TEXT")) r.kpt_text = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 16;
+        if (const char* e = getenv("SFX_RADIX_KPT_KV")) r.kpt_kv = atoi(e) == 9 ? 9 : 8;
         if (const char* e = getenv("SFX_RADIX_NW")) r.nw = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 4);
         return r;
     }();
@@ -629,6 +630,11 @@ static int run_pass(const char* name, double algo_bytes, const Src& src, const D
             const int kk = Src::kFromText ? t.kpt_text : t.kpt;
             if (kk == 16) SFX_PASS_NW(16, 16);
             if (kk == 11) SFX_PASS_NW(11, 16);
+        }
+        if constexpr (Src::kHasVal && !Src::kFromText) {
+            // KV passes (12-byte elements): 9 per thread is the largest tile without spills;
+            // 8 / 9 / 10 measured 106.2 / 102.0 / 105.1 ms over the 23 KV passes of config 3
+            if (t.kpt_kv == 9) SFX_PASS_NW(9, 16);
         }
         SFX_PASS_NW(8, 16);
     }
