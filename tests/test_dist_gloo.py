@@ -22,7 +22,7 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 eng = suffix_amd.Engine(os.path.join({here!r}, "emu", "libsuffix_emu.so"))
 kind = os.environ["SFX_CASE"]
-m = 6000
+m = 1200 if kind == "periodic" else 6000        # (periodic text: one text round per 32 symbols of LCP)
 if kind == "dna":
     full = _gen.dna(m * world, seed=99)
 elif kind == "text":
@@ -38,7 +38,7 @@ np.save(os.path.join(os.environ["SFX_OUT"], f"off{{rank}}.npy"), np.array([offse
 lcp = sdist.build_lcp_partitioned(text, part, engine=eng)
 np.save(os.path.join(os.environ["SFX_OUT"], f"lcp{{rank}}.npy"), lcp.numpy().view(np.uint32))
 fb = full.tobytes()
-qs = [fb[100:106], fb[-7:], b"zzzz", fb[3000:3002], fb[m - 2:m + 3], fb[5:6]]
+qs = [fb[100:106], fb[-7:], b"zzzz", fb[m // 2:m // 2 + 2], fb[m - 2:m + 3], fb[5:6]]
 qb = torch.from_numpy(np.frombuffer(b"".join(qs), dtype=np.uint8).copy())
 qoff = torch.tensor(np.concatenate([[0], np.cumsum([len(q) for q in qs])]), dtype=torch.int64)
 gs, ge = sdist.positions_partitioned(text, part, offset, qb, qoff, engine=eng)
@@ -69,7 +69,7 @@ def test_partitioned_build_two_ranks(tmp_path, oracle, case):
                            str(script)], env=env, timeout=600)
     sys.path.insert(0, HERE)
     import _gen
-    m, world = 6000, 2
+    m, world = (1200 if case == "periodic" else 6000), 2
     if case == "dna":
         full = _gen.dna(m * world, seed=99)
     elif case == "text":
@@ -85,7 +85,7 @@ def test_partitioned_build_two_ranks(tmp_path, oracle, case):
     text = full.tobytes()
     lcps = [np.load(tmp_path / f"lcp{r}.npy") for r in range(world)]
     assert np.array_equal(np.concatenate(lcps), oracle.lcp_quadratic(text, exp))
-    qs = [text[100:106], text[-7:], b"zzzz", text[3000:3002], text[m - 2:m + 3], text[5:6]]
+    qs = [text[100:106], text[-7:], b"zzzz", text[m // 2:m // 2 + 2], text[m - 2:m + 3], text[5:6]]
     for r in range(world):                                   # every rank holds the same global answer
         q = np.load(tmp_path / f"q{r}.npy")
         for k, query in enumerate(qs):

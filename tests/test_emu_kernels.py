@@ -111,9 +111,9 @@ def test_build_stats_and_profile(emu):
 @pytest.mark.parametrize("nranges", [1, 3, 11])
 def test_range_build_virtual_ranks(emu, oracle, nranges):
     import _gen
-    _cases.range_slices(emu, oracle, _gen.dna(7001, seed=8).tobytes(), nranges, packed=(nranges != 3))
-    _cases.range_slices(emu, oracle, _gen.english_like(5003).tobytes(), nranges, packed=(nranges == 3))
+    _cases.range_slices(emu, oracle, _gen.dna(3001, seed=8).tobytes(), nranges, packed=(nranges != 3))
+    _cases.range_slices(emu, oracle, _gen.english_like(2503).tobytes(), nranges, packed=(nranges == 3))
     _cases.range_slices(emu, oracle, (b"ab" * 900 + b"b"), nranges)
     rng = np.random.default_rng(5)
-    _cases.range_slices(emu, oracle, rng.integers(0, 256, 2500, dtype=np.uint8).tobytes(), nranges, packed=True)
-    _cases.range_slices(emu, oracle, (rng.integers(0, 11, 2500, dtype=np.uint8) + 65).tobytes(), nranges)
+    _cases.range_slices(emu, oracle, rng.integers(0, 256, 1500, dtype=np.uint8).tobytes(), nranges, packed=True)
+    _cases.range_slices(emu, oracle, (rng.integers(0, 11, 1500, dtype=np.uint8) + 65).tobytes(), nranges)
