@@ -113,7 +113,7 @@ def test_range_build_virtual_ranks(emu, oracle, nranges):
     import _gen
     _cases.range_slices(emu, oracle, _gen.dna(3001, seed=8).tobytes(), nranges, packed=(nranges != 3))
     _cases.range_slices(emu, oracle, _gen.english_like(2503).tobytes(), nranges, packed=(nranges == 3))
-    _cases.range_slices(emu, oracle, (b"ab" * 900 + b"b"), nranges)
+    _cases.range_slices(emu, oracle, (b"ab" * 150 + b"b"), nranges)
     rng = np.random.default_rng(5)
     _cases.range_slices(emu, oracle, rng.integers(0, 256, 1500, dtype=np.uint8).tobytes(), nranges, packed=True)
     _cases.range_slices(emu, oracle, (rng.integers(0, 11, 1500, dtype=np.uint8) + 65).tobytes(), nranges)
