@@ -185,3 +185,31 @@ def test_range_build_many_ranges(eng, oracle, nranges):
     _cases.range_slices(eng, oracle, _gen.dna(1_000_003, seed=8).tobytes(), nranges, device="cuda", packed=True)
     _cases.range_slices(eng, oracle, _gen.dna(300_001, seed=9).tobytes(), nranges, device="cuda")
     _cases.range_slices(eng, oracle, _gen.english_like(400_000).tobytes(), nranges, device="cuda", packed=(nranges == 9))
+
+
+def test_lcp_routes_at_scale(eng, oracle):
+    """The three routes of lcp_lens above the 1 MB threshold: direct on packed symbols, direct on
+    raw bytes, and a pair that reaches the cap of the direct pass (Phi/PLCP then redoes the array)."""
+    from suffix_amd import SuffixTable
+
+    def kernels_of_lcp(text):
+        st = SuffixTable(text, engine=eng)
+        exp_sa = oracle.sais(text)
+        assert np.array_equal(st.table(), exp_sa)
+        eng.profile(True)
+        eng.profile_reset()
+        got = st.lcp_lens()
+        names = [r["name"] for r in eng.profile_report()]
+        eng.profile(False)
+        assert np.array_equal(got, oracle.lcp_kasai(text, exp_sa))
+        return names
+
+    d = _gen.dna(1_500_000, seed=77).tobytes()
+    k = kernels_of_lcp(d)
+    assert "lcp_windows_packed" in k and "plcp" not in k, k
+    k = kernels_of_lcp(_gen.utf8_mixed(1_200_000).tobytes())
+    assert "lcp_windows" in k and "plcp" not in k, k
+    k = kernels_of_lcp(d[:1_000_000] + b"A" * 3000 + d[1_000_000:])
+    assert "lcp_windows_packed" in k and "plcp" in k, k
+    k = kernels_of_lcp((_gen.english_like(30_000).tobytes()) * 40)         # the sample says: repetitive
+    assert "lcp_windows" not in k and "lcp_windows_packed" not in k and "plcp" in k, k
