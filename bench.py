@@ -142,6 +142,39 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # second test hook: SFX_BENCH_FORCE_PARTITIONED=1 times the partitioned build at world = 1 (its
+    # collectives degenerate), i.e. the host-side cost of the multi-GPU path on top of its kernels
+    force_part = os.environ.get("SFX_BENCH_FORCE_PARTITIONED") == "1" and world == 1
+    if force_part:
+        class _Done:
+            def wait(self):
+                return True
+
+        class _OneRank:                                  # the collectives of a 1-rank world, on the device
+            ReduceOp = dist.ReduceOp
+
+            @staticmethod
+            def get_world_size(group=None):
+                return 1
+
+            @staticmethod
+            def get_rank(group=None):
+                return 0
+
+            @staticmethod
+            def all_reduce(t, op=None, group=None):
+                return None
+
+            @staticmethod
+            def all_gather_into_tensor(dst, src, group=None, async_op=False):
+                dst.copy_(src)
+                return _Done() if async_op else None
+
+            @staticmethod
+            def all_gather(lst, src, group=None, async_op=False):
+                lst[0].copy_(src)
+                return _Done() if async_op else None
+        sdist.dist = _OneRank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
@@ -166,6 +199,9 @@ def main():
 
         def step():
             sdev.build_sa(text, out=sa, workspace=ws)
+        if force_part:
+            def step():                                        # noqa: F811  (test hook, see above)
+                sa.copy_(sdist.build_sa_partitioned(text)[0])
     else:
         result = {}
 
