@@ -60,7 +60,12 @@ int sfx_widen_u32_to_u64_dev(const uint32_t* d_in, uint64_t count, uint64_t* d_o
 void sfx_release_cached_buffers(void);
 
 /* ---- lcp_lens (:130-138 -> lcp_lens_quadratic :348-361): LCP array ---------- */
-/* lcp_out[0] = 0, lcp_out[r] = |lcp(text[sa[r-1]..], text[sa[r]..])| in bytes. */
+/* lcp_out[0] = 0, lcp_out[r] = |lcp(text[sa[r-1]..], text[sa[r]..])| in bytes.
+ * The array is the same whichever route computes it: from 1 MiB of text up a sample of
+ * adjacent pairs picks the reference's direct comparison (one window gather per suffix, capped;
+ * the right choice for low-LCP text) or the linear Phi/PLCP form; a pair that reaches the cap
+ * of the direct route sends the whole array through Phi/PLCP, so the cost stays linear in n.
+ * The _dev entry synchronises the stream once or twice to read that choice back. */
 int sfx_build_lcp_u32(const uint8_t* text, uint64_t n, const uint32_t* sa, uint32_t* lcp_out);
 uint64_t sfx_lcp_workspace_bytes(uint64_t n);
 int sfx_build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa,
