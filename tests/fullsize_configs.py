@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Full-size runs of BASELINE.json configs 3 and 5 (and a 1 GB DNA control) on one
 MI355X: device-resident SA (+LCP, + 1M batched queries), size-independent property
-checks, sampled comparison with the oracle.  Writes gpurun_out/big/results.jsonl."""
+checks, sampled comparison with the oracle.  Writes gpurun_out/big/results.jsonl.
+Lives under tests/ because it uses the oracle (as checker and as the timed CPU baseline);
+it is a script, not a pytest module:
+    gpurun --timeout 1500 -- 'python tests/fullsize_configs.py [c3 c5 dna1g dna2g eng2g c4single]'"""
 import json
 import os
 import sys
