@@ -2,6 +2,7 @@
 // libsuffix_hip.so: status codes, HIP error capture, a bump allocator over the
 // caller's device workspace, and the optional per-kernel event profiler.
 #pragma once
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -102,6 +103,28 @@ void profile_end(hipStream_t st);
         if (::sfx::profile_on()) ::sfx::profile_end(stream);                            \
         SFX_HIP(hipGetLastError());                                                     \
     } while (0)
+
+// Small device -> host read-backs (round totals, alphabet bins, counters) go through a
+// per-thread pinned staging buffer: a copy into pageable memory is staged by the runtime
+// itself, synchronously and more slowly, and every build waits on three or four of them.
+inline int read_back(void* dst, const void* d_src, size_t bytes, hipStream_t st)
+{
+    constexpr size_t kStage = 4096;
+    thread_local void* stage = nullptr;
+    thread_local bool tried = false;
+    if (!tried) {
+        tried = true;
+        if (hipHostMalloc(&stage, kStage, hipHostMallocDefault) != hipSuccess) {
+            stage = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    void* via = (stage && bytes <= kStage) ? stage : dst;
+    SFX_HIP(hipMemcpyAsync(via, d_src, bytes, hipMemcpyDeviceToHost, st));
+    SFX_HIP(hipStreamSynchronize(st));
+    if (via != dst) std::memcpy(dst, via, bytes);
+    return SFX_OK;
+}
 
 // ---- cross-TU entry points ----------------------------------------------------------
 struct BuildStats;   // = sfx_build_stats

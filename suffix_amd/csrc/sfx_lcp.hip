@@ -370,8 +370,7 @@ int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, u
         const uint64_t every = (n - 1) / samples;
         SFX_LAUNCH("lcp_sample", (double)samples * 24, k_lcp_sample, (samples + kBlock - 1) / kBlock, kBlock, st, d_text,
                    n, d_sa, samples, every, counters);
-        SFX_HIP(hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, st));
-        SFX_HIP(hipStreamSynchronize(st));
+        SFX_TRY(read_back(host, counters, sizeof(host), st));
         if (host[0] <= kSampleMeanMax * samples) {
             PackedText pt;
             bool packed = false;
@@ -381,8 +380,7 @@ int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, u
                            counters);
             else
                 SFX_LAUNCH("lcp_windows", (double)n * 24, k_lcp_windows, grid, kBlock, st, d_text, n, d_sa, d_lcp, counters);
-            SFX_HIP(hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, st));
-            SFX_HIP(hipStreamSynchronize(st));
+            SFX_TRY(read_back(host, counters, sizeof(host), st));
             if (host[1] == 0) return SFX_OK;
         }
     }

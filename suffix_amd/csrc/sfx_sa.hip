@@ -1102,8 +1102,7 @@ static int round_totals(const KeyT* K, uint64_t m, SaBuffers& b, hipStream_t st,
     SFX_LAUNCH("groups_scan", 0.0, k_groups_scan, 1, kBlock, st, b.part_head, b.part_keep,
                b.part_ghead, ch.blocks, b.totals);
     uint32_t host_totals[2] = {0, 0};
-    SFX_HIP(hipMemcpyAsync(host_totals, b.totals, sizeof(host_totals), hipMemcpyDeviceToHost, st));
-    SFX_HIP(hipStreamSynchronize(st));
+    SFX_TRY(read_back(host_totals, b.totals, sizeof(host_totals), st));
     *kept = host_totals[0];
     *kept_groups = host_totals[1];
     return SFX_OK;
@@ -1162,9 +1161,8 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
                         PackedText* pt, uint64_t n_words_out = 0, const uint32_t* packed_in = nullptr)
 {
     unsigned long long host_bins[256];
-    SFX_HIP(hipMemcpyAsync(host_bins, d_bins, sizeof(host_bins), hipMemcpyDeviceToHost, st));
     if (!packed_in) SFX_LAUNCH("make_lut", 0.0, k_make_lut, 1, kBlock, st, d_bins, d_lut);
-    SFX_HIP(hipStreamSynchronize(st));
+    SFX_TRY(read_back(host_bins, d_bins, sizeof(host_bins), st));
     *alpha = make_alphabet(host_bins);
     if (packed_in) {
         pt->words = packed_in;
@@ -1216,8 +1214,7 @@ int pack_small_alphabet(const uint8_t* d_text, uint64_t n, int max_bits, void* s
     const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock * 64 - 1) / (kBlock * 64), kMaxGrid);
     SFX_LAUNCH("byte_presence", (double)n, k_byte_presence, grid, kBlock, st, d_text, n, bins);
     unsigned long long host_bins[256];
-    SFX_HIP(hipMemcpyAsync(host_bins, bins, sizeof(host_bins), hipMemcpyDeviceToHost, st));
-    SFX_HIP(hipStreamSynchronize(st));
+    SFX_TRY(read_back(host_bins, bins, sizeof(host_bins), st));
     const Alphabet alpha = make_alphabet(host_bins);
     if (alpha.bits > max_bits || packed_words(n, &alpha) > n / 8 + 8) return SFX_OK;
     Alphabet a2;
@@ -1247,8 +1244,7 @@ static int small_groups_pass(const PackedText& pt, uint64_t h, SaBuffers& b, uin
                chunk, 0, b.block_counts, S_next, *V_cur, b.G);
     SFX_LAUNCH("flag_scan", 0.0, k_scan_block_counts, 1, kBlock, st, b.block_counts, ch.blocks, b.totals);
     uint32_t left = 0;
-    SFX_HIP(hipMemcpyAsync(&left, b.totals, sizeof(left), hipMemcpyDeviceToHost, st));
-    SFX_HIP(hipStreamSynchronize(st));
+    SFX_TRY(read_back(&left, b.totals, sizeof(left), st));
     if (left > 0) {
         SFX_LAUNCH("flag_compact", (double)cnt * 4 + (double)left * 24, k_flag_compact, ch.blocks, kBlock, st, flag,
                    *S_cur, V_other, b.G1, cnt, chunk, 1, b.block_counts, S_next, *V_cur, b.G);
@@ -1424,8 +1420,7 @@ int key_histogram_dev(const uint8_t* d_text, uint64_t n, uint64_t begin, uint64_
     SFX_HIP(hipMemsetAsync(d_bins, 0, sizeof(uint64_t) << top_bits, st));
     if (begin == end) return SFX_OK;
     unsigned long long host_bins[256];
-    SFX_HIP(hipMemcpyAsync(host_bins, d_byte_bins, sizeof(host_bins), hipMemcpyDeviceToHost, st));
-    SFX_HIP(hipStreamSynchronize(st));
+    SFX_TRY(read_back(host_bins, d_byte_bins, sizeof(host_bins), st));
     const Alphabet alpha = make_alphabet(host_bins);
     int key_bits, cpk;
     choose_key(alpha, n, &key_bits, &cpk);                  // (key width from the WHOLE text's length)
@@ -1459,8 +1454,7 @@ static int range_build(const PackedText& pt, int cpk, int top_bits, uint32_t bin
                    pt.bits * cpk, top_bits, bin_lo, bin_hi, chunk, 0, block_counts, capacity, k0, b.VA, (uint32_t*)nullptr);
     SFX_LAUNCH("range_scan", 0.0, k_scan_block_counts, 1, kBlock, st, block_counts, ch.blocks, b.totals);
     uint32_t host_total = 0;
-    SFX_HIP(hipMemcpyAsync(&host_total, b.totals, sizeof(host_total), hipMemcpyDeviceToHost, st));
-    SFX_HIP(hipStreamSynchronize(st));
+    SFX_TRY(read_back(&host_total, b.totals, sizeof(host_total), st));
     *count_out = host_total;
     if (host_total > capacity) return SFX_ERR_WORKSPACE;
     if (host_total == 0) return SFX_OK;

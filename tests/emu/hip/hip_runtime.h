@@ -63,6 +63,9 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t st);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 template <class T> hipError_t hipMalloc(T** p, size_t bytes) { return hipMalloc((void**)p, bytes); }
+constexpr unsigned hipHostMallocDefault = 0;
+inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned = 0) { return hipMalloc(p, bytes); }
+inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 
 // ---- launch ----------------------------------------------------------------
 void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
