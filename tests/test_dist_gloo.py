@@ -1,4 +1,4 @@
-"""world_size-2 CPU test of the range-partitioned (multi-GPU) construction:
+"""world_size 2 and 3 CPU tests of the range-partitioned (multi-GPU) construction:
 torch.distributed over gloo, compute through the emulator build of the product
 kernels (tensors live in host memory).  The slices of the two ranks must
 concatenate to the oracle's suffix array."""
@@ -22,11 +22,13 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 eng = suffix_amd.Engine(os.path.join({here!r}, "emu", "libsuffix_emu.so"))
 kind = os.environ["SFX_CASE"]
-m = 1200 if kind == "periodic" else 6000        # (periodic text: one text round per 32 symbols of LCP)
+m = {{"periodic": 1200, "unary": 600}}.get(kind, 6000)   # (repetitive text: one text round per 32 symbols of LCP)
 if kind == "dna":
     full = _gen.dna(m * world, seed=99)
 elif kind == "text":
     full = _gen.english_like(m * world, seed=7)
+elif kind == "unary":
+    full = np.frombuffer(b"a" * (m * world), dtype=np.uint8)      # one key bin: every rank but one gets an empty slice
 else:
     full = np.frombuffer((b"ab" * (m * world // 2)), dtype=np.uint8)
 shard = torch.from_numpy(np.ascontiguousarray(full[rank * m:(rank + 1) * m]).copy())
@@ -58,28 +60,32 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("case", ["dna", "text", "periodic"])
-def test_partitioned_build_two_ranks(tmp_path, oracle, case):
+@pytest.mark.parametrize("case,world", [("dna", 2), ("text", 2), ("periodic", 2), ("unary", 2), ("dna", 3)])
+def test_partitioned_build_ranks(tmp_path, oracle, case, world):
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(HERE, "emu")])
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, here=HERE))
     env = dict(os.environ, SFX_CASE=case, SFX_OUT=str(tmp_path), OMP_NUM_THREADS="1")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-                           "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29731",
+                           f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", "29731",
                            str(script)], env=env, timeout=600)
     sys.path.insert(0, HERE)
     import _gen
-    m, world = (1200 if case == "periodic" else 6000), 2
+    m = {"periodic": 1200, "unary": 600}.get(case, 6000)
     if case == "dna":
         full = _gen.dna(m * world, seed=99)
     elif case == "text":
         full = _gen.english_like(m * world, seed=7)
+    elif case == "unary":
+        full = np.frombuffer(b"a" * (m * world), dtype=np.uint8)
     else:
         full = np.frombuffer((b"ab" * (m * world // 2)), dtype=np.uint8)
     exp = oracle.sais(full.tobytes())
     parts = [np.load(tmp_path / f"part{r}.npy") for r in range(world)]
     offs = [np.load(tmp_path / f"off{r}.npy") for r in range(world)]
-    assert int(offs[0][0]) == 0 and int(offs[1][0]) == parts[0].size
+    assert int(offs[0][0]) == 0
+    for r in range(1, world):
+        assert int(offs[r][0]) == sum(p.size for p in parts[:r])
     assert int(offs[0][1]) == m * world
     assert np.array_equal(np.concatenate(parts), exp)
     text = full.tobytes()
