@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--no-microbench", action="store_true", help="skip the scatter/gather roofline probes")
     args = ap.parse_args()
 
+    # multi-process GPU work on this host driver needs dmabuf IPC (RCCL fails with
+    # hipIpcGetMemHandle: invalid argument otherwise); exported already, kept if it is not
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
