@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Out-of-bounds check of the kernels' global-memory accesses: the product .hip sources built
+with AddressSanitizer against the fiber emulator (make -C tests/emu asan), driven through the
+same C ABI.  Not part of the pytest suite (several minutes); run by hand after kernel changes:
+
+    make -C tests/emu asan
+    LD_PRELOAD=$(gcc -print-file-name=libasan.so) \\
+    ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 \\
+    SFX_LCP_DIRECT_MIN=8 python tests/asan_check.py            # add SFX_PARTITION_MIN=1 SFX_MAX_GRID=3 for the variants
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import numpy as np  # noqa: E402
+
+import _cases  # noqa: E402
+import _gen  # noqa: E402
+import oracle  # noqa: E402
+from suffix_amd import Engine, SuffixTable  # noqa: E402
+
+oracle.build()
+eng = Engine(os.path.join(HERE, "emu", "asan", "libsuffix_emu.so"))
+texts = [_gen.dna(30000, seed=9).tobytes(), _gen.english_like(9000, seed=3).tobytes(),
+         b"AAAAAAAAAAAAAAAAAAAAAAAC" * 300, _gen.dna(5000, seed=3).tobytes() + b"A" * 1500,
+         _gen.utf8_mixed(4001).tobytes(), b"a", b"ab", b"",
+         _gen.dna(20000, seed=11).tobytes() + b"A" * 1200 + _gen.dna(1000, seed=12).tobytes()]
+for t in texts:
+    st = SuffixTable(t, engine=eng)
+    exp = oracle.sais(t)
+    assert np.array_equal(st.table(), exp)
+    assert np.array_equal(st.lcp_lens(), oracle.lcp_quadratic(t, exp))
+    if len(t) > 10:
+        q = t[5:9]
+        s, e = oracle.positions(t, exp, q)
+        assert sorted(st.positions(q).tolist()) == sorted(exp[s:e].tolist())
+print("tables ok")
+for nr in (1, 3, 11):
+    _cases.range_slices(eng, oracle, _gen.dna(3001, seed=8).tobytes(), nr, packed=True)
+    _cases.range_slices(eng, oracle, _gen.english_like(2503).tobytes(), nr)
+    _cases.range_slices(eng, oracle, b"ab" * 150 + b"b", nr)
+print("ranges ok")
