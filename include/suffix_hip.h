@@ -31,7 +31,9 @@ enum {
     SFX_ERR_NO_DEVICE = 3,    /* no HIP device visible                        */
     SFX_ERR_HIP = 4,          /* a HIP runtime call or kernel failed          */
     SFX_ERR_WORKSPACE = 5,    /* caller workspace smaller than *_workspace_bytes */
-    SFX_ERR_INTERNAL = 6      /* engine invariant violated (bug)              */
+    SFX_ERR_INTERNAL = 6,     /* engine invariant violated (bug)              */
+    SFX_ERR_NEEDS_RANKS = 7   /* range build only: the slice holds repeats too long for text-symbol
+                                 refinement; build the whole suffix array instead (suffix_amd/dist.py does) */
 };
 
 const char* sfx_strerror(int status);
@@ -196,6 +198,10 @@ typedef struct {
     uint64_t radix_passes;
     uint64_t elements_sorted; /* sum over passes of elements moved             */
     uint64_t small_bucket_resolved; /* suffixes placed by direct comparison of small buckets */
+    uint64_t tile_sorted;     /* elements ordered by the in-LDS bucket sort, summed over rounds   */
+    uint64_t large_sorted;    /* elements of buckets too large for LDS, summed over rounds        */
+    uint32_t text_rounds;     /* refinement rounds keyed by text symbols                          */
+    uint32_t rank_rounds;     /* refinement rounds keyed by ranks (prefix doubling)               */
 } sfx_build_stats;
 void sfx_last_build_stats(sfx_build_stats* out);
 

@@ -31,7 +31,8 @@ class BuildStats(ctypes.Structure):
     _fields_ = [("n", _u64), ("sigma", _u32), ("bits_per_symbol", _u32), ("key_bits", _u32),
                 ("symbols_per_key", _u32), ("rounds", _u32), ("reserved", _u32),
                 ("active_after_initial", _u64), ("radix_passes", _u64),
-                ("elements_sorted", _u64), ("small_bucket_resolved", _u64)]
+                ("elements_sorted", _u64), ("small_bucket_resolved", _u64),
+                ("tile_sorted", _u64), ("large_sorted", _u64), ("text_rounds", _u32), ("rank_rounds", _u32)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}

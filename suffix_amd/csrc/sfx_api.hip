@@ -173,6 +173,7 @@ const char* sfx_strerror(int status)
     case SFX_ERR_HIP: return "HIP runtime error (see sfx_last_hip_error)";
     case SFX_ERR_WORKSPACE: return "device workspace too small";
     case SFX_ERR_INTERNAL: return "internal invariant violated";
+    case SFX_ERR_NEEDS_RANKS: return "slice needs rank refinement: build the whole suffix array";
     default: return "unknown status";
     }
 }

@@ -285,57 +285,6 @@ struct RadixSmem {
     uint32_t stage_v[HAS_VAL ? NW * kWave * KPT : 1];
 };
 
-// exclusive prefix of one value per thread; ONE barrier (callers alternate `par`)
-template <int NW>
-__device__ __forceinline__ uint32_t block_scan_excl_1b(uint32_t v, uint32_t (*part)[NW], unsigned& par)
-{
-    const uint32_t incl = wave_scan_add(v);
-    if (lane_id() == 63) part[par][wave_id()] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-#pragma unroll
-    for (unsigned k = 0; k < (unsigned)NW; k++)
-        if (k < wave_id()) base += part[par][k];
-    par ^= 1u;
-    return base + incl - v;
-}
-
-__device__ __forceinline__ unsigned lanes_below(unsigned long long peers)
-{
-    return __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
-}
-
-// rank of this lane's key among the keys with the same digit that its wave has seen so
-// far in this tile (earlier rounds, then lower lanes of this round)
-template <bool RANK_ATOMIC>
-__device__ __forceinline__ uint32_t rank_round(unsigned d, unsigned long long* flags_w, uint32_t* cnt_w,
-                                               unsigned long long mybit)
-{
-    unsigned long long peers;
-    if (RANK_ATOMIC) {
-        atomicOr(&flags_w[d], mybit);
-        wave_sync();
-        peers = flags_w[d];
-    } else {
-        peers = ~0ull;
-#pragma unroll
-        for (int b = 0; b < kRadixBits; b++) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long vote = __ballot(bit);
-            peers &= bit ? vote : ~vote;
-        }
-    }
-    const uint32_t pre = cnt_w[d];
-    wave_sync();
-    const unsigned below = lanes_below(peers);
-    if (below == 0) {
-        if (RANK_ATOMIC) flags_w[d] = 0ull;
-        cnt_w[d] = pre + (uint32_t)__popcll(peers);
-    }
-    wave_sync();
-    return pre + below;
-}
-
 // decoupled look-back for digit `tid` of tile `tile_no`: publishes the tile's count,
 // returns the number of elements with this digit in all earlier tiles.
 #ifndef SFX_LOOKAHEAD

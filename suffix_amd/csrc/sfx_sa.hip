@@ -931,9 +931,11 @@ k_flag_compact(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ S
         uint32_t total;
         const uint32_t ex = block_scan_add_excl<uint32_t>(keep ? 1u : 0u, part, total);
         if (phase == 1 && keep) {
+            // a class that stays unresolved stays whole and contiguous: the distance to its head is
+            // kept, so the id can again be the list position of the head
             S_next[running + ex] = S[p];
             V_next[running + ex] = V2[p];
-            G_next[running + ex] = G[p];
+            G_next[running + ex] = (uint32_t)(running + ex) - ((uint32_t)p - G[p]);
         }
         running += total;
     }
@@ -956,9 +958,10 @@ k_isa_from_sa(const uint32_t* __restrict__ sa, uint64_t n, uint32_t* __restrict_
             if (s0 + u * stride < n) isa[v[u]] = (uint32_t)(s0 + u * stride);
     }
 }
-// ... except the members of still-unresolved buckets, which share their head's slot.
+// ... except the members of still-unresolved buckets, which share their head's slot
+// (slot[gid[q]]: bucket id = list position of the bucket's head).
 __global__ void __launch_bounds__(kBlock)
-k_isa_fix_active(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ head_slot,
+k_isa_fix_active(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ slot, const uint32_t* __restrict__ gid,
                  uint64_t m, uint32_t* __restrict__ isa)
 {
     constexpr int U = 4;
@@ -969,7 +972,7 @@ k_isa_fix_active(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ 
         for (int u = 0; u < U; u++) {
             const uint64_t q = q0 + u * stride;
             a[u] = q < m ? suf[q] : 0u;
-            b[u] = q < m ? head_slot[q] : 0u;
+            b[u] = q < m ? slot[gid[q]] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
@@ -1008,7 +1011,9 @@ static void choose_key(const Alphabet& a, uint64_t n, int* key_bits, int* cpk)
     int spw = a.spw;
     int l2 = bits_for(a.sigma) - 1;                 // floor(log2 sigma), sigma >= 1
     if (l2 < 1) l2 = 1;
-    if (spw * l2 >= bits_for(n) + 1) { *key_bits = 32; *cpk = spw; }
+    // SFX_FORCE_KEY64=1 is a test hook (the 64-bit-key path on inputs small enough for the emulator)
+    static const bool force64 = [] { const char* e = getenv("SFX_FORCE_KEY64"); return e && atoi(e) != 0; }();
+    if (!force64 && spw * l2 >= bits_for(n) + 1) { *key_bits = 32; *cpk = spw; }
     else { *key_bits = 64; *cpk = 2 * spw; }
 }
 
@@ -1031,8 +1036,10 @@ struct SaBuffers {
     uint32_t* G;                                        // bucket ids of the active list (G/G1 ping-pong)
     uint32_t* G1;
     uint16_t* F;                                        // head / single bits, 16 per 8 elements
+    uint8_t* F8;                                        // one flag byte per element (tile rounds)
+    unsigned long long* counters;                       // 2
     uint32_t* block_counts;                             // kMaxGrid
-    uint32_t* R;                                        // bucket-head slots (text rounds of a full build)
+    uint32_t* R;                                        // scratch (positions of the large-bucket members of a tile round)
     uint32_t* isa;
     uint32_t* packed;                                   // PackedText words
     uint32_t* hist;                                     // radix_scratch_words(cap)
@@ -1059,7 +1066,9 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint32_t* G1 = ar.template take<uint32_t>(cap);
     uint16_t* F = ar.template take<uint16_t>(cap / kGroupItems + kBlock * kApplySub);
     uint32_t* bc = ar.template take<uint32_t>(kMaxGrid);
-    uint32_t* R = ar.template take<uint32_t>(isa_len ? cap + 1024 : 0);     // (a text round may keep up to cap elements)
+    uint8_t* F8 = ar.template take<uint8_t>(cap + 64);
+    unsigned long long* counters = ar.template take<unsigned long long>(2);
+    uint32_t* R = ar.template take<uint32_t>(cap + 1024);
     uint32_t* isa = ar.template take<uint32_t>(isa_len);
     uint32_t* packed = ar.template take<uint32_t>(packed_words(n, nullptr));
     uint32_t* hist = ar.template take<uint32_t>(radix_scratch_words(cap));
@@ -1070,7 +1079,8 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     unsigned long long* bins = ar.template take<unsigned long long>(256);
     uint8_t* lut = ar.template take<uint8_t>(256);
     if (b) {
-        b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->G1 = G1; b->F = F; b->block_counts = bc; b->R = R;
+        b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->G1 = G1; b->F = F; b->F8 = F8;
+        b->counters = counters; b->block_counts = bc; b->R = R;
         b->isa = isa; b->packed = packed; b->hist = hist; b->part_head = ph; b->part_keep = pk;
         b->part_ghead = pg; b->totals = totals; b->bins = bins; b->lut = lut;
     }
@@ -1257,19 +1267,21 @@ static int small_groups_pass(const PackedText& pt, uint64_t h, SaBuffers& b, uin
 // worth it when the average unresolved bucket is small
 static bool small_groups_pay(uint64_t m, uint64_t groups) { return m > 0 && groups * 4 >= m; }
 
-// refinement rounds shared by the full and the partitioned build.
+// Device-wide composite-key rounds (round 1 of this engine): kept for rank rounds whose key2 = rank + h
+// does not fit 32 bits (n > 2^31 with deep repeats); the tile rounds below are the normal path.
 //   rank round: key2 = rank of the suffix h symbols on (needs ISA), h doubles
 //   text round: key2 = the next spw symbols (needs only the packed text), h += spw
 // The partitioned build (isa == nullptr) only has text rounds.  A full build runs
 // `text_rounds` text rounds first (0 or 1, see kTextFirstDivisor) and rank rounds after.
-static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uint32_t* isa,
-                  int text_rounds, uint32_t* S_cur, uint32_t* V_cur, uint64_t m, uint64_t id_bound,
-                  hipStream_t st, sfx_build_stats& stats)
+static int refine_composite(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uint32_t* isa,
+                            int text_rounds, uint32_t* S_cur, uint32_t* V_cur, uint64_t m, uint64_t id_bound,
+                            hipStream_t st, sfx_build_stats& stats, uint64_t h0)
 {
     // bucket ids are positions in the active list as it was when they were assigned
     // (< id_bound); the direct pass and its compaction shrink the list but keep the ids
     const uint64_t n = pt.n;
-    uint64_t h = (uint64_t)cpk;
+    uint64_t h = h0;
+    (void)cpk;
     const int spw = pt.spw;
     const int flag_shift = dmax(pt.kbits, bits_for(n));
     int rounds = 0;
@@ -1308,7 +1320,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
             unsigned g2 = (unsigned)dmin<uint64_t>((kept + kBlock - 1) / kBlock, kMaxGrid);
             SFX_LAUNCH("isa_from_sa", (double)n * 8, k_isa_from_sa, g1, kBlock, st, sa, n, isa);
             SFX_LAUNCH("isa_fix_active", (double)kept * 12, k_isa_fix_active, g2, kBlock, st, V_next,
-                       b.R, kept, isa);
+                       S_next, b.G, kept, isa);
         }
         S_cur = S_next;
         V_cur = V_next;
@@ -1320,6 +1332,76 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
             uint32_t* live_isa = (isa && text_rounds <= 0) ? isa : nullptr;
             SFX_TRY(small_groups_pass(pt, h, b, sa, live_isa, &S_cur, &V_cur, &m, st, stats));
         }
+    }
+    return SFX_OK;
+}
+
+
+// Refinement rounds shared by the full and the partitioned build: every round sorts each bucket of
+// the active list by key2 inside LDS (sfx_tile.hip), large buckets through the device-wide sort.
+//   text round: key2 = the next wsym symbols (needs only the packed text), h += wsym
+//   rank round: key2 = rank of the suffix h symbols on (needs ISA), h doubles
+// Rounds start on text symbols -- no rank array, so its n-element scatter is only paid if the
+// text rounds stall: when a round resolves less than a third of what it was given, and the
+// rounds spent stalling have cost about what building the rank array costs, the build switches
+// to ranks (prefix doubling).  The partitioned build (isa == nullptr) only has text rounds and
+// reports SFX_ERR_NEEDS_RANKS when they do not converge.
+constexpr int kMaxTextOnlyRounds = 4096;
+static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uint32_t* isa, uint32_t* S_cur,
+                  uint32_t* V_cur, uint64_t m, hipStream_t st, sfx_build_stats& stats)
+{
+    const uint64_t n = pt.n;
+    uint64_t h = (uint64_t)cpk;
+    const int wsym = pt.kbits == 32 ? pt.spw - 1 : pt.spw;     // symbols of a text round (31-bit key2 + flag)
+    bool rank_mode = false;
+    uint64_t stalled = 0;
+    int rounds = 0;
+    while (m > 0) {
+        if (++rounds > kMaxTextOnlyRounds + 80) return SFX_ERR_INTERNAL;
+        if (rank_mode && n - 1 + h > 0xFFFFFFFFull)              // key2 = rank + h would not fit 32 bits
+            return refine_composite(pt, cpk, b, sa, isa, 0, S_cur, V_cur, m, m, st, stats, h);
+        if (rank_mode) SFX_TRY(compose_rank_e64(V_cur, m, isa, n, h, b.K0, st));
+        else SFX_TRY(compose_text_e64(V_cur, m, pt, h, b.K0, st));
+        uint32_t* V_next = (V_cur == b.VA) ? b.VB : b.VA;
+        uint32_t* S_next = (S_cur == b.S0) ? b.S1 : b.S0;
+        TileRound tr;
+        tr.E = b.K0; tr.G = b.G; tr.V = V_cur; tr.F8 = b.F8; tr.F = b.F;
+        tr.part_head = b.part_head; tr.part_keep = b.part_keep; tr.part_ghead = b.part_ghead;
+        tr.block_counts = b.block_counts; tr.totals = b.totals; tr.counters = b.counters;
+        tr.KL0 = b.K1; tr.KL1 = b.K0; tr.VL0 = b.G1; tr.VL1 = S_next; tr.P = b.R; tr.radix_scratch = b.hist;
+        SFX_TRY(tile_round(tr, m, st, &stats));
+        Chunking ch = make_chunking(m, kApplyTile);
+        SFX_LAUNCH("groups_scan", 0.0, k_groups_scan, 1, kBlock, st, b.part_head, b.part_keep, b.part_ghead, ch.blocks,
+                   b.totals);
+        uint32_t host_totals[2] = {0, 0};
+        SFX_TRY(read_back(host_totals, b.totals, sizeof(host_totals), st));
+        const uint64_t kept = host_totals[0], kept_groups = host_totals[1];
+        SFX_TRY(round_apply<uint64_t>(b.K0, V_cur, S_cur, m, b, sa, rank_mode ? isa : nullptr, S_next, V_next, nullptr,
+                                      st, false, n, stats, kept));
+        h = rank_mode ? h * 2 : h + (uint64_t)wsym;
+        stats.rounds++;
+        if (rank_mode) stats.rank_rounds++; else stats.text_rounds++;
+        if (!rank_mode && kept > 0) {
+            // a text round is worth another one while it keeps resolving; a stalled one costs about
+            // (kept + launch overheads) against ~n for the rank array
+            if (kept * 3 > m * 2) stalled += kept + (4u << 20);
+            if (isa && stalled * 2 > n) {
+                // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
+                unsigned g1 = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
+                unsigned g2 = (unsigned)dmin<uint64_t>((kept + kBlock - 1) / kBlock, kMaxGrid);
+                SFX_LAUNCH("isa_from_sa", (double)n * 8, k_isa_from_sa, g1, kBlock, st, sa, n, isa);
+                SFX_LAUNCH("isa_fix_active", (double)kept * 16, k_isa_fix_active, g2, kBlock, st, V_next, S_next, b.G,
+                           kept, isa);
+                rank_mode = true;
+            } else if (!isa && stats.text_rounds > (uint32_t)kMaxTextOnlyRounds) {
+                return SFX_ERR_NEEDS_RANKS;
+            }
+        }
+        S_cur = S_next;
+        V_cur = V_next;
+        m = kept;
+        if (small_groups_pay(m, kept_groups))
+            SFX_TRY(small_groups_pass(pt, h, b, sa, rank_mode ? isa : nullptr, &S_cur, &V_cur, &m, st, stats));
     }
     return SFX_OK;
 }
@@ -1357,19 +1439,13 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     uint64_t kept = 0, groups = 0;
     SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups));
     stats.active_after_initial = kept;
-    // few unresolved suffixes, or small buckets that the direct pass will order: no rank array
-    // yet (its n-element scatter is only paid if a rank round turns out to be needed)
-    const int text_rounds =
-        (isa && ((kept * kTextFirstDivisor <= count && pt.spw >= 8) || small_groups_pay(kept, groups))) ? 1 : 0;
-    SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, (isa && !text_rounds) ? isa : nullptr, b.S0, V_next,
-                              nullptr, st, in_place, pt.n, stats, kept));
+    // no rank array yet: its n-element scatter is only paid if the text rounds stall (refine)
+    SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place, pt.n, stats,
+                              kept));
     uint32_t* S_cur = b.S0;
-    const uint64_t id_bound = kept;
-    if (small_groups_pay(kept, groups)) {
-        SFX_TRY(small_groups_pass(pt, (uint64_t)cpk, b, sa, (isa && !text_rounds) ? isa : nullptr, &S_cur, &V_next,
-                                  &kept, st, stats));
-    }
-    return refine(pt, cpk, b, sa, isa, text_rounds, S_cur, V_next, kept, id_bound, st, stats);
+    if (small_groups_pay(kept, groups))
+        SFX_TRY(small_groups_pass(pt, (uint64_t)cpk, b, sa, nullptr, &S_cur, &V_next, &kept, st, stats));
+    return refine(pt, cpk, b, sa, isa, S_cur, V_next, kept, st, stats);
 }
 
 int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,

@@ -4,6 +4,7 @@ environment variables are read once per process, so every variant runs in a subp
   SFX_MAX_GRID                           multi-tile chunks per workgroup on small inputs
   SFX_PARTITION_MIN                      partitioned (cache-confined) rank / Phi scatters
   SFX_LCP_DIRECT_MIN                     sampled choice between direct and Phi/PLCP LCP, cap + fallback
+  SFX_TILE_SMALL / SFX_FORCE_KEY64       small LDS windows of the refinement rounds; 64-bit initial keys
 Every run compares SA and LCP with the oracle on a few texts that exercise the path."""
 import os
 import subprocess
@@ -68,6 +69,10 @@ VARIANTS = {
     "one-sweep-8-waves-kpt8": {"SFX_RADIX_NW": "8", "SFX_RADIX_KPT": "8", "SFX_MAX_GRID": "3"},
     "partitioned-scatter": {"SFX_PARTITION_MIN": "1"},
     "direct-lcp": {"SFX_LCP_DIRECT_MIN": "8"},
+    # 256-element LDS windows: buckets cross tile boundaries, > 128 members take the large-bucket path
+    "small-tiles": {"SFX_TILE_SMALL": "1"},
+    "small-tiles-key64-multi-tile": {"SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "3"},
+    "key64": {"SFX_FORCE_KEY64": "1"},
 }
 
 
