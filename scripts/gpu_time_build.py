@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Development timing of one full-size build: python scripts/gpu_time_build.py <eng|utf8|dup|dna|engr1> [n]
+Prints one JSON line: sa_ms (best of 2), build stats, per-kernel ms, sha256 of the SA (compare across variants)."""
+import hashlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import _gen, suffix_amd
+from suffix_amd import device as sdev
+kind = sys.argv[1]; n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000_000
+if kind == "engr1":
+    import _gen_r1
+    host = _gen_r1.english_like(n)
+else:
+    host = {"eng": _gen.english_like, "utf8": _gen.utf8_mixed, "dup": _gen.near_duplicates,
+            "dna": lambda k: _gen.dna_fast(k, seed=0x5AF1C5 + 4)}[kind](n)
+eng = suffix_amd.default_engine(); eng.require_device()
+dev = torch.device("cuda", 0)
+text = torch.from_numpy(host).to(dev)
+ws = sdev.sa_workspace(n, dev); sa = torch.empty(n, dtype=torch.int32, device=dev)
+best = None
+for _ in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    sdev.build_sa(text, out=sa, workspace=ws); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0; best = dt if best is None else min(best, dt)
+st = eng.build_stats()
+eng.profile(True); eng.profile_reset(); sdev.build_sa(text, out=sa, workspace=ws); torch.cuda.synchronize()
+k = {r["name"]: round(r["total_ms"], 2) for r in eng.profile_report()}; eng.profile(False)
+rec = {"kind": kind, "n": n, "env": {a: b for a, b in os.environ.items() if a.startswith("SFX_")}, "sa_ms": round(best * 1e3, 2),
+       "stats": st, "kernel_ms": dict(sorted(k.items(), key=lambda x: -x[1])[:12])}
+if os.environ.get("TIME_SHA", "1") == "1":
+    rec["sha256_sa"] = hashlib.sha256(sa.cpu().numpy().tobytes()).hexdigest()[:16]
+print(json.dumps(rec), flush=True)

@@ -170,13 +170,13 @@ inline uint64_t partitioned_scatter_min()
 inline int radix_pass_count(int bit_lo, int bit_hi) { return (bit_hi - bit_lo + 7) / 8; }
 
 // ---- refinement rounds on 64-bit (key2, suffix) elements (sfx_tile.hip) -----------------------
-// One round over the active list (m elements): E[p] = key2 << 32 | suffix, G[p] = list position of the
-// head of p's bucket.  On return V holds, at the same list positions, the suffixes of every bucket
+// One round over the active list (m elements): V[p] = suffix, G[p] = list position of the head of
+// p's bucket; key2 of a suffix = its next symbols (text round) or the rank of the suffix h symbols on
+// (rank round).  On return V holds, at the same list positions, the suffixes of every bucket
 // ordered by key2; F the head / singleton bits and part_* the per-chunk partials that
 // k_groups_scan + k_groups_apply consume (chunks of kFlagChunkTile elements, make_chunking).
 constexpr int kFlagChunkTile = 8192;
 struct TileRound {
-    const uint64_t* E;
     const uint32_t* G;
     uint32_t* V;
     uint8_t* F8;                  // m bytes (+ 8), scratch
@@ -185,14 +185,15 @@ struct TileRound {
     uint32_t* block_counts;       // kMaxGrid
     uint32_t* totals;
     unsigned long long* counters; // 2
-    uint64_t* KL0; uint64_t* KL1; // large buckets: m u64 each (KL0 may not alias E)
+    uint64_t* KL0; uint64_t* KL1; // large buckets: m u64 each
     uint32_t* VL0; uint32_t* VL1; uint32_t* P;   // m u32 each
     uint32_t* radix_scratch;
 };
-int tile_round(const TileRound& r, uint64_t m, hipStream_t st, sfx_build_stats* stats);
-int compose_text_e64(const uint32_t* V, uint64_t m, const PackedText& pt, uint64_t h, uint64_t* E, hipStream_t st);
-int compose_rank_e64(const uint32_t* V, uint64_t m, const uint32_t* isa, uint64_t n, uint64_t h, uint64_t* E,
-                     hipStream_t st);
+int tile_round_text(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
+                    sfx_build_stats* stats);
+// (needs n - 1 + h < 2^32: key2 = rank + h)
+int tile_round_rank(const uint32_t* isa, uint64_t n, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
+                    sfx_build_stats* stats);
 __global__ void k_scan_block_counts(uint32_t* __restrict__ counts, unsigned nb, uint32_t* __restrict__ out_total);
 
 uint64_t sa_workspace_bytes(uint64_t n);

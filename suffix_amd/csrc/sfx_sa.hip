@@ -942,42 +942,47 @@ k_flag_compact(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ S
     if (phase == 0 && tid == 0) block_counts[blockIdx.x] = (uint32_t)running;
 }
 
-// (Re)build the rank array when refinement switches from text symbols to ranks:
-// every slot is its own rank ...
+// (Re)build the rank array when refinement switches from text symbols to ranks: rank of a
+// suffix = its slot, except the members of still-unresolved buckets, which share their head's
+// slot.  H[r] = r for every slot, then H[slot] = head slot for the active list (slots ascend
+// along the list: near-sequential writes); then ISA[SA[r]] = H[r] -- ONE n-element scatter, sent
+// through the partitioned scatter for large texts.
 __global__ void __launch_bounds__(kBlock)
-k_isa_from_sa(const uint32_t* __restrict__ sa, uint64_t n, uint32_t* __restrict__ isa)
+k_iota(uint32_t* __restrict__ out, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) out[r] = (uint32_t)r;
+}
+__global__ void __launch_bounds__(kBlock)
+k_head_slots(const uint32_t* __restrict__ slot, const uint32_t* __restrict__ gid, uint64_t m, uint32_t* __restrict__ H)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < m; q += stride) H[slot[q]] = slot[gid[q]];
+}
+__global__ void __launch_bounds__(kBlock)
+k_isa_from_sa(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ H, uint64_t n, uint32_t* __restrict__ isa)
 {
     constexpr int U = 4;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t s0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s0 < n; s0 += U * stride) {
-        uint32_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) v[u] = (s0 + u * stride < n) ? sa[s0 + u * stride] : 0u;
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if (s0 + u * stride < n) isa[v[u]] = (uint32_t)(s0 + u * stride);
-    }
-}
-// ... except the members of still-unresolved buckets, which share their head's slot
-// (slot[gid[q]]: bucket id = list position of the bucket's head).
-__global__ void __launch_bounds__(kBlock)
-k_isa_fix_active(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ slot, const uint32_t* __restrict__ gid,
-                 uint64_t m, uint32_t* __restrict__ isa)
-{
-    constexpr int U = 4;
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t q0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q0 < m; q0 += U * stride) {
-        uint32_t a[U], b[U];
+        uint32_t v[U], r[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint64_t q = q0 + u * stride;
-            a[u] = q < m ? suf[q] : 0u;
-            b[u] = q < m ? slot[gid[q]] : 0u;
+            v[u] = (s0 + u * stride < n) ? sa[s0 + u * stride] : 0u;
+            r[u] = (s0 + u * stride < n) ? H[s0 + u * stride] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
-            if (q0 + u * stride < m) isa[a[u]] = b[u];
+            if (s0 + u * stride < n) isa[v[u]] = r[u];
     }
+}
+// the same as (suffix << 32 | rank) pairs in slot order, for scatter_pairs_u32
+__global__ void __launch_bounds__(kBlock)
+k_rank_pairs(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ H, uint64_t n, uint64_t* __restrict__ pairs)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride)
+        pairs[r] = ((uint64_t)sa[r] << 32) | (uint64_t)H[r];
 }
 
 // ---------------------------------------------------------------------------------
@@ -1048,6 +1053,8 @@ struct SaBuffers {
     unsigned long long* bins;                           // 256
     uint8_t* lut;                                       // 256
 };
+
+static inline uint32_t* isa_scratch_h(SaBuffers& b) { return b.R; }       // n + 1024 u32, free between rounds
 
 struct SizerArena : ArenaSizer {
     template <class T> T* take(uint64_t c) { ArenaSizer::take<T>(c); return nullptr; }
@@ -1267,6 +1274,25 @@ static int small_groups_pass(const PackedText& pt, uint64_t h, SaBuffers& b, uin
 // worth it when the average unresolved bucket is small
 static bool small_groups_pay(uint64_t m, uint64_t groups) { return m > 0 && groups * 4 >= m; }
 
+// rank array from the suffix array as far as it is known (see k_iota): b.R holds H, K0/K1 the pairs
+static int build_ranks(SaBuffers& b, const uint32_t* sa, uint64_t n, const uint32_t* V_act, const uint32_t* S_act,
+                       uint64_t m_act, uint32_t* isa, hipStream_t st, sfx_build_stats& stats)
+{
+    (void)V_act;
+    const unsigned g1 = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
+    const unsigned g2 = (unsigned)dmin<uint64_t>((m_act + kBlock - 1) / kBlock, kMaxGrid);
+    uint32_t* H = isa_scratch_h(b);
+    SFX_LAUNCH("rank_iota", (double)n * 4, k_iota, g1, kBlock, st, H, n);
+    if (m_act) SFX_LAUNCH("rank_head_slots", (double)m_act * 16, k_head_slots, g2, kBlock, st, S_act, b.G, m_act, H);
+    if (n >= partitioned_scatter_min()) {
+        SFX_LAUNCH("rank_pairs", (double)n * 16, k_rank_pairs, g1, kBlock, st, sa, H, n, b.K0);
+        SFX_TRY(scatter_pairs_u32(b.K0, b.K1, n, n, isa, b.hist, st, &stats));
+    } else {
+        SFX_LAUNCH("isa_from_sa", (double)n * 12, k_isa_from_sa, g1, kBlock, st, sa, H, n, isa);
+    }
+    return SFX_OK;
+}
+
 // Device-wide composite-key rounds (round 1 of this engine): kept for rank rounds whose key2 = rank + h
 // does not fit 32 bits (n > 2^31 with deep repeats); the tile rounds below are the normal path.
 //   rank round: key2 = rank of the suffix h symbols on (needs ISA), h doubles
@@ -1314,14 +1340,8 @@ static int refine_composite(const PackedText& pt, int cpk, SaBuffers& b, uint32_
         SFX_TRY(round_apply<uint64_t>(Kr, Vr, S_cur, m, b, sa, (isa && !text_round) ? isa : nullptr,
                                       S_next, V_next, full_text_round ? b.R : nullptr, st, false, n, stats, kept));
         h = text_round ? h + (uint64_t)spw : h * 2;
-        if (full_text_round && --text_rounds == 0 && kept > 0) {
-            // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
-            unsigned g1 = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
-            unsigned g2 = (unsigned)dmin<uint64_t>((kept + kBlock - 1) / kBlock, kMaxGrid);
-            SFX_LAUNCH("isa_from_sa", (double)n * 8, k_isa_from_sa, g1, kBlock, st, sa, n, isa);
-            SFX_LAUNCH("isa_fix_active", (double)kept * 12, k_isa_fix_active, g2, kBlock, st, V_next,
-                       S_next, b.G, kept, isa);
-        }
+        if (full_text_round && --text_rounds == 0 && kept > 0)
+            SFX_TRY(build_ranks(b, sa, n, V_next, S_next, kept, isa, st, stats));
         S_cur = S_next;
         V_cur = V_next;
         m = kept;
@@ -1360,16 +1380,15 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         if (++rounds > kMaxTextOnlyRounds + 80) return SFX_ERR_INTERNAL;
         if (rank_mode && n - 1 + h > 0xFFFFFFFFull)              // key2 = rank + h would not fit 32 bits
             return refine_composite(pt, cpk, b, sa, isa, 0, S_cur, V_cur, m, m, st, stats, h);
-        if (rank_mode) SFX_TRY(compose_rank_e64(V_cur, m, isa, n, h, b.K0, st));
-        else SFX_TRY(compose_text_e64(V_cur, m, pt, h, b.K0, st));
         uint32_t* V_next = (V_cur == b.VA) ? b.VB : b.VA;
         uint32_t* S_next = (S_cur == b.S0) ? b.S1 : b.S0;
         TileRound tr;
-        tr.E = b.K0; tr.G = b.G; tr.V = V_cur; tr.F8 = b.F8; tr.F = b.F;
+        tr.G = b.G; tr.V = V_cur; tr.F8 = b.F8; tr.F = b.F;
         tr.part_head = b.part_head; tr.part_keep = b.part_keep; tr.part_ghead = b.part_ghead;
         tr.block_counts = b.block_counts; tr.totals = b.totals; tr.counters = b.counters;
         tr.KL0 = b.K1; tr.KL1 = b.K0; tr.VL0 = b.G1; tr.VL1 = S_next; tr.P = b.R; tr.radix_scratch = b.hist;
-        SFX_TRY(tile_round(tr, m, st, &stats));
+        if (rank_mode) SFX_TRY(tile_round_rank(isa, n, h, tr, m, st, &stats));
+        else SFX_TRY(tile_round_text(pt, h, tr, m, st, &stats));
         Chunking ch = make_chunking(m, kApplyTile);
         SFX_LAUNCH("groups_scan", 0.0, k_groups_scan, 1, kBlock, st, b.part_head, b.part_keep, b.part_ghead, ch.blocks,
                    b.totals);
@@ -1384,14 +1403,12 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         if (!rank_mode && kept > 0) {
             // a text round is worth another one while it keeps resolving; a stalled one costs about
             // (kept + launch overheads) against ~n for the rank array
+            // SFX_SWITCH=text|rank is a development hook: never / always switch after the first round
+            static const int force = [] { const char* e = getenv("SFX_SWITCH"); return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'r' ? 2 : 0)); }();
             if (kept * 3 > m * 2) stalled += kept + (4u << 20);
-            if (isa && stalled * 2 > n) {
+            if (isa && force != 1 && (stalled * 2 > n || force == 2)) {
                 // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
-                unsigned g1 = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
-                unsigned g2 = (unsigned)dmin<uint64_t>((kept + kBlock - 1) / kBlock, kMaxGrid);
-                SFX_LAUNCH("isa_from_sa", (double)n * 8, k_isa_from_sa, g1, kBlock, st, sa, n, isa);
-                SFX_LAUNCH("isa_fix_active", (double)kept * 16, k_isa_fix_active, g2, kBlock, st, V_next, S_next, b.G,
-                           kept, isa);
+                SFX_TRY(build_ranks(b, sa, n, V_next, S_next, kept, isa, st, stats));
                 rank_mode = true;
             } else if (!isa && stats.text_rounds > (uint32_t)kMaxTextOnlyRounds) {
                 return SFX_ERR_NEEDS_RANKS;

@@ -8,13 +8,14 @@
 // that with a device-wide LSD sort of the composite (bucket id, key2): 8 passes whose
 // high half only keeps every element where it already is.  Here:
 //
-//   k_compose_*_e64   one 64-bit element per active suffix: (key2 << 32) | suffix
 //   k_tile_sort       buckets of at most kTmax members are sorted ENTIRELY IN LDS: a
 //                     workgroup owns the buckets whose head lies in its stretch of kT
 //                     list positions, loads the kT + kTmax window that is guaranteed to
-//                     contain them, sorts (local bucket, key2) with an LDS radix sort and
-//                     writes the suffixes back in place together with one flag byte per
-//                     element (bucket head / singleton): one read and one write of the list
+//                     contain them, gathers key2 of the members, orders them (all-pairs
+//                     ranking for buckets of <= 32, LDS radix sort on (local bucket, key2)
+//                     for the rest) and writes the suffixes back in place together with one
+//                     flag byte per element (bucket head / singleton): one read and one
+//                     write of the list, one gather per member
 //   large buckets     (> kTmax members: a few per cent of a natural-language text, all of a
 //                     unary one) are extracted, sorted by (bucket id, key2) with the
 //                     device-wide radix sort and written back to their positions
@@ -24,60 +25,35 @@
 
 namespace sfx {
 
-// ---- composite elements of a round ---------------------------------------------------
-// text round: key2 = 1 << 31 | the next wsym symbols (big-endian), or n-1-i (< h) when the
-// suffix has no symbol left at offset h ("shorter sorts first", :422-425)
-__global__ void __launch_bounds__(kBlock)
-k_compose_text_e64(const uint32_t* __restrict__ suf, uint64_t m, PackedText src, uint64_t h, int drop_bits,
-                   uint64_t* __restrict__ E)
-{
-    constexpr int U = 4;                                   // independent gathers in flight per thread
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t q0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q0 < m; q0 += U * stride) {
-        uint64_t i[U];
-        uint32_t tk[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) i[u] = (q0 + u * stride < m) ? suf[q0 + u * stride] : 0;
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            tk[u] = (q0 + u * stride < m && i[u] + h < src.n) ? packed_key32(src, i[u] + h) >> drop_bits : 0u;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint64_t q = q0 + u * stride;
-            if (q < m) {
-                const uint32_t key2 = (i[u] + h < src.n) ? (0x80000000u | tk[u]) : (uint32_t)(src.n - 1 - i[u]);
-                E[q] = ((uint64_t)key2 << 32) | i[u];
-            }
-        }
+// ---- key2 of a suffix ------------------------------------------------------------------------
+// text round: key2 = 1 << 31 | the next wsym symbols (big-endian), or n-1-i (< h) when the suffix
+// has no symbol left at offset h ("shorter sorts first", :422-425)
+struct TextKey {
+    PackedText t;
+    uint64_t h;
+    int drop_bits;              // 32-bit packed words give up their last symbol to make room for the flag
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const
+    {
+        const uint64_t p = (uint64_t)i + h;
+        if (p >= t.n) return (uint32_t)(t.n - 1 - (uint64_t)i);
+        return 0x80000000u | (packed_key32(t, p) >> drop_bits);
     }
-}
+};
 // rank round: key2 = rank of suffix i+h (+h), or n-1-i; the caller guarantees n-1+h < 2^32
-__global__ void __launch_bounds__(kBlock)
-k_compose_rank_e64(const uint32_t* __restrict__ suf, uint64_t m, const uint32_t* __restrict__ isa, uint64_t n,
-                   uint64_t h, uint64_t* __restrict__ E)
-{
-    constexpr int U = 4;
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t q0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q0 < m; q0 += U * stride) {
-        uint64_t i[U];
-        uint32_t rk[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) i[u] = (q0 + u * stride < m) ? suf[q0 + u * stride] : 0;
-#pragma unroll
-        for (int u = 0; u < U; u++) rk[u] = (q0 + u * stride < m && i[u] + h < n) ? isa[i[u] + h] : 0u;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint64_t q = q0 + u * stride;
-            if (q < m) {
-                const uint32_t key2 = (i[u] + h < n) ? (uint32_t)((uint64_t)rk[u] + h) : (uint32_t)(n - 1 - i[u]);
-                E[q] = ((uint64_t)key2 << 32) | i[u];
-            }
-        }
+struct RankKey {
+    const uint32_t* isa;
+    uint64_t n, h;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const
+    {
+        const uint64_t p = (uint64_t)i + h;
+        if (p >= n) return (uint32_t)(n - 1 - (uint64_t)i);
+        return (uint32_t)((uint64_t)isa[p] + h);
     }
-}
+};
 
 // ---- LDS bucket sort --------------------------------------------------------------------
 constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
+constexpr int kPairMaxDefault = 32;                         // buckets up to this size are ranked by all-pairs comparison
 
 template <int NW, int KPT>
 struct TileSmem {
@@ -86,19 +62,27 @@ struct TileSmem {
     uint64_t stage[kWin];                                   // bucket-id window, then the elements being sorted
     uint64_t masks[kAliasMasks ? 1 : NW * kRadixDev];
     uint32_t sufwin[kWin];                                  // suffix of every window position
-    uint16_t posmap[kWin];                                  // window offset of the j-th owned element
+    uint16_t posmap[kWin];                                  // window offset that slot j of `stage` writes to
+    uint16_t hslot[kWin / 2];                               // slot of the head of the bucket with local id g
+    uint8_t blabel[kWin / 2];                               // big buckets: dense label (rank among the tile's big buckets)
     uint32_t cnt[NW][kRadixDev];
     uint32_t part[2][NW];
+    uint64_t part64[NW];
 };
 
-// E: (key2 << 32 | suffix) per list position, G: bucket id = list position of the bucket's head.
+// V: suffix per list position, G: bucket id = list position of the bucket's head.
 // Sorts every bucket of <= kTmax members whose head lies in [blockIdx * kT, (blockIdx+1) * kT) by
-// key2 (stable), writes the suffixes to V at the same list positions and F8 = 1 (first of its
-// (bucket, key2) class) | 2 (class of one).  owned_total += elements handled.
-template <int NW, int KPT>
+// key2 = keyfn(suffix) (stable), writes the suffixes back to V at the same list positions and
+// F8 = 1 (first of its (bucket, key2) class) | 2 (class of one).  owned_total += elements handled.
+// Buckets of <= kPairMax members (half of all elements of a natural-language text, nearly all in the
+// late rounds) are ranked by comparing every member with every other one; the rest goes through an LDS
+// radix sort: four passes on key2, then ONE pass on the bucket's dense label (its rank among the
+// tile's big buckets, < 256) -- after the key2 passes the labels are interleaved at random, which is
+// what the match-mask ranking likes; the raw bucket ids would cost two passes on clustered digits.
+template <int NW, int KPT, int kPairMax, class KeyFn>
 __global__ void __launch_bounds__(NW * kWave)
-k_tile_sort(const uint64_t* __restrict__ E, const uint32_t* __restrict__ G, uint64_t m,
-            uint32_t* __restrict__ V, uint8_t* __restrict__ F8, unsigned long long* __restrict__ owned_total)
+k_tile_sort(KeyFn keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* __restrict__ V,
+            uint8_t* __restrict__ F8, unsigned long long* __restrict__ owned_total)
 {
     constexpr int kThreads = NW * kWave;
     constexpr int kWin = kThreads * KPT;
@@ -109,6 +93,9 @@ k_tile_sort(const uint64_t* __restrict__ E, const uint32_t* __restrict__ G, uint
     static_assert((1 << kIdxBits) == kWin, "window must be a power of two");
     static_assert(kThreads >= kRadixDev, "thread d owns digit d");
     static_assert(kIdxBits + kGidBits <= 32, "element = key2 | local bucket | window offset");
+    static_assert(kPairMax < kTmax, "the size test looks kPairMax positions past the head");
+    static_assert(kWin / (kPairMax + 1) < 256, "dense labels of the big buckets fit one radix digit");
+    constexpr int kLabelBits = 8;
     __shared__ TileSmem<NW, KPT> s;
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const unsigned long long mybit = 1ull << lane;
@@ -117,123 +104,199 @@ k_tile_sort(const uint64_t* __restrict__ E, const uint32_t* __restrict__ G, uint
     for (unsigned i = tid; i < (unsigned)kWin; i += kThreads) gwin[i] = (base + i < m) ? G[base + i] : 0xFFFFFFFFu;
     __syncthreads();
 
-    // ownership of the thread's KPT consecutive window positions
-    uint64_t e[KPT];
-    uint32_t lg[KPT];
-    unsigned own = 0;
+    // ownership and size class of the thread's KPT consecutive window positions
+    uint32_t suf[KPT], key2[KPT], lg[KPT];
+    unsigned own = 0, big = 0;
     const unsigned i0 = tid * KPT;
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
         const uint64_t p = base + i0 + j;
-        e[j] = p < m ? E[p] : 0ull;
+        suf[j] = p < m ? V[p] : 0u;
         const uint32_t g = gwin[i0 + j];
         bool o = p < m && (uint64_t)g >= base && (uint64_t)g < base + kT;
-        if (o) {                                            // a bucket is large iff position head + kTmax is still in it
+        bool bg = false;
+        if (o) {                                            // position head + k is in the bucket iff it has > k members
+            const unsigned lh = (unsigned)((uint64_t)g - base);
             const uint64_t far = (uint64_t)g + kTmax;       // (<= base + kWin - 1: inside the window)
-            if (far < m && gwin[(unsigned)(far - base)] == g) o = false;
+            if (far < m && gwin[lh + kTmax] == g) o = false;
+            else bg = (uint64_t)g + kPairMax < m && gwin[lh + kPairMax] == g;
+            lg[j] = lh;
+        } else {
+            lg[j] = 0u;
         }
-        lg[j] = o ? (uint32_t)((uint64_t)g - base) : 0u;
         own |= (o ? 1u : 0u) << j;
+        big |= ((o && bg) ? 1u : 0u) << j;
     }
-    const uint32_t cnt = (uint32_t)__popc(own);
-    const uint32_t incl = wave_scan_add(cnt);
-    if (lane == 63) s.part[0][w] = incl;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) key2[j] = ((own >> j) & 1u) ? keyfn(suf[j]) : 0u;   // gathers of all owned positions in flight together
+    // exclusive prefix of (small members, big members, big heads) counts, packed 16 + 16 + 16 bits
+    unsigned bighead = 0;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) bighead |= (((big >> j) & 1u) && lg[j] == i0 + j) ? (1u << j) : 0u;
+    const uint64_t cnt = (uint64_t)__popc(own & ~big) | ((uint64_t)__popc(big) << 16) | ((uint64_t)__popc(bighead) << 32);
+    const uint64_t incl = wave_scan_add(cnt);
+    if (lane == 63) s.part64[w] = incl;
     __syncthreads();                                        // (every read of gwin is behind this barrier)
-    uint32_t before = 0, total = 0;
+    uint64_t before = 0, total = 0;
 #pragma unroll
     for (unsigned k = 0; k < (unsigned)NW; k++) {
-        const uint32_t q = s.part[0][k];
+        const uint64_t q = s.part64[k];
         if (k < w) before += q;
         total += q;
     }
-    if (total == 0) return;
+    const unsigned ns = (unsigned)total & 0xFFFFu, nb = (unsigned)(total >> 16) & 0xFFFFu;   // small region [0, ns), big region [ns, ns + nb)
+    if (ns + nb == 0) return;
     {
-        uint32_t at = before + incl - cnt;
+        const uint64_t ex = before + incl - cnt;
+        unsigned at_s = (unsigned)ex & 0xFFFFu, at_b = ns + ((unsigned)(ex >> 16) & 0xFFFFu), lab = (unsigned)(ex >> 32);
 #pragma unroll
         for (int j = 0; j < KPT; j++) {
-            s.sufwin[i0 + j] = (uint32_t)e[j];
+            s.sufwin[i0 + j] = suf[j];
+            if ((bighead >> j) & 1u) s.blabel[lg[j]] = (uint8_t)lab++;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
             if ((own >> j) & 1u) {
-                s.stage[at] = (e[j] & 0xFFFFFFFF00000000ull) | ((uint64_t)lg[j] << kIdxBits) | (uint64_t)(i0 + j);
+                const bool bg = (big >> j) & 1u;
+                const unsigned at = bg ? at_b++ : at_s++;
+                // small: (key2, local bucket id, offset) -- big: (key2, dense label, offset)
+                const unsigned mid = bg ? (unsigned)s.blabel[lg[j]] : lg[j];
+                s.stage[at] = ((uint64_t)key2[j] << 32) | ((uint64_t)mid << kIdxBits) | (uint64_t)(i0 + j);
                 s.posmap[at] = (uint16_t)(i0 + j);
-                at++;
+                if (!bg && lg[j] == i0 + j) s.hslot[lg[j]] = (uint16_t)at;
             }
         }
-        for (unsigned i = total + tid; i < (unsigned)kWin; i += kThreads) s.stage[i] = ~0ull;   // padding sorts last
     }
     __syncthreads();
 
-    // LSD radix sort of stage[0, total) on key2 (bits 32..63), then on the local bucket id: stable,
-    // so every bucket ends up where it was, ordered by key2
-    unsigned long long* const my_flags =
-        TileSmem<NW, KPT>::kAliasMasks ? reinterpret_cast<unsigned long long*>(s.stage) + w * kRadixDev
-                                       : reinterpret_cast<unsigned long long*>(s.masks) + w * kRadixDev;
-    unsigned par = 1;
-    auto pass = [&](int shift, int nbits) {
-        const unsigned mask = (1u << nbits) - 1u;
-        uint64_t key[KPT];
-        uint32_t pos[KPT];
+    // small buckets: slot of an element = bucket start + number of members that sort before it
+    {
+        constexpr int kPer = (kWin + kThreads - 1) / kThreads;
+        uint64_t mine[kPer];
+        unsigned dest[kPer];
 #pragma unroll
-        for (int r = 0; r < KPT; r++) key[r] = s.stage[w * (kWave * KPT) + r * kWave + lane];
-        __syncthreads();                                    // all keys are in registers: stage may hold the masks
-#pragma unroll
-        for (int k = 0; k < kRadixDev / kWave; k++) {
-            my_flags[k * kWave + lane] = 0ull;
-            s.cnt[w][k * kWave + lane] = 0u;
-        }
-        wave_sync();
-#pragma unroll
-        for (int r = 0; r < KPT; r++) {
-            pos[r] = 0;
-            if (w * (kWave * KPT) + r * kWave < total)      // (rounds that hold nothing but padding stay where they are)
-                pos[r] = rank_round<true>((unsigned)(key[r] >> shift) & mask, my_flags, s.cnt[w], mybit);
+        for (int k = 0; k < kPer; k++) {
+            const unsigned j = tid + (unsigned)k * kThreads;
+            dest[k] = 0xFFFFFFFFu;
+            if (j < ns) {
+                const uint64_t key = s.stage[j];
+                const unsigned lgj = (unsigned)(key >> kIdxBits) & (unsigned)(kT - 1);
+                const unsigned b0 = s.hslot[lgj];
+                unsigned r = 0;
+                for (unsigned t = b0; t < ns && t < b0 + (unsigned)kPairMax; t++) {
+                    const uint64_t kt = s.stage[t];
+                    if (((unsigned)(kt >> kIdxBits) & (unsigned)(kT - 1)) != lgj) break;
+                    r += kt < key ? 1u : 0u;                // same bucket: order by key2, then by window offset (stable)
+                }
+                mine[k] = key;
+                dest[k] = b0 + r;
+            }
         }
         __syncthreads();
-        {
-            const bool owner = tid < (unsigned)kRadixDev;
-            uint32_t c[NW], tile_count = 0;
 #pragma unroll
-            for (int k = 0; k < NW; k++) {
-                c[k] = owner ? s.cnt[k][tid] : 0u;
-                tile_count += c[k];
+        for (int k = 0; k < kPer; k++)
+            if (dest[k] != 0xFFFFFFFFu) s.stage[dest[k]] = mine[k];
+    }
+    __syncthreads();
+
+    // big buckets: LSD radix sort of stage[ns, ns + nb) on key2 (bits 32..63), then on the local bucket
+    // id: stable, so every bucket ends up where it was, ordered by key2
+    if (nb > 0) {
+        unsigned long long* const my_flags =
+            TileSmem<NW, KPT>::kAliasMasks ? reinterpret_cast<unsigned long long*>(s.stage) + w * kRadixDev
+                                           : reinterpret_cast<unsigned long long*>(s.masks) + w * kRadixDev;
+        // the match masks live in stage[0, NW * 256): when they would overlap live elements of the small
+        // region... they may: the masks are only written between the two barriers that bracket the ranking,
+        // when every element of BOTH regions that a thread needs is in its registers -- so the small region
+        // is saved to registers as well and restored afterwards
+        unsigned par = 1;
+        auto pass = [&](int shift, int nbits) {
+            const unsigned mask = (1u << nbits) - 1u;
+            uint64_t key[KPT];
+            uint32_t pos[KPT];
+#pragma unroll
+            for (int r = 0; r < KPT; r++) {
+                const unsigned q = w * (kWave * KPT) + r * kWave + lane;
+                key[r] = q < nb ? s.stage[ns + q] : ~0ull;
             }
-            const uint32_t ex = block_scan_excl_1b<NW>(tile_count, s.part, par);
-            if (owner) {
-                uint32_t run = ex;
+            // keep what the masks are about to overwrite: slots [0, NW * 256) of the small region
+            constexpr int kSave = TileSmem<NW, KPT>::kAliasMasks ? (NW * kRadixDev + kThreads - 1) / kThreads : 0;
+            uint64_t saved[kSave > 0 ? kSave : 1];
+#pragma unroll
+            for (int k = 0; k < kSave; k++) {
+                const unsigned q = tid + (unsigned)k * kThreads;
+                saved[k] = (q < (unsigned)(NW * kRadixDev) && q < ns) ? s.stage[q] : 0ull;
+            }
+            __syncthreads();                                // all keys are in registers: stage may hold the masks
+#pragma unroll
+            for (int k = 0; k < kRadixDev / kWave; k++) {
+                my_flags[k * kWave + lane] = 0ull;
+                s.cnt[w][k * kWave + lane] = 0u;
+            }
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < KPT; r++) {
+                pos[r] = 0;
+                if (w * (kWave * KPT) + r * kWave < nb)     // (rounds that hold nothing but padding are skipped)
+                    pos[r] = rank_round<true>((unsigned)(key[r] >> shift) & mask, my_flags, s.cnt[w], mybit);
+            }
+            __syncthreads();
+            {
+                const bool owner = tid < (unsigned)kRadixDev;
+                uint32_t c[NW], tile_count = 0;
 #pragma unroll
                 for (int k = 0; k < NW; k++) {
-                    s.cnt[k][tid] = run;
-                    run += c[k];
+                    c[k] = owner ? s.cnt[k][tid] : 0u;
+                    tile_count += c[k];
+                }
+                const uint32_t ex = block_scan_excl_1b<NW>(tile_count, s.part, par);
+                if (owner) {
+                    uint32_t run = ex;
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        s.cnt[k][tid] = run;
+                        run += c[k];
+                    }
                 }
             }
-        }
-        __syncthreads();
+            __syncthreads();
 #pragma unroll
-        for (int r = 0; r < KPT; r++)
-            if (w * (kWave * KPT) + r * kWave < total)
-                s.stage[pos[r] + s.cnt[w][(unsigned)(key[r] >> shift) & mask]] = key[r];
-        __syncthreads();
-    };
-    for (int sh = 32; sh < 64; sh += 8) pass(sh, 8);
-    for (int sh = kIdxBits; sh < kIdxBits + kGidBits; sh += 8) pass(sh, dmin(8, kIdxBits + kGidBits - sh));
+            for (int k = 0; k < kSave; k++) {
+                const unsigned q = tid + (unsigned)k * kThreads;
+                if (q < (unsigned)(NW * kRadixDev) && q < ns) s.stage[q] = saved[k];
+            }
+#pragma unroll
+            for (int r = 0; r < KPT; r++) {
+                const unsigned q = w * (kWave * KPT) + r * kWave + lane;
+                if (q < nb) s.stage[ns + pos[r] + s.cnt[w][(unsigned)(key[r] >> shift) & mask]] = key[r];
+            }
+            __syncthreads();
+        };
+        for (int sh = 32; sh < 64; sh += 8) pass(sh, 8);
+        pass(kIdxBits, kLabelBits);
+    }
 
-    for (unsigned i = tid; i < total; i += kThreads) {
+    const unsigned tot = ns + nb;
+    for (unsigned i = tid; i < tot; i += kThreads) {
         const uint64_t key = s.stage[i];
         const uint64_t cls = key >> kIdxBits;               // (key2, local bucket)
-        const bool head = i == 0 || (s.stage[i - 1] >> kIdxBits) != cls;
-        const bool last = i + 1 == total || (s.stage[i + 1] >> kIdxBits) != cls;
+        const bool head = i == 0 || i == ns || (s.stage[i - 1] >> kIdxBits) != cls;
+        const bool last = i + 1 == tot || i + 1 == ns || (s.stage[i + 1] >> kIdxBits) != cls;
         const uint64_t p = base + s.posmap[i];
         V[p] = s.sufwin[(unsigned)key & (unsigned)(kWin - 1)];
         F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
     }
-    if (tid == 0) atomicAdd(owned_total, (unsigned long long)total);
+    if (tid == 0) atomicAdd(owned_total, (unsigned long long)tot);
 }
 
 // ---- large buckets ----------------------------------------------------------------------
 // stream compaction of the members of buckets with more than tmax members (order kept):
 // phase 0 counts per workgroup, phase 1 emits KL = (bucket id << 32 | key2), VL = suffix,
 // P = list position.
+template <class KeyFn>
 __global__ void __launch_bounds__(kBlock)
-k_large_extract(const uint64_t* __restrict__ E, const uint32_t* __restrict__ G, uint64_t m, uint64_t tmax,
+k_large_extract(KeyFn keyfn, const uint32_t* __restrict__ V, const uint32_t* __restrict__ G, uint64_t m, uint64_t tmax,
                 uint64_t chunk, int phase, uint32_t* __restrict__ block_counts, uint64_t* __restrict__ KL,
                 uint32_t* __restrict__ VL, uint32_t* __restrict__ P)
 {
@@ -255,9 +318,9 @@ k_large_extract(const uint64_t* __restrict__ E, const uint32_t* __restrict__ G, 
         uint32_t total;
         const uint32_t ex = block_scan_add_excl<uint32_t>(large ? 1u : 0u, part, total);
         if (phase == 1 && large) {
-            const uint64_t e = E[p];
-            KL[running + ex] = ((uint64_t)g << 32) | (e >> 32);
-            VL[running + ex] = (uint32_t)e;
+            const uint32_t i = V[p];
+            KL[running + ex] = ((uint64_t)g << 32) | (uint64_t)keyfn(i);
+            VL[running + ex] = i;
             P[running + ex] = (uint32_t)p;
         }
         running += total;
@@ -331,41 +394,52 @@ static bool tile_small()
     static const bool v = [] { const char* e = getenv("SFX_TILE_SMALL"); return e && atoi(e) != 0; }();
     return v;
 }
-constexpr int kTileNW = 16, kTileKPT = 8;                   // 8192-element windows, buckets of <= 4096 in LDS
-
-int compose_text_e64(const uint32_t* V, uint64_t m, const PackedText& pt, uint64_t h, uint64_t* E, hipStream_t st)
+// SFX_TILE_GEOM (development): 0 = 1024 threads x 8 (8192-element windows, one workgroup per CU),
+// 1 = 1024 x 4 (4096, two per CU), 2 = 512 x 8 (4096, two per CU), 3 = 512 x 4 (2048, four per CU: the
+// default); SFX_TILE_PAIR = 32 (default) | 64: all-pairs threshold.  Measured on 1 GB of English-like
+// text (tile_sort ms, profiles/r2_tile_geometry_sweep.jsonl): 66 / 76 / 50 / 34 at pair 64, 62 / 72 / 46 / 33
+// at pair 32 -- small workgroups hide the gather latency better and leave fewer members to the radix passes
+static int tile_geom()
 {
-    const unsigned grid = (unsigned)dmin<uint64_t>((m + kBlock - 1) / kBlock, kMaxGrid);
-    SFX_LAUNCH("compose_text_e64", (double)m * 16, k_compose_text_e64, grid, kBlock, st, V, m, pt, h,
-               pt.kbits == 32 ? pt.bits : 0, E);
+    static const int v = [] { const char* e = getenv("SFX_TILE_GEOM"); int x = e ? atoi(e) : 3; return x >= 0 && x <= 3 ? x : 3; }();
+    return v;
+}
+static int tile_pair()
+{
+    static const int v = [] { const char* e = getenv("SFX_TILE_PAIR"); int x = e ? atoi(e) : kPairMaxDefault; return x == 64 ? 64 : 32; }();
+    return v;
+}
+
+template <int NW, int KPT, int PM, class KeyFn>
+static int launch_tile(const KeyFn& keyfn, const TileRound& r, uint64_t m, hipStream_t st, uint64_t* tmax)
+{
+    constexpr int kWin = NW * kWave * KPT;
+    *tmax = kWin - kWin / 2;
+    const uint64_t tiles = (m + kWin / 2 - 1) / (kWin / 2);
+    if (tiles > 0x7FFFFFFFull) return SFX_ERR_TOO_LARGE;
+    // read V + G, gather key2 (one sector), write V + F8
+    SFX_LAUNCH("tile_sort", (double)m * (4 + 4 + 4 + 4 + 1), (k_tile_sort<NW, KPT, PM, KeyFn>), (unsigned)tiles, NW * kWave, st,
+               keyfn, r.G, m, r.V, r.F8, r.counters);
     return SFX_OK;
 }
-int compose_rank_e64(const uint32_t* V, uint64_t m, const uint32_t* isa, uint64_t n, uint64_t h, uint64_t* E,
-                     hipStream_t st)
-{
-    const unsigned grid = (unsigned)dmin<uint64_t>((m + kBlock - 1) / kBlock, kMaxGrid);
-    SFX_LAUNCH("compose_rank_e64", (double)m * 16, k_compose_rank_e64, grid, kBlock, st, V, m, isa, n, h, E);
-    return SFX_OK;
-}
 
-int tile_round(const TileRound& r, uint64_t m, hipStream_t st, sfx_build_stats* stats)
+template <class KeyFn>
+static int tile_round_impl(const KeyFn& keyfn, const TileRound& r, uint64_t m, hipStream_t st, sfx_build_stats* stats)
 {
     if (m == 0) return SFX_OK;
     if (m > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
     SFX_HIP(hipMemsetAsync(r.counters, 0, 2 * sizeof(unsigned long long), st));
-    uint64_t tmax;
+    uint64_t tmax = 0;
     if (tile_small()) {
-        constexpr int kWin = 4 * kWave * 1;
-        tmax = kWin - kWin / 2;
-        const unsigned grid = (unsigned)((m + kWin / 2 - 1) / (kWin / 2));
-        SFX_LAUNCH("tile_sort", (double)m * 17, (k_tile_sort<4, 1>), grid, 4 * kWave, st, r.E, r.G, m, r.V, r.F8, r.counters);
+        SFX_TRY((launch_tile<4, 1, 32, KeyFn>(keyfn, r, m, st, &tmax)));
     } else {
-        constexpr int kWin = kTileNW * kWave * kTileKPT;
-        tmax = kWin - kWin / 2;
-        const uint64_t tiles = (m + kWin / 2 - 1) / (kWin / 2);
-        if (tiles > 0x7FFFFFFFull) return SFX_ERR_TOO_LARGE;
-        SFX_LAUNCH("tile_sort", (double)m * 17, (k_tile_sort<kTileNW, kTileKPT>), (unsigned)tiles, kTileNW * kWave, st, r.E,
-                   r.G, m, r.V, r.F8, r.counters);
+        const int g = tile_geom(), pm = tile_pair();
+#define SFX_TILE(NW, KPT) (pm == 32 ? launch_tile<NW, KPT, 32, KeyFn>(keyfn, r, m, st, &tmax) : launch_tile<NW, KPT, 64, KeyFn>(keyfn, r, m, st, &tmax))
+        if (g == 1) SFX_TRY(SFX_TILE(16, 4));
+        else if (g == 2) SFX_TRY(SFX_TILE(8, 8));
+        else if (g == 3) SFX_TRY(SFX_TILE(8, 4));
+        else SFX_TRY(SFX_TILE(16, 8));
+#undef SFX_TILE
     }
     unsigned long long owned = 0;
     SFX_TRY(read_back(&owned, r.counters, sizeof(owned), st));
@@ -375,11 +449,11 @@ int tile_round(const TileRound& r, uint64_t m, hipStream_t st, sfx_build_stats* 
     if (nlarge > 0) {
         Chunking ch = make_chunking(m, 1024);
         const uint64_t chunk = ch.tiles_per_block * 1024;
-        SFX_LAUNCH("large_count", (double)m * 4, k_large_extract, ch.blocks, kBlock, st, r.E, r.G, m, tmax, chunk, 0,
-                   r.block_counts, r.KL0, r.VL0, r.P);
+        SFX_LAUNCH("large_count", (double)m * 4, (k_large_extract<KeyFn>), ch.blocks, kBlock, st, keyfn, r.V, r.G, m, tmax,
+                   chunk, 0, r.block_counts, r.KL0, r.VL0, r.P);
         SFX_LAUNCH("large_scan", 0.0, k_scan_block_counts, 1, kBlock, st, r.block_counts, ch.blocks, r.totals);
-        SFX_LAUNCH("large_extract", (double)m * 4 + (double)nlarge * 24, k_large_extract, ch.blocks, kBlock, st, r.E,
-                   r.G, m, tmax, chunk, 1, r.block_counts, r.KL0, r.VL0, r.P);
+        SFX_LAUNCH("large_extract", (double)m * 4 + (double)nlarge * 24, (k_large_extract<KeyFn>), ch.blocks, kBlock, st,
+                   keyfn, r.V, r.G, m, tmax, chunk, 1, r.block_counts, r.KL0, r.VL0, r.P);
         int in1 = 0;
         SFX_TRY(radix_sort_kv64(r.KL0, r.VL0, r.KL1, r.VL1, nlarge, 0, 32 + bits_for(m - 1), r.radix_scratch, st, &in1,
                                 stats, nullptr));
@@ -392,6 +466,17 @@ int tile_round(const TileRound& r, uint64_t m, hipStream_t st, sfx_build_stats* 
     SFX_LAUNCH("flags_reduce", (double)m * 1.25, k_flags_reduce, ch.blocks, kBlock, st, r.F8, m,
                ch.tiles_per_block * kFlagChunkTile, r.part_head, r.part_keep, r.part_ghead, r.F);
     return SFX_OK;
+}
+
+int tile_round_text(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
+                    sfx_build_stats* stats)
+{
+    return tile_round_impl(TextKey{pt, h, pt.kbits == 32 ? pt.bits : 0}, r, m, st, stats);
+}
+int tile_round_rank(const uint32_t* isa, uint64_t n, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
+                    sfx_build_stats* stats)
+{
+    return tile_round_impl(RankKey{isa, n, h}, r, m, st, stats);
 }
 
 }  // namespace sfx

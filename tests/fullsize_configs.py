@@ -74,21 +74,23 @@ def run(name, host_text, with_lcp=True, queries=0, reps=2, cpu_sample=20_000_000
     if queries:
         import oracle
         rng = np.random.default_rng(17)
-        starts = rng.integers(0, n - 64, size=queries)
-        lens = rng.integers(1, 33, size=queries)
-        # move to code-point boundaries (not a continuation byte) at both ends
-        for _ in range(3):
-            starts = np.where((host_text[starts] & 0xC0) == 0x80, starts + 1, starts)
-        ends = starts + lens
-        for _ in range(3):
-            ends = np.where((host_text[np.minimum(ends, n - 1)] & 0xC0) == 0x80, ends + 1, ends)
-        lens = (ends - starts).astype(np.int64)
-        off = np.zeros(queries + 1, dtype=np.int64)
-        off[1:] = np.cumsum(lens)
-        idx = np.arange(off[-1], dtype=np.int64) - np.repeat(off[:-1], lens) + np.repeat(starts, lens)
-        qb = host_text[idx].copy()
-        miss = np.arange(queries // 2, queries)               # second half: corrupt the last byte
-        qb[off[miss + 1] - 1] ^= 0x15
+        if os.environ.get("SFX_R1_QUERIES") == "1":       # round 1's query sample (numpy), for its pinned results
+            starts = rng.integers(0, n - 64, size=queries)
+            lens = rng.integers(1, 33, size=queries)
+            for _ in range(3):
+                starts = np.where((host_text[starts] & 0xC0) == 0x80, starts + 1, starts)
+            ends = starts + lens
+            for _ in range(3):
+                ends = np.where((host_text[np.minimum(ends, n - 1)] & 0xC0) == 0x80, ends + 1, ends)
+            lens = (ends - starts).astype(np.int64)
+            off = np.zeros(queries + 1, dtype=np.int64)
+            off[1:] = np.cumsum(lens)
+            idx = np.arange(off[-1], dtype=np.int64) - np.repeat(off[:-1], lens) + np.repeat(starts, lens)
+            qb = host_text[idx].copy()
+            miss = np.arange(queries // 2, queries)
+            qb[off[miss + 1] - 1] ^= 0x15
+        else:                                              # code-point substrings, half of them corrupted
+            qb, off = _gen.queries(host_text, queries)
         d_qb, d_off = torch.from_numpy(qb).to(dev), torch.from_numpy(off).to(dev)
         (s, e, f, a), t_q = timed(lambda: sdev.query_batch(text, sa, d_qb, d_off), reps)
         rec["queries"] = queries
@@ -151,18 +153,32 @@ if __name__ == "__main__":
     size = int(os.environ.get("SFX_BIG_N", "1000000000"))
     if "c3" in which:
         t0 = time.time(); h = _gen.english_like(size); print("gen english", round(time.time() - t0, 1), "s", flush=True)
-        run("config3: 1 GB English-like ASCII, SA + LCP", h)
+        run("config3: 1 GB English-like ASCII (SURVEY 8d generator), SA + LCP", h)
     if "c5" in which:
         t0 = time.time(); h = _gen.utf8_mixed(size); print("gen utf8", round(time.time() - t0, 1), "s", flush=True)
-        run("config5: 1 GB UTF-8 mixed-script, SA + LCP + 1M positions() queries", h, queries=1_000_000)
+        run("config5: 1 GB UTF-8 mixed-script (SURVEY 8d generator), SA + LCP + 1M positions() queries", h,
+            queries=1_000_000)
+    if "dup" in which:
+        t0 = time.time(); h = _gen.near_duplicates(size); print("gen near-duplicates", round(time.time() - t0, 1), "s", flush=True)
+        run("high-LCP: 1 GB near-duplicate documents (16 x 1 MiB, one substitution per ~400 B), SA + LCP", h)
+    if "c3r1" in which or "c5r1" in which:
+        import _gen_r1
+        if "c3r1" in which:
+            t0 = time.time(); h = _gen_r1.english_like(size); print("gen english (r1)", round(time.time() - t0, 1), "s", flush=True)
+            run("config3 (round-1 input): 1 GB English-like ASCII, SA + LCP", h)
+        if "c5r1" in which:
+            os.environ["SFX_R1_QUERIES"] = "1"
+            t0 = time.time(); h = _gen_r1.utf8_mixed(size); print("gen utf8 (r1)", round(time.time() - t0, 1), "s", flush=True)
+            run("config5 (round-1 input): 1 GB UTF-8 mixed-script, SA + LCP + 1M positions() queries", h, queries=1_000_000)
+            os.environ["SFX_R1_QUERIES"] = "0"
     if "dna1g" in which:
-        t0 = time.time(); h = _gen.dna(size, seed=0x5AF1C5 + 4); print("gen dna", round(time.time() - t0, 1), "s", flush=True)
+        t0 = time.time(); h = _gen.dna_fast(size, seed=0x5AF1C5 + 4); print("gen dna", round(time.time() - t0, 1), "s", flush=True)
         run("control: 1 GB uniform DNA, SA + LCP", h)
     if "dna2g" in which:
         # n >= 2^30: the one-sweep status words no longer fit, the chunked radix schedule takes over;
         # also the largest single-GPU input tried (2 * 10^9 positions, ~93 GB of workspace)
         big = int(os.environ.get("SFX_HUGE_N", "2000000000"))
-        t0 = time.time(); h = _gen.dna(big, seed=0x5AF1C5 + 5); print("gen dna", round(time.time() - t0, 1), "s", flush=True)
+        t0 = time.time(); h = _gen.dna_fast(big, seed=0x5AF1C5 + 5); print("gen dna", round(time.time() - t0, 1), "s", flush=True)
         run(f"stress: {big} B uniform DNA (n >= 2^30: chunked radix schedule), SA + LCP", h, reps=1)
     if "eng2g" in which:
         big = int(os.environ.get("SFX_HUGE_N", "1500000000"))
@@ -173,7 +189,7 @@ if __name__ == "__main__":
         # u32 (src/table.rs:380), so the u32 engine runs (~198 GB of workspace) and the array is widened
         import hashlib
         big = int(os.environ.get("SFX_HUGE_N", "4000000000"))
-        t0 = time.time(); h = _gen.dna(big, seed=0x5AF1C5 + 3); print("gen dna", round(time.time() - t0, 1), "s", flush=True)
+        t0 = time.time(); h = _gen.dna_fast(big, seed=0x5AF1C5 + 3); print("gen dna", round(time.time() - t0, 1), "s", flush=True)
         rec = {"config": f"config 4 input on one GPU: {big} B uniform DNA, u32 engine + u64 widening", "n": int(big),
                "sha256_text": hashlib.sha256(h.tobytes()).hexdigest()}
         text = torch.from_numpy(h).to(dev)

@@ -60,6 +60,13 @@ dist.destroy_process_group()
 """
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 @pytest.mark.parametrize("case,world", [("dna", 2), ("text", 2), ("periodic", 2), ("unary", 2), ("dna", 3)])
 def test_partitioned_build_ranks(tmp_path, oracle, case, world):
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(HERE, "emu")])
@@ -67,7 +74,7 @@ def test_partitioned_build_ranks(tmp_path, oracle, case, world):
     script.write_text(WORKER.format(root=ROOT, here=HERE))
     env = dict(os.environ, SFX_CASE=case, SFX_OUT=str(tmp_path), OMP_NUM_THREADS="1")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-                           f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", "29731",
+                           f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                            str(script)], env=env, timeout=600)
     sys.path.insert(0, HERE)
     import _gen

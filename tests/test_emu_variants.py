@@ -73,6 +73,9 @@ VARIANTS = {
     "small-tiles": {"SFX_TILE_SMALL": "1"},
     "small-tiles-key64-multi-tile": {"SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "3"},
     "key64": {"SFX_FORCE_KEY64": "1"},
+    "tile-1024x4-pair32": {"SFX_TILE_GEOM": "1", "SFX_TILE_PAIR": "32"},
+    "tile-512x8": {"SFX_TILE_GEOM": "2"},
+    "tile-512x4-key64": {"SFX_TILE_GEOM": "3", "SFX_FORCE_KEY64": "1"},
 }
 
 
