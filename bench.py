@@ -104,6 +104,93 @@ def verify_sa_chunked(torch, sdev, text, sa, chunk=200_000_000):
     return True, "permutation + adjacent-order (all pairs, in slices of %d)" % chunk
 
 
+def _sha_u32(t):
+    """sha256 of a device int32/uint32 tensor as little-endian u32."""
+    import hashlib
+    return hashlib.sha256(memoryview(t.cpu().numpy())).hexdigest()
+
+
+def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
+    """One BASELINE config at full size on one GPU: device-resident SA (+ LCP, + the
+    10^6 positions() queries of config 5), timed with the inputs already in HBM; sha256 of the text, SA,
+    LCP and query answers compared with tests/golden/fullsize_pins.json, whose values come from a run
+    in which the complete arrays were compared element by element with the oracle
+    (profiles/r2_fullsize_full_oracle.jsonl) -- so no 3-minute CPU oracle inside the bench."""
+    import hashlib
+    spec = {"c3": ("config 3: %d B English-like ASCII (SURVEY 8d), SA + LCP", _gen.english_like),
+            "c5": ("config 5: %d B UTF-8 mixed-script (SURVEY 8d), SA + LCP + 10^6 positions()", _gen.utf8_mixed),
+            "dup": ("high-LCP: %d B near-duplicate documents (16 x 1 MiB, one substitution per ~400 B), SA + LCP",
+                    _gen.near_duplicates)}[key]
+    t0 = time.perf_counter()
+    host = spec[1](size)
+    n = int(host.size)
+    rec = {"config": spec[0] % n, "n": n, "gen_s": round(time.perf_counter() - t0, 2),
+           "sha256_text": hashlib.sha256(memoryview(host)).hexdigest()}
+    text = torch.from_numpy(host).to(dev)
+    ws = sdev.sa_workspace(n, dev)
+    sa = torch.empty(n, dtype=torch.int32, device=dev)
+    sdev.build_sa(text, out=sa, workspace=ws)                       # warm-up (first touch of 50 GB of workspace)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        sdev.build_sa(text, out=sa, workspace=ws)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    rec["sa_ms"] = round(best * 1e3, 2)
+    rec["sa_MB/s"] = round(n / best / 1e6, 1)
+    rec["build"] = eng.build_stats()
+    eng.profile(True); eng.profile_reset()
+    sdev.build_sa(text, out=sa, workspace=ws); torch.cuda.synchronize()
+    prof = sorted(eng.profile_report(), key=lambda r: -r["total_ms"])
+    eng.profile(False)
+    rec["top_kernels_ms"] = {r["name"]: round(r["total_ms"], 2) for r in prof[:8]}
+    del ws
+    lws = sdev.lcp_workspace(n, dev)
+    lcp = torch.empty(n, dtype=torch.int32, device=dev)
+    sdev.build_lcp(text, sa, out=lcp, workspace=lws); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sdev.build_lcp(text, sa, out=lcp, workspace=lws); torch.cuda.synchronize()
+    t_lcp = time.perf_counter() - t0
+    rec["lcp_ms"] = round(t_lcp * 1e3, 2)
+    rec["sa_plus_lcp_MB/s"] = round(n / (best + t_lcp) / 1e6, 1)
+    # SURVEY.md 8d: W_SA(u32) ~ 69 B per input byte for deep-recursion text, W_LCP = 22
+    rec["roofline"] = {"whole_path": {"algo_bytes_per_input_byte": 69.0, "achieved_GB/s": round(69.0 * n / best / 1e9, 1),
+                                      "frac_of_hbm_peak": round(69.0 * n / best / 1e9 / HBM_PEAK_GBS, 4)},
+                       "lcp": {"algo_bytes_per_input_byte": 22.0, "achieved_GB/s": round(22.0 * n / t_lcp / 1e9, 1)}}
+    rec["sha256_sa"] = _sha_u32(sa)
+    rec["sha256_lcp"] = _sha_u32(lcp)
+    del lcp, lws
+    if key == "c5":
+        qb, off = _gen.queries(host, 1_000_000)
+        d_qb, d_off = torch.from_numpy(qb).to(dev), torch.from_numpy(off).to(dev)
+        sdev.query_batch(text, sa, d_qb, d_off); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s, e, f, a = sdev.query_batch(text, sa, d_qb, d_off); torch.cuda.synchronize()
+        t_q = time.perf_counter() - t0
+        rec["queries"] = {"count": 1_000_000, "ms": round(t_q * 1e3, 3), "Mqueries/s": round(1.0 / t_q, 1),
+                          "hit_fraction": round(float(f.float().mean()), 4),
+                          "sha256_start_end": hashlib.sha256(memoryview(torch.stack([s, e]).cpu().numpy())).hexdigest()}
+    pin = (pins or {}).get(key, {}).get(str(n))
+    if pin:
+        checks = {k: rec.get(k) == pin.get(k) for k in ("sha256_text", "sha256_sa", "sha256_lcp") if pin.get(k)}
+        if "queries" in rec and pin.get("sha256_start_end"):
+            checks["sha256_start_end"] = rec["queries"]["sha256_start_end"] == pin["sha256_start_end"]
+        rec["bit_exact_vs_pins"] = bool(checks) and all(checks.values())
+        rec["pin_checks"] = checks
+        rec["pin_source"] = pin.get("source")
+    else:
+        # no pin for this size: fall back to the size-independent property gate
+        ok, how = verify_sa_on_device(torch, sdev, text, sa)
+        rec["bit_exact_vs_pins"] = None
+        rec["verified_by_properties"] = bool(ok)
+        rec["verification"] = how
+    del text, sa
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +204,11 @@ def main():
                     help="also launch the known-byte-count copy / run-scatter micro-benchmarks once, so a "
                          "rocprofv3 --pmc pass of this command can calibrate FETCH_SIZE / WRITE_SIZE")
     ap.add_argument("--no-microbench", action="store_true", help="skip the scatter/gather roofline probes")
+    ap.add_argument("--configs", default="c3,c5,dup",
+                    help="full-size BASELINE configs reported next to the headline at N = 1 (c3 = 1 GB English-like "
+                         "SA + LCP, c5 = 1 GB UTF-8 + 10^6 positions(), dup = 1 GB near-duplicate documents); "
+                         "'' = none")
+    ap.add_argument("--config-size", type=int, default=1_000_000_000)
     args = ap.parse_args()
 
     # multi-process GPU work on this host driver needs dmabuf IPC (RCCL fails with
@@ -245,6 +337,21 @@ def main():
                     "sa_plus_lcp_MB/s": round(n_local / (lcp_ms + ms_per_step) / 1e3, 1),
                     "note": "lcp_lens (src/table.rs:130-138) on the device-resident text and SA; not part of `value`"}
         del lcp_ws
+        # SuffixTable::new + lcp_lens as ONE engine call (sfx_build_sa_lcp_u32_dev): the LCP of every pair the
+        # initial key sort tells apart is read off the sorted keys inside the build
+        ws2 = sdev.sa_lcp_workspace(n_local, dev)
+        sa2 = torch.empty_like(sa)
+        lcp2 = torch.empty_like(lcp)
+        sdev.build_sa_lcp(text, out_sa=sa2, out_lcp=lcp2, workspace=ws2)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sdev.build_sa_lcp(text, out_sa=sa2, out_lcp=lcp2, workspace=ws2)
+        barrier()
+        fused_ms = (time.perf_counter() - t0) * 1e3 / max(args.steps, 1)
+        lcp_info["fused_sa_lcp"] = {"ms_per_step": round(fused_ms, 3), "MB/s": round(n_local / fused_ms / 1e3, 1),
+                                    "same_arrays_as_separate_calls": bool(torch.equal(sa2, sa) and torch.equal(lcp2, lcp))}
+        del ws2, sa2, lcp2
 
     # ---- per-kernel roofline: HIP events on the launch stream, separate untimed build ----
     eng.profile(True)
@@ -373,6 +480,22 @@ def main():
                          f"src/table.rs:388-574, gcc -O3 -march=native), pinned to one core, best of 3: {cpu_s:.1f} s",
                "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
 
+    configs = None
+    if rank == 0 and world == 1 and args.configs:
+        del text, sa
+        torch.cuda.empty_cache()
+        pins = {}
+        try:
+            pins = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_pins.json")))
+        except (OSError, ValueError):
+            pass
+        configs = []
+        for key in [k for k in args.configs.split(",") if k]:
+            try:
+                configs.append(fullsize_config(torch, eng, sdev, _gen, key, args.config_size, pins, dev))
+            except Exception as exc:                    # a failing extra must not cost the headline its line
+                configs.append({"config": key, "error": f"{type(exc).__name__}: {exc}"})
+
     if rank == 0:
         out = {
             "metric": METRIC, "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
@@ -385,7 +508,7 @@ def main():
                                       f"text {n_total} B"),
                        "text_bytes_total": n_total, "build": stats},
             "roofline": roofline, "cpu_baseline": cpu, "lcp": lcp_info,
-            "verified": verified, "verification": how,
+            "verified": verified, "verification": how, "configs": configs,
         }
         print(json.dumps(out))
     if world > 1:

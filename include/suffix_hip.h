@@ -74,6 +74,16 @@ int sfx_build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_s
                           uint32_t* d_lcp, void* d_workspace, uint64_t workspace_bytes,
                           void* stream);
 
+/* ---- SuffixTable::new + lcp_lens in one call (:78-85 + :130-138; the pair suffix_tree/src/lib.rs:71,
+ * :413 makes) -------------------------------------------------------------------
+ * The same two arrays as sfx_build_sa_u32 followed by sfx_build_lcp_u32.  Where the initial key sort
+ * already tells two neighbours apart (98 % of the pairs of uniform DNA) their LCP is read off the sorted
+ * keys inside the build; only the remaining pairs are compared on the text. */
+int sfx_build_sa_lcp_u32(const uint8_t* text, uint64_t n, uint32_t* sa_out, uint32_t* lcp_out);
+uint64_t sfx_sa_lcp_workspace_bytes(uint64_t n);
+int sfx_build_sa_lcp_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, uint32_t* d_lcp,
+                             void* d_workspace, uint64_t workspace_bytes, void* stream);
+
 /* ---- positions / contains / any_position (:223-293), batched ---------------- */
 /* Device-resident index = text + suffix array kept in HBM across calls. */
 typedef struct sfx_index sfx_index;

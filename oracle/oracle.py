@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "libsfx_oracle.so")
 _lib = None
 
 __all__ = ["build", "sais", "naive_sa", "lcp_quadratic", "lcp_kasai", "positions",
-           "any_position", "definitional_sa"]
+           "positions_batch", "any_position", "definitional_sa"]
 
 
 def build(force=False):
@@ -44,6 +44,8 @@ def _load():
         L.orc_positions.argtypes = [u8p, u64, u32p, u8p, u64,
                                     ctypes.POINTER(u64), ctypes.POINTER(u64)]
         L.orc_positions.restype = None
+        L.orc_positions_batch.argtypes = [u8p, u64, u32p, u8p, ctypes.c_void_p, u64, u32p, u32p]
+        L.orc_positions_batch.restype = None
         L.orc_any_position.argtypes = [u8p, u64, u32p, u8p, u64,
                                        ctypes.POINTER(ctypes.c_uint32)]
         L.orc_any_position.restype = ctypes.c_int
@@ -113,6 +115,20 @@ def positions(text, sa, query):
     _load().orc_positions(_p(t), t.size, _p(sa), _p(q), q.size,
                           ctypes.byref(s), ctypes.byref(e))
     return int(s.value), int(e.value)
+
+
+def positions_batch(text, sa, qbytes, qoff):
+    """positions() for every query k = qbytes[qoff[k]:qoff[k+1]] -> (start, end) uint32 arrays
+    (OpenMP over the host cores)."""
+    t = _bytes_arr(text)
+    sa = np.ascontiguousarray(sa, dtype=np.uint32)
+    qb = np.ascontiguousarray(qbytes, dtype=np.uint8)
+    off = np.ascontiguousarray(qoff, dtype=np.uint64)
+    nq = off.size - 1
+    s = np.zeros(nq, dtype=np.uint32)
+    e = np.zeros(nq, dtype=np.uint32)
+    _load().orc_positions_batch(_p(t), t.size, _p(sa), _p(qb), _p(off), nq, _p(s), _p(e))
+    return s, e
 
 
 def any_position(text, sa, query):

@@ -223,6 +223,20 @@ void orc_positions(const uint8_t *text, uint64_t n, const uint32_t *sa,
  * m bytes of each suffix with the query.  Returns 1 and *pos when found.  The
  * index returned is "arbitrary" by contract (:261-262); callers may only check
  * that it is a real occurrence. */
+/* positions() for a batch of queries (query k = qbytes[qoff[k] .. qoff[k+1])): the same routine in a
+ * loop, spread over the host cores with OpenMP -- a checker convenience for the 10^6-query config */
+void orc_positions_batch(const uint8_t *text, uint64_t n, const uint32_t *sa, const uint8_t *qbytes,
+                         const uint64_t *qoff, uint64_t nq, uint32_t *start, uint32_t *end)
+{
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t k = 0; k < (int64_t)nq; k++) {
+        uint64_t s, e;
+        orc_positions(text, n, sa, qbytes + qoff[k], qoff[k + 1] - qoff[k], &s, &e);
+        start[k] = (uint32_t)s;
+        end[k] = (uint32_t)e;
+    }
+}
+
 int orc_any_position(const uint8_t *text, uint64_t n, const uint32_t *sa,
                      const uint8_t *q, uint64_t m, uint32_t *pos)
 {

@@ -52,6 +52,9 @@ ABI = [
     ("sfx_build_lcp_u32", _int, [_vp, _u64, _vp, _vp]),
     ("sfx_lcp_workspace_bytes", _u64, [_u64]),
     ("sfx_build_lcp_u32_dev", _int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp]),
+    ("sfx_build_sa_lcp_u32", _int, [_vp, _u64, _vp, _vp]),
+    ("sfx_sa_lcp_workspace_bytes", _u64, [_u64]),
+    ("sfx_build_sa_lcp_u32_dev", _int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp]),
     ("sfx_index_create", _int, [_vp, _u64, _vp, ctypes.POINTER(_vp)]),
     ("sfx_index_destroy", None, [_vp]),
     ("sfx_index_len", _u64, [_vp]),

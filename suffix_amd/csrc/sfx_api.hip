@@ -271,6 +271,36 @@ int sfx_build_lcp_u32(const uint8_t* text, uint64_t n, const uint32_t* sa, uint3
     return SFX_OK;
 }
 
+// ---- SA + LCP in one call --------------------------------------------------------------------
+uint64_t sfx_sa_lcp_workspace_bytes(uint64_t n) { return sa_lcp_workspace_bytes(n); }
+
+int sfx_build_sa_lcp_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, uint32_t* d_lcp, void* d_workspace,
+                             uint64_t workspace_bytes, void* stream)
+{
+    return build_sa_lcp_u32_dev(d_text, n, d_sa, d_lcp, d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int sfx_build_sa_lcp_u32(const uint8_t* text, uint64_t n, uint32_t* sa_out, uint32_t* lcp_out)
+{
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    if (n == 0) return SFX_OK;
+    if (!text || !sa_out || !lcp_out) return SFX_ERR_ARG;
+    SFX_TRY(check_device());
+    DevBuf dt, ds, dl, dw;
+    uint64_t wsb = sa_lcp_workspace_bytes(n);
+    SFX_TRY(dt.alloc(n));
+    SFX_TRY(ds.alloc(n * sizeof(uint32_t)));
+    SFX_TRY(dl.alloc(n * sizeof(uint32_t)));
+    SFX_TRY(dw.alloc(wsb));
+    hipStream_t st = nullptr;
+    SFX_HIP(hipMemcpyAsync(dt.p, text, n, hipMemcpyHostToDevice, st));
+    SFX_TRY(build_sa_lcp_u32_dev((const uint8_t*)dt.p, n, (uint32_t*)ds.p, (uint32_t*)dl.p, dw.p, wsb, st));
+    SFX_HIP(hipMemcpyAsync(sa_out, ds.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SFX_HIP(hipMemcpyAsync(lcp_out, dl.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SFX_HIP(hipStreamSynchronize(st));
+    return SFX_OK;
+}
+
 // ---- index + queries ---------------------------------------------------------------------
 int sfx_index_create(const uint8_t* text, uint64_t n, const uint32_t* sa, sfx_index** out)
 {

@@ -201,6 +201,13 @@ int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws
                      hipStream_t st);
 int pack_small_alphabet(const uint8_t* d_text, uint64_t n, int max_bits, void* small, uint32_t* d_packed,
                         hipStream_t st, PackedText* pt, bool* packed);
+uint64_t sa_lcp_workspace_bytes(uint64_t n);
+int build_sa_lcp_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, uint32_t* d_lcp, void* ws,
+                         uint64_t ws_bytes, hipStream_t st);
+// lcp[r] == 0xFFFFFFFF marks the pairs still to compare (they share their first h0 symbols unless one
+// of them ends earlier); *done = false if a pair reached the direct cap (caller recomputes the array)
+int lcp_finish_pending_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint32_t* d_lcp, uint64_t h0,
+                           void* ws, uint64_t ws_bytes, hipStream_t st, bool* done);
 uint64_t lcp_workspace_bytes(uint64_t n);
 int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint32_t* d_lcp,
                       void* ws, uint64_t ws_bytes, hipStream_t st);

@@ -275,6 +275,70 @@ k_lcp_windows_packed(PackedText t, const uint32_t* __restrict__ sa, uint32_t* __
     }
 }
 
+// ---- fused SA + LCP: the pairs the initial sort could not tell apart ------------------------------
+constexpr uint32_t kLcpPendingMark = 0xFFFFFFFFu;
+__global__ void __launch_bounds__(kBlock)
+k_lcp_pending(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint32_t* __restrict__ lcp,
+              uint64_t h0, unsigned long long* __restrict__ counters)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint32_t capped = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) {
+        if (lcp[r] != kLcpPendingMark) continue;
+        const uint64_t a = sa[r - 1], b = sa[r];                     // (r = 0 is never pending)
+        const uint64_t h = (a + h0 <= n && b + h0 <= n) ? h0 : 0;    // equal keys = equal first h0 symbols, padding aside
+        const uint64_t l = extend_match_capped(text, n, a, b, h, h + kDirectCap);
+        if (l >= h + kDirectCap) capped++;
+        lcp[r] = (uint32_t)l;
+    }
+    if (capped) atomicAdd(&counters[1], (unsigned long long)capped);
+}
+// The keys of suffixes shorter than the key are zero-padded, so a key comparison may overstate their
+// common prefix with a neighbour.  There are fewer than h0 such suffixes: find each one's rank by
+// binary search and redo its two LCP entries on the text.
+__device__ __forceinline__ bool suffix_less(const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t b)
+{
+    if (a == b) return false;
+    const uint64_t c = extend_match(text, n, a, b, 0);
+    if (a + c >= n) return true;                                     // a is a proper prefix of b: shorter first
+    if (b + c >= n) return false;
+    return text[a + c] < text[b + c];
+}
+__global__ void __launch_bounds__(kBlock)
+k_lcp_tail_fix(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint32_t* __restrict__ lcp,
+               uint64_t h0)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x + 1;
+    if (k >= h0 || k > n) return;
+    const uint64_t i = n - k;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {                                                // first rank whose suffix is not less than suffix i
+        const uint64_t mid = (lo + hi) / 2;
+        if (suffix_less(text, n, (uint64_t)sa[mid], i)) lo = mid + 1; else hi = mid;
+    }
+    const uint64_t r = lo;
+    if (r >= n || sa[r] != (uint32_t)i) return;                      // (cannot happen on a valid suffix array)
+    lcp[r] = r ? (uint32_t)extend_match(text, n, (uint64_t)sa[r - 1], i, 0) : 0u;
+    if (r + 1 < n) lcp[r + 1] = (uint32_t)extend_match(text, n, i, (uint64_t)sa[r + 1], 0);
+}
+
+int lcp_finish_pending_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint32_t* d_lcp, uint64_t h0,
+                           void* ws, uint64_t ws_bytes, hipStream_t st, bool* done)
+{
+    *done = false;
+    if (!ws || ws_bytes < 64) return SFX_ERR_WORKSPACE;
+    unsigned long long* counters = reinterpret_cast<unsigned long long*>(ws);
+    unsigned long long host[2] = {0, 0};
+    SFX_HIP(hipMemsetAsync(counters, 0, sizeof(host), st));
+    const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
+    SFX_LAUNCH("lcp_pending", (double)n * 4, k_lcp_pending, grid, kBlock, st, d_text, n, d_sa, d_lcp, h0, counters);
+    SFX_LAUNCH("lcp_tail_fix", 0.0, k_lcp_tail_fix, (unsigned)((h0 + kBlock - 1) / kBlock), kBlock, st, d_text, n, d_sa,
+               d_lcp, h0);
+    SFX_TRY(read_back(host, counters, sizeof(host), st));
+    *done = host[1] == 0;
+    return SFX_OK;
+}
+
 // LCP of one contiguous SLICE of the suffix array (range-partitioned index): every rank
 // compares each suffix of its slice with its predecessor directly, 8 bytes per step --
 // the reference's own formulation (lcp_lens_quadratic :348-361), which is the right one

@@ -580,11 +580,22 @@ __device__ __forceinline__ unsigned valid_mask(uint64_t i0, uint64_t m)
 #define SFX_REDUCE_DEPTH 2
 #endif
 // per-workgroup partials: last bucket-head index (+1) in the chunk, #kept, #kept bucket heads
+// Fused LCP (sfx_build_sa_lcp_u32_dev): the sorted keys of the initial sort are in registers here, and
+// for two neighbours with DIFFERENT keys the common prefix is the number of equal leading symbols of the
+// keys -- no text access (97.7 % of the pairs of 100 MB of DNA).  Neighbours with equal keys get
+// kLcpPending and are compared on the text once the suffix array is final (k_lcp_pending).
+struct LcpFuse {
+    uint32_t* lcp;          // nullptr = off
+    int pad_bits;           // unused high bits of a key
+    uint32_t inv_bits;      // ceil(65536 / bits): x / bits for x < 64 (checked on the host)
+};
+constexpr uint32_t kLcpPending = 0xFFFFFFFFu;
+
 template <class KeyT>
 __global__ void __launch_bounds__(kBlock)
 k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t chunk,
                 uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep,
-                uint32_t* __restrict__ part_ghead, uint16_t* __restrict__ flags_out)
+                uint32_t* __restrict__ part_ghead, uint16_t* __restrict__ flags_out, LcpFuse fuse)
 {
     __shared__ uint32_t red[3][kWavesPerBlock];
     const unsigned tid = threadIdx.x;
@@ -611,6 +622,23 @@ k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t chunk,
             group_flags(cur, iu, m, head, single);
             // the apply kernel reads these 2 bits per element instead of the keys again
             flags_out[iu / kGroupItems] = (uint16_t)(head | (single << 8));
+            if (fuse.lcp) {
+                uint32_t l[kGroupItems];
+#pragma unroll
+                for (int j = 0; j < kGroupItems; j++) {
+                    const uint64_t x = (uint64_t)(cur.k[j] ^ cur.k[j + 1]);
+                    const unsigned lz = (unsigned)__clzll((long long)x) - (unsigned)(64 - 8 * (int)sizeof(KeyT)) - (unsigned)fuse.pad_bits;
+                    l[j] = (iu + j == 0) ? 0u : (x ? (lz * fuse.inv_bits) >> 16 : kLcpPending);
+                }
+                if (iu + kGroupItems <= m) {
+                    *reinterpret_cast<uint4*>(fuse.lcp + iu) = uint4{l[0], l[1], l[2], l[3]};
+                    *reinterpret_cast<uint4*>(fuse.lcp + iu + 4) = uint4{l[4], l[5], l[6], l[7]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kGroupItems; j++)
+                        if (iu + j < m) fuse.lcp[iu + j] = l[j];
+                }
+            }
             const unsigned valid = valid_mask(iu, m);
             if (head) last_head = (uint32_t)iu + (32u - (unsigned)__clz((int)head));   // index+1 of the highest head bit
             keep += (uint32_t)__popc(valid & ~single);
@@ -1111,11 +1139,11 @@ uint64_t sa_range_workspace_bytes(uint64_t n, uint64_t max_count)
 // bucket statistics of the sorted active list: reduce -> scan -> {kept, kept buckets} on the host
 template <class KeyT>
 static int round_totals(const KeyT* K, uint64_t m, SaBuffers& b, hipStream_t st, uint64_t* kept,
-                        uint64_t* kept_groups)
+                        uint64_t* kept_groups, LcpFuse fuse = LcpFuse{nullptr, 0, 0})
 {
     Chunking ch = make_chunking(m, kApplyTile);
-    SFX_LAUNCH("groups_reduce", (double)m * sizeof(KeyT), (k_groups_reduce<KeyT>), ch.blocks, kBlock,
-               st, K, m, ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, b.F);
+    SFX_LAUNCH("groups_reduce", (double)m * (sizeof(KeyT) + (fuse.lcp ? 4 : 0)), (k_groups_reduce<KeyT>), ch.blocks, kBlock,
+               st, K, m, ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, b.F, fuse);
     SFX_LAUNCH("groups_scan", 0.0, k_groups_scan, 1, kBlock, st, b.part_head, b.part_keep,
                b.part_ghead, ch.blocks, b.totals);
     uint32_t host_totals[2] = {0, 0};
@@ -1429,7 +1457,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
 template <class KeyT>
 static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool from_text, SaBuffers& b,
                            uint32_t* sa, uint32_t* isa, hipStream_t st, sfx_build_stats& stats,
-                           unsigned hist_blocks = 0)
+                           unsigned hist_blocks = 0, uint32_t* lcp_fuse = nullptr)
 {
     const KeyT* Kr;
     const uint32_t* Vr;
@@ -1454,7 +1482,15 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         V_next = in1 ? b.VA : b.VB;
     }
     uint64_t kept = 0, groups = 0;
-    SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups));
+    LcpFuse fuse = {nullptr, 0, 0};
+    if (lcp_fuse) {                                     // (full builds only: slot r of the sorted keys is SA slot r)
+        fuse.lcp = lcp_fuse;
+        fuse.pad_bits = 8 * (int)sizeof(KeyT) - pt.bits * cpk;
+        fuse.inv_bits = (65536u + (unsigned)pt.bits - 1u) / (unsigned)pt.bits;
+        for (unsigned x = 0; x < 64; x++)
+            if (((x * fuse.inv_bits) >> 16) != x / (unsigned)pt.bits) return SFX_ERR_INTERNAL;
+    }
+    SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups, fuse));
     stats.active_after_initial = kept;
     // no rank array yet: its n-element scatter is only paid if the text rounds stall (refine)
     SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place, pt.n, stats,
@@ -1465,8 +1501,10 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     return refine(pt, cpk, b, sa, isa, S_cur, V_next, kept, st, stats);
 }
 
-int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,
-                     hipStream_t st)
+// lcp_fuse != nullptr: also leave, in lcp_fuse[r], the LCP of every adjacent pair that the initial sort
+// already told apart (kLcpPending elsewhere); *cpk_out = symbols of the initial key
+static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,
+                         hipStream_t st, uint32_t* lcp_fuse, int* cpk_out)
 {
     sfx_build_stats& stats = tls_build_stats();
     memset(&stats, 0, sizeof(stats));
@@ -1499,9 +1537,47 @@ int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws
     stats.bits_per_symbol = (uint32_t)alpha.bits;
     stats.key_bits = (uint32_t)key_bits;
     stats.symbols_per_key = (uint32_t)cpk;
-    if (key_bits == 32) return sort_and_refine<uint32_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats);
-    return sort_and_refine<uint64_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats);
+    if (cpk_out) *cpk_out = cpk;
+    if (key_bits == 32) return sort_and_refine<uint32_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats, 0, lcp_fuse);
+    return sort_and_refine<uint64_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats, 0, lcp_fuse);
 }
+
+int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,
+                     hipStream_t st)
+{
+    return build_sa_impl(d_text, n, d_sa, ws, ws_bytes, st, nullptr, nullptr);
+}
+
+// SuffixTable::new + lcp_lens in one call (src/table.rs:78-85 + :130-138).  When the initial sort
+// separates most suffixes (uniform DNA: 98 %) the LCP of those pairs falls out of the sorted keys and
+// only the rest is compared on the text; otherwise the separate LCP routine runs on the finished array.
+uint64_t sa_lcp_workspace_bytes(uint64_t n)
+{
+    return dmax(sa_workspace_bytes(n), lcp_workspace_bytes(n));
+}
+int build_sa_lcp_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, uint32_t* d_lcp, void* ws,
+                         uint64_t ws_bytes, hipStream_t st)
+{
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    if (n == 0) return SFX_OK;
+    if (!d_text || !d_sa || !d_lcp) return SFX_ERR_ARG;
+    if (!ws || ws_bytes < sa_lcp_workspace_bytes(n)) return SFX_ERR_WORKSPACE;
+    if (n == 1) {
+        SFX_HIP(hipMemsetAsync(d_sa, 0, sizeof(uint32_t), st));
+        SFX_HIP(hipMemsetAsync(d_lcp, 0, sizeof(uint32_t), st));
+        return SFX_OK;
+    }
+    int cpk = 0;
+    SFX_TRY(build_sa_impl(d_text, n, d_sa, ws, ws_bytes, st, d_lcp, &cpk));
+    const sfx_build_stats stats = tls_build_stats();
+    bool done = false;
+    if (stats.active_after_initial * 4 <= n)
+        SFX_TRY(lcp_finish_pending_dev(d_text, n, d_sa, d_lcp, (uint64_t)cpk, ws, ws_bytes, st, &done));
+    if (!done) SFX_TRY(build_lcp_u32_dev(d_text, n, d_sa, d_lcp, ws, ws_bytes, st));
+    tls_build_stats() = stats;
+    return SFX_OK;
+}
+
 
 // ---- partitioned build -----------------------------------------------------------
 int key_histogram_dev(const uint8_t* d_text, uint64_t n, uint64_t begin, uint64_t end,

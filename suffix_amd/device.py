@@ -49,6 +49,29 @@ def build_sa(text, out=None, workspace=None, engine=None):
     return out
 
 
+def sa_lcp_workspace(n, device, engine=None):
+    eng = engine or default_engine()
+    return torch.empty(int(eng.lib.sfx_sa_lcp_workspace_bytes(int(n))), dtype=torch.uint8, device=device)
+
+
+def build_sa_lcp(text, out_sa=None, out_lcp=None, workspace=None, engine=None):
+    """SuffixTable::new + lcp_lens in one call: -> (sa, lcp), both uint32 in int32 storage."""
+    eng = engine or default_engine()
+    _check_u8(text)
+    n = text.numel()
+    if text.is_cuda:
+        eng.require_device()
+    if out_sa is None:
+        out_sa = torch.empty(n, dtype=torch.int32, device=text.device)
+    if out_lcp is None:
+        out_lcp = torch.empty(n, dtype=torch.int32, device=text.device)
+    if workspace is None:
+        workspace = sa_lcp_workspace(n, text.device, eng)
+    eng.check(eng.lib.sfx_build_sa_lcp_u32_dev(_p(text), n, _p(out_sa), _p(out_lcp), _p(workspace), workspace.numel(),
+                                               _stream_ptr(text)), "sfx_build_sa_lcp_u32_dev")
+    return out_sa, out_lcp
+
+
 def lcp_workspace(n, device, engine=None):
     eng = engine or default_engine()
     return torch.empty(int(eng.lib.sfx_lcp_workspace_bytes(int(n))), dtype=torch.uint8, device=device)

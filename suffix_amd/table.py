@@ -68,6 +68,20 @@ class SuffixTable:
         return cls(text, engine=engine)
 
     @classmethod
+    def new_with_lcp(cls, text, engine=None):
+        """SuffixTable::new + lcp_lens in one engine call (sfx_build_sa_lcp_u32): -> (table, lcp array).
+        The pair of calls suffix_tree/src/lib.rs:71 + :413 makes; same arrays as new() then lcp_lens()."""
+        eng = engine or default_engine()
+        tarr = np.frombuffer(_as_bytes(text), dtype=np.uint8)
+        n = tarr.size
+        table = np.zeros(n, dtype=np.uint32)
+        lcp = np.zeros(n, dtype=np.uint32)
+        if n:
+            eng.require_device()
+        eng.check(eng.lib.sfx_build_sa_lcp_u32(_ptr(tarr), n, _ptr(table), _ptr(lcp)), "SuffixTable::new + lcp_lens")
+        return cls(text, _table=table, engine=engine), lcp
+
+    @classmethod
     def from_parts(cls, text, table, engine=None):
         """Unchecked, like the reference (:105-119): only the lengths must agree."""
         t = np.ascontiguousarray(table, dtype=np.uint32)

@@ -23,7 +23,10 @@ def check_text(eng, orc, text, lcp=True, queries=()):
     assert st.len() == len(st._text)                                    # prop_length
     assert np.array_equal(st.table(), exp), f"SA mismatch on {st._text[:40]!r}..."
     if lcp:
-        assert np.array_equal(st.lcp_lens(), orc.lcp_quadratic(st._text, exp))
+        exp_lcp = orc.lcp_quadratic(st._text, exp)
+        assert np.array_equal(st.lcp_lens(), exp_lcp)
+        st2, lcp2 = SuffixTable.new_with_lcp(text, engine=eng)          # the fused entry point: same two arrays
+        assert np.array_equal(st2.table(), exp) and np.array_equal(lcp2, exp_lcp), "fused SA+LCP"
     if queries:
         s, e = st.positions_batch(queries)
         found, anyp = st.contains_batch(queries)
@@ -192,6 +195,32 @@ def small_buckets(eng, orc, scale=1):
     # the deep repeats cannot all be settled within the comparison depth
     check_text(eng, orc, cases["dna deep"][0], lcp=False)
     assert eng.build_stats()["rounds"] > 0
+
+
+def fused_lcp_tails(eng, orc, iters=40, scale=1):
+    """sfx_build_sa_lcp_u32 on texts whose initial key sort separates most suffixes (the LCP of those
+    pairs is read off the sorted keys) and whose END is made of the smallest symbol: suffixes shorter
+    than the key have zero-padded keys that overstate the common prefix, which the tail fix-up redoes."""
+    rng = np.random.default_rng(3)
+    fused = 0
+    for it in range(iters):
+        n = int(rng.integers(200, 4000)) * scale
+        base = _gen.dna(n, seed=100 + it).tobytes()
+        tail = [b"", b"A" * int(rng.integers(1, 40)), b"CA" + b"A" * int(rng.integers(1, 20)), b"AAAC", b"T" * 5][it % 5]
+        t = base + tail
+        st, lcp = SuffixTable.new_with_lcp(t, engine=eng)
+        fused += eng.build_stats()["active_after_initial"] * 4 <= len(t)
+        exp = orc.sais(t)
+        assert np.array_equal(st.table(), exp)
+        assert np.array_equal(lcp, orc.lcp_quadratic(t, exp)), (it, len(t))
+    for it in range(iters // 3):
+        t = _gen.uniform_bytes(3000 * scale, 256, 500 + it).tobytes() + bytes(int(rng.integers(0, 12)))
+        st, lcp = SuffixTable.new_with_lcp(t, engine=eng)
+        exp = orc.sais(t)
+        assert np.array_equal(st.table(), exp) and np.array_equal(lcp, orc.lcp_quadratic(t, exp))
+    assert fused >= iters // 2, fused
+    assert SuffixTable.new_with_lcp(b"", engine=eng)[1].size == 0
+    assert SuffixTable.new_with_lcp(b"x", engine=eng)[1].tolist() == [0]
 
 
 def range_slices(eng, orc, text, nranges, device="cpu", packed=False, top_bits=14):

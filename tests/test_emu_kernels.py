@@ -69,6 +69,10 @@ def test_small_buckets_direct_ordering(emu, oracle):
     _cases.small_buckets(emu, oracle)
 
 
+def test_fused_sa_lcp(emu, oracle):
+    _cases.fused_lcp_tails(emu, oracle, iters=30)
+
+
 def test_multi_tile_and_multi_block(emu, oracle):
     # > 4096-key radix tiles, several persistent workgroups, u32 and u64 initial keys
     import _gen

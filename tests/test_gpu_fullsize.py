@@ -1,0 +1,135 @@
+"""BASELINE.json configs 3 and 5 AT THEIR STATED SIZE (1 GB) on a real MI355X, plus the two
+size-gated code paths the small parity cases cannot reach (run with -m gpu):
+
+  * config 3 / config 5: SA, LCP (and the 10^6 positions() queries) through the C ABI, sha256 of the
+    complete arrays compared with tests/golden/fullsize_pins.json -- the pins were recorded by the run in
+    which the complete SA and LCP arrays were compared element by element with the oracle
+    (profiles/r2_fullsize_full_oracle.jsonl); config 5's query answers are compared with the oracle here,
+    all 10^6 of them;
+  * n >= 2^27: rank rounds whose rank-array updates go through the partitioned scatter
+    (scatter_pairs_u32), complete SA and LCP compared with the oracle;
+  * n >= 2^30: the chunked radix schedule (one-sweep status words no longer fit), property gate.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch  # noqa: F401
+
+import _gen
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PINS = os.path.join(ROOT, "tests", "golden", "fullsize_pins.json")
+N = 1_000_000_000
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import suffix_amd
+    e = suffix_amd.default_engine()
+    e.require_device()
+    assert e.path.endswith("libsuffix_hip.so")
+    return e
+
+
+def _sha(t):
+    return hashlib.sha256(memoryview(t.cpu().numpy())).hexdigest()
+
+
+def _pin(key, n):
+    with open(PINS) as f:
+        return json.load(f)[key][str(n)]
+
+
+def _build(host):
+    from suffix_amd import device as sdev
+    dev = torch.device("cuda", 0)
+    text = torch.from_numpy(host).to(dev)
+    sa = sdev.build_sa(text)
+    lcp = sdev.build_lcp(text, sa)
+    torch.cuda.synchronize()
+    return text, sa, lcp
+
+
+def test_config3_1gb_english_sa_lcp(eng):
+    host = _gen.english_like(N)
+    pin = _pin("c3", N)
+    assert hashlib.sha256(memoryview(host)).hexdigest() == pin["sha256_text"]
+    text, sa, lcp = _build(host)
+    st = eng.build_stats()
+    assert st["n"] == N and st["tile_sorted"] > 0
+    assert _sha(sa) == pin["sha256_sa"]
+    assert _sha(lcp) == pin["sha256_lcp"]
+    del text, sa, lcp
+    torch.cuda.empty_cache()
+
+
+def test_config5_1gb_utf8_sa_lcp_queries(eng, oracle):
+    from suffix_amd import device as sdev
+    host = _gen.utf8_mixed(N)
+    pin = _pin("c5", N)
+    assert hashlib.sha256(memoryview(host)).hexdigest() == pin["sha256_text"]
+    text, sa, lcp = _build(host)
+    assert _sha(sa) == pin["sha256_sa"]
+    assert _sha(lcp) == pin["sha256_lcp"]
+    del lcp
+    qb, off = _gen.queries(host, 1_000_000)
+    dev = text.device
+    s, e, f, a = sdev.query_batch(text, sa, torch.from_numpy(qb).to(dev), torch.from_numpy(off).to(dev))
+    torch.cuda.synchronize()
+    sa_h = sa.cpu().numpy().view(np.uint32)
+    es, ee = oracle.positions_batch(host, sa_h, qb, off)                 # every one of the 10^6 queries
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), es)
+    assert np.array_equal(e.cpu().numpy().view(np.uint32), ee)
+    found = f.cpu().numpy().astype(bool)
+    assert np.array_equal(found, ee > es)
+    hit = np.flatnonzero(found)[:2000]                                   # any_position: a real occurrence
+    anyp = a.cpu().numpy().view(np.uint32)
+    for k in hit.tolist():
+        q = qb[off[k]:off[k + 1]]
+        p = int(anyp[k])
+        assert np.array_equal(host[p:p + q.size], q)
+    assert 0.4 < found.mean() < 0.8
+    del text, sa
+    torch.cuda.empty_cache()
+
+
+def test_rank_rounds_through_partitioned_scatter_2p27(eng, oracle):
+    """150 MB of near-duplicate documents: mean LCP in the hundreds forces rank rounds, and n >= 2^27
+    sends every rank-array update through scatter_pairs_u32; complete SA and LCP vs the oracle."""
+    n = 150_000_000
+    host = _gen.near_duplicates(n, ndocs=4, every=300)
+    text, sa, lcp = _build(host)
+    st = eng.build_stats()
+    assert st["rank_rounds"] >= 2 and n >= (1 << 27), st
+    exp = oracle.sais(host)
+    assert np.array_equal(sa.cpu().numpy().view(np.uint32), exp)
+    assert np.array_equal(lcp.cpu().numpy().view(np.uint32), oracle.lcp_kasai(host, exp))
+    del text, sa, lcp
+    torch.cuda.empty_cache()
+
+
+def test_chunked_radix_schedule_2p30(eng):
+    """1.1 * 10^9 B of DNA: m >= 2^30 elements per pass, the chunked schedule takes over."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from suffix_amd import device as sdev
+    n = 1_100_000_000
+    host = _gen.dna_fast(n, seed=0x5AF1C5 + 9)
+    dev = torch.device("cuda", 0)
+    text = torch.from_numpy(host).to(dev)
+    eng.profile(True); eng.profile_reset()
+    sa = sdev.build_sa(text)
+    torch.cuda.synchronize()
+    names = {r["name"] for r in eng.profile_report()}
+    eng.profile(False)
+    assert "radix_hist" in names, names                                  # (only the chunked schedule launches it)
+    ok, how = bench.verify_sa_chunked(torch, sdev, text, sa)
+    assert ok, how
+    del text, sa
+    torch.cuda.empty_cache()

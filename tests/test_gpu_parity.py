@@ -54,6 +54,10 @@ def test_generated_medium(eng, oracle):
     _cases.generated(eng, oracle, n_dna=3_000_000, n_text=1_500_000)
 
 
+def test_fused_sa_lcp(eng, oracle):
+    _cases.fused_lcp_tails(eng, oracle, iters=40, scale=50)
+
+
 def test_planted_repeats_switch_text_to_rank_rounds(eng, oracle):
     _cases.planted_repeats(eng, oracle, 2_000_000)
 
