@@ -87,8 +87,17 @@ int sfx_build_sa_lcp_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, 
 /* ---- positions / contains / any_position (:223-293), batched ---------------- */
 /* Device-resident index = text + suffix array kept in HBM across calls. */
 typedef struct sfx_index sfx_index;
-/* sa == NULL => build it on the device.  Host pointers. */
+/* sa == NULL => build it on the device.  Host pointers.  A caller-supplied table is checked for
+ * entries >= n (SFX_ERR_ARG; the reference's from_parts is unchecked and "fails in weird ways", :105-107 --
+ * a memory-safe panic there, so the engine must not read out of bounds either).  The index also holds a
+ * BUCKET DIRECTORY: for every k-symbol prefix (k * ceil(log2 sigma) <= 24 bits) the first rank whose suffix
+ * is not smaller -- a query looks its first k symbols up and binary-searches only inside that bucket. */
 int sfx_index_create(const uint8_t* text, uint64_t n, const uint32_t* sa, sfx_index** out);
+/* the same over text and suffix array that already live in HBM (borrowed, not copied: keep them alive and
+ * unchanged while the index exists); only the directory is built.  Queries with device buffers: */
+int sfx_index_create_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, void* stream, sfx_index** out);
+int sfx_index_query_dev(const sfx_index* ix, const uint8_t* d_qbytes, const uint64_t* d_qoff, uint64_t nq,
+                        uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, void* stream);
 void sfx_index_destroy(sfx_index* ix);
 uint64_t sfx_index_len(const sfx_index* ix);
 /* copy the index's suffix array back to the host (n u32) */

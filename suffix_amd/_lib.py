@@ -56,6 +56,8 @@ ABI = [
     ("sfx_sa_lcp_workspace_bytes", _u64, [_u64]),
     ("sfx_build_sa_lcp_u32_dev", _int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp]),
     ("sfx_index_create", _int, [_vp, _u64, _vp, ctypes.POINTER(_vp)]),
+    ("sfx_index_create_dev", _int, [_vp, _u64, _vp, _vp, ctypes.POINTER(_vp)]),
+    ("sfx_index_query_dev", _int, [_vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     ("sfx_index_destroy", None, [_vp]),
     ("sfx_index_len", _u64, [_vp]),
     ("sfx_index_table", _int, [_vp, _vp]),

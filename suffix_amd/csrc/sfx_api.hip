@@ -159,7 +159,41 @@ struct sfx_index {
     uint8_t* d_text = nullptr;
     uint32_t* d_sa = nullptr;
     uint64_t n = 0;
+    bool owns_arrays = true;        // false: created over the caller's device arrays (sfx_index_create_dev)
+    // bucket directory (sfx_query.hip): first k symbols of a query -> its stretch of the suffix array
+    uint32_t* d_dir = nullptr;
+    uint16_t* d_lut = nullptr;      // 256 entries: byte -> symbol code + 1, 0 = byte absent from the text
+    int bits = 0, k = 0;
+    uint64_t entries = 0;
 };
+
+namespace sfx {
+// alphabet -> dense codes, directory shape, device build; SFX_ERR_ARG if the table holds an entry >= n
+static int index_build_directory(sfx_index* ix, hipStream_t st)
+{
+    if (ix->n == 0) return SFX_OK;
+    void* small = nullptr;
+    SFX_HIP(hipMalloc(&small, 4096));
+    unsigned long long bins[256];
+    int rc = byte_presence_host(ix->d_text, ix->n, small, bins, st);
+    (void)hipFree(small);
+    if (rc != SFX_OK) return rc;
+    uint16_t lut[256];
+    unsigned sigma = 0;
+    for (int c = 0; c < 256; c++) lut[c] = bins[c] ? (uint16_t)(++sigma) : (uint16_t)0;
+    ix->bits = bits_for(sigma > 1 ? sigma - 1 : 1);
+    SFX_TRY(dir_shape(ix->n, ix->bits, &ix->k, &ix->entries));
+    SFX_HIP(hipMalloc((void**)&ix->d_dir, ix->entries * sizeof(uint32_t)));
+    SFX_HIP(hipMalloc((void**)&ix->d_lut, 256 * sizeof(uint16_t)));
+    uint32_t* scratch = nullptr;
+    SFX_HIP(hipMalloc((void**)&scratch, (dir_scratch_words(ix->entries) + 2) * sizeof(uint32_t)));
+    uint64_t bad = 0;
+    rc = dir_build_dev(ix->d_text, ix->n, ix->d_sa, lut, ix->bits, ix->k, ix->entries, ix->d_lut, ix->d_dir, scratch, st, &bad);
+    (void)hipFree(scratch);
+    if (rc != SFX_OK) return rc;
+    return bad ? SFX_ERR_ARG : SFX_OK;
+}
+}  // namespace sfx
 
 extern "C" {
 
@@ -315,12 +349,18 @@ int sfx_index_create(const uint8_t* text, uint64_t n, const uint32_t* sa, sfx_in
     if (n) {
         hipStream_t st = nullptr;
         DevBuf dw;
+        auto hip_ok = [&](hipError_t e, const char* what) {
+            if (e == hipSuccess) return true;
+            note_hip_error(e, what, __FILE__, __LINE__);
+            rc = SFX_ERR_HIP;
+            return false;
+        };
         do {
-            if (hipMalloc((void**)&ix->d_text, n) != hipSuccess ||
-                hipMalloc((void**)&ix->d_sa, n * sizeof(uint32_t)) != hipSuccess) { rc = SFX_ERR_HIP; break; }
-            if (hipMemcpyAsync(ix->d_text, text, n, hipMemcpyHostToDevice, st) != hipSuccess) { rc = SFX_ERR_HIP; break; }
+            if (!hip_ok(hipMalloc((void**)&ix->d_text, n), "hipMalloc(text)") ||
+                !hip_ok(hipMalloc((void**)&ix->d_sa, n * sizeof(uint32_t)), "hipMalloc(sa)")) break;
+            if (!hip_ok(hipMemcpyAsync(ix->d_text, text, n, hipMemcpyHostToDevice, st), "H2D text")) break;
             if (sa) {
-                if (hipMemcpyAsync(ix->d_sa, sa, n * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess) { rc = SFX_ERR_HIP; break; }
+                if (!hip_ok(hipMemcpyAsync(ix->d_sa, sa, n * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D sa")) break;
             } else {
                 uint64_t wsb = sa_workspace_bytes(n);
                 rc = dw.alloc(wsb);
@@ -328,19 +368,59 @@ int sfx_index_create(const uint8_t* text, uint64_t n, const uint32_t* sa, sfx_in
                 rc = build_sa_u32_dev(ix->d_text, n, ix->d_sa, dw.p, wsb, st);
                 if (rc != SFX_OK) break;
             }
-            if (hipStreamSynchronize(st) != hipSuccess) { rc = SFX_ERR_HIP; break; }
+            // the directory build also checks every table entry against n (an unchecked from_parts table
+            // must not make the kernels read out of bounds: SFX_ERR_ARG instead of the reference's panic)
+            rc = index_build_directory(ix, st);
+            if (rc != SFX_OK) break;
+            if (!hip_ok(hipStreamSynchronize(st), "sync")) break;
         } while (0);
+        if (rc != SFX_OK) (void)hipStreamSynchronize(st);          // nothing may still use the buffers we release
     }
     if (rc != SFX_OK) { sfx_index_destroy(ix); return rc; }
     *out = ix;
     return SFX_OK;
 }
 
+// The same over arrays that already live in HBM (not copied: the caller keeps d_text / d_sa alive and
+// unchanged for the life of the index); builds only the bucket directory.
+int sfx_index_create_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, void* stream, sfx_index** out)
+{
+    if (!out) return SFX_ERR_ARG;
+    *out = nullptr;
+    if (n > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    if (n && (!d_text || !d_sa)) return SFX_ERR_ARG;
+    SFX_TRY(check_device());
+    sfx_index* ix = new sfx_index();
+    ix->n = n;
+    ix->owns_arrays = false;
+    ix->d_text = const_cast<uint8_t*>(d_text);
+    ix->d_sa = const_cast<uint32_t*>(d_sa);
+    int rc = index_build_directory(ix, (hipStream_t)stream);
+    if (rc != SFX_OK) { (void)hipStreamSynchronize((hipStream_t)stream); sfx_index_destroy(ix); return rc; }
+    *out = ix;
+    return SFX_OK;
+}
+
+int sfx_index_query_dev(const sfx_index* ix, const uint8_t* d_qbytes, const uint64_t* d_qoff, uint64_t nq,
+                        uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, void* stream)
+{
+    if (!ix) return SFX_ERR_ARG;
+    if (ix->n == 0 || !ix->d_dir)
+        return query_batch_dev(ix->d_text, ix->n, ix->d_sa, ix->n, d_qbytes, d_qoff, nq, d_start, d_end, d_found, d_any,
+                               (hipStream_t)stream);
+    return query_batch_dir_dev(ix->d_text, ix->n, ix->d_sa, ix->d_dir, ix->d_lut, ix->bits, ix->k, d_qbytes, d_qoff, nq,
+                               d_start, d_end, d_found, d_any, (hipStream_t)stream);
+}
+
 void sfx_index_destroy(sfx_index* ix)
 {
     if (!ix) return;
-    if (ix->d_text) (void)hipFree(ix->d_text);
-    if (ix->d_sa) (void)hipFree(ix->d_sa);
+    if (ix->owns_arrays) {
+        if (ix->d_text) (void)hipFree(ix->d_text);
+        if (ix->d_sa) (void)hipFree(ix->d_sa);
+    }
+    if (ix->d_dir) (void)hipFree(ix->d_dir);
+    if (ix->d_lut) (void)hipFree(ix->d_lut);
     delete ix;
 }
 
@@ -398,8 +478,8 @@ static int query_host(const sfx_index* ix, const uint8_t* qbytes, const uint64_t
     hipStream_t st = nullptr;
     if (qtotal) SFX_HIP(hipMemcpyAsync(dq.p, qbytes, qtotal, hipMemcpyHostToDevice, st));
     SFX_HIP(hipMemcpyAsync(doff.p, qoff, (nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    SFX_TRY(query_batch_dev(ix->d_text, ix->n, ix->d_sa, ix->n, (const uint8_t*)dq.p, (const uint64_t*)doff.p,
-                            nq, (uint32_t*)ds.p, (uint32_t*)de.p, (uint8_t*)df.p, (uint32_t*)da.p, st));
+    SFX_TRY(sfx_index_query_dev(ix, (const uint8_t*)dq.p, (const uint64_t*)doff.p, nq, (uint32_t*)ds.p, (uint32_t*)de.p,
+                                (uint8_t*)df.p, (uint32_t*)da.p, st));
     if (start_out) SFX_HIP(hipMemcpyAsync(start_out, ds.p, nq * 4, hipMemcpyDeviceToHost, st));
     if (end_out) SFX_HIP(hipMemcpyAsync(end_out, de.p, nq * 4, hipMemcpyDeviceToHost, st));
     if (found_out) SFX_HIP(hipMemcpyAsync(found_out, df.p, nq, hipMemcpyDeviceToHost, st));

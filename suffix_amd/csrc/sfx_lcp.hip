@@ -181,7 +181,10 @@ k_lcp_sample(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __res
     uint64_t l = 0;
     if (j < samples) {
         const uint64_t r = 1 + j * every;
-        if (r < n) l = extend_match_capped(text, n, (uint64_t)sa[r - 1], (uint64_t)sa[r], 0, kSampleCap);
+        if (r < n) {
+            const uint64_t a = sa[r - 1], b = sa[r];                 // (an invalid table is reported by k_sa_range_check)
+            if (a < n && b < n) l = extend_match_capped(text, n, a, b, 0, kSampleCap);
+        }
     }
     for (int d = 32; d >= 1; d >>= 1) l += __shfl_xor(l, d);
     if (lane_id() == 0 && l) atomicAdd(&counters[0], (unsigned long long)l);
@@ -384,6 +387,17 @@ int widen_u32_to_u64_dev(const uint32_t* d_in, uint64_t count, uint64_t* d_out, 
     return SFX_OK;
 }
 
+// counters[2] += entries of sa that are not valid text positions (a from_parts table is unchecked,
+// src/table.rs:105-119; the kernels below index the text and the Phi array with these values)
+__global__ void __launch_bounds__(kBlock)
+k_sa_range_check(const uint32_t* __restrict__ sa, uint64_t n, unsigned long long* __restrict__ counters)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint32_t bad = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) bad += sa[r] >= n ? 1u : 0u;
+    if (bad) atomicAdd(&counters[2], (unsigned long long)bad);
+}
+
 // SFX_LCP_DIRECT_MIN=<n> is a test hook (the direct path from n bytes up; default 2^20)
 static uint64_t direct_lcp_min()
 {
@@ -424,17 +438,19 @@ int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, u
     uint32_t* packed_words = ar.take<uint32_t>(n / 8 + 8);
     if (ar.overflow) return SFX_ERR_WORKSPACE;
     unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
+    unsigned long long* counters = reinterpret_cast<unsigned long long*>(small + 3072);  // (past the alphabet bins and LUT)
+    unsigned long long host[3] = {0, 0, 0};
+    SFX_HIP(hipMemsetAsync(counters, 0, sizeof(host), st));
+    SFX_LAUNCH("sa_range_check", (double)n * 4, k_sa_range_check, grid, kBlock, st, d_sa, n, counters);
     if (n >= direct_lcp_min()) {
         // low-LCP text (by a sample of adjacent pairs): compare directly, fall through to the
         // linear path only if some pair reached the cap
-        unsigned long long* counters = reinterpret_cast<unsigned long long*>(phi);      // (phi is not in use yet)
-        unsigned long long host[2] = {0, 0};
-        SFX_HIP(hipMemsetAsync(counters, 0, sizeof(host), st));
         const uint32_t samples = (uint32_t)dmin<uint64_t>(kSamples, n - 1);
         const uint64_t every = (n - 1) / samples;
         SFX_LAUNCH("lcp_sample", (double)samples * 24, k_lcp_sample, (samples + kBlock - 1) / kBlock, kBlock, st, d_text,
                    n, d_sa, samples, every, counters);
         SFX_TRY(read_back(host, counters, sizeof(host), st));
+        if (host[2]) return SFX_ERR_ARG;
         if (host[0] <= kSampleMeanMax * samples) {
             PackedText pt;
             bool packed = false;
@@ -447,6 +463,9 @@ int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, u
             SFX_TRY(read_back(host, counters, sizeof(host), st));
             if (host[1] == 0) return SFX_OK;
         }
+    } else {
+        SFX_TRY(read_back(host, counters, sizeof(host), st));
+        if (host[2]) return SFX_ERR_ARG;
     }
     if (n >= partitioned_scatter_min()) {
         uint64_t* pairs = ar.take<uint64_t>(n);

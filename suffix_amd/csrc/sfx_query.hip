@@ -104,6 +104,219 @@ k_query_batch(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __re
     }
 }
 
+// ---- bucket directory of the resident index ---------------------------------
+// dir[c] = first rank whose suffix's first k symbols (dense symbol codes of `bits` bits, zero-padded
+// past the end of the text) are >= c, for every k-symbol code c, plus dir[2^(k*bits)] = n: the bucket
+// structure the build's initial sort works with, kept next to the suffix array.  A query first looks
+// its own first k symbols up -- one read instead of the ~ k*bits top levels of the binary search, and
+// no probe at all for queries of <= k symbols or with a byte the text does not contain.
+struct DirParams {
+    const uint32_t* dir;
+    const uint16_t* lut;        // byte -> symbol code + 1, 0 = byte does not occur in the text
+    int bits, k;
+};
+__device__ __forceinline__ uint32_t dir_code_of_suffix(const uint8_t* __restrict__ text, uint64_t n, uint64_t s,
+                                                       const uint16_t* __restrict__ lut, int bits, int k)
+{
+    uint32_t c = 0;
+    for (int j = 0; j < k; j++) c = (c << bits) | (s + j < n ? (uint32_t)lut[text[s + j]] - 1u : 0u);
+    return c;
+}
+// dir[code of rank r] = r wherever the code changes (dir pre-filled with 0xFFFFFFFF); bad[0] counts
+// suffix-array entries >= n (from_parts hands the engine an unchecked table, :105-119)
+__global__ void __launch_bounds__(kBlock)
+k_dir_mark(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, const uint16_t* __restrict__ lut,
+           int bits, int k, uint32_t* __restrict__ dir, unsigned long long* __restrict__ bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const unsigned lane = lane_id();
+    for (uint64_t r0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); r0 < n; r0 += stride) {
+        const uint64_t r = r0 + lane;
+        const bool live = r < n;
+        uint64_t s = live ? (uint64_t)sa[r] : 0;
+        const bool ok = s < n;
+        if (live && !ok) atomicAdd(bad, 1ull);
+        if (!ok) s = 0;
+        const uint32_t c = live ? dir_code_of_suffix(text, n, s, lut, bits, k) : 0u;
+        uint32_t cp = __shfl_up(c, 1u);
+        if (lane == 0 && live && r > 0) {
+            const uint64_t sp = sa[r - 1];
+            cp = sp < n ? dir_code_of_suffix(text, n, sp, lut, bits, k) : 0u;
+        }
+        if (live && (r == 0 || c != cp)) dir[c] = (uint32_t)r;
+    }
+}
+// empty buckets take the start of the next non-empty one: suffix-min over the directory, three steps
+constexpr int kDirRun = 16;
+constexpr int kDirTile = kBlock * kDirRun;
+__global__ void __launch_bounds__(kBlock)
+k_dir_block_min(const uint32_t* __restrict__ dir, uint64_t entries, uint32_t* __restrict__ bmin)
+{
+    __shared__ uint32_t red[kWavesPerBlock];
+    const uint64_t base = (uint64_t)blockIdx.x * kDirTile;
+    uint32_t v = 0xFFFFFFFFu;
+    for (int j = 0; j < kDirRun; j++) {
+        const uint64_t i = base + (uint64_t)j * kBlock + threadIdx.x;
+        if (i < entries) v = dmin(v, dir[i]);
+    }
+    for (int d = 32; d >= 1; d >>= 1) v = dmin(v, __shfl_xor(v, d));
+    if (lane_id() == 0) red[wave_id()] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = red[0];
+        for (int w = 1; w < kWavesPerBlock; w++) a = dmin(a, red[w]);
+        bmin[blockIdx.x] = a;
+    }
+}
+__global__ void k_dir_scan_mins(uint32_t* __restrict__ bmin, uint64_t nb)      // one thread: nb <= 4097
+{
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t run = 0xFFFFFFFFu;
+    for (uint64_t b = nb; b-- > 0;) {
+        const uint32_t mine = bmin[b];
+        bmin[b] = run;                                               // min over the blocks to the right
+        run = dmin(run, mine);
+    }
+}
+__global__ void __launch_bounds__(kBlock)
+k_dir_fill(uint32_t* __restrict__ dir, uint64_t entries, const uint32_t* __restrict__ bmin)
+{
+    __shared__ uint32_t tmin[kBlock];
+    const uint64_t i0 = (uint64_t)blockIdx.x * kDirTile + (uint64_t)threadIdx.x * kDirRun;
+    uint32_t v[kDirRun], run = 0xFFFFFFFFu;
+    for (int j = kDirRun - 1; j >= 0; j--) {
+        v[j] = i0 + j < entries ? dir[i0 + j] : 0xFFFFFFFFu;
+        run = dmin(run, v[j]);
+    }
+    tmin[threadIdx.x] = run;
+    __syncthreads();
+    uint32_t right = bmin[blockIdx.x];
+    for (unsigned t = threadIdx.x + 1; t < (unsigned)kBlock; t++) right = dmin(right, tmin[t]);   // (256 LDS reads: one-time index build)
+    for (int j = kDirRun - 1; j >= 0; j--) {
+        right = dmin(right, v[j]);
+        if (i0 + j < entries) dir[i0 + j] = right;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_query_batch_dir(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, DirParams dp,
+                  const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, uint64_t nq,
+                  uint32_t* __restrict__ start_out, uint32_t* __restrict__ end_out,
+                  uint8_t* __restrict__ found_out, uint32_t* __restrict__ any_out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t qi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; qi < nq; qi += stride) {
+        const uint8_t* q = qbytes + qoff[qi];
+        const uint64_t m = qoff[qi + 1] - qoff[qi];
+        uint64_t start = 0, end = 0;
+        if (n != 0 && m != 0) {                                       // :228-229
+            const int L = m < (uint64_t)dp.k ? (int)m : dp.k;
+            uint32_t c = 0;
+            bool absent = false;
+            for (int j = 0; j < L; j++) {
+                const uint32_t sym = dp.lut[q[j]];
+                absent |= sym == 0u;
+                c = (c << dp.bits) | (sym - 1u);
+            }
+            if (!absent) {
+                const int rest = dp.bits * (dp.k - L);
+                uint64_t lo = dp.dir[(uint64_t)c << rest], hi = dp.dir[((uint64_t)c + 1) << rest];
+                if (m <= (uint64_t)dp.k) {
+                    // every suffix in these buckets starts with q, except suffixes shorter than q whose
+                    // zero padding imitates q's tail: they are the first entries of the first bucket
+                    while (lo < hi && n - (uint64_t)sa[lo] < m) lo++;
+                    start = lo;
+                    end = hi;
+                } else {
+                    const uint64_t top = hi;
+                    while (lo < hi) {                                 // :244-246 inside the bucket
+                        const uint64_t mid = (lo + hi) >> 1;
+                        if (query_le_suffix(q, m, text, n, sa[mid])) hi = mid; else lo = mid + 1;
+                    }
+                    start = lo;
+                    uint64_t cnt = 0;                                 // :247-250 as in k_query_batch, bounded by the bucket
+                    if (start < top && suffix_starts_with(q, m, text, n, sa[start])) {
+                        cnt = 1;
+                        uint64_t step = 1;
+                        while (start + cnt - 1 + step < top && suffix_starts_with(q, m, text, n, sa[start + cnt - 1 + step])) {
+                            cnt += step;
+                            step <<= 1;
+                        }
+                        lo = start + cnt;
+                        hi = dmin<uint64_t>(top, start + cnt - 1 + step);
+                        while (lo < hi) {
+                            const uint64_t mid = (lo + hi) >> 1;
+                            if (!suffix_starts_with(q, m, text, n, sa[mid])) hi = mid; else lo = mid + 1;
+                        }
+                        cnt = lo - start;
+                    }
+                    end = start + cnt;
+                }
+            }
+        }
+        const bool found = end > start;
+        if (!found) start = end = 0;
+        if (start_out) start_out[qi] = (uint32_t)start;
+        if (end_out) end_out[qi] = (uint32_t)end;
+        if (found_out) found_out[qi] = found ? 1 : 0;
+        if (any_out) any_out[qi] = found ? sa[start] : 0xFFFFFFFFu;
+    }
+}
+
+// symbols per directory key: k * bits <= 24 and about n / 4 buckets at most
+int dir_shape(uint64_t n, int bits, int* k_out, uint64_t* entries_out)
+{
+    int budget = bits_for(n) - 2;
+    if (budget > 24) budget = 24;
+    int k = budget / bits;
+    if (k < 1) k = 1;
+    while (k > 1 && k * bits > 24) k--;
+    *k_out = k;
+    *entries_out = (1ull << (k * bits)) + 1;
+    return SFX_OK;
+}
+uint64_t dir_scratch_words(uint64_t entries) { return (entries + kDirTile - 1) / kDirTile + 8; }
+
+// d_lut256 (256 u16: byte -> code + 1) and d_dir (entries u32) are filled; d_scratch: dir_scratch_words(entries) u32
+// + 8 bytes.  *bad_out = suffix-array entries >= n (the table is not usable then).
+int dir_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint16_t* host_lut256, int bits, int k,
+                  uint64_t entries, uint16_t* d_lut256, uint32_t* d_dir, uint32_t* d_scratch, hipStream_t st,
+                  uint64_t* bad_out)
+{
+    unsigned long long* bad = reinterpret_cast<unsigned long long*>(d_scratch);
+    uint32_t* bmin = d_scratch + 2;
+    SFX_HIP(hipMemcpyAsync(d_lut256, host_lut256, 256 * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    SFX_HIP(hipMemsetAsync(d_dir, 0xFF, entries * sizeof(uint32_t), st));
+    SFX_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned long long), st));
+    const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
+    SFX_LAUNCH("dir_mark", (double)n * 12, k_dir_mark, grid, kBlock, st, d_text, n, d_sa, d_lut256, bits, k, d_dir, bad);
+    const uint32_t n32 = (uint32_t)n;
+    SFX_HIP(hipMemcpyAsync(d_dir + (entries - 1), &n32, sizeof(n32), hipMemcpyHostToDevice, st));
+    const uint64_t nb = (entries + kDirTile - 1) / kDirTile;
+    SFX_LAUNCH("dir_block_min", (double)entries * 4, k_dir_block_min, (unsigned)nb, kBlock, st, d_dir, entries, bmin);
+    SFX_LAUNCH("dir_scan_mins", 0.0, k_dir_scan_mins, 1, 64, st, bmin, nb);
+    SFX_LAUNCH("dir_fill", (double)entries * 8, k_dir_fill, (unsigned)nb, kBlock, st, d_dir, entries, bmin);
+    unsigned long long host_bad = 0;
+    SFX_TRY(read_back(&host_bad, bad, sizeof(host_bad), st));
+    *bad_out = host_bad;
+    return SFX_OK;
+}
+
+int query_batch_dir_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint32_t* d_dir,
+                        const uint16_t* d_lut256, int bits, int k, const uint8_t* d_q, const uint64_t* d_qoff, uint64_t nq,
+                        uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st)
+{
+    if (nq == 0) return SFX_OK;
+    if (!d_qoff || (n && (!d_text || !d_sa || !d_dir || !d_lut256))) return SFX_ERR_ARG;
+    const unsigned grid = (unsigned)dmin<uint64_t>((nq + kBlock - 1) / kBlock, kMaxGrid);
+    // one directory read, then 2 * log2(bucket) probes of 12 bytes: ~ half of the undirected search
+    const double probes = 1.0 + (double)dmax(2, 2 * (bits_for(n ? n : 1) - bits * k));
+    DirParams dp = {d_dir, d_lut256, bits, k};
+    SFX_LAUNCH("query_batch_dir", (double)nq * probes * 12.0, k_query_batch_dir, grid, kBlock, st, d_text, n, d_sa, dp,
+               d_q, d_qoff, nq, d_start, d_end, d_found, d_any);
+    return SFX_OK;
+}
+
 // sa_len == n: the whole suffix array.  sa_len < n: a contiguous SLICE of it (one rank of
 // the range-partitioned index); start/end are then positions inside the slice.
 int query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint64_t sa_len, const uint8_t* d_q,

@@ -1247,6 +1247,19 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
     return SFX_OK;
 }
 
+// which byte values occur in the text (host copy of the 256 presence flags); d_small4k: 4 KiB of device scratch
+int byte_presence_host(const uint8_t* d_text, uint64_t n, void* d_small4k, unsigned long long* host_bins256,
+                       hipStream_t st)
+{
+    unsigned long long* bins = reinterpret_cast<unsigned long long*>(d_small4k);
+    SFX_HIP(hipMemsetAsync(bins, 0, 256 * sizeof(unsigned long long), st));
+    if (n) {
+        const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock * 64 - 1) / (kBlock * 64), kMaxGrid);
+        SFX_LAUNCH("byte_presence", (double)n, k_byte_presence, grid, kBlock, st, d_text, n, bins);
+    }
+    return read_back(host_bins256, bins, 256 * sizeof(unsigned long long), st);
+}
+
 // For consumers outside the SA build (the direct LCP pass): pack the text if its alphabet needs
 // at most max_bits per symbol.  small = 4 KiB of device scratch, d_packed = n / 8 + 8 words.
 int pack_small_alphabet(const uint8_t* d_text, uint64_t n, int max_bits, void* small, uint32_t* d_packed,

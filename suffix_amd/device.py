@@ -107,6 +107,39 @@ def query_batch(text, sa, qbytes, qoff, engine=None):
     return start, end, found, anyp
 
 
+class DeviceIndex:
+    """Resident index over device tensors (text, suffix array): the engine adds its bucket directory
+    (sfx_index_create_dev); `query` = batched positions() / contains() / any_position()."""
+
+    def __init__(self, text, sa, engine=None):
+        self._eng = engine or default_engine()
+        _check_u8(text)
+        self._text, self._sa = text, sa                     # (borrowed by the index: keep them alive)
+        h = ctypes.c_void_p()
+        self._eng.check(self._eng.lib.sfx_index_create_dev(_p(text), text.numel(), _p(sa), _stream_ptr(text),
+                                                           ctypes.byref(h)), "sfx_index_create_dev")
+        self._h = h
+
+    def query(self, qbytes, qoff):
+        nq = qoff.numel() - 1
+        dev = self._text.device
+        start = torch.empty(nq, dtype=torch.int32, device=dev)
+        end = torch.empty(nq, dtype=torch.int32, device=dev)
+        found = torch.empty(nq, dtype=torch.uint8, device=dev)
+        anyp = torch.empty(nq, dtype=torch.int32, device=dev)
+        self._eng.check(self._eng.lib.sfx_index_query_dev(self._h, _p(qbytes), _p(qoff), nq, _p(start), _p(end),
+                                                          _p(found), _p(anyp), _stream_ptr(self._text)),
+                        "sfx_index_query_dev")
+        return start, end, found, anyp
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._eng.lib.sfx_index_destroy(h)
+
+    __del__ = close
+
+
 def widen_u64(sa32, engine=None):
     """u32 index tensor (int32 storage) -> int64 tensor holding the same indices (config 4)."""
     eng = engine or default_engine()

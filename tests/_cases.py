@@ -77,6 +77,16 @@ def parts_roundtrip(eng):
         raise RuntimeError("from_parts accepted mismatched lengths")
     except AssertionError:
         pass
+    # from_parts is unchecked by contract (:105-107), but a table entry >= n must come back as an error
+    # from the engine, never as an out-of-bounds device access
+    from suffix_amd._lib import SuffixHipError
+    bad = SuffixTable.from_parts("abcdef", np.array([5, 4, 9, 2, 1, 0], dtype=np.uint32), engine=eng)
+    for call in (lambda: bad.positions("a"), lambda: bad.lcp_lens()):
+        try:
+            call()
+            raise RuntimeError("engine accepted a table with an entry >= n")
+        except SuffixHipError:
+            pass
 
 
 def fasta_fixture(eng, orc, golden, fasta, name):
@@ -221,6 +231,54 @@ def fused_lcp_tails(eng, orc, iters=40, scale=1):
     assert fused >= iters // 2, fused
     assert SuffixTable.new_with_lcp(b"", engine=eng)[1].size == 0
     assert SuffixTable.new_with_lcp(b"x", engine=eng)[1].tolist() == [0]
+
+
+def directory_queries(eng, orc, device="cpu", scale=1):
+    """The resident index with its bucket directory (sfx_index_create_dev / sfx_index_query_dev) against the
+    undirected search and the oracle: queries shorter than, equal to and longer than the directory key,
+    bytes the text does not contain, queries ending in the smallest symbol, texts ending in it."""
+    import torch
+
+    from suffix_amd import device as sdev
+    rng = np.random.default_rng(11)
+    texts = [_gen.dna(30000 * scale, seed=5).tobytes() + b"AAAA", _gen.english_like(20000 * scale).tobytes(),
+             _gen.utf8_mixed(20000 * scale).tobytes(), bytes(range(256)) * (8 * scale) + b"\x00\x00",
+             b"a" * 300, b"ab" * 200 + b"a", _gen.uniform_bytes(5000 * scale, 3, 9, base=65).tobytes() + b"AA"]
+    for text in texts:
+        n = len(text)
+        exp = orc.sais(text)
+        qs = [b"", text[-1:], text[-2:], text[-3:], text[:1], b"\xfe\xfd", text[:40], b"A", b"AA", b"AAA", b"AAAA", b"AAAAA"]
+        for _ in range(300):
+            a = int(rng.integers(0, n))
+            q = text[a:a + int(rng.integers(1, 14))]
+            r = rng.random()
+            if r < 0.25:
+                q = q[:-1] + bytes([q[-1] ^ 0x55])
+            elif r < 0.35:
+                q = q + bytes([int(rng.integers(0, 256))])
+            qs.append(q)
+        off = np.zeros(len(qs) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(q) for q in qs])
+        t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(device)
+        sa = torch.from_numpy(exp.view(np.int32).copy()).to(device)
+        qb = torch.frombuffer(bytearray(b"".join(qs) + b"\x00"), dtype=torch.uint8).to(device)
+        d_off = torch.from_numpy(off).to(device)
+        ix = sdev.DeviceIndex(t, sa, engine=eng)
+        s, e, f, a = [x.cpu().numpy() for x in ix.query(qb, d_off)]
+        s0, e0, f0, a0 = [x.cpu().numpy() for x in sdev.query_batch(t, sa, qb, d_off, engine=eng)]
+        assert np.array_equal(s, s0) and np.array_equal(e, e0) and np.array_equal(f, f0) and np.array_equal(a, a0)
+        for k, q in enumerate(qs):
+            assert (int(s[k]), int(e[k])) == orc.positions(text, exp, q), (q, int(s[k]), int(e[k]))
+        ix.close()
+    # a table with an entry >= n is refused when the index is made
+    from suffix_amd._lib import SuffixHipError
+    t = torch.frombuffer(bytearray(b"abcdef"), dtype=torch.uint8).to(device)
+    bad = torch.tensor([5, 4, 9, 2, 1, 0], dtype=torch.int32).to(device)
+    try:
+        sdev.DeviceIndex(t, bad, engine=eng)
+        raise RuntimeError("index accepted a table with an entry >= n")
+    except SuffixHipError:
+        pass
 
 
 def range_slices(eng, orc, text, nranges, device="cpu", packed=False, top_bits=14):

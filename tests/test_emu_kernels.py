@@ -69,6 +69,10 @@ def test_small_buckets_direct_ordering(emu, oracle):
     _cases.small_buckets(emu, oracle)
 
 
+def test_index_directory_queries(emu, oracle):
+    _cases.directory_queries(emu, oracle)
+
+
 def test_fused_sa_lcp(emu, oracle):
     _cases.fused_lcp_tails(emu, oracle, iters=30)
 

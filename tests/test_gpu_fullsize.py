@@ -80,8 +80,14 @@ def test_config5_1gb_utf8_sa_lcp_queries(eng, oracle):
     del lcp
     qb, off = _gen.queries(host, 1_000_000)
     dev = text.device
-    s, e, f, a = sdev.query_batch(text, sa, torch.from_numpy(qb).to(dev), torch.from_numpy(off).to(dev))
+    d_qb, d_off = torch.from_numpy(qb).to(dev), torch.from_numpy(off).to(dev)
+    s0, e0, f0, a0 = sdev.query_batch(text, sa, d_qb, d_off)            # undirected binary search
+    ix = sdev.DeviceIndex(text, sa)                                     # resident index with its bucket directory
+    s, e, f, a = ix.query(d_qb, d_off)
     torch.cuda.synchronize()
+    assert torch.equal(s, s0) and torch.equal(e, e0) and torch.equal(f, f0)
+    assert hashlib.sha256(memoryview(torch.stack([s, e]).cpu().numpy())).hexdigest() == pin["sha256_start_end"]
+    ix.close()
     sa_h = sa.cpu().numpy().view(np.uint32)
     es, ee = oracle.positions_batch(host, sa_h, qb, off)                 # every one of the 10^6 queries
     assert np.array_equal(s.cpu().numpy().view(np.uint32), es)

@@ -54,6 +54,10 @@ def test_generated_medium(eng, oracle):
     _cases.generated(eng, oracle, n_dna=3_000_000, n_text=1_500_000)
 
 
+def test_index_directory_queries(eng, oracle):
+    _cases.directory_queries(eng, oracle, device="cuda", scale=20)
+
+
 def test_fused_sa_lcp(eng, oracle):
     _cases.fused_lcp_tails(eng, oracle, iters=40, scale=50)
 
