@@ -4,7 +4,7 @@
  * The reference is pure Rust with no FFI of its own; these entry points are
  * what a Rust `extern "C"` block binds at the private seams listed below
  * (citations are /root/reference/src/table.rs; the Rust side a maintainer
- * would add is shown in INTEGRATION.md and rust/suffix_hip_shim.rs).
+ * would add is shown in INTEGRATION.md and rust/suffix-hip/src/lib.rs).
  *
  * Conventions
  *  - caller allocates, callee fills (mirrors `vec![0u32; n]` at :381);

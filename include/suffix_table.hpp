@@ -2,7 +2,7 @@
 // type `SuffixTable` (/root/reference/src/table.rs:54-294) on top of the C ABI
 // (suffix_hip.h).  Header-only; link with -lsuffix_hip.  The reference is
 // compiled code (Rust) and this image has no Rust toolchain, so this is the
-// compiled-language host side; rust/suffix_hip_shim.rs shows the Rust binding.
+// compiled-language host side; rust/suffix-hip/src/lib.rs shows the Rust binding.
 //
 // Same names, argument meaning and error behaviour as the Rust API:
 //   new_ / new_naive(absent: the naive path is the CPU oracle's business) /

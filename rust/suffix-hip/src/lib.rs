@@ -1,21 +1,23 @@
-//! rust/suffix_hip_shim.rs -- the Rust side of the drop-in boundary.
+//! suffix-hip -- the Rust side of the drop-in boundary of the MI355X suffix-array engine.
 //!
-//! NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no rustc/cargo
-//!.  This is the binding a maintainer of BurntSushi/suffix
-//! adds to `src/table.rs` (v1.3.0) to route the hot path through
-//! `libsuffix_hip.so`; every signature below is exactly what
-//! `include/suffix_hip.h` exports, and the ctypes binding in
-//! `suffix_amd/_lib.py` exercises the same symbols with the same argument
-//! meaning on the GPU box.
+//! A cargo crate: `rust/suffix-hip/{Cargo.toml, build.rs, src/lib.rs}` plus two patches for a checkout
+//! of BurntSushi/suffix v1.3.0 (`table.rs.patch`, `Cargo.toml.patch`).  With them applied,
+//!
+//!     SUFFIX_HIP_LIB_DIR=<dir of libsuffix_hip.so> cargo test --features hip
+//!
+//! runs the upstream `tests/tests.rs` (31 tests, 5 QuickCheck properties) with `SuffixTable::new`,
+//! `lcp_lens` and the additive `positions_batch` going through `libsuffix_hip.so`.
+//! NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no rustc/cargo; what is
+//! checked here, on the CPU, is that the patches apply to the reference sources and that every
+//! signature in the `extern "C"` block below equals its declaration in `include/suffix_hip.h`
+//! (tests/test_rust_crate.py).  The ctypes binding in `suffix_amd/_lib.py` and the C++ mirror
+//! exercise the same symbols with the same argument meaning on the GPU box.
 //!
 //! What changes in the crate (nothing in `:140-312` or `lib.rs` changes):
 //!   * `sais_table`  (src/table.rs:378-386)  body after `vec![0u32; n]`
 //!   * `lcp_lens`    (src/table.rs:130-138)  body
 //!   * new additive  `SuffixTable::positions_batch` / `contains_batch`
-//! `sais()`, `Bins`, `SuffixTypes` stay in the crate as the reference CPU path.
-//!
-//! build.rs:   println!("cargo:rustc-link-lib=dylib=suffix_hip");
-//!             println!("cargo:rustc-link-search=native={}", env!("SUFFIX_HIP_LIB_DIR"));
+//! `sais()`, `Bins`, `SuffixTypes` stay in the crate as the reference CPU path (feature `hip` off).
 
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -32,9 +34,12 @@ extern "C" {
     fn sfx_build_sa_u32(text: *const u8, n: u64, sa_out: *mut u32) -> c_int;
     // lcp_lens
     fn sfx_build_lcp_u32(text: *const u8, n: u64, sa: *const u32, lcp_out: *mut u32) -> c_int;
+    // SuffixTable::new + lcp_lens in one engine call (what suffix_tree's to_suffix_tree needs)
+    fn sfx_build_sa_lcp_u32(text: *const u8, n: u64, sa_out: *mut u32, lcp_out: *mut u32) -> c_int;
     // device-resident index for batched queries
     fn sfx_index_create(text: *const u8, n: u64, sa: *const u32, out: *mut *mut SfxIndex) -> c_int;
     fn sfx_index_destroy(ix: *mut SfxIndex);
+    fn sfx_index_len(ix: *const SfxIndex) -> u64;
     fn sfx_positions_batch(ix: *const SfxIndex, qbytes: *const u8, qoff: *const u64, nq: u64,
                            start_out: *mut u32, end_out: *mut u32) -> c_int;
     fn sfx_contains_batch(ix: *const SfxIndex, qbytes: *const u8, qoff: *const u64, nq: u64,
@@ -74,6 +79,18 @@ pub fn lcp_lens(text: &str, table: &[u32]) -> Vec<u32> {
         sfx_build_lcp_u32(text.as_ptr(), text.len() as u64, table.as_ptr(), lcp.as_mut_ptr())
     }, "sfx_build_lcp_u32");
     lcp
+}
+
+/// `SuffixTable::new` and `lcp_lens` in one engine call: (table, lcp).
+pub fn sais_table_with_lcp(text: &str) -> (Vec<u32>, Vec<u32>) {
+    let text = text.as_bytes();
+    assert!(text.len() <= u32::MAX as usize);
+    let mut sa = vec![0u32; text.len()];
+    let mut lcp = vec![0u32; text.len()];
+    check(unsafe {
+        sfx_build_sa_lcp_u32(text.as_ptr(), text.len() as u64, sa.as_mut_ptr(), lcp.as_mut_ptr())
+    }, "sfx_build_sa_lcp_u32");
+    (sa, lcp)
 }
 
 /// Additive API: many `positions()` at once.  Returns (start, end) pairs;
@@ -117,6 +134,11 @@ impl DeviceIndex {
                                f.as_mut_ptr(), std::ptr::null_mut())
         }, "sfx_contains_batch");
         f.into_iter().map(|b| b != 0).collect()
+    }
+}
+impl DeviceIndex {
+    pub fn len(&self) -> usize {
+        unsafe { sfx_index_len(self.0) as usize }
     }
 }
 impl Drop for DeviceIndex {

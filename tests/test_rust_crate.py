@@ -1,0 +1,101 @@
+"""The cargo crate under rust/suffix-hip cannot be compiled here (no rustc / cargo in the image), so the CPU
+suite checks what can go wrong silently: (1) every function in its `extern "C"` block exists in
+include/suffix_hip.h with the same arity and argument / return types; (2) the crate has the files cargo needs;
+(3) the patches apply to the reference checkout (`patch --dry-run`; skipped where /root/reference is absent,
+i.e. on the GPU box)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CRATE = os.path.join(ROOT, "rust", "suffix-hip")
+
+C2RUST = {
+    "const uint8_t*": "*const u8", "uint8_t*": "*mut u8", "const uint32_t*": "*const u32", "uint32_t*": "*mut u32",
+    "const uint64_t*": "*const u64", "uint64_t*": "*mut u64", "uint64_t": "u64", "uint32_t": "u32", "int": "c_int",
+    "void*": "*mut c_void", "const char*": "*const c_char", "sfx_index**": "*mut *mut SfxIndex",
+    "const sfx_index*": "*const SfxIndex", "sfx_index*": "*mut SfxIndex", "double*": "*mut f64", "void": None,
+}
+
+
+def _strip_c_comments(s):
+    return re.sub(r"/\*.*?\*/", " ", s, flags=re.S)
+
+
+def c_declarations():
+    src = _strip_c_comments(open(os.path.join(ROOT, "include", "suffix_hip.h")).read())
+    decls = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(sfx_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "typedef" in ret or "enum" in ret:
+            continue
+        params = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                ty = re.sub(r"\b[A-Za-z_]\w*$", "", a).strip() if not a.endswith("*") else a     # drop the name
+                ty = ty.replace(" *", "*").replace("* ", "*")
+                params.append(ty)
+        decls[name] = (" ".join(ret.split()).replace(" *", "*"), params)
+    return decls
+
+
+def rust_externs():
+    src = open(os.path.join(CRATE, "src", "lib.rs")).read()
+    block = re.search(r'extern "C" \{(.*?)\n\}', src, flags=re.S).group(1)
+    block = re.sub(r"//[^\n]*", "", block)
+    block = re.sub(r"#\[[^\]]*\]", "", block)
+    out = {}
+    for m in re.finditer(r"fn\s+(sfx_\w+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+        name, args, ret = m.group(1), m.group(2), (m.group(3) or "").strip() or None
+        params = [" ".join(a.split(":", 1)[1].split()) for a in args.split(",") if a.strip()]
+        out[name] = (ret, params)
+    return out
+
+
+def test_extern_block_matches_the_c_header():
+    c, r = c_declarations(), rust_externs()
+    assert len(r) >= 10, sorted(r)
+    for name, (rret, rparams) in r.items():
+        assert name in c, f"{name} is not declared in include/suffix_hip.h"
+        cret, cparams = c[name]
+        assert C2RUST[cret] == rret, (name, cret, rret)
+        assert [C2RUST[p] for p in cparams] == rparams, (name, cparams, rparams)
+    # the three seams of the drop-in boundary are bound
+    for must in ("sfx_build_sa_u32", "sfx_build_lcp_u32", "sfx_positions_batch", "sfx_contains_batch",
+                 "sfx_index_create", "sfx_index_destroy", "sfx_build_sa_lcp_u32"):
+        assert must in r, must
+
+
+def test_crate_is_cargo_ready():
+    for f in ("Cargo.toml", "build.rs", os.path.join("src", "lib.rs"), "table.rs.patch", "Cargo.toml.patch"):
+        assert os.path.exists(os.path.join(CRATE, f)), f
+    manifest = open(os.path.join(CRATE, "Cargo.toml")).read()
+    assert 'name = "suffix-hip"' in manifest and 'build = "build.rs"' in manifest and 'links = "suffix_hip"' in manifest
+    build = open(os.path.join(CRATE, "build.rs")).read()
+    assert "rustc-link-lib=dylib=suffix_hip" in build and "SUFFIX_HIP_LIB_DIR" in build
+    lib = open(os.path.join(CRATE, "src", "lib.rs")).read()
+    for fn in ("pub fn sais_table(text: &str) -> Vec<u32>", "pub fn lcp_lens(text: &str, table: &[u32]) -> Vec<u32>",
+               "pub fn positions_batch", "impl Drop for DeviceIndex"):
+        assert fn in lib, fn
+    # the patch only touches the two private seams + the additive API, behind the `hip` feature
+    patch = open(os.path.join(CRATE, "table.rs.patch")).read()
+    added = [l[1:] for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++")]
+    removed = [l for l in patch.splitlines() if l.startswith("-") and not l.startswith("---")]
+    assert not removed, "the patch must not delete reference code (the CPU path stays)"
+    assert sum('cfg(feature = "hip")' in l for l in added) == 4
+    assert any("::suffix_hip::sais_table(text)" in l for l in added)
+    assert any("::suffix_hip::lcp_lens(self.text(), self.table())" in l for l in added)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src") or shutil.which("patch") is None,
+                    reason="reference checkout / patch(1) not available")
+def test_patches_apply_to_the_reference():
+    for p in ("table.rs.patch", "Cargo.toml.patch"):
+        out = subprocess.run(["patch", "--dry-run", "-p1", "-d", "/root/reference", "-i", os.path.join(CRATE, p)],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "FAILED" not in out.stdout and "fuzz" not in out.stdout, out.stdout
