@@ -334,6 +334,18 @@ def main():
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     value = n_total * args.steps / elapsed / 1e6
     stats = eng.build_stats()
+    phases = None
+    if world > 1:
+        # one more, untimed, build with a device synchronisation at every phase boundary: where the
+        # partitioned path spends its time on this rank (max over ranks per phase)
+        ph = {}
+        sdist.build_sa_partitioned(text, timings=ph)
+        names = ["byte_hist", "all_gather_issue", "key_hist", "all_gather_wait", "plan", "range_build"]
+        tv = torch.tensor([ph.get(k, 0.0) for k in names], dtype=torch.float64, device=dev)
+        dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+        phases = {k: round(float(v), 3) for k, v in zip(names, tv.tolist())}
+        if "fallback" in ph:
+            phases["fallback"] = ph["fallback"]
 
     # ---- lcp_lens on the same text (reported next to the headline, never part of `value`:
     # SuffixTable::new builds the suffix array only, src/table.rs:79-91; the LCP array is a
@@ -522,7 +534,7 @@ def main():
                                    f"u32 indices, device-resident text -> device SA"
                                    + ("" if world == 1 else f"; range-partitioned over {world} GPUs, "
                                       f"text {n_total} B"),
-                       "text_bytes_total": n_total, "build": stats},
+                       "text_bytes_total": n_total, "build": stats, "partitioned_phases_ms": phases},
             "roofline": roofline, "cpu_baseline": cpu, "lcp": lcp_info,
             "verified": verified, "verification": how, "configs": configs,
         }

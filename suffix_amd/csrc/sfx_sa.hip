@@ -1451,7 +1451,9 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
                 // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
                 SFX_TRY(build_ranks(b, sa, n, V_next, S_next, kept, isa, st, stats));
                 rank_mode = true;
-            } else if (!isa && stats.text_rounds > (uint32_t)kMaxTextOnlyRounds) {
+            } else if (!isa && (stalled * 2 > n || stats.text_rounds > (uint32_t)kMaxTextOnlyRounds)) {
+                // a slice of the partitioned build cannot switch (the ranks of other slices' suffixes are
+                // not here): the caller falls back to a whole-array build (suffix_amd/dist.py)
                 return SFX_ERR_NEEDS_RANKS;
             }
         }

@@ -5,7 +5,7 @@ SA-IS induction does not shard (it sweeps all buckets left-to-right then
 right-to-left, src/table.rs:426-448), but the *suffix array itself* does,
 because it is unique: split the SA index space at bucket boundaries.
 
-    1. every rank owns a contiguous shard of the byte stream; the shards are
+    1. every rank owns a contiguous shard of the byte stream (lengths may differ); the shards are
        all-gathered so each GPU holds the whole text in HBM (the one bulk
        exchange) -- as PACKED symbol codes (bits/8 of the raw bytes over xGMI)
        whenever a shard packs into whole words, after step 2 has fixed the codes;
@@ -30,6 +30,7 @@ from ._lib import default_engine
 from .device import _p, _stream_ptr
 
 TOP_BITS = 14
+SFX_ERR_NEEDS_RANKS = 7
 
 
 def plan_ranges(bins, world):
@@ -53,29 +54,89 @@ def plan_ranges(bins, world):
     return out
 
 
+def _gather_flat(dst, src, group=None, async_op=False):
+    """All-gather equal-sized pieces into one flat receive buffer (RCCL's native form); backends
+    without it fall back to the list form.  Errors of the collective itself propagate."""
+    fn = getattr(dist, "all_gather_into_tensor", None)
+    if fn is not None:
+        try:
+            return fn(dst, src, group=group, async_op=async_op)
+        except (NotImplementedError, AttributeError):
+            pass
+    return dist.all_gather(list(dst.split(src.numel())), src, group=group, async_op=async_op)
+
+
+def gather_shards(shard, lens, group=None):
+    """The whole text on every rank from shards of possibly different lengths `lens` (list of ints,
+    one per rank): padded all-gather + compaction when they differ."""
+    world = len(lens)
+    dev = shard.device
+    n = sum(lens)
+    text = torch.empty(n, dtype=torch.uint8, device=dev)
+    if len(set(lens)) == 1:
+        _gather_flat(text, shard.contiguous(), group)
+        return text
+    mx = max(lens)
+    padded = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    padded[:shard.numel()] = shard
+    allp = torch.empty(mx * world, dtype=torch.uint8, device=dev)
+    _gather_flat(allp, padded, group)
+    off = 0
+    for r, ln in enumerate(lens):
+        text[off:off + ln] = allp[r * mx:r * mx + ln]
+        off += ln
+    return text
+
+
+class _Phase:
+    """Per-phase wall times of a partitioned build (bench.py, N > 1): the device is synchronised at
+    every phase boundary only when a `timings` dict is passed."""
+
+    def __init__(self, timings, dev):
+        self.t, self.dev, self.t0 = timings, dev, None
+        if timings is not None:
+            import time
+            self._now = time.perf_counter
+            self._sync()
+            self.t0 = self._now()
+
+    def _sync(self):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+
+    def mark(self, name):
+        if self.t is None:
+            return
+        self._sync()
+        t1 = self._now()
+        self.t[name] = self.t.get(name, 0.0) + (t1 - self.t0) * 1e3
+        self.t0 = t1
+
+
 def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, return_text=False,
-                         index_dtype=torch.int32):
-    """shard: this rank's contiguous uint8 piece of the text (all ranks the same
-    length), on this rank's device.  Returns (sa_part, offset, n): sa_part is an
-    int32-storage tensor holding u32 suffix indices, the slice
+                         index_dtype=torch.int32, timings=None):
+    """shard: this rank's contiguous uint8 piece of the text, on this rank's device; the shards may
+    have different lengths (the text is their concatenation in rank order).  Returns
+    (sa_part, offset, n): sa_part is an int32-storage tensor holding u32 suffix indices, the slice
     SA[offset : offset + sa_part.numel()] of the global suffix array.
     index_dtype=torch.int64 widens the slice to u64 indices (BASELINE config 4);
-    return_text=True appends the all-gathered text (needed for LCP / queries)."""
+    return_text=True appends the all-gathered text (needed for LCP / queries);
+    timings = {} collects per-phase milliseconds (byte_hist, all_gather, key_hist, plan, range_build)."""
     eng = engine or default_engine()
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = shard.device
     m = shard.numel()
-    n = m * world
+    ph = _Phase(timings, dev)
+    # shard lengths: one tiny all-gather (the byte stream need not divide evenly)
+    lens_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(lens_t, torch.tensor([m], dtype=torch.int64, device=dev), group=group)
+    lens = [int(x) for x in lens_t]
+    n = sum(lens)
+    begin = sum(lens[:rank])
     if n > 0xFFFFFFFF:
         raise OverflowError("text longer than u32::MAX bytes")     # src/table.rs:380
     stream = _stream_ptr(shard)
-
-    def gather(dst, src, async_op=False):
-        try:
-            return dist.all_gather_into_tensor(dst, src, group=group, async_op=async_op)   # one flat receive buffer (RCCL)
-        except (RuntimeError, NotImplementedError, AttributeError):
-            return dist.all_gather(list(dst.split(src.numel())), src, group=group, async_op=async_op)
 
     # 2. global alphabet: byte histogram of the own shard, all-reduced
     shard = shard.contiguous()
@@ -86,25 +147,27 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
     sym_bits = max(1, (max(sigma, 2) - 1).bit_length())
     spw = 32 // sym_bits
     tb = min(top_bits, sym_bits * max(1, spw))
+    ph.mark("byte_hist")
 
     # 1. the text on every GPU -- packed when the shards pack into whole words (bits/8 of the
-    #    raw volume over xGMI, and no rank packs the whole text), raw otherwise or on request
-    packed_path = (m % spw == 0) and m >= 64
+    #    raw volume over xGMI, and no rank packs the whole text), raw otherwise or on request.
+    #    Equal shard lengths that are multiples of the symbols-per-word: the common case of a
+    #    byte stream cut by the launcher; anything else takes the raw text.
+    packed_path = len(set(lens)) == 1 and (m % spw == 0) and m >= 64
     text = None
     if packed_path:
         # key bits near the end of a shard reach into the next shard: a 64-byte halo is enough
         heads = torch.empty(64 * world, dtype=torch.uint8, device=dev)
-        gather(heads, shard[:64].contiguous())
+        _gather_flat(heads, shard[:64].contiguous(), group)
         if rank + 1 < world:
             local = torch.cat([shard, heads[64 * (rank + 1):64 * (rank + 2)]])
         else:
             local = shard
         hist_text, hist_n, hist_lo, hist_hi = local, local.numel(), 0, m
     if not packed_path or return_text:
-        text = torch.empty(n, dtype=torch.uint8, device=dev)
-        gather(text, shard)
+        text = gather_shards(shard, lens, group)
     if not packed_path:
-        hist_text, hist_n, hist_lo, hist_hi = text, n, rank * m, (rank + 1) * m
+        hist_text, hist_n, hist_lo, hist_hi = text, n, begin, begin + m
 
     # the big exchange (the packed shards) starts now and runs under the key histogram
     packed = mine = packed_work = None
@@ -115,18 +178,22 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
         scratch = torch.empty(256, dtype=torch.uint8, device=dev)
         eng.check(eng.lib.sfx_pack_text_dev(_p(shard), m, _p(byte_bins), _p(scratch), _p(mine), wps, stream),
                   "sfx_pack_text_dev")
-        packed_work = gather(packed[:wps * world], mine, async_op=True)
+        packed_work = _gather_flat(packed[:wps * world], mine, group, async_op=True)
+    ph.mark("all_gather_issue")
 
     # 3. bucket-boundary histogram
     key_bins = torch.zeros(1 << tb, dtype=torch.int64, device=dev)
     eng.check(eng.lib.sfx_key_histogram_dev(_p(hist_text), hist_n, hist_lo, hist_hi, _p(byte_bins), tb,
                                             _p(key_bins), stream), "sfx_key_histogram_dev")
+    ph.mark("key_hist")
     if packed_work is not None:
         packed_work.wait()
+    ph.mark("all_gather_wait")
     dist.all_reduce(key_bins, op=dist.ReduceOp.SUM, group=group)
 
     # 4. plan (tiny, on the host; identical on every rank)
     lo, hi, offset, count = plan_ranges(key_bins.cpu(), world)[rank]
+    ph.mark("plan")
 
     # 5. this rank's slice
     cap = max(count, 1)
@@ -134,16 +201,32 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
     ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(n, cap)), dtype=torch.uint8, device=dev)
     got = ctypes.c_uint64(0)
     if packed_path:
-        eng.check(eng.lib.sfx_build_sa_range_packed_u32_dev(_p(packed), n, _p(byte_bins), tb, lo, hi, cap,
-                                                            _p(sa_part), ctypes.byref(got), _p(ws), ws.numel(),
-                                                            stream), "sfx_build_sa_range_packed_u32_dev")
+        rc = eng.lib.sfx_build_sa_range_packed_u32_dev(_p(packed), n, _p(byte_bins), tb, lo, hi, cap, _p(sa_part),
+                                                       ctypes.byref(got), _p(ws), ws.numel(), stream)
     else:
-        eng.check(eng.lib.sfx_build_sa_range_u32_dev(_p(text), n, _p(byte_bins), tb, lo, hi, cap,
-                                                     _p(sa_part), ctypes.byref(got), _p(ws), ws.numel(),
-                                                     stream), "sfx_build_sa_range_u32_dev")
-    if int(got.value) != count:
-        raise RuntimeError(f"rank {rank}: range build produced {got.value} suffixes, plan said {count}")
-    part = sa_part[:count]
+        rc = eng.lib.sfx_build_sa_range_u32_dev(_p(text), n, _p(byte_bins), tb, lo, hi, cap, _p(sa_part),
+                                                ctypes.byref(got), _p(ws), ws.numel(), stream)
+    # a slice whose repeats are too long for text-symbol refinement needs ranks of suffixes that other
+    # ranks own: every rank then builds the whole suffix array (replicas) and keeps its slice -- correct
+    # for any text, not scalable, and announced in `timings`
+    need = torch.tensor([1 if rc == SFX_ERR_NEEDS_RANKS else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(need, op=dist.ReduceOp.MAX, group=group)
+    if int(need.item()):
+        del ws
+        if text is None:
+            text = gather_shards(shard, lens, group)
+        from .device import build_sa
+        full = build_sa(text, engine=eng)
+        part = full[offset:offset + count].clone()
+        del full
+        if timings is not None:
+            timings["fallback"] = "replicated build (a slice needed rank refinement)"
+    else:
+        eng.check(rc, "sfx_build_sa_range_u32_dev")
+        if int(got.value) != count:
+            raise RuntimeError(f"rank {rank}: range build produced {got.value} suffixes, plan said {count}")
+        part = sa_part[:count]
+    ph.mark("range_build")
     if index_dtype == torch.int64:
         from .device import widen_u64
         part = widen_u64(part, engine=eng)
@@ -186,11 +269,10 @@ def verify_partitioned(shard, sa_part, n, group=None, engine=None):
     the first difference.  -> (ok, description), identical on every rank."""
     world = dist.get_world_size(group)
     dev = shard.device
-    text = torch.empty(n, dtype=torch.uint8, device=dev)
-    try:
-        dist.all_gather_into_tensor(text, shard.contiguous(), group=group)
-    except (RuntimeError, NotImplementedError, AttributeError):
-        dist.all_gather(list(text.split(shard.numel())), shard.contiguous(), group=group)
+    lens_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(lens_t, torch.tensor([shard.numel()], dtype=torch.int64, device=dev), group=group)
+    text = gather_shards(shard.contiguous(), [int(x) for x in lens_t], group)
+    assert text.numel() == n
     cur = sa_part.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
     marks = torch.zeros(n, dtype=torch.int32, device=dev)
     marks.index_add_(0, cur, torch.ones(cur.numel(), dtype=torch.int32, device=dev))

@@ -22,17 +22,31 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 eng = suffix_amd.Engine(os.path.join({here!r}, "emu", "libsuffix_emu.so"))
 kind = os.environ["SFX_CASE"]
-m = {{"periodic": 1200, "unary": 600}}.get(kind, 6000)   # (repetitive text: one text round per 32 symbols of LCP)
+m = {{"periodic": 1200, "unary": 600}}.get(kind, 6000)
+if kind == "ragged":                                       # shards of different lengths (and not multiples of a word)
+    m = [5000, 6001, 4377][rank]
 if kind == "dna":
     full = _gen.dna(m * world, seed=99)
 elif kind == "text":
     full = _gen.english_like(m * world, seed=7)
 elif kind == "unary":
     full = np.frombuffer(b"a" * (m * world), dtype=np.uint8)      # one key bin: every rank but one gets an empty slice
+elif kind == "ragged":
+    full = _gen.dna(5000 + 6001 + 4377, seed=98)
 else:
     full = np.frombuffer((b"ab" * (m * world // 2)), dtype=np.uint8)
-shard = torch.from_numpy(np.ascontiguousarray(full[rank * m:(rank + 1) * m]).copy())
-part, offset, n, text = sdist.build_sa_partitioned(shard, engine=eng, top_bits=10, return_text=True)
+if kind == "ragged":
+    lo = sum([5000, 6001, 4377][:rank])
+    shard = torch.from_numpy(np.ascontiguousarray(full[lo:lo + m]).copy())
+else:
+    shard = torch.from_numpy(np.ascontiguousarray(full[rank * m:(rank + 1) * m]).copy())
+timings = {{}}
+part, offset, n, text = sdist.build_sa_partitioned(shard, engine=eng, top_bits=10, return_text=True, timings=timings)
+assert "range_build" in timings and "key_hist" in timings, timings
+if kind in ("periodic", "unary"):                          # repeats longer than text refinement can settle inside a slice
+    assert "fallback" in timings, timings
+else:
+    assert "fallback" not in timings, timings
 np.save(os.path.join(os.environ["SFX_OUT"], f"part{{rank}}.npy"), part.numpy().view(np.uint32))
 np.save(os.path.join(os.environ["SFX_OUT"], f"off{{rank}}.npy"), np.array([offset, n]))
 # the partitioned index in use: per-slice LCP (one suffix index exchanged per rank) and
@@ -40,7 +54,8 @@ np.save(os.path.join(os.environ["SFX_OUT"], f"off{{rank}}.npy"), np.array([offse
 lcp = sdist.build_lcp_partitioned(text, part, engine=eng)
 np.save(os.path.join(os.environ["SFX_OUT"], f"lcp{{rank}}.npy"), lcp.numpy().view(np.uint32))
 fb = full.tobytes()
-qs = [fb[100:106], fb[-7:], b"zzzz", fb[m // 2:m // 2 + 2], fb[m - 2:m + 3], fb[5:6]]
+qm = 4000 if kind == "ragged" else m
+qs = [fb[100:106], fb[-7:], b"zzzz", fb[qm // 2:qm // 2 + 2], fb[qm - 2:qm + 3], fb[5:6]]
 qb = torch.from_numpy(np.frombuffer(b"".join(qs), dtype=np.uint8).copy())
 qoff = torch.tensor(np.concatenate([[0], np.cumsum([len(q) for q in qs])]), dtype=torch.int64)
 gs, ge = sdist.positions_partitioned(text, part, offset, qb, qoff, engine=eng)
@@ -67,7 +82,7 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-@pytest.mark.parametrize("case,world", [("dna", 2), ("text", 2), ("periodic", 2), ("unary", 2), ("dna", 3)])
+@pytest.mark.parametrize("case,world", [("dna", 2), ("text", 2), ("periodic", 2), ("unary", 2), ("dna", 3), ("ragged", 3)])
 def test_partitioned_build_ranks(tmp_path, oracle, case, world):
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(HERE, "emu")])
     script = tmp_path / "worker.py"
@@ -85,6 +100,8 @@ def test_partitioned_build_ranks(tmp_path, oracle, case, world):
         full = _gen.english_like(m * world, seed=7)
     elif case == "unary":
         full = np.frombuffer(b"a" * (m * world), dtype=np.uint8)
+    elif case == "ragged":
+        full = _gen.dna(5000 + 6001 + 4377, seed=98)
     else:
         full = np.frombuffer((b"ab" * (m * world // 2)), dtype=np.uint8)
     exp = oracle.sais(full.tobytes())
@@ -93,12 +110,13 @@ def test_partitioned_build_ranks(tmp_path, oracle, case, world):
     assert int(offs[0][0]) == 0
     for r in range(1, world):
         assert int(offs[r][0]) == sum(p.size for p in parts[:r])
-    assert int(offs[0][1]) == m * world
+    assert int(offs[0][1]) == full.size
     assert np.array_equal(np.concatenate(parts), exp)
     text = full.tobytes()
     lcps = [np.load(tmp_path / f"lcp{r}.npy") for r in range(world)]
     assert np.array_equal(np.concatenate(lcps), oracle.lcp_quadratic(text, exp))
-    qs = [text[100:106], text[-7:], b"zzzz", text[m // 2:m // 2 + 2], text[m - 2:m + 3], text[5:6]]
+    qm = 4000 if case == "ragged" else m
+    qs = [text[100:106], text[-7:], b"zzzz", text[qm // 2:qm // 2 + 2], text[qm - 2:qm + 3], text[5:6]]
     for r in range(world):                                   # every rank holds the same global answer
         q = np.load(tmp_path / f"q{r}.npy")
         for k, query in enumerate(qs):

@@ -139,3 +139,25 @@ def test_chunked_radix_schedule_2p30(eng):
     assert ok, how
     del text, sa
     torch.cuda.empty_cache()
+
+
+def test_two_gpu_bench_over_rccl():
+    """bench.py --gpus 2 under torch.distributed.run with the nccl (= RCCL) backend, one rank per GPU: the
+    partitioned build's first contact with RCCL.  Skipped on 1-GPU boxes (the driver's multi-GPU node runs it)."""
+    import subprocess
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "20000000"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["verified"] is True, rec
+    assert rec["config"]["partitioned_phases_ms"]["range_build"] > 0
