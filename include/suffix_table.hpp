@@ -13,6 +13,8 @@
 // std::length_error here.  Text is indexed by BYTES (:379).
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -49,15 +51,14 @@ public:
     SuffixTable(SuffixTable&& o) noexcept { *this = std::move(o); }
     SuffixTable& operator=(SuffixTable&& o) noexcept
     {
-        drop_index();
         text_ = std::move(o.text_);
         table_ = std::move(o.table_);
-        index_ = o.index_;
-        o.index_ = nullptr;
+        lazy_ = std::move(o.lazy_);
+        o.lazy_ = std::make_unique<LazyIndex>();
         return *this;
     }
     SuffixTable(const SuffixTable& o) : text_(o.text_), table_(o.table_) {}      // derive(Clone)
-    ~SuffixTable() { drop_index(); }
+    ~SuffixTable() = default;
     bool operator==(const SuffixTable& o) const { return text_ == o.text_ && table_ == o.table_; }   // :54
 
     // lcp_lens (:130-138)
@@ -121,19 +122,26 @@ private:
         if (status == SFX_ERR_TOO_LARGE) throw std::length_error(msg);               // assert! at :380
         throw std::runtime_error(msg);
     }
+    // The device-resident index is made on the first query.  positions(&self) is lock-free and callable
+    // from many threads in the reference, so the lazy creation must be race-free: std::call_once; a
+    // creation that throws leaves the flag unset and the next caller tries again.  Queries on the finished
+    // index only read it (the C ABI's *_batch calls are safe to run concurrently on one sfx_index).
+    struct LazyIndex {
+        std::once_flag once;
+        sfx_index* ix = nullptr;
+        ~LazyIndex() { if (ix) sfx_index_destroy(ix); }
+    };
     sfx_index* index() const
     {
-        if (!index_) check(sfx_index_create(bytes(text_), text_.size(), table_.data(), &index_), "sfx_index_create");
-        return index_;
-    }
-    void drop_index()
-    {
-        if (index_) sfx_index_destroy(index_);
-        index_ = nullptr;
+        LazyIndex& l = *lazy_;
+        std::call_once(l.once, [&] {
+            check(sfx_index_create(bytes(text_), text_.size(), table_.data(), &l.ix), "sfx_index_create");
+        });
+        return l.ix;
     }
     std::string text_;
     std::vector<uint32_t> table_;
-    mutable sfx_index* index_ = nullptr;
+    mutable std::unique_ptr<LazyIndex> lazy_ = std::make_unique<LazyIndex>();
 };
 
 }  // namespace suffix

@@ -144,6 +144,28 @@ struct DevBuf {
     }
 };
 
+// Stream of the host-pointer entry points: one non-blocking stream per calling thread, created on first
+// use, so that SuffixTable::new from several threads runs concurrently on the device instead of
+// serialising on the NULL stream ("per-call stream").  nullptr if creation fails.
+static hipStream_t call_stream()
+{
+    thread_local hipStream_t st = nullptr;
+    thread_local bool tried = false;
+    if (!tried) {
+        tried = true;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+            st = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    return st;
+}
+// pooled device buffers must not go back to the pool while work that uses them may still be queued
+struct StreamDrain {
+    hipStream_t st;
+    ~StreamDrain() { (void)hipStreamSynchronize(st); }
+};
+
 static int check_device()
 {
     int cnt = 0;
@@ -241,7 +263,8 @@ int sfx_build_sa_u32(const uint8_t* text, uint64_t n, uint32_t* sa_out)
     SFX_TRY(dt.alloc(n));
     SFX_TRY(ds.alloc(n * sizeof(uint32_t)));
     SFX_TRY(dw.alloc(wsb));
-    hipStream_t st = nullptr;
+    hipStream_t st = call_stream();
+    StreamDrain drain{st};            // (declared after the buffers: runs before they return to the pool)
     SFX_HIP(hipMemcpyAsync(dt.p, text, n, hipMemcpyHostToDevice, st));
     SFX_TRY(build_sa_u32_dev((const uint8_t*)dt.p, n, (uint32_t*)ds.p, dw.p, wsb, st));
     SFX_HIP(hipMemcpyAsync(sa_out, ds.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -262,7 +285,8 @@ int sfx_build_sa_u64(const uint8_t* text, uint64_t n, uint64_t* sa_out)
     SFX_TRY(dt.alloc(n));
     SFX_TRY(ds.alloc(n * sizeof(uint32_t)));
     SFX_TRY(dw.alloc(wsb));
-    hipStream_t st = nullptr;
+    hipStream_t st = call_stream();
+    StreamDrain drain{st};            // (declared after the buffers: runs before they return to the pool)
     SFX_HIP(hipMemcpyAsync(dt.p, text, n, hipMemcpyHostToDevice, st));
     SFX_TRY(build_sa_u32_dev((const uint8_t*)dt.p, n, (uint32_t*)ds.p, dw.p, wsb, st));
     SFX_HIP(hipStreamSynchronize(st));
@@ -295,7 +319,8 @@ int sfx_build_lcp_u32(const uint8_t* text, uint64_t n, const uint32_t* sa, uint3
     SFX_TRY(ds.alloc(n * sizeof(uint32_t)));
     SFX_TRY(dl.alloc(n * sizeof(uint32_t)));
     SFX_TRY(dw.alloc(wsb));
-    hipStream_t st = nullptr;
+    hipStream_t st = call_stream();
+    StreamDrain drain{st};            // (declared after the buffers: runs before they return to the pool)
     SFX_HIP(hipMemcpyAsync(dt.p, text, n, hipMemcpyHostToDevice, st));
     SFX_HIP(hipMemcpyAsync(ds.p, sa, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     SFX_TRY(build_lcp_u32_dev((const uint8_t*)dt.p, n, (const uint32_t*)ds.p, (uint32_t*)dl.p, dw.p,
@@ -326,7 +351,8 @@ int sfx_build_sa_lcp_u32(const uint8_t* text, uint64_t n, uint32_t* sa_out, uint
     SFX_TRY(ds.alloc(n * sizeof(uint32_t)));
     SFX_TRY(dl.alloc(n * sizeof(uint32_t)));
     SFX_TRY(dw.alloc(wsb));
-    hipStream_t st = nullptr;
+    hipStream_t st = call_stream();
+    StreamDrain drain{st};            // (declared after the buffers: runs before they return to the pool)
     SFX_HIP(hipMemcpyAsync(dt.p, text, n, hipMemcpyHostToDevice, st));
     SFX_TRY(build_sa_lcp_u32_dev((const uint8_t*)dt.p, n, (uint32_t*)ds.p, (uint32_t*)dl.p, dw.p, wsb, st));
     SFX_HIP(hipMemcpyAsync(sa_out, ds.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -347,8 +373,9 @@ int sfx_index_create(const uint8_t* text, uint64_t n, const uint32_t* sa, sfx_in
     ix->n = n;
     int rc = SFX_OK;
     if (n) {
-        hipStream_t st = nullptr;
         DevBuf dw;
+        hipStream_t st = call_stream();
+        StreamDrain drain{st};        // (declared after the buffer: runs before it returns to the pool)
         auto hip_ok = [&](hipError_t e, const char* what) {
             if (e == hipSuccess) return true;
             note_hip_error(e, what, __FILE__, __LINE__);
@@ -475,7 +502,8 @@ static int query_host(const sfx_index* ix, const uint8_t* qbytes, const uint64_t
     if (end_out) SFX_TRY(de.alloc(nq * 4));
     if (found_out) SFX_TRY(df.alloc(nq));
     if (any_out) SFX_TRY(da.alloc(nq * 4));
-    hipStream_t st = nullptr;
+    hipStream_t st = call_stream();
+    StreamDrain drain{st};            // (declared after the buffers: runs before they return to the pool)
     if (qtotal) SFX_HIP(hipMemcpyAsync(dq.p, qbytes, qtotal, hipMemcpyHostToDevice, st));
     SFX_HIP(hipMemcpyAsync(doff.p, qoff, (nq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     SFX_TRY(sfx_index_query_dev(ix, (const uint8_t*)dq.p, (const uint64_t*)doff.p, nq, (uint32_t*)ds.p, (uint32_t*)de.p,

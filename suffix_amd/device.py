@@ -6,11 +6,21 @@ Inputs stay in HBM, outputs are left in HBM, scratch comes from a caller-owned
 device memory on this path, so a build is a pure kernel sequence on the
 caller's stream.
 """
+import contextlib
 import ctypes
 
 import torch
 
 from ._lib import default_engine
+
+
+def _on(t):
+    """Make the tensor's device the current one for the duration of an engine call: the C side launches
+    on, allocates pinned staging for and pools scratch by the CURRENT device, and the stream handed over
+    belongs to the tensor's device."""
+    if t is not None and t.is_cuda:
+        return torch.cuda.device(t.device)
+    return contextlib.nullcontext()
 
 
 def _stream_ptr(t):
@@ -44,8 +54,9 @@ def build_sa(text, out=None, workspace=None, engine=None):
         out = torch.empty(n, dtype=torch.int32, device=text.device)
     if workspace is None:
         workspace = sa_workspace(n, text.device, eng)
-    eng.check(eng.lib.sfx_build_sa_u32_dev(_p(text), n, _p(out), _p(workspace), workspace.numel(),
-                                           _stream_ptr(text)), "sfx_build_sa_u32_dev")
+    with _on(text):
+        eng.check(eng.lib.sfx_build_sa_u32_dev(_p(text), n, _p(out), _p(workspace), workspace.numel(),
+                                               _stream_ptr(text)), "sfx_build_sa_u32_dev")
     return out
 
 
@@ -67,8 +78,9 @@ def build_sa_lcp(text, out_sa=None, out_lcp=None, workspace=None, engine=None):
         out_lcp = torch.empty(n, dtype=torch.int32, device=text.device)
     if workspace is None:
         workspace = sa_lcp_workspace(n, text.device, eng)
-    eng.check(eng.lib.sfx_build_sa_lcp_u32_dev(_p(text), n, _p(out_sa), _p(out_lcp), _p(workspace), workspace.numel(),
-                                               _stream_ptr(text)), "sfx_build_sa_lcp_u32_dev")
+    with _on(text):
+        eng.check(eng.lib.sfx_build_sa_lcp_u32_dev(_p(text), n, _p(out_sa), _p(out_lcp), _p(workspace), workspace.numel(),
+                                                   _stream_ptr(text)), "sfx_build_sa_lcp_u32_dev")
     return out_sa, out_lcp
 
 
@@ -85,9 +97,10 @@ def build_lcp(text, sa, out=None, workspace=None, engine=None):
         out = torch.empty(n, dtype=torch.int32, device=text.device)
     if workspace is None:
         workspace = lcp_workspace(n, text.device, eng)
-    eng.check(eng.lib.sfx_build_lcp_u32_dev(_p(text), n, _p(sa), _p(out), _p(workspace),
-                                            workspace.numel(), _stream_ptr(text)),
-              "sfx_build_lcp_u32_dev")
+    with _on(text):
+        eng.check(eng.lib.sfx_build_lcp_u32_dev(_p(text), n, _p(sa), _p(out), _p(workspace),
+                                                workspace.numel(), _stream_ptr(text)),
+                  "sfx_build_lcp_u32_dev")
     return out
 
 
@@ -101,9 +114,10 @@ def query_batch(text, sa, qbytes, qoff, engine=None):
     end = torch.empty(nq, dtype=torch.int32, device=dev)
     found = torch.empty(nq, dtype=torch.uint8, device=dev)
     anyp = torch.empty(nq, dtype=torch.int32, device=dev)
-    eng.check(eng.lib.sfx_query_batch_dev(_p(text), text.numel(), _p(sa), _p(qbytes), _p(qoff), nq,
-                                          _p(start), _p(end), _p(found), _p(anyp), _stream_ptr(text)),
-              "sfx_query_batch_dev")
+    with _on(text):
+        eng.check(eng.lib.sfx_query_batch_dev(_p(text), text.numel(), _p(sa), _p(qbytes), _p(qoff), nq,
+                                              _p(start), _p(end), _p(found), _p(anyp), _stream_ptr(text)),
+                  "sfx_query_batch_dev")
     return start, end, found, anyp
 
 
@@ -116,8 +130,9 @@ class DeviceIndex:
         _check_u8(text)
         self._text, self._sa = text, sa                     # (borrowed by the index: keep them alive)
         h = ctypes.c_void_p()
-        self._eng.check(self._eng.lib.sfx_index_create_dev(_p(text), text.numel(), _p(sa), _stream_ptr(text),
-                                                           ctypes.byref(h)), "sfx_index_create_dev")
+        with _on(text):
+            self._eng.check(self._eng.lib.sfx_index_create_dev(_p(text), text.numel(), _p(sa), _stream_ptr(text),
+                                                               ctypes.byref(h)), "sfx_index_create_dev")
         self._h = h
 
     def query(self, qbytes, qoff):
@@ -127,9 +142,10 @@ class DeviceIndex:
         end = torch.empty(nq, dtype=torch.int32, device=dev)
         found = torch.empty(nq, dtype=torch.uint8, device=dev)
         anyp = torch.empty(nq, dtype=torch.int32, device=dev)
-        self._eng.check(self._eng.lib.sfx_index_query_dev(self._h, _p(qbytes), _p(qoff), nq, _p(start), _p(end),
-                                                          _p(found), _p(anyp), _stream_ptr(self._text)),
-                        "sfx_index_query_dev")
+        with _on(self._text):
+            self._eng.check(self._eng.lib.sfx_index_query_dev(self._h, _p(qbytes), _p(qoff), nq, _p(start), _p(end),
+                                                              _p(found), _p(anyp), _stream_ptr(self._text)),
+                            "sfx_index_query_dev")
         return start, end, found, anyp
 
     def close(self):
@@ -144,8 +160,9 @@ def widen_u64(sa32, engine=None):
     """u32 index tensor (int32 storage) -> int64 tensor holding the same indices (config 4)."""
     eng = engine or default_engine()
     out = torch.empty(sa32.numel(), dtype=torch.int64, device=sa32.device)
-    eng.check(eng.lib.sfx_widen_u32_to_u64_dev(_p(sa32), sa32.numel(), _p(out), _stream_ptr(sa32)),
-              "sfx_widen_u32_to_u64_dev")
+    with _on(sa32):
+        eng.check(eng.lib.sfx_widen_u32_to_u64_dev(_p(sa32), sa32.numel(), _p(out), _stream_ptr(sa32)),
+                  "sfx_widen_u32_to_u64_dev")
     return out
 
 
@@ -156,8 +173,9 @@ def build_lcp_range(text, sa_part, prev_suffix=None, engine=None):
     _check_u8(text)
     out = torch.empty(sa_part.numel(), dtype=torch.int32, device=text.device)
     prev = 0xFFFFFFFF if prev_suffix is None else int(prev_suffix) & 0xFFFFFFFF
-    eng.check(eng.lib.sfx_build_lcp_range_u32_dev(_p(text), text.numel(), _p(sa_part), sa_part.numel(), prev,
-                                                  _p(out), _stream_ptr(text)), "sfx_build_lcp_range_u32_dev")
+    with _on(text):
+        eng.check(eng.lib.sfx_build_lcp_range_u32_dev(_p(text), text.numel(), _p(sa_part), sa_part.numel(), prev,
+                                                      _p(out), _stream_ptr(text)), "sfx_build_lcp_range_u32_dev")
     return out
 
 
@@ -170,7 +188,8 @@ def query_batch_range(text, sa_part, qbytes, qoff, engine=None):
     end = torch.empty(nq, dtype=torch.int32, device=dev)
     found = torch.empty(nq, dtype=torch.uint8, device=dev)
     anyp = torch.empty(nq, dtype=torch.int32, device=dev)
-    eng.check(eng.lib.sfx_query_batch_range_dev(_p(text), text.numel(), _p(sa_part), sa_part.numel(), _p(qbytes),
-                                                _p(qoff), nq, _p(start), _p(end), _p(found), _p(anyp),
-                                                _stream_ptr(text)), "sfx_query_batch_range_dev")
+    with _on(text):
+        eng.check(eng.lib.sfx_query_batch_range_dev(_p(text), text.numel(), _p(sa_part), sa_part.numel(), _p(qbytes),
+                                                    _p(qoff), nq, _p(start), _p(end), _p(found), _p(anyp),
+                                                    _stream_ptr(text)), "sfx_query_batch_range_dev")
     return start, end, found, anyp

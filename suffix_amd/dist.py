@@ -127,6 +127,8 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
     rank = dist.get_rank(group)
     dev = shard.device
     m = shard.numel()
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)        # the engine launches on / pools by the CURRENT device (one rank = one GPU)
     ph = _Phase(timings, dev)
     # shard lengths: one tiny all-gather (the byte stream need not divide evenly)
     lens_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]

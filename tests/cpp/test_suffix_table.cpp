@@ -3,7 +3,9 @@
 // link check only); executed on the MI355X by the gpu-marked test.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "suffix_table.hpp"
@@ -61,6 +63,32 @@ int main()
     EXPECT(a == c);
     // lcp_lens, SURVEY.md 8c literal
     EXPECT((SuffixTable::new_("banana").lcp_lens() == std::vector<uint32_t>{0, 1, 3, 0, 0, 2}));
+    // positions(&self) is lock-free and Sync in the reference: many threads, one table, first query races for
+    // the lazily created device index (GPU only: the emulator runs one workgroup at a time on one OS thread)
+    if (std::getenv("SFX_CPP_THREADS")) {
+        std::string big;
+        for (int i = 0; i < 20000; i++) big += "the quick brown fox " + std::to_string(i * 7919 % 1000) + " ";
+        SuffixTable shared = SuffixTable::new_(big);
+        const std::vector<uint32_t> want = pos(shared, "fox 7 ");
+        SuffixTable fresh = SuffixTable::from_parts(shared.text(), shared.table());     // index not created yet
+        std::vector<std::thread> th;
+        std::vector<int> ok(16, 0);
+        for (int t = 0; t < 16; t++)
+            th.emplace_back([&, t] {
+                bool good = true;
+                for (int r = 0; r < 20; r++) good = good && pos(fresh, "fox 7 ") == want && fresh.contains("quick");
+                ok[t] = good;
+            });
+        for (auto& x : th) x.join();
+        for (int t = 0; t < 16; t++) EXPECT(ok[t]);
+        // concurrent SuffixTable::new from several threads (per-thread streams in the host entry points)
+        std::vector<std::thread> nb;
+        std::vector<int> ok2(8, 0);
+        for (int t = 0; t < 8; t++)
+            nb.emplace_back([&, t] { ok2[t] = SuffixTable::new_(big).table() == shared.table(); });
+        for (auto& x : nb) x.join();
+        for (int t = 0; t < 8; t++) EXPECT(ok2[t]);
+    }
     std::printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
     return failures ? 1 : 0;
 }

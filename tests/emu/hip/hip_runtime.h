@@ -56,6 +56,8 @@ hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int* d);
 hipError_t hipStreamCreate(hipStream_t* st);
+constexpr unsigned hipStreamNonBlocking = 1;
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned) { return hipStreamCreate(st); }
 hipError_t hipStreamDestroy(hipStream_t st);
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventDestroy(hipEvent_t e);

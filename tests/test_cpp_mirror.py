@@ -15,7 +15,7 @@ SRC = os.path.join(HERE, "cpp", "test_suffix_table.cpp")
 def _build(tmp_path, libdir, libname):
     exe = str(tmp_path / f"test_st_{libname}")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), SRC,
-                           "-L", libdir, f"-l{libname}", f"-Wl,-rpath,{libdir}", "-o", exe])
+                           "-L", libdir, f"-l{libname}", f"-Wl,-rpath,{libdir}", "-pthread", "-o", exe])
     return exe
 
 
@@ -37,5 +37,5 @@ def test_cpp_mirror_links_against_product_library(tmp_path):
 @pytest.mark.gpu
 def test_cpp_mirror_on_gpu(tmp_path):
     exe = _build(tmp_path, os.path.join(ROOT, "suffix_amd"), "suffix_hip")
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, SFX_CPP_THREADS="1"))
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout + out.stderr
