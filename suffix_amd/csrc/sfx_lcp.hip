@@ -8,9 +8,12 @@
 // (:314-346), which is exact on bytes:
 //   k_phi_scatter  phi[sa[r]] = sa[r-1]            (the predecessor in SA order)
 //   k_plcp         PLCP in TEXT order: each thread walks 32 consecutive text
-//                  positions carrying h (PLCP[i+1] >= PLCP[i]-1), restarting
-//                  from h=0 only at the start of its run; phi/PLCP tiles are
-//                  staged through LDS so global traffic is coalesced
+//                  positions carrying h; REDUCIBLE positions (text[i-1] ==
+//                  text[phi[i]-1]) take PLCP[i-1] - 1 without a comparison, runs
+//                  that start inside a reducible stretch get their base from a
+//                  block scan, so only irreducible values are ever compared
+//                  (O(n log n) symbols in total, whatever the text); phi/PLCP
+//                  tiles are staged through LDS so global traffic is coalesced
 //   k_lcp_gather   lcp[r] = PLCP[sa[r]]
 // Algorithmic bytes per text byte: 8 (phi) + 4+4+2 (plcp) + 4+4+4 (gather) = 30.
 //
@@ -73,35 +76,87 @@ __device__ __forceinline__ uint64_t extend_match(const uint8_t* __restrict__ tex
     return h;
 }
 
+// PLCP in text order.  PLCP[i] is REDUCIBLE when text[i-1] == text[phi[i]-1]: then PLCP[i] = PLCP[i-1] - 1
+// exactly, no comparison needed (Karkkainen, Manzini, Puglisi: the irreducible values sum to O(n log n),
+// whatever the text).  A thread walks kRun consecutive positions carrying h; a reducible position whose
+// predecessor's value is not known yet (the run started inside a reducible stretch) stays relative until the
+// block scan below hands every run the value just before it.  Only the first position of a workgroup's chunk
+// is always compared from scratch, so the worst case is one long comparison per chunk (<= kMaxGrid of them),
+// not one per run: a unary text costs n reads, not n^2 / 512 comparisons.
+constexpr uint32_t kPlcpRel = 0xFFFFFFFFu;
+// (flag << 32 | v): flag 1 = "the value after this stretch is v"; flag 0 = "it is (value before) - v"
+__device__ __forceinline__ uint64_t plcp_combine(uint64_t a, uint64_t b)
+{
+    if (b >> 32) return b;
+    const uint32_t av = (uint32_t)a, bv = (uint32_t)b;
+    return (a >> 32) ? ((1ull << 32) | (uint64_t)(av - bv)) : (uint64_t)(av + bv);
+}
 __global__ void __launch_bounds__(kBlock)
 k_plcp(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ phi_plcp,
        uint64_t tiles_per_block)
 {
     __shared__ uint32_t s[kBlock * (kRun + 1)];          // +1 pad: conflict-free per-thread rows
-    const unsigned tid = threadIdx.x;
+    __shared__ uint64_t wsum[kWavesPerBlock];
+    __shared__ uint32_t tile_carry;
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
     uint64_t begin = (uint64_t)blockIdx.x * tiles_per_block * kPlcpTile;
     uint64_t end = begin + tiles_per_block * kPlcpTile;
     if (end > n) end = n;
+    uint32_t carry = 0;                                  // PLCP of the position just before the tile (known from the 2nd tile on)
     for (uint64_t tile = begin; tile < end; tile += kPlcpTile) {
         for (unsigned j = tid; j < (unsigned)kPlcpTile; j += kBlock) {
             uint64_t g = tile + j;
             s[(j / kRun) * (kRun + 1) + (j % kRun)] = (g < end) ? phi_plcp[g] : kNoPhi;
         }
         __syncthreads();
+        // the thread's run: values, or kPlcpRel while the run is still relative to what precedes it
+        bool known = false;
         uint64_t h = 0;
+        int first_known = kRun;
+        uint32_t steps = 0;                              // positions walked (the relative decrement of an all-relative run)
         for (int k = 0; k < kRun; k++) {
-            uint64_t i = tile + (uint64_t)tid * kRun + k;
+            const uint64_t i = tile + (uint64_t)tid * kRun + k;
             if (i >= end) break;
-            uint32_t j = s[tid * (kRun + 1) + k];
-            if (j == kNoPhi) {
-                h = 0;
-            } else {
-                h = extend_match(text, n, i, (uint64_t)j, h);
+            steps++;
+            const uint32_t j = s[tid * (kRun + 1) + k];
+            uint32_t val;
+            if (j == kNoPhi) {                           // first suffix of the array: no predecessor
+                h = 0; known = true; val = 0;
+            } else if (i > 0 && j > 0 && i != begin && text[i - 1] == text[j - 1]) {
+                if (known) { h--; val = (uint32_t)h; }   // reducible: PLCP[i] = PLCP[i-1] - 1
+                else val = kPlcpRel;
+            } else {                                     // irreducible (or the chunk's first position): compare
+                h = extend_match(text, n, i, (uint64_t)j, known && h ? h - 1 : 0);
+                known = true;
+                val = (uint32_t)h;
             }
-            s[tid * (kRun + 1) + k] = (uint32_t)h;
-            if (h) h--;
+            if (known && first_known == kRun) first_known = k;
+            s[tid * (kRun + 1) + k] = val;
+        }
+        // exclusive scan of the runs' summaries -> the value just before every run
+        const uint64_t mine = steps == 0 ? 0ull : (known ? ((1ull << 32) | (uint64_t)(uint32_t)h) : (uint64_t)steps);
+        uint64_t incl = mine;
+#pragma unroll
+        for (unsigned d = 1; d < 64; d <<= 1) {
+            const uint64_t o = __shfl_up(incl, d);
+            if (lane >= d) incl = plcp_combine(o, incl);
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint64_t before = (1ull << 32) | (uint64_t)carry;            // what precedes the tile is always absolute
+        for (unsigned k = 0; k < w; k++) before = plcp_combine(before, wsum[k]);
+        uint64_t prev = __shfl_up(incl, 1u);
+        if (lane == 0) prev = 0ull;                                  // (identity: relative, decrement 0)
+        const uint64_t excl = plcp_combine(before, prev);            // absolute: `before` is
+        const uint32_t base = (uint32_t)excl;                        // PLCP of the position before my run
+        for (int k = 0; k < first_known && k < (int)steps; k++) s[tid * (kRun + 1) + k] = base - (uint32_t)(k + 1);
+        if (tid == kBlock - 1) {
+            uint64_t all = before;
+            for (unsigned k = w; k < (unsigned)kWavesPerBlock; k++) all = plcp_combine(all, wsum[k]);
+            tile_carry = (uint32_t)all;
         }
         __syncthreads();
+        carry = tile_carry;
         for (unsigned j = tid; j < (unsigned)kPlcpTile; j += kBlock) {
             uint64_t g = tile + j;
             if (g < end) phi_plcp[g] = s[(j / kRun) * (kRun + 1) + (j % kRun)];
