@@ -323,11 +323,16 @@ def range_slices(eng, orc, text, nranges, device="cpu", packed=False, top_bits=1
         ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(n, cap)), dtype=torch.uint8, device=device)
         got = ctypes.c_uint64(0)
         if packed:
-            eng.check(eng.lib.sfx_build_sa_range_packed_u32_dev(_p(d_packed), n, _p(bb), tb, lo, hi, cap, _p(part),
-                                                                ctypes.byref(got), _p(ws), ws.numel(), None), "range")
+            rc = eng.lib.sfx_build_sa_range_packed_u32_dev(_p(d_packed), n, _p(bb), tb, lo, hi, cap, _p(part),
+                                                           ctypes.byref(got), _p(ws), ws.numel(), None)
         else:
-            eng.check(eng.lib.sfx_build_sa_range_u32_dev(_p(t), n, _p(bb), tb, lo, hi, cap, _p(part),
-                                                         ctypes.byref(got), _p(ws), ws.numel(), None), "range")
-        assert int(got.value) == cnt and off == sum(p.size for p in pieces)
+            rc = eng.lib.sfx_build_sa_range_u32_dev(_p(t), n, _p(bb), tb, lo, hi, cap, _p(part),
+                                                    ctypes.byref(got), _p(ws), ws.numel(), None)
+        assert off == sum(p.size for p in pieces)
+        if rc == 7:          # SFX_ERR_NEEDS_RANKS: repeats too long for a slice on its own -> whole-array build (dist.py's fallback)
+            pieces.append(SuffixTable(text, engine=eng).table()[off:off + cnt])
+            continue
+        eng.check(rc, "range")
+        assert int(got.value) == cnt
         pieces.append(part[:cnt].cpu().numpy().view(np.uint32))
     assert np.array_equal(np.concatenate(pieces), exp)
