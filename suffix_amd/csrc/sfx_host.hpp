@@ -152,6 +152,26 @@ inline uint32_t* radix_partial(uint32_t* scratch) { return scratch; }
 int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, int bit_lo,
                     int bit_hi, uint32_t* scratch, hipStream_t st, int* result_in_1,
                     sfx_build_stats* stats, const PackedText* text);
+// Segmented sort of the large buckets of a refinement round (sfx_radix.hip).  Scratch:
+//   segs      8 B per segment, filled by the caller          tiles    32 B per tile (<= nlarge / tile + nseg)
+//   tilehist  4 KiB per tile of a multi-tile segment (<= 2 * nlarge / tile)
+//   segexcl   4 KiB per multi-tile segment (<= nlarge / tile)   status   1 KiB per such tile
+//   counters  16 u32
+struct SegSort {
+    void* segs;
+    void* tiles;
+    uint32_t* tilehist;
+    uint32_t* segexcl;
+    uint32_t* status;
+    uint64_t status_words;
+    uint32_t* counters;
+};
+uint32_t seg_tile_elems();
+int segmented_layout(const SegSort& q, uint32_t nseg, hipStream_t st);
+// one entry of the tile table (32 bytes): list positions [begin, begin + count) of one segment
+struct SegTileHost { uint32_t begin, count, seg_start, info, mseg, pad[3]; };
+int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg, uint64_t nlarge, uint32_t* V,
+                       uint8_t* F8, hipStream_t st, sfx_build_stats* stats);
 // target[idx] = val for m (idx << 32 | val) pairs, idx < n: one partitioning pass on the top
 // bits of idx, then a scatter whose writes stay inside a cache-sized window of `target`.
 // `tmp` is m u64 of scratch, `radix_scratch` as for the sorts.  Pays for 4n >> Infinity Cache.
@@ -185,9 +205,8 @@ struct TileRound {
     uint32_t* block_counts;       // kMaxGrid
     uint32_t* totals;
     unsigned long long* counters; // 2
-    uint64_t* KL0; uint64_t* KL1; // large buckets: m u64 each
-    uint32_t* VL0; uint32_t* VL1; uint32_t* P;   // m u32 each
-    uint32_t* radix_scratch;
+    uint64_t* EA; uint64_t* EB;   // large buckets: m u64 each (key2 << 32 | suffix at the list positions, ping-pong)
+    SegSort seg;                  // scratch of the segmented sort
 };
 int tile_round_text(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
                     sfx_build_stats* stats);

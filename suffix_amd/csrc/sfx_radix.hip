@@ -297,10 +297,13 @@ struct LookBack {
 // Publish this tile's count for digit `tid` and START the look-back: the status words of the
 // next kLookAhead predecessors are fetched together (independent uncached loads) and not
 // waited for -- the caller does its LDS staging in between.
-__device__ __forceinline__ void lookback_begin(uint32_t* status, uint32_t tile_no, unsigned tid, uint32_t agg, LookBack& lb)
+// `first`: the tile opens its sequence (tile 0 of a sort; the first tile of a segment of a segmented
+// sort): it publishes a prefix at once, which is also where the look-back of its successors ends.
+__device__ __forceinline__ void lookback_begin(uint32_t* status, uint32_t tile_no, unsigned tid, uint32_t agg, LookBack& lb,
+                                               bool first)
 {
     uint32_t* mine = status + (uint64_t)tile_no * kRadix + tid;
-    __hip_atomic_store(mine, (tile_no == 0 ? kStatusPrefix : kStatusAgg) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine, (first ? kStatusPrefix : kStatusAgg) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int u = 0; u < kLookAhead; u++) {
         const int64_t t = (int64_t)tile_no - 1 - u;
@@ -309,9 +312,10 @@ __device__ __forceinline__ void lookback_begin(uint32_t* status, uint32_t tile_n
     }
 }
 // Finish: number of elements with this digit in all earlier tiles; publishes the inclusive prefix.
-__device__ __forceinline__ uint32_t lookback_finish(uint32_t* status, uint32_t tile_no, unsigned tid, uint32_t agg, LookBack& lb)
+__device__ __forceinline__ uint32_t lookback_finish(uint32_t* status, uint32_t tile_no, unsigned tid, uint32_t agg, LookBack& lb,
+                                                    bool first)
 {
-    if (tile_no == 0) return 0u;
+    if (first) return 0u;
     uint32_t* mine = status + (uint64_t)tile_no * kRadix + tid;
     uint32_t excl = 0;
     int64_t j = (int64_t)tile_no - 1;
@@ -344,11 +348,31 @@ __device__ __forceinline__ uint32_t lookback_finish(uint32_t* status, uint32_t t
 #ifndef SFX_RADIX_MIN_WAVES
 #define SFX_RADIX_MIN_WAVES 1
 #endif
-template <class Src, class Dst, int KPT, bool ONESWEEP, bool RANK_ATOMIC, int NW>
+// SEG (segmented one-sweep, refinement rounds): the elements of many independent segments (the large
+// buckets of the active list) are sorted segment by segment in ONE launch.  Tiles come from a table
+// (a segment is cut into consecutive tiles, none straddles two segments); the head of digit d is
+// seg_start + (digit offsets inside the segment) + (look-back over the EARLIER TILES OF THE SAME SEGMENT).
+// A segment of one tile needs neither table nor look-back: its digit offsets are the tile's own scan.
+struct SegTile {
+    uint32_t begin, count;      // list positions [begin, begin + count)
+    uint32_t seg_start;         // list position of the segment's first element
+    uint32_t info;              // bit 0: first tile of its segment, bit 1: the segment's only tile; bits 2..: dense index
+                                // among the tiles of multi-tile segments (status words, per-tile digit counts)
+    uint32_t mseg;              // multi-tile segments: index of the segment's digit-offset table
+    uint32_t pad[3];
+};
+struct SegArgs {
+    const SegTile* tiles;
+    const uint32_t* ntiles;     // device-side count (made by k_seg_layout: no host round trip)
+    const uint32_t* segexcl;    // [mseg][4][256]: elements of the segment with a smaller digit, per pass
+    int pass;
+};
+
+template <class Src, class Dst, int KPT, bool ONESWEEP, bool RANK_ATOMIC, int NW, bool SEG = false>
 __global__ void __launch_bounds__(NW * kWave, SFX_RADIX_MIN_WAVES)
 k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t chunk,
              const uint32_t* __restrict__ hist, const uint32_t* __restrict__ digit_total,
-             uint32_t* __restrict__ status, uint32_t* __restrict__ ticket)
+             uint32_t* __restrict__ status, uint32_t* __restrict__ ticket, SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0})
 {
     constexpr bool HAS_VAL = Src::kHasVal;
     constexpr int kThreads = NW * kWave;
@@ -366,7 +390,10 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
         for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0u;
     }
     // one-sweep: global start of bucket `tid`; chunked: this workgroup's running head of bucket `tid`
-    uint32_t my_head = block_scan_excl_1b<NW>(owner ? digit_total[tid] : 0u, s.part, par);
+    // (segmented: set per tile)
+    uint32_t my_head = SEG ? 0u : block_scan_excl_1b<NW>(owner ? digit_total[tid] : 0u, s.part, par);
+    static_assert(!SEG || ONESWEEP, "segments are handed out by ticket");
+    const uint32_t seg_ntiles = SEG ? *seg.ntiles : 0u;
     if (!ONESWEEP && owner) my_head += hist[(uint64_t)tid * gridDim.x + blockIdx.x];
 
     uint64_t next = (uint64_t)blockIdx.x * chunk;
@@ -393,11 +420,25 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
     for (;;) {
         uint64_t tile;
         uint32_t tile_no = 0;
+        bool seq_first = false, seg_single = false;
+        uint32_t seg_start = 0;
         if (ONESWEEP) {
             if (tid == 0) s.ticket = atomicAdd(ticket, 1u);
             __syncthreads();
             tile_no = s.ticket;
             tile = (uint64_t)tile_no * kTile;
+            seq_first = tile_no == 0;
+            if (SEG) {
+                if (tile_no >= seg_ntiles) break;
+                const SegTile d = seg.tiles[tile_no];
+                tile = d.begin;
+                limit = (uint64_t)d.begin + d.count;
+                seq_first = d.info & 1u;
+                seg_single = d.info & 2u;
+                seg_start = d.seg_start;
+                if (owner && !seg_single) my_head = d.seg_start + seg.segexcl[((uint64_t)d.mseg * 4 + seg.pass) * kRadix + tid];
+                tile_no = d.info >> 2;                              // status words are indexed by the dense multi-tile index
+            }
         } else {
             tile = next;
             next += kTile;
@@ -447,7 +488,8 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
                 real_count = tile_count - ((tid == mask) ? (uint32_t)(kTile - nvalid) : 0u);
                 tile_ex = ex;
                 if (ONESWEEP) {
-                    lookback_begin(status, tile_no, tid, real_count, lb);     // loads in flight during the staging
+                    if (!(SEG && seg_single))
+                        lookback_begin(status, tile_no, tid, real_count, lb, seq_first);     // loads in flight during the staging
                 } else {
                     s.off[tid] = my_head - ex;
                     my_head += real_count;
@@ -463,7 +505,10 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
             s.stage[p] = key[r];
             if (HAS_VAL) s.stage_v[p] = val[r];
         }
-        if (ONESWEEP && owner) s.off[tid] = my_head + lookback_finish(status, tile_no, tid, real_count, lb) - tile_ex;
+        if (ONESWEEP && owner) {
+            if (SEG && seg_single) s.off[tid] = seg_start;            // digit offsets = the tile's own scan
+            else s.off[tid] = my_head + lookback_finish(status, tile_no, tid, real_count, lb, seq_first) - tile_ex;
+        }
         __syncthreads();
         // batches of 8 slots: within a batch all LDS reads of a kind are in flight together;
         // more than 8 at once only costs registers (16-element threads spilled)
@@ -739,6 +784,159 @@ int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
         if (stats) { stats->radix_passes++; stats->elements_sorted += m; }
     }
     *result_in_1 = flips;
+    return SFX_OK;
+}
+
+// ---- segmented sort of the large buckets of a refinement round ---------------------------------
+// segs[k] = (start, size) of bucket k (list positions, any order).  The elements E[p] = key2 << 32 |
+// suffix of those positions are sorted by key2 inside every bucket: four one-sweep passes over 16 bytes
+// per element -- against eight passes over 24 bytes for the composite (bucket id, key2) key of round 1,
+// and no extraction or write-back of a sub-list.
+constexpr int kSegKPT = 11, kSegNW = 16;                  // the E64 geometry: 11264-element tiles
+constexpr int kSegSmallKPT = 16, kSegSmallNW = 4;         // SFX_SEG_SMALL=1 (tests): 4096-element tiles
+static bool seg_small()
+{
+    static const bool v = [] { const char* e = getenv("SFX_SEG_SMALL"); return e && atoi(e) != 0; }();
+    return v;
+}
+// counters: [0] tiles, [1] tiles of multi-tile segments, [2] multi-tile segments
+__global__ void __launch_bounds__(kBlock)
+k_seg_layout(const uint2* __restrict__ segs, uint32_t nseg, uint32_t tile_elems, SegTile* __restrict__ tiles,
+             uint32_t* __restrict__ counters)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= nseg) return;
+    const uint32_t start = segs[k].x, size = segs[k].y;
+    const uint32_t nt = (size + tile_elems - 1) / tile_elems;
+    const uint32_t t0 = atomicAdd(&counters[0], nt);
+    if (nt == 1) {
+        tiles[t0] = SegTile{start, size, start, 3u, 0u, {1u, size, 0u}};
+        return;
+    }
+    const uint32_t mt0 = atomicAdd(&counters[1], nt);
+    const uint32_t ms = atomicAdd(&counters[2], 1u);
+    for (uint32_t j = 0; j < nt; j++) {
+        const uint32_t b = j * tile_elems;
+        tiles[t0 + j] = SegTile{start + b, dmin(tile_elems, size - b), start, (j == 0 ? 1u : 0u) | ((mt0 + j) << 2), ms,
+                                {nt, size, 0u}};
+    }
+}
+// digit counts of the four passes for every tile of a multi-tile segment: tilehist[mt][4][256]
+__global__ void __launch_bounds__(kBlock)
+k_seg_hist(const uint64_t* __restrict__ E, const SegTile* __restrict__ tiles, const uint32_t* __restrict__ ntiles,
+           uint32_t* __restrict__ tilehist)
+{
+    __shared__ uint32_t h[4][kRadix];
+    const unsigned tid = threadIdx.x;
+    const uint32_t nt = *ntiles;
+    for (uint32_t t = blockIdx.x; t < nt; t += gridDim.x) {
+        const SegTile d = tiles[t];
+        if (d.info & 2u) continue;
+        for (int p = 0; p < 4; p++) h[p][tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < d.count; i += kBlock) {
+            const uint32_t key = (uint32_t)(E[(uint64_t)d.begin + i] >> 32);
+            atomicAdd(&h[0][key & 255u], 1u);
+            atomicAdd(&h[1][(key >> 8) & 255u], 1u);
+            atomicAdd(&h[2][(key >> 16) & 255u], 1u);
+            atomicAdd(&h[3][key >> 24], 1u);
+        }
+        __syncthreads();
+        uint32_t* out = tilehist + (uint64_t)(d.info >> 2) * 4 * kRadix;
+        for (int p = 0; p < 4; p++) out[p * kRadix + tid] = h[p][tid];
+        __syncthreads();
+    }
+}
+// per multi-tile segment and pass: elements of the segment with a smaller digit
+__global__ void __launch_bounds__(kBlock)
+k_seg_scan(const SegTile* __restrict__ tiles, const uint32_t* __restrict__ ntiles, const uint32_t* __restrict__ tilehist,
+           uint32_t* __restrict__ segexcl)
+{
+    __shared__ uint32_t part[kWavesPerBlock];
+    const unsigned tid = threadIdx.x;
+    const uint32_t nt = *ntiles;
+    for (uint32_t t = blockIdx.x; t < nt; t += gridDim.x) {
+        const SegTile d = tiles[t];
+        if ((d.info & 3u) != 1u) continue;                         // first tile of a multi-tile segment
+        const uint32_t mt0 = d.info >> 2, cnt = d.pad[0];
+        for (int p = 0; p < 4; p++) {
+            uint32_t tot = 0;
+            for (uint32_t j = 0; j < cnt; j++) tot += tilehist[((uint64_t)(mt0 + j) * 4 + p) * kRadix + tid];
+            uint32_t total;
+            const uint32_t ex = block_scan_add_excl(tot, part, total);
+            segexcl[((uint64_t)d.mseg * 4 + p) * kRadix + tid] = ex;
+        }
+    }
+}
+// suffixes back to the list, head / singleton flags from the sorted key2 values
+__global__ void __launch_bounds__(kBlock)
+k_seg_finish(const uint64_t* __restrict__ E, const SegTile* __restrict__ tiles, const uint32_t* __restrict__ ntiles,
+             uint32_t* __restrict__ V, uint8_t* __restrict__ F8)
+{
+    const uint32_t nt = *ntiles;
+    for (uint32_t t = blockIdx.x; t < nt; t += gridDim.x) {
+        const SegTile d = tiles[t];
+        const uint64_t seg_end = (uint64_t)d.seg_start + d.pad[1];
+        for (uint32_t i = threadIdx.x; i < d.count; i += kBlock) {
+            const uint64_t p = (uint64_t)d.begin + i;
+            const uint64_t e = E[p];
+            const uint32_t key = (uint32_t)(e >> 32);
+            const bool head = p == d.seg_start || (uint32_t)(E[p - 1] >> 32) != key;
+            const bool last = p + 1 == seg_end || (uint32_t)(E[p + 1] >> 32) != key;
+            V[p] = (uint32_t)e;
+            F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
+        }
+    }
+}
+
+uint32_t seg_tile_elems() { return seg_small() ? kSegSmallNW * kWave * kSegSmallKPT : kSegNW * kWave * kSegKPT; }
+
+template <int KPT, int NW>
+static int seg_passes(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t* status, uint64_t status_words, hipStream_t st,
+                      double algo)
+{
+    for (int p = 0; p < 4; p++) {
+        SFX_HIP(hipMemsetAsync(status, 0, status_words * sizeof(uint32_t), st));
+        SegArgs sa = {reinterpret_cast<const SegTile*>(q.tiles), q.counters, q.segexcl, p};
+        const uint64_t* src = (p & 1) ? B : A;
+        uint64_t* dst = (p & 1) ? A : B;
+        SFX_LAUNCH("seg_radix_pass", algo, (k_radix_pass<SrcE64, DstE64, KPT, true, true, NW, true>), kMaxGrid / 4, NW * kWave, st,
+                   SrcE64{src}, DstE64{dst}, (uint64_t)0, 32 + 8 * p, 255u, (uint64_t)0, (const uint32_t*)nullptr,
+                   (const uint32_t*)nullptr, status, q.counters + 4 + p, sa);
+    }
+    return SFX_OK;
+}
+
+// tile table of the segments q.segs[0, nseg) (device side; the tile count stays on the device)
+int segmented_layout(const SegSort& q, uint32_t nseg, hipStream_t st)
+{
+    if (nseg == 0) return SFX_OK;
+    SFX_HIP(hipMemsetAsync(q.counters, 0, 16 * sizeof(uint32_t), st));
+    SFX_LAUNCH("seg_layout", (double)nseg * 24, k_seg_layout, (nseg + kBlock - 1) / kBlock, kBlock, st,
+               reinterpret_cast<const uint2*>(q.segs), nseg, seg_tile_elems(), reinterpret_cast<SegTile*>(q.tiles), q.counters);
+    return SFX_OK;
+}
+
+// E (= A) holds key2 << 32 | suffix at the positions of the nseg segments (anything elsewhere is left
+// alone; segmented_layout has run); on return V and F8 are written for those positions.  nlarge = sum of
+// the segment sizes.
+int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg, uint64_t nlarge, uint32_t* V,
+                       uint8_t* F8, hipStream_t st, sfx_build_stats* stats)
+{
+    if (nseg == 0) return SFX_OK;
+    const uint32_t te = seg_tile_elems();
+    const unsigned grid = (unsigned)dmin<uint64_t>(nlarge / te + nseg, kMaxGrid);
+    SFX_LAUNCH("seg_hist", (double)nlarge * 8, k_seg_hist, grid, kBlock, st, A, reinterpret_cast<const SegTile*>(q.tiles),
+               q.counters, q.tilehist);
+    SFX_LAUNCH("seg_scan", 0.0, k_seg_scan, grid, kBlock, st, reinterpret_cast<const SegTile*>(q.tiles), q.counters,
+               q.tilehist, q.segexcl);
+    const uint64_t status_words = (2 * (nlarge / te) + 2) * kRadix;
+    if (status_words > q.status_words) return SFX_ERR_WORKSPACE;
+    if (seg_small()) SFX_TRY((seg_passes<kSegSmallKPT, kSegSmallNW>(A, B, q, q.status, status_words, st, (double)nlarge * 16)));
+    else SFX_TRY((seg_passes<kSegKPT, kSegNW>(A, B, q, q.status, status_words, st, (double)nlarge * 16)));
+    SFX_LAUNCH("seg_finish", (double)nlarge * 13, k_seg_finish, grid, kBlock, st, A, reinterpret_cast<const SegTile*>(q.tiles),
+               q.counters, V, F8);
+    if (stats) { stats->radix_passes += 4; stats->elements_sorted += 4 * nlarge; }
     return SFX_OK;
 }
 

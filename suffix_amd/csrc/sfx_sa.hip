@@ -1427,7 +1427,17 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         tr.G = b.G; tr.V = V_cur; tr.F8 = b.F8; tr.F = b.F;
         tr.part_head = b.part_head; tr.part_keep = b.part_keep; tr.part_ghead = b.part_ghead;
         tr.block_counts = b.block_counts; tr.totals = b.totals; tr.counters = b.counters;
-        tr.KL0 = b.K1; tr.KL1 = b.K0; tr.VL0 = b.G1; tr.VL1 = S_next; tr.P = b.R; tr.radix_scratch = b.hist;
+        // scratch of the segmented sort: element ping-pong in K0 / K1; tile table and segment list in the
+        // slot list of the next round (free until round_apply), per-tile digit counts in G1, per-segment
+        // digit offsets in R, status words in the radix scratch
+        tr.EA = b.K0; tr.EB = b.K1;
+        tr.seg.tiles = S_next;
+        tr.seg.segs = S_next + (m / 4) * 3;                    // (8 B per segment, <= m / 1025 of them; tiles: 32 B each)
+        tr.seg.tilehist = b.G1;
+        tr.seg.segexcl = b.R;
+        tr.seg.status = b.hist + 64;
+        tr.seg.status_words = radix_scratch_words(m) - 64;
+        tr.seg.counters = b.hist;
         if (rank_mode) SFX_TRY(tile_round_rank(isa, n, h, tr, m, st, &stats));
         else SFX_TRY(tile_round_text(pt, h, tr, m, st, &stats));
         Chunking ch = make_chunking(m, kApplyTile);

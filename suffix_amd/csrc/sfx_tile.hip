@@ -16,9 +16,10 @@
 //                     for the rest) and writes the suffixes back in place together with one
 //                     flag byte per element (bucket head / singleton): one read and one
 //                     write of the list, one gather per member
-//   large buckets     (> kTmax members: a few per cent of a natural-language text, all of a
-//                     unary one) are extracted, sorted by (bucket id, key2) with the
-//                     device-wide radix sort and written back to their positions
+//   large buckets     (> kTmax members) are announced by the tile that holds their last member and
+//                     sorted where they are by the SEGMENTED one-sweep radix sort of
+//                     sfx_radix.hip: four 16-byte passes on key2 alone, tiles never straddle
+//                     two buckets, look-back only over the earlier tiles of the same bucket
 //   k_flags_reduce    flag bytes -> the 2-bit-per-element words and per-chunk partials that
 //                     k_groups_scan / k_groups_apply (sfx_sa.hip) consume
 #include "sfx_host.hpp"
@@ -82,7 +83,7 @@ struct TileSmem {
 template <int NW, int KPT, int kPairMax, class KeyFn>
 __global__ void __launch_bounds__(NW * kWave)
 k_tile_sort(KeyFn keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* __restrict__ V,
-            uint8_t* __restrict__ F8, unsigned long long* __restrict__ owned_total)
+            uint8_t* __restrict__ F8, unsigned long long* __restrict__ owned_total, uint2* __restrict__ segs)
 {
     constexpr int kThreads = NW * kWave;
     constexpr int kWin = kThreads * KPT;
@@ -104,6 +105,17 @@ k_tile_sort(KeyFn keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* _
     for (unsigned i = tid; i < (unsigned)kWin; i += kThreads) gwin[i] = (base + i < m) ? G[base + i] : 0xFFFFFFFFu;
     __syncthreads();
 
+    // a bucket of more than kTmax members is announced by the tile in whose home range its LAST member
+    // lies (one report per bucket): (start, size) into the segment list, owned_total[1] counts them
+    for (unsigned i = tid; i < (unsigned)kT; i += kThreads) {
+        const uint64_t p = base + i;
+        if (p >= m) break;
+        const uint32_t g = gwin[i];
+        if ((p + 1 == m || gwin[i + 1] != g) && p - g + 1 > (uint64_t)kTmax) {
+            const unsigned long long k = atomicAdd(&owned_total[1], 1ull);
+            segs[k] = uint2{g, (uint32_t)(p - g + 1)};
+        }
+    }
     // ownership and size class of the thread's KPT consecutive window positions
     uint32_t suf[KPT], key2[KPT], lg[KPT];
     unsigned own = 0, big = 0;
@@ -291,56 +303,27 @@ k_tile_sort(KeyFn keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* _
 }
 
 // ---- large buckets ----------------------------------------------------------------------
-// stream compaction of the members of buckets with more than tmax members (order kept):
-// phase 0 counts per workgroup, phase 1 emits KL = (bucket id << 32 | key2), VL = suffix,
-// P = list position.
+// key2 << 32 | suffix at the list positions of the large buckets (the tile table of the segmented sort
+// says where they are): the one gather per member that the LDS path does inside k_tile_sort
 template <class KeyFn>
 __global__ void __launch_bounds__(kBlock)
-k_large_extract(KeyFn keyfn, const uint32_t* __restrict__ V, const uint32_t* __restrict__ G, uint64_t m, uint64_t tmax,
-                uint64_t chunk, int phase, uint32_t* __restrict__ block_counts, uint64_t* __restrict__ KL,
-                uint32_t* __restrict__ VL, uint32_t* __restrict__ P)
+k_seg_gather(KeyFn keyfn, const uint32_t* __restrict__ V, const SegTileHost* __restrict__ tiles,
+             const uint32_t* __restrict__ ntiles, uint64_t* __restrict__ E)
 {
-    __shared__ uint32_t part[kWavesPerBlock];
-    const unsigned tid = threadIdx.x;
-    uint64_t begin = (uint64_t)blockIdx.x * chunk;
-    uint64_t end = begin + chunk;
-    if (end > m) end = m;
-    uint64_t running = (phase == 1) ? (uint64_t)block_counts[blockIdx.x] : 0ull;
-    for (uint64_t b0 = begin; b0 < end; b0 += kBlock) {
-        const uint64_t p = b0 + tid;
-        uint32_t g = 0;
-        bool large = false;
-        if (p < end) {
-            g = G[p];
-            const uint64_t far = (uint64_t)g + tmax;
-            large = far < m && G[far] == g;
+    const uint32_t nt = *ntiles;
+    for (uint32_t t = blockIdx.x; t < nt; t += gridDim.x) {
+        const uint32_t begin = tiles[t].begin, count = tiles[t].count;
+        constexpr int U = 4;
+        for (uint32_t i0 = threadIdx.x; i0 < count; i0 += U * kBlock) {
+            uint32_t sfx[U], k2[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) sfx[u] = (i0 + u * kBlock < count) ? V[(uint64_t)begin + i0 + u * kBlock] : 0u;
+#pragma unroll
+            for (int u = 0; u < U; u++) k2[u] = (i0 + u * kBlock < count) ? keyfn(sfx[u]) : 0u;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (i0 + u * kBlock < count) E[(uint64_t)begin + i0 + u * kBlock] = ((uint64_t)k2[u] << 32) | (uint64_t)sfx[u];
         }
-        uint32_t total;
-        const uint32_t ex = block_scan_add_excl<uint32_t>(large ? 1u : 0u, part, total);
-        if (phase == 1 && large) {
-            const uint32_t i = V[p];
-            KL[running + ex] = ((uint64_t)g << 32) | (uint64_t)keyfn(i);
-            VL[running + ex] = i;
-            P[running + ex] = (uint32_t)p;
-        }
-        running += total;
-    }
-    if (phase == 0 && tid == 0) block_counts[blockIdx.x] = (uint32_t)running;
-}
-// the sorted sub-list goes back to the positions it came from (P is increasing and the sort is
-// by bucket first, so sorted element j belongs at P[j])
-__global__ void __launch_bounds__(kBlock)
-k_large_writeback(const uint64_t* __restrict__ K, const uint32_t* __restrict__ Vs, const uint32_t* __restrict__ P,
-                  uint64_t cnt, uint32_t* __restrict__ V, uint8_t* __restrict__ F8)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < cnt; j += stride) {
-        const uint64_t k = K[j];
-        const bool head = j == 0 || K[j - 1] != k;
-        const bool last = j + 1 == cnt || K[j + 1] != k;
-        const uint32_t p = P[j];
-        V[p] = Vs[j];
-        F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
     }
 }
 
@@ -419,7 +402,7 @@ static int launch_tile(const KeyFn& keyfn, const TileRound& r, uint64_t m, hipSt
     if (tiles > 0x7FFFFFFFull) return SFX_ERR_TOO_LARGE;
     // read V + G, gather key2 (one sector), write V + F8
     SFX_LAUNCH("tile_sort", (double)m * (4 + 4 + 4 + 4 + 1), (k_tile_sort<NW, KPT, PM, KeyFn>), (unsigned)tiles, NW * kWave, st,
-               keyfn, r.G, m, r.V, r.F8, r.counters);
+               keyfn, r.G, m, r.V, r.F8, r.counters, reinterpret_cast<uint2*>(r.seg.segs));
     return SFX_OK;
 }
 
@@ -441,25 +424,19 @@ static int tile_round_impl(const KeyFn& keyfn, const TileRound& r, uint64_t m, h
         else SFX_TRY(SFX_TILE(16, 8));
 #undef SFX_TILE
     }
-    unsigned long long owned = 0;
-    SFX_TRY(read_back(&owned, r.counters, sizeof(owned), st));
-    if (owned > m) return SFX_ERR_INTERNAL;
-    const uint64_t nlarge = m - owned;
-    if (stats) stats->tile_sorted += owned;
-    if (nlarge > 0) {
-        Chunking ch = make_chunking(m, 1024);
-        const uint64_t chunk = ch.tiles_per_block * 1024;
-        SFX_LAUNCH("large_count", (double)m * 4, (k_large_extract<KeyFn>), ch.blocks, kBlock, st, keyfn, r.V, r.G, m, tmax,
-                   chunk, 0, r.block_counts, r.KL0, r.VL0, r.P);
-        SFX_LAUNCH("large_scan", 0.0, k_scan_block_counts, 1, kBlock, st, r.block_counts, ch.blocks, r.totals);
-        SFX_LAUNCH("large_extract", (double)m * 4 + (double)nlarge * 24, (k_large_extract<KeyFn>), ch.blocks, kBlock, st,
-                   keyfn, r.V, r.G, m, tmax, chunk, 1, r.block_counts, r.KL0, r.VL0, r.P);
-        int in1 = 0;
-        SFX_TRY(radix_sort_kv64(r.KL0, r.VL0, r.KL1, r.VL1, nlarge, 0, 32 + bits_for(m - 1), r.radix_scratch, st, &in1,
-                                stats, nullptr));
-        const unsigned grid = (unsigned)dmin<uint64_t>((nlarge + kBlock - 1) / kBlock, kMaxGrid);
-        SFX_LAUNCH("large_writeback", (double)nlarge * 21, k_large_writeback, grid, kBlock, st, in1 ? r.KL1 : r.KL0,
-                   in1 ? r.VL1 : r.VL0, r.P, nlarge, r.V, r.F8);
+    unsigned long long host[2] = {0, 0};                      // elements sorted in LDS, buckets left to the segmented sort
+    SFX_TRY(read_back(host, r.counters, sizeof(host), st));
+    if (host[0] > m || host[1] > m / (tmax + 1)) return SFX_ERR_INTERNAL;
+    const uint64_t nlarge = m - host[0];
+    const uint32_t nseg = (uint32_t)host[1];
+    if ((nlarge == 0) != (nseg == 0)) return SFX_ERR_INTERNAL;
+    if (stats) stats->tile_sorted += host[0];
+    if (nseg > 0) {
+        SFX_TRY(segmented_layout(r.seg, nseg, st));
+        const unsigned grid = (unsigned)dmin<uint64_t>(nlarge / seg_tile_elems() + nseg, kMaxGrid);
+        SFX_LAUNCH("seg_gather", (double)nlarge * 16, (k_seg_gather<KeyFn>), grid, kBlock, st, keyfn, (const uint32_t*)r.V,
+                   reinterpret_cast<const SegTileHost*>(r.seg.tiles), (const uint32_t*)r.seg.counters, r.EA);
+        SFX_TRY(segmented_sort_e64(r.EA, r.EB, r.seg, nseg, nlarge, r.V, r.F8, st, stats));
         if (stats) stats->large_sorted += nlarge;
     }
     Chunking ch = make_chunking(m, kFlagChunkTile);

@@ -5,6 +5,7 @@ environment variables are read once per process, so every variant runs in a subp
   SFX_PARTITION_MIN                      partitioned (cache-confined) rank / Phi scatters
   SFX_LCP_DIRECT_MIN                     sampled choice between direct and Phi/PLCP LCP, cap + fallback
   SFX_TILE_SMALL / SFX_FORCE_KEY64       small LDS windows of the refinement rounds; 64-bit initial keys
+  SFX_SEG_SMALL                          small tiles in the segmented sort of the large buckets
 Every run compares SA and LCP with the oracle on a few texts that exercise the path."""
 import os
 import subprocess
@@ -71,7 +72,9 @@ VARIANTS = {
     "direct-lcp": {"SFX_LCP_DIRECT_MIN": "8"},
     # 256-element LDS windows: buckets cross tile boundaries, > 128 members take the large-bucket path
     "small-tiles": {"SFX_TILE_SMALL": "1"},
-    "small-tiles-key64-multi-tile": {"SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "3"},
+    # ... and 4096-element tiles in the segmented sort of the large buckets: multi-tile segments, look-back inside a segment
+    "small-tiles-small-segments": {"SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
+    "small-tiles-key64-multi-tile": {"SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "3", "SFX_SEG_SMALL": "1"},
     "key64": {"SFX_FORCE_KEY64": "1"},
     "tile-1024x4-pair32": {"SFX_TILE_GEOM": "1", "SFX_TILE_PAIR": "32"},
     "tile-512x8": {"SFX_TILE_GEOM": "2"},
