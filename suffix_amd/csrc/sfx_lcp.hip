@@ -31,8 +31,10 @@ constexpr uint32_t kNoPhi = 0xFFFFFFFFu;
 constexpr int kRun = 32;                         // consecutive text positions per thread
 constexpr int kPlcpTile = kBlock * kRun;         // 8192 positions per workgroup step
 
+// (entries of sa that are not text positions -- an unchecked from_parts table, src/table.rs:105-119 -- are
+// counted in counters[2] and skipped by every kernel here: the call then fails with SFX_ERR_ARG)
 __global__ void __launch_bounds__(kBlock)
-k_phi_scatter(const uint32_t* __restrict__ sa, uint64_t n, uint32_t* __restrict__ phi)
+k_phi_scatter(const uint32_t* __restrict__ sa, uint64_t n, uint32_t* __restrict__ phi, unsigned long long* __restrict__ counters)
 {
     constexpr int U = 4;                     // independent scatters in flight per thread
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -45,18 +47,29 @@ k_phi_scatter(const uint32_t* __restrict__ sa, uint64_t n, uint32_t* __restrict_
             prev[u] = (r < n && r) ? sa[r - 1] : kNoPhi;
         }
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            if (r0 + u * stride < n) phi[cur[u]] = prev[u];
+        for (int u = 0; u < U; u++) {
+            if (r0 + u * stride < n) {
+                if (cur[u] < n && (prev[u] < n || prev[u] == kNoPhi)) phi[cur[u]] = prev[u];
+                else atomicAdd(&counters[2], 1ull);
+            }
+        }
     }
 }
 
 // large texts: (position, predecessor) pairs in SA order for scatter_pairs_u32
 __global__ void __launch_bounds__(kBlock)
-k_phi_pairs(const uint32_t* __restrict__ sa, uint64_t n, uint64_t* __restrict__ pairs)
+k_phi_pairs(const uint32_t* __restrict__ sa, uint64_t n, uint64_t* __restrict__ pairs, unsigned long long* __restrict__ counters)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride)
-        pairs[r] = ((uint64_t)sa[r] << 32) | (uint64_t)(r ? sa[r - 1] : kNoPhi);
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) {
+        uint32_t cur = sa[r], prev = r ? sa[r - 1] : kNoPhi;
+        if (cur >= n || (prev >= n && prev != kNoPhi)) {             // keep the scatter in bounds; the call fails anyway
+            atomicAdd(&counters[2], 1ull);
+            cur = (uint32_t)r;
+            prev = kNoPhi;
+        }
+        pairs[r] = ((uint64_t)cur << 32) | (uint64_t)prev;
+    }
 }
 
 // length of the common prefix of text[a..] and text[b..] beyond the first h bytes, 8 bytes
@@ -118,7 +131,8 @@ k_plcp(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ phi_
             const uint64_t i = tile + (uint64_t)tid * kRun + k;
             if (i >= end) break;
             steps++;
-            const uint32_t j = s[tid * (kRun + 1) + k];
+            uint32_t j = s[tid * (kRun + 1) + k];
+            if (j >= n) j = kNoPhi;                      // (also: a slot an invalid table never wrote)
             uint32_t val;
             if (j == kNoPhi) {                           // first suffix of the array: no predecessor
                 h = 0; known = true; val = 0;
@@ -176,7 +190,7 @@ k_lcp_gather(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ plcp,
 #pragma unroll
         for (int u = 0; u < U; u++) v[u] = (r0 + u * stride < n) ? sa[r0 + u * stride] : 0u;
 #pragma unroll
-        for (int u = 0; u < U; u++) v[u] = (r0 + u * stride < n) ? plcp[v[u]] : 0u;
+        for (int u = 0; u < U; u++) v[u] = (r0 + u * stride < n && v[u] < n) ? plcp[v[u]] : 0u;
 #pragma unroll
         for (int u = 0; u < U; u++)
             if (r0 + u * stride < n) lcp[r0 + u * stride] = v[u];
@@ -257,12 +271,14 @@ k_lcp_windows(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __re
     for (uint64_t r0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); r0 < n; r0 += stride) {
         const uint64_t r = r0 + lane;
         const bool live = r < n;
-        const uint64_t cur = live ? (uint64_t)sa[r] : 0;
+        uint64_t cur = live ? (uint64_t)sa[r] : 0;
+        if (cur >= n) { atomicAdd(&counters[2], 1ull); cur = 0; }
         uint64_t c0 = 0, c1 = 0;
         if (live) load_window(text, n, cur, c0, c1);
         uint64_t prev = __shfl_up(cur, 1u), p0 = __shfl_up(c0, 1u), p1 = __shfl_up(c1, 1u);
         if (lane == 0 && live && r > 0) {
             prev = (uint64_t)sa[r - 1];
+            if (prev >= n) prev = 0;                                 // (counted by the lane that owns r - 1)
             load_window(text, n, prev, p0, p1);
         }
         if (!live) continue;
@@ -303,11 +319,13 @@ k_lcp_windows_packed(PackedText t, const uint32_t* __restrict__ sa, uint32_t* __
     for (uint64_t r0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); r0 < n; r0 += stride) {
         const uint64_t r = r0 + lane;
         const bool live = r < n;
-        const uint64_t cur = live ? (uint64_t)sa[r] : 0;
+        uint64_t cur = live ? (uint64_t)sa[r] : 0;
+        if (cur >= n) { atomicAdd(&counters[2], 1ull); cur = 0; }
         const uint64_t kc = live ? packed_key64(t, cur) : 0;
         uint64_t prev = __shfl_up(cur, 1u), kp = __shfl_up(kc, 1u);
         if (lane == 0 && live && r > 0) {
             prev = (uint64_t)sa[r - 1];
+            if (prev >= n) prev = 0;
             kp = packed_key64(t, prev);
         }
         if (!live) continue;
@@ -442,17 +460,6 @@ int widen_u32_to_u64_dev(const uint32_t* d_in, uint64_t count, uint64_t* d_out, 
     return SFX_OK;
 }
 
-// counters[2] += entries of sa that are not valid text positions (a from_parts table is unchecked,
-// src/table.rs:105-119; the kernels below index the text and the Phi array with these values)
-__global__ void __launch_bounds__(kBlock)
-k_sa_range_check(const uint32_t* __restrict__ sa, uint64_t n, unsigned long long* __restrict__ counters)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    uint32_t bad = 0;
-    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) bad += sa[r] >= n ? 1u : 0u;
-    if (bad) atomicAdd(&counters[2], (unsigned long long)bad);
-}
-
 // SFX_LCP_DIRECT_MIN=<n> is a test hook (the direct path from n bytes up; default 2^20)
 static uint64_t direct_lcp_min()
 {
@@ -496,7 +503,6 @@ int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, u
     unsigned long long* counters = reinterpret_cast<unsigned long long*>(small + 3072);  // (past the alphabet bins and LUT)
     unsigned long long host[3] = {0, 0, 0};
     SFX_HIP(hipMemsetAsync(counters, 0, sizeof(host), st));
-    SFX_LAUNCH("sa_range_check", (double)n * 4, k_sa_range_check, grid, kBlock, st, d_sa, n, counters);
     if (n >= direct_lcp_min()) {
         // low-LCP text (by a sample of adjacent pairs): compare directly, fall through to the
         // linear path only if some pair reached the cap
@@ -505,7 +511,6 @@ int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, u
         SFX_LAUNCH("lcp_sample", (double)samples * 24, k_lcp_sample, (samples + kBlock - 1) / kBlock, kBlock, st, d_text,
                    n, d_sa, samples, every, counters);
         SFX_TRY(read_back(host, counters, sizeof(host), st));
-        if (host[2]) return SFX_ERR_ARG;
         if (host[0] <= kSampleMeanMax * samples) {
             PackedText pt;
             bool packed = false;
@@ -516,26 +521,26 @@ int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, u
             else
                 SFX_LAUNCH("lcp_windows", (double)n * 24, k_lcp_windows, grid, kBlock, st, d_text, n, d_sa, d_lcp, counters);
             SFX_TRY(read_back(host, counters, sizeof(host), st));
+            if (host[2]) return SFX_ERR_ARG;
             if (host[1] == 0) return SFX_OK;
         }
-    } else {
-        SFX_TRY(read_back(host, counters, sizeof(host), st));
-        if (host[2]) return SFX_ERR_ARG;
     }
     if (n >= partitioned_scatter_min()) {
         uint64_t* pairs = ar.take<uint64_t>(n);
         uint64_t* tmp = ar.take<uint64_t>(n);
         uint32_t* scratch = ar.take<uint32_t>(radix_scratch_words(n));
         if (ar.overflow) return SFX_ERR_WORKSPACE;
-        SFX_LAUNCH("phi_pairs", (double)n * 12, k_phi_pairs, grid, kBlock, st, d_sa, n, pairs);
+        SFX_LAUNCH("phi_pairs", (double)n * 12, k_phi_pairs, grid, kBlock, st, d_sa, n, pairs, counters);
         SFX_TRY(scatter_pairs_u32(pairs, tmp, n, n, phi, scratch, st, nullptr));
     } else {
-        SFX_LAUNCH("phi_scatter", (double)n * 8, k_phi_scatter, grid, kBlock, st, d_sa, n, phi);
+        SFX_LAUNCH("phi_scatter", (double)n * 8, k_phi_scatter, grid, kBlock, st, d_sa, n, phi, counters);
     }
     Chunking ch = make_chunking(n, kPlcpTile);
     SFX_LAUNCH("plcp", (double)n * 10, k_plcp, ch.blocks, kBlock, st, d_text, n, phi,
                ch.tiles_per_block);
     SFX_LAUNCH("lcp_gather", (double)n * 12, k_lcp_gather, grid, kBlock, st, d_sa, phi, n, d_lcp);
+    SFX_TRY(read_back(host, counters, sizeof(host), st));            // (an invalid table: every kernel above skipped it)
+    if (host[2]) return SFX_ERR_ARG;
     return SFX_OK;
 }
 

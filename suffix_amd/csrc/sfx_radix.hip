@@ -461,9 +461,16 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
             for (int k = 0; k < kRadix / kWave; k++) my_flags[k * kWave + lane] = 0ull;
             wave_sync();
         }
+        // (segmented: a bucket rarely fills its last tile -- rounds that hold nothing but padding are not ranked)
+        const unsigned ranked = SEG ? (nvalid / (kWave * KPT)) * (kWave * KPT) + ((nvalid % (kWave * KPT) + kWave - 1) / kWave) * kWave
+                                    : (unsigned)kTile;
 #pragma unroll
-        for (int r = 0; r < KPT; r++)
-            pos[r] = rank_round<RANK_ATOMIC>(digit_of(key[r], shift, mask), my_flags, s.cnt[w], mybit);
+        for (int r = 0; r < KPT; r++) {
+            if (!SEG || w * (kWave * KPT) + r * kWave < nvalid)
+                pos[r] = rank_round<RANK_ATOMIC>(digit_of(key[r], shift, mask), my_flags, s.cnt[w], mybit);
+            else
+                pos[r] = 0;
+        }
         __syncthreads();
 
         // thread d: bucket d's size in this tile -> tile-local start, per-wave bases, global head
@@ -485,7 +492,7 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
                     run += c[k];
                 }
                 // padding elements all carry the largest digit (== mask)
-                real_count = tile_count - ((tid == mask) ? (uint32_t)(kTile - nvalid) : 0u);
+                real_count = tile_count - ((tid == mask) ? (uint32_t)(ranked - nvalid) : 0u);
                 tile_ex = ex;
                 if (ONESWEEP) {
                     if (!(SEG && seg_single))
@@ -501,6 +508,7 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
         // reorder through LDS: every bucket's elements become one contiguous run
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
+            if (SEG && w * (kWave * KPT) + r * kWave >= nvalid) continue;
             const unsigned p = pos[r] + s.cnt[w][digit_of(key[r], shift, mask)];
             s.stage[p] = key[r];
             if (HAS_VAL) s.stage_v[p] = val[r];

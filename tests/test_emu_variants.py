@@ -58,7 +58,7 @@ if os.environ.get("SFX_LCP_DIRECT_MIN"):
     k = lcp_kernels(texts[1])                          # sigma > 16: direct, on the raw bytes
     assert "lcp_windows" in k and "plcp" not in k, k
     k = lcp_kernels(texts[2])                          # the sample says no
-    assert k == ["sa_range_check", "lcp_sample", "phi_scatter", "plcp", "lcp_gather"], k
+    assert k == ["lcp_sample", "phi_scatter", "plcp", "lcp_gather"], k
     k = lcp_kernels(texts[4])                          # cap reached: Phi/PLCP redoes the array
     assert "lcp_windows_packed" in k and k[-3:] == ["phi_scatter", "plcp", "lcp_gather"], k
 print("OK")
