@@ -419,6 +419,15 @@ def main():
                 roofline["traffic"] = round(ent["hbm_bytes_per_launch"])
                 roofline["traffic_detail"] = {k: ent[k] for k in ("fetch_bytes", "write_bytes", "launches")}
                 roofline["traffic_source"] = pmc.get("source", "profiles/pmc_latest.json")
+                # the counters come from their own rocprofv3 passes (they cannot be collected inside this run):
+                # the commit they were collected at, next to the commit that is running, if it can be told
+                roofline["traffic_commit"] = pmc.get("commit", "unknown")
+                try:
+                    import subprocess
+                    roofline["this_commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                                             text=True, timeout=5).stdout.strip() or os.environ.get("SFX_COMMIT", "unknown")
+                except (OSError, subprocess.SubprocessError):
+                    roofline["this_commit"] = os.environ.get("SFX_COMMIT", "unknown")
         except (ValueError, KeyError, OSError):
             pass
 

@@ -24,7 +24,9 @@ NAMES = [("k_radix_pass<sfx::SrcE64", "radix_scatter_u32"), ("k_radix_pass<sfx::
          ("k_radix_pass<sfx::SrcKV", "radix_scatter_u64"), ("k_radix_pass<sfx::SrcText64", "radix_scatter_text_u64"),
          ("k_groups_apply<unsigned int>", "groups_apply_u32"), ("k_groups_apply<unsigned long>", "groups_apply_u64"),
          ("k_groups_reduce", "groups_reduce"), ("k_radix_hist_all<sfx::SrcText32", "radix_hist_all_text_u32"),
-         ("k_pack_text", "pack_text"), ("k_small_groups", "small_groups"), ("k_byte_presence", "byte_presence")]
+         ("k_pack_text", "pack_text"), ("k_small_groups", "small_groups"), ("k_byte_presence", "byte_presence"),
+         ("k_tile_sort", "tile_sort"), ("k_seg_gather", "seg_gather"), ("k_lcp_windows_packed", "lcp_windows_packed"),
+         ("k_lcp_pending", "lcp_pending")]
 
 acc = defaultdict(lambda: [0.0, 0])
 for d in args:
@@ -56,7 +58,8 @@ if json_out:
     known = float(1 << 30)
     f_cal = known / (f_copy * 1024.0) if f_copy else 2.0
     w_cal = known / (w_copy * 1024.0) if w_copy else 1.0
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps 1 --calibrate` "
+    out = {"commit": os.environ.get("SFX_COMMIT", "unknown"),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps 1 --calibrate` "
                      "(scripts/gpu_pmc.sh); counters in KiB x calibration factor from sfx::k_mb_copy (1 GiB in, 1 GiB out)",
            "fetch_calibration": round(f_cal, 4), "write_calibration": round(w_cal, 4), "kernels": {}}
     for sym, prof in NAMES:
