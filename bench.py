@@ -155,6 +155,20 @@ def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
     t_lcp = time.perf_counter() - t0
     rec["lcp_ms"] = round(t_lcp * 1e3, 2)
     rec["sa_plus_lcp_MB/s"] = round(n / (best + t_lcp) / 1e6, 1)
+    # SuffixTable::new + lcp_lens as ONE engine call: the LCP of every pair that the initial sort or a text
+    # round separates is read off the keys inside the build; only the rest is compared on the text
+    del lws
+    ws2 = sdev.sa_lcp_workspace(n, dev)
+    sa2 = torch.empty_like(sa)
+    lcp2 = torch.empty_like(lcp)
+    sdev.build_sa_lcp(text, out_sa=sa2, out_lcp=lcp2, workspace=ws2); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sdev.build_sa_lcp(text, out_sa=sa2, out_lcp=lcp2, workspace=ws2); torch.cuda.synchronize()
+    t_fused = time.perf_counter() - t0
+    rec["fused_sa_lcp"] = {"ms": round(t_fused * 1e3, 2), "MB/s": round(n / t_fused / 1e6, 1),
+                           "same_arrays_as_separate_calls": bool(torch.equal(sa2, sa) and torch.equal(lcp2, lcp))}
+    del ws2, sa2, lcp2
+    lws = None
     # W_SA(u32) ~ 69 B per input byte for deep-recursion text, W_LCP = 22
     rec["roofline"] = {"whole_path": {"algo_bytes_per_input_byte": 69.0, "achieved_GB/s": round(69.0 * n / best / 1e9, 1),
                                       "frac_of_hbm_peak": round(69.0 * n / best / 1e9 / HBM_PEAK_GBS, 4)},

@@ -157,6 +157,7 @@ int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
 //   tilehist  4 KiB per tile of a multi-tile segment (<= 2 * nlarge / tile)
 //   segexcl   4 KiB per multi-tile segment (<= nlarge / tile)   status   1 KiB per such tile
 //   counters  16 u32
+struct LcpEmit;
 struct SegSort {
     void* segs;
     void* tiles;
@@ -171,7 +172,7 @@ int segmented_layout(const SegSort& q, uint32_t nseg, hipStream_t st);
 // one entry of the tile table (32 bytes): list positions [begin, begin + count) of one segment
 struct SegTileHost { uint32_t begin, count, seg_start, info, mseg, pad[3]; };
 int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg, uint64_t nlarge, uint32_t* V,
-                       uint8_t* F8, hipStream_t st, sfx_build_stats* stats);
+                       uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit);
 // target[idx] = val for m (idx << 32 | val) pairs, idx < n: one partitioning pass on the top
 // bits of idx, then a scatter whose writes stay inside a cache-sized window of `target`.
 // `tmp` is m u64 of scratch, `radix_scratch` as for the sorts.  Pays for 4n >> Infinity Cache.
@@ -196,7 +197,32 @@ inline int radix_pass_count(int bit_lo, int bit_hi) { return (bit_hi - bit_lo + 
 // ordered by key2; F the head / singleton bits and part_* the per-chunk partials that
 // k_groups_scan + k_groups_apply consume (chunks of kFlagChunkTile elements, make_chunking).
 constexpr int kFlagChunkTile = 8192;
+// Fused LCP (sfx_build_sa_lcp_u32_dev): when a round puts two neighbours of a bucket into different
+// classes, their common prefix is h + the equal leading symbols of their key2 values (text rounds) --
+// known right there, no text access.  Pairs split by rank rounds or by the direct pass only get a lower
+// bound: 0x80000000 | h, finished on the text at the end (k_lcp_pending).  lcp == nullptr: off.
+struct LcpEmit {
+    uint32_t* lcp;
+    const uint32_t* S;          // SA slot of every list position
+    uint32_t h;                 // symbols the members of a bucket share
+    uint32_t n;
+    int rank_mode;
+    int field_bits;             // width of the symbol field of a text key2
+    uint32_t inv_bits;          // ceil(65536 / bits)
+};
+constexpr uint32_t kLcpBoundFlag = 0x80000000u;
+__device__ __forceinline__ uint32_t lcp_from_key2(const LcpEmit& L, uint32_t ka, uint32_t kb, uint32_t sa, uint32_t sb)
+{
+    if (L.rank_mode) return kLcpBoundFlag | L.h;
+    const uint32_t la = L.n - sa, lb = L.n - sb, cap = la < lb ? la : lb;
+    if (!(ka & kb & 0x80000000u)) return cap;            // one of them ends before offset h: the shorter is a prefix
+    const uint32_t x = ka ^ kb;                          // (!= 0: different classes)
+    const uint32_t lz = (uint32_t)__clz((int)x) - (32u - (uint32_t)L.field_bits);
+    const uint32_t v = L.h + ((lz * L.inv_bits) >> 16);
+    return v < cap ? v : cap;
+}
 struct TileRound {
+    LcpEmit emit;
     const uint32_t* G;
     uint32_t* V;
     uint8_t* F8;                  // m bytes (+ 8), scratch
@@ -210,6 +236,7 @@ struct TileRound {
 };
 int tile_round_text(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
                     sfx_build_stats* stats);
+LcpEmit make_lcp_emit(uint32_t* lcp, const uint32_t* S, const PackedText& pt, uint64_t h, bool rank_mode);
 // (needs n - 1 + h < 2^32: key2 = rank + h)
 int tile_round_rank(const uint32_t* isa, uint64_t n, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
                     sfx_build_stats* stats);

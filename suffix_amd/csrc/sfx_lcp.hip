@@ -352,17 +352,19 @@ k_lcp_windows_packed(PackedText t, const uint32_t* __restrict__ sa, uint32_t* __
 }
 
 // ---- fused SA + LCP: the pairs the initial sort could not tell apart ------------------------------
-constexpr uint32_t kLcpPendingMark = 0xFFFFFFFFu;
+// lcp[r] = kLcpBoundFlag | b: the pair (r - 1, r) shares at least b symbols (unless one of them ends earlier)
 __global__ void __launch_bounds__(kBlock)
 k_lcp_pending(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint32_t* __restrict__ lcp,
-              uint64_t h0, unsigned long long* __restrict__ counters)
+              unsigned long long* __restrict__ counters)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     uint32_t capped = 0;
     for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) {
-        if (lcp[r] != kLcpPendingMark) continue;
+        const uint32_t v = lcp[r];
+        if (!(v & kLcpBoundFlag)) continue;
+        const uint64_t h0 = v & ~kLcpBoundFlag;
         const uint64_t a = sa[r - 1], b = sa[r];                     // (r = 0 is never pending)
-        const uint64_t h = (a + h0 <= n && b + h0 <= n) ? h0 : 0;    // equal keys = equal first h0 symbols, padding aside
+        const uint64_t h = (a + h0 <= n && b + h0 <= n) ? h0 : 0;    // equal keys = equal symbols, padding aside
         const uint64_t l = extend_match_capped(text, n, a, b, h, h + kDirectCap);
         if (l >= h + kDirectCap) capped++;
         lcp[r] = (uint32_t)l;
@@ -407,7 +409,7 @@ int lcp_finish_pending_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_
     unsigned long long host[2] = {0, 0};
     SFX_HIP(hipMemsetAsync(counters, 0, sizeof(host), st));
     const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
-    SFX_LAUNCH("lcp_pending", (double)n * 4, k_lcp_pending, grid, kBlock, st, d_text, n, d_sa, d_lcp, h0, counters);
+    SFX_LAUNCH("lcp_pending", (double)n * 4, k_lcp_pending, grid, kBlock, st, d_text, n, d_sa, d_lcp, counters);
     SFX_LAUNCH("lcp_tail_fix", 0.0, k_lcp_tail_fix, (unsigned)((h0 + kBlock - 1) / kBlock), kBlock, st, d_text, n, d_sa,
                d_lcp, h0);
     SFX_TRY(read_back(host, counters, sizeof(host), st));

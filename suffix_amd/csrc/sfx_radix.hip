@@ -879,7 +879,7 @@ k_seg_scan(const SegTile* __restrict__ tiles, const uint32_t* __restrict__ ntile
 // suffixes back to the list, head / singleton flags from the sorted key2 values
 __global__ void __launch_bounds__(kBlock)
 k_seg_finish(const uint64_t* __restrict__ E, const SegTile* __restrict__ tiles, const uint32_t* __restrict__ ntiles,
-             uint32_t* __restrict__ V, uint8_t* __restrict__ F8)
+             uint32_t* __restrict__ V, uint8_t* __restrict__ F8, LcpEmit emit)
 {
     const uint32_t nt = *ntiles;
     for (uint32_t t = blockIdx.x; t < nt; t += gridDim.x) {
@@ -893,6 +893,10 @@ k_seg_finish(const uint64_t* __restrict__ E, const SegTile* __restrict__ tiles, 
             const bool last = p + 1 == seg_end || (uint32_t)(E[p + 1] >> 32) != key;
             V[p] = (uint32_t)e;
             F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
+            if (emit.lcp && head && p != d.seg_start) {               // split from its predecessor in this round
+                const uint64_t ep = E[p - 1];
+                emit.lcp[emit.S[p]] = lcp_from_key2(emit, (uint32_t)(ep >> 32), key, (uint32_t)ep, (uint32_t)e);
+            }
         }
     }
 }
@@ -929,7 +933,7 @@ int segmented_layout(const SegSort& q, uint32_t nseg, hipStream_t st)
 // alone; segmented_layout has run); on return V and F8 are written for those positions.  nlarge = sum of
 // the segment sizes.
 int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg, uint64_t nlarge, uint32_t* V,
-                       uint8_t* F8, hipStream_t st, sfx_build_stats* stats)
+                       uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit)
 {
     if (nseg == 0) return SFX_OK;
     const uint32_t te = seg_tile_elems();
@@ -943,7 +947,7 @@ int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg
     if (seg_small()) SFX_TRY((seg_passes<kSegSmallKPT, kSegSmallNW>(A, B, q, q.status, status_words, st, (double)nlarge * 16)));
     else SFX_TRY((seg_passes<kSegKPT, kSegNW>(A, B, q, q.status, status_words, st, (double)nlarge * 16)));
     SFX_LAUNCH("seg_finish", (double)nlarge * 13, k_seg_finish, grid, kBlock, st, A, reinterpret_cast<const SegTile*>(q.tiles),
-               q.counters, V, F8);
+               q.counters, V, F8, emit);
     if (stats) { stats->radix_passes += 4; stats->elements_sorted += 4 * nlarge; }
     return SFX_OK;
 }

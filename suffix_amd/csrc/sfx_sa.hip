@@ -588,8 +588,8 @@ struct LcpFuse {
     uint32_t* lcp;          // nullptr = off
     int pad_bits;           // unused high bits of a key
     uint32_t inv_bits;      // ceil(65536 / bits): x / bits for x < 64 (checked on the host)
+    uint32_t pending;       // kLcpBoundFlag | symbols of the key: what neighbours with equal keys are known to share
 };
-constexpr uint32_t kLcpPending = 0xFFFFFFFFu;
 
 template <class KeyT>
 __global__ void __launch_bounds__(kBlock)
@@ -628,7 +628,7 @@ k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t chunk,
                 for (int j = 0; j < kGroupItems; j++) {
                     const uint64_t x = (uint64_t)(cur.k[j] ^ cur.k[j + 1]);
                     const unsigned lz = (unsigned)__clzll((long long)x) - (unsigned)(64 - 8 * (int)sizeof(KeyT)) - (unsigned)fuse.pad_bits;
-                    l[j] = (iu + j == 0) ? 0u : (x ? (lz * fuse.inv_bits) >> 16 : kLcpPending);
+                    l[j] = (iu + j == 0) ? 0u : (x ? (lz * fuse.inv_bits) >> 16 : fuse.pending);
                 }
                 if (iu + kGroupItems <= m) {
                     *reinterpret_cast<uint4*>(fuse.lcp + iu) = uint4{l[0], l[1], l[2], l[3]};
@@ -889,11 +889,14 @@ __device__ __forceinline__ int direct_compare(const PackedText& t, uint64_t a, u
 __global__ void __launch_bounds__(kBlock)
 k_small_groups(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, const uint32_t* __restrict__ G,
                uint64_t m, PackedText t, uint64_t h, uint32_t* __restrict__ sa, uint32_t* __restrict__ isa,
-               uint32_t* __restrict__ V2, uint32_t* __restrict__ G2, uint32_t* __restrict__ flag)
+               uint32_t* __restrict__ V2, uint32_t* __restrict__ G2, uint32_t* __restrict__ flag, uint32_t* __restrict__ lcp)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < m; q += stride) {
         const uint32_t g = G[q];
+        // fused LCP: whatever order the members end up in, neighbours inside the bucket share >= h symbols; the
+        // exact value is found on the text at the end (ties that go on to later rounds are overwritten there)
+        if (lcp && q != (uint64_t)g) lcp[S[q]] = kLcpBoundFlag | (uint32_t)h;
         const uint64_t lo = g;                                   // bucket id = position of its head
         const uint32_t my = V[q];
         // buckets of exactly two (the common case): the head orders the pair alone -- one
@@ -1139,7 +1142,7 @@ uint64_t sa_range_workspace_bytes(uint64_t n, uint64_t max_count)
 // bucket statistics of the sorted active list: reduce -> scan -> {kept, kept buckets} on the host
 template <class KeyT>
 static int round_totals(const KeyT* K, uint64_t m, SaBuffers& b, hipStream_t st, uint64_t* kept,
-                        uint64_t* kept_groups, LcpFuse fuse = LcpFuse{nullptr, 0, 0})
+                        uint64_t* kept_groups, LcpFuse fuse = LcpFuse{nullptr, 0, 0, 0})
 {
     Chunking ch = make_chunking(m, kApplyTile);
     SFX_LAUNCH("groups_reduce", (double)m * (sizeof(KeyT) + (fuse.lcp ? 4 : 0)), (k_groups_reduce<KeyT>), ch.blocks, kBlock,
@@ -1287,7 +1290,7 @@ int pack_small_alphabet(const uint8_t* d_text, uint64_t n, int max_bits, void* s
 // still unresolved.  On return the active list is (*S_cur, *V_cur, b.G) with *m elements.
 static int small_groups_pass(const PackedText& pt, uint64_t h, SaBuffers& b, uint32_t* sa, uint32_t* isa,
                              uint32_t** S_cur, uint32_t** V_cur, uint64_t* m, hipStream_t st,
-                             sfx_build_stats& stats)
+                             sfx_build_stats& stats, uint32_t* lcp = nullptr)
 {
     const uint64_t cnt = *m;
     uint32_t* V_other = (*V_cur == b.VA) ? b.VB : b.VA;
@@ -1295,7 +1298,7 @@ static int small_groups_pass(const PackedText& pt, uint64_t h, SaBuffers& b, uin
     uint32_t* flag = (uint32_t*)b.K0;                       // free between rounds
     unsigned grid = (unsigned)dmin<uint64_t>((cnt + kBlock - 1) / kBlock, kMaxGrid);
     SFX_LAUNCH("small_groups", (double)cnt * 32, k_small_groups, grid, kBlock, st, *V_cur, *S_cur, b.G, cnt, pt, h,
-               sa, isa, V_other, b.G1, flag);
+               sa, isa, V_other, b.G1, flag, lcp);
     Chunking ch = make_chunking(cnt, 1024);
     const uint64_t chunk = ch.tiles_per_block * 1024;
     SFX_LAUNCH("flag_count", (double)cnt * 4, k_flag_compact, ch.blocks, kBlock, st, flag, *S_cur, V_other, b.G1, cnt,
@@ -1403,13 +1406,13 @@ static int refine_composite(const PackedText& pt, int cpk, SaBuffers& b, uint32_
 //   text round: key2 = the next wsym symbols (needs only the packed text), h += wsym
 //   rank round: key2 = rank of the suffix h symbols on (needs ISA), h doubles
 // Rounds start on text symbols -- no rank array, so its n-element scatter is only paid if the
-// text rounds stall: when a round resolves less than a third of what it was given, and the
+// text rounds stall: when a round resolves less than a quarter of what it was given, and the
 // rounds spent stalling have cost about what building the rank array costs, the build switches
 // to ranks (prefix doubling).  The partitioned build (isa == nullptr) only has text rounds and
 // reports SFX_ERR_NEEDS_RANKS when they do not converge.
 constexpr int kMaxTextOnlyRounds = 4096;
 static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uint32_t* isa, uint32_t* S_cur,
-                  uint32_t* V_cur, uint64_t m, hipStream_t st, sfx_build_stats& stats)
+                  uint32_t* V_cur, uint64_t m, hipStream_t st, sfx_build_stats& stats, uint32_t* lcp = nullptr)
 {
     const uint64_t n = pt.n;
     uint64_t h = (uint64_t)cpk;
@@ -1424,6 +1427,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         uint32_t* V_next = (V_cur == b.VA) ? b.VB : b.VA;
         uint32_t* S_next = (S_cur == b.S0) ? b.S1 : b.S0;
         TileRound tr;
+        tr.emit = make_lcp_emit(lcp, S_cur, pt, h, rank_mode);
         tr.G = b.G; tr.V = V_cur; tr.F8 = b.F8; tr.F = b.F;
         tr.part_head = b.part_head; tr.part_keep = b.part_keep; tr.part_ghead = b.part_ghead;
         tr.block_counts = b.block_counts; tr.totals = b.totals; tr.counters = b.counters;
@@ -1456,7 +1460,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
             // (kept + launch overheads) against ~n for the rank array
             // SFX_SWITCH=text|rank is a development hook: never / always switch after the first round
             static const int force = [] { const char* e = getenv("SFX_SWITCH"); return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'r' ? 2 : 0)); }();
-            if (kept * 3 > m * 2) stalled += kept + (4u << 20);
+            if (kept * 4 > m * 3) stalled += kept + (4u << 20);
             if (isa && force != 1 && (stalled * 2 > n || force == 2)) {
                 // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
                 SFX_TRY(build_ranks(b, sa, n, V_next, S_next, kept, isa, st, stats));
@@ -1471,7 +1475,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         V_cur = V_next;
         m = kept;
         if (small_groups_pay(m, kept_groups))
-            SFX_TRY(small_groups_pass(pt, h, b, sa, rank_mode ? isa : nullptr, &S_cur, &V_cur, &m, st, stats));
+            SFX_TRY(small_groups_pass(pt, h, b, sa, rank_mode ? isa : nullptr, &S_cur, &V_cur, &m, st, stats, lcp));
     }
     return SFX_OK;
 }
@@ -1507,9 +1511,10 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         V_next = in1 ? b.VA : b.VB;
     }
     uint64_t kept = 0, groups = 0;
-    LcpFuse fuse = {nullptr, 0, 0};
+    LcpFuse fuse = {nullptr, 0, 0, 0};
     if (lcp_fuse) {                                     // (full builds only: slot r of the sorted keys is SA slot r)
         fuse.lcp = lcp_fuse;
+        fuse.pending = kLcpBoundFlag | (uint32_t)cpk;
         fuse.pad_bits = 8 * (int)sizeof(KeyT) - pt.bits * cpk;
         fuse.inv_bits = (65536u + (unsigned)pt.bits - 1u) / (unsigned)pt.bits;
         for (unsigned x = 0; x < 64; x++)
@@ -1522,8 +1527,8 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
                               kept));
     uint32_t* S_cur = b.S0;
     if (small_groups_pay(kept, groups))
-        SFX_TRY(small_groups_pass(pt, (uint64_t)cpk, b, sa, nullptr, &S_cur, &V_next, &kept, st, stats));
-    return refine(pt, cpk, b, sa, isa, S_cur, V_next, kept, st, stats);
+        SFX_TRY(small_groups_pass(pt, (uint64_t)cpk, b, sa, nullptr, &S_cur, &V_next, &kept, st, stats, lcp_fuse));
+    return refine(pt, cpk, b, sa, isa, S_cur, V_next, kept, st, stats, lcp_fuse);
 }
 
 // lcp_fuse != nullptr: also leave, in lcp_fuse[r], the LCP of every adjacent pair that the initial sort
@@ -1593,10 +1598,14 @@ int build_sa_lcp_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, uint
         return SFX_OK;
     }
     int cpk = 0;
-    SFX_TRY(build_sa_impl(d_text, n, d_sa, ws, ws_bytes, st, d_lcp, &cpk));
+    // the lower-bound encoding needs the top bit of an LCP value
+    const bool fuse = n < 0x80000000ull;
+    SFX_TRY(build_sa_impl(d_text, n, d_sa, ws, ws_bytes, st, fuse ? d_lcp : nullptr, &cpk));
     const sfx_build_stats stats = tls_build_stats();
     bool done = false;
-    if (stats.active_after_initial * 4 <= n)
+    // pairs split by rank rounds only carry a lower bound: when the text needed ranks for most of its
+    // suffixes, finishing those pairs one by one is the separate routine's job (sampling, Phi / PLCP)
+    if (fuse && (stats.rank_rounds == 0 || stats.active_after_initial * 4 <= n))
         SFX_TRY(lcp_finish_pending_dev(d_text, n, d_sa, d_lcp, (uint64_t)cpk, ws, ws_bytes, st, &done));
     if (!done) SFX_TRY(build_lcp_u32_dev(d_text, n, d_sa, d_lcp, ws, ws_bytes, st));
     tls_build_stats() = stats;

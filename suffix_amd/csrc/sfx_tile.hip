@@ -83,7 +83,7 @@ struct TileSmem {
 template <int NW, int KPT, int kPairMax, class KeyFn>
 __global__ void __launch_bounds__(NW * kWave)
 k_tile_sort(KeyFn keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* __restrict__ V,
-            uint8_t* __restrict__ F8, unsigned long long* __restrict__ owned_total, uint2* __restrict__ segs)
+            uint8_t* __restrict__ F8, unsigned long long* __restrict__ owned_total, uint2* __restrict__ segs, LcpEmit emit)
 {
     constexpr int kThreads = NW * kWave;
     constexpr int kWin = kThreads * KPT;
@@ -296,8 +296,17 @@ k_tile_sort(KeyFn keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* _
         const bool head = i == 0 || i == ns || (s.stage[i - 1] >> kIdxBits) != cls;
         const bool last = i + 1 == tot || i + 1 == ns || (s.stage[i + 1] >> kIdxBits) != cls;
         const uint64_t p = base + s.posmap[i];
-        V[p] = s.sufwin[(unsigned)key & (unsigned)(kWin - 1)];
+        const uint32_t sfx = s.sufwin[(unsigned)key & (unsigned)(kWin - 1)];
+        V[p] = sfx;
         F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
+        if (emit.lcp && head && i != 0 && i != ns) {
+            // a class head that is not the first member of its bucket: split from its predecessor by this round
+            const uint64_t kp = s.stage[i - 1];
+            constexpr uint64_t kMid = ((1ull << (32 - kIdxBits)) - 1ull) << kIdxBits;       // bucket id / label field
+            if ((kp & kMid) == (key & kMid))
+                emit.lcp[emit.S[p]] = lcp_from_key2(emit, (uint32_t)(kp >> 32), (uint32_t)(key >> 32),
+                                                    s.sufwin[(unsigned)kp & (unsigned)(kWin - 1)], sfx);
+        }
     }
     if (tid == 0) atomicAdd(owned_total, (unsigned long long)tot);
 }
@@ -402,7 +411,7 @@ static int launch_tile(const KeyFn& keyfn, const TileRound& r, uint64_t m, hipSt
     if (tiles > 0x7FFFFFFFull) return SFX_ERR_TOO_LARGE;
     // read V + G, gather key2 (one sector), write V + F8
     SFX_LAUNCH("tile_sort", (double)m * (4 + 4 + 4 + 4 + 1), (k_tile_sort<NW, KPT, PM, KeyFn>), (unsigned)tiles, NW * kWave, st,
-               keyfn, r.G, m, r.V, r.F8, r.counters, reinterpret_cast<uint2*>(r.seg.segs));
+               keyfn, r.G, m, r.V, r.F8, r.counters, reinterpret_cast<uint2*>(r.seg.segs), r.emit);
     return SFX_OK;
 }
 
@@ -436,13 +445,26 @@ static int tile_round_impl(const KeyFn& keyfn, const TileRound& r, uint64_t m, h
         const unsigned grid = (unsigned)dmin<uint64_t>(nlarge / seg_tile_elems() + nseg, kMaxGrid);
         SFX_LAUNCH("seg_gather", (double)nlarge * 16, (k_seg_gather<KeyFn>), grid, kBlock, st, keyfn, (const uint32_t*)r.V,
                    reinterpret_cast<const SegTileHost*>(r.seg.tiles), (const uint32_t*)r.seg.counters, r.EA);
-        SFX_TRY(segmented_sort_e64(r.EA, r.EB, r.seg, nseg, nlarge, r.V, r.F8, st, stats));
+        SFX_TRY(segmented_sort_e64(r.EA, r.EB, r.seg, nseg, nlarge, r.V, r.F8, st, stats, r.emit));
         if (stats) stats->large_sorted += nlarge;
     }
     Chunking ch = make_chunking(m, kFlagChunkTile);
     SFX_LAUNCH("flags_reduce", (double)m * 1.25, k_flags_reduce, ch.blocks, kBlock, st, r.F8, m,
                ch.tiles_per_block * kFlagChunkTile, r.part_head, r.part_keep, r.part_ghead, r.F);
     return SFX_OK;
+}
+
+LcpEmit make_lcp_emit(uint32_t* lcp, const uint32_t* S, const PackedText& pt, uint64_t h, bool rank_mode)
+{
+    LcpEmit e;
+    e.lcp = lcp;
+    e.S = S;
+    e.h = (uint32_t)h;
+    e.n = (uint32_t)pt.n;
+    e.rank_mode = rank_mode ? 1 : 0;
+    e.field_bits = pt.kbits == 32 ? 32 - pt.bits : pt.kbits;       // (see TextKey: a 32-bit word gives up its last symbol)
+    e.inv_bits = (65536u + (unsigned)pt.bits - 1u) / (unsigned)pt.bits;
+    return e;
 }
 
 int tile_round_text(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,

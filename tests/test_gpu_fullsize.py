@@ -65,7 +65,13 @@ def test_config3_1gb_english_sa_lcp(eng):
     assert st["n"] == N and st["tile_sorted"] > 0
     assert _sha(sa) == pin["sha256_sa"]
     assert _sha(lcp) == pin["sha256_lcp"]
-    del text, sa, lcp
+    del sa, lcp
+    # the same two arrays from the fused entry point (LCP read off the keys of the initial sort and the text rounds)
+    from suffix_amd import device as sdev
+    sa2, lcp2 = sdev.build_sa_lcp(text)
+    torch.cuda.synchronize()
+    assert _sha(sa2) == pin["sha256_sa"] and _sha(lcp2) == pin["sha256_lcp"]
+    del text, sa2, lcp2
     torch.cuda.empty_cache()
 
 
