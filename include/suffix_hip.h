@@ -90,8 +90,9 @@ typedef struct sfx_index sfx_index;
 /* sa == NULL => build it on the device.  Host pointers.  A caller-supplied table is checked for
  * entries >= n (SFX_ERR_ARG; the reference's from_parts is unchecked and "fails in weird ways", :105-107 --
  * a memory-safe panic there, so the engine must not read out of bounds either).  The index also holds a
- * BUCKET DIRECTORY: for every k-symbol prefix (k * ceil(log2 sigma) <= 24 bits) the first rank whose suffix
- * is not smaller -- a query looks its first k symbols up and binary-searches only inside that bucket. */
+ * BUCKET DIRECTORY: for every prefix of dbits bits of dense symbol codes (dbits = log2 n - 2, at most 28:
+ * about one bucket per four suffixes, n bytes of HBM) the first rank whose suffix is not smaller -- a query
+ * looks its own first dbits bits up and binary-searches only inside that bucket. */
 int sfx_index_create(const uint8_t* text, uint64_t n, const uint32_t* sa, sfx_index** out);
 /* the same over text and suffix array that already live in HBM (borrowed, not copied: keep them alive and
  * unchanged while the index exists); only the directory is built.  Queries with device buffers: */

@@ -185,7 +185,7 @@ struct sfx_index {
     // bucket directory (sfx_query.hip): first k symbols of a query -> its stretch of the suffix array
     uint32_t* d_dir = nullptr;
     uint16_t* d_lut = nullptr;      // 256 entries: byte -> symbol code + 1, 0 = byte absent from the text
-    int bits = 0, k = 0;
+    int bits = 0, k = 0, dbits = 0;
     uint64_t entries = 0;
 };
 
@@ -204,13 +204,13 @@ static int index_build_directory(sfx_index* ix, hipStream_t st)
     unsigned sigma = 0;
     for (int c = 0; c < 256; c++) lut[c] = bins[c] ? (uint16_t)(++sigma) : (uint16_t)0;
     ix->bits = bits_for(sigma > 1 ? sigma - 1 : 1);
-    SFX_TRY(dir_shape(ix->n, ix->bits, &ix->k, &ix->entries));
+    SFX_TRY(dir_shape(ix->n, ix->bits, &ix->k, &ix->dbits, &ix->entries));
     SFX_HIP(hipMalloc((void**)&ix->d_dir, ix->entries * sizeof(uint32_t)));
     SFX_HIP(hipMalloc((void**)&ix->d_lut, 256 * sizeof(uint16_t)));
     uint32_t* scratch = nullptr;
     SFX_HIP(hipMalloc((void**)&scratch, (dir_scratch_words(ix->entries) + 2) * sizeof(uint32_t)));
     uint64_t bad = 0;
-    rc = dir_build_dev(ix->d_text, ix->n, ix->d_sa, lut, ix->bits, ix->k, ix->entries, ix->d_lut, ix->d_dir, scratch, st, &bad);
+    rc = dir_build_dev(ix->d_text, ix->n, ix->d_sa, lut, ix->bits, ix->k, ix->dbits, ix->entries, ix->d_lut, ix->d_dir, scratch, st, &bad);
     (void)hipFree(scratch);
     if (rc != SFX_OK) return rc;
     return bad ? SFX_ERR_ARG : SFX_OK;
@@ -435,7 +435,7 @@ int sfx_index_query_dev(const sfx_index* ix, const uint8_t* d_qbytes, const uint
     if (ix->n == 0 || !ix->d_dir)
         return query_batch_dev(ix->d_text, ix->n, ix->d_sa, ix->n, d_qbytes, d_qoff, nq, d_start, d_end, d_found, d_any,
                                (hipStream_t)stream);
-    return query_batch_dir_dev(ix->d_text, ix->n, ix->d_sa, ix->d_dir, ix->d_lut, ix->bits, ix->k, d_qbytes, d_qoff, nq,
+    return query_batch_dir_dev(ix->d_text, ix->n, ix->d_sa, ix->d_dir, ix->d_lut, ix->bits, ix->k, ix->dbits, d_qbytes, d_qoff, nq,
                                d_start, d_end, d_found, d_any, (hipStream_t)stream);
 }
 

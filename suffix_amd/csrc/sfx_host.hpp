@@ -261,13 +261,13 @@ int query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uin
                     const uint8_t* d_q, const uint64_t* d_qoff, uint64_t nq, uint32_t* d_start,
                     uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st);
 // bucket directory of the resident index (sfx_query.hip)
-int dir_shape(uint64_t n, int bits, int* k_out, uint64_t* entries_out);
+int dir_shape(uint64_t n, int bits, int* k_out, int* dbits_out, uint64_t* entries_out);
 uint64_t dir_scratch_words(uint64_t entries);
 int dir_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint16_t* host_lut256, int bits, int k,
-                  uint64_t entries, uint16_t* d_lut256, uint32_t* d_dir, uint32_t* d_scratch, hipStream_t st,
+                  int dbits, uint64_t entries, uint16_t* d_lut256, uint32_t* d_dir, uint32_t* d_scratch, hipStream_t st,
                   uint64_t* bad_out);
 int query_batch_dir_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint32_t* d_dir,
-                        const uint16_t* d_lut256, int bits, int k, const uint8_t* d_q, const uint64_t* d_qoff, uint64_t nq,
+                        const uint16_t* d_lut256, int bits, int k, int dbits, const uint8_t* d_q, const uint64_t* d_qoff, uint64_t nq,
                         uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st);
 int byte_presence_host(const uint8_t* d_text, uint64_t n, void* d_small4k, unsigned long long* host_bins256,
                        hipStream_t st);

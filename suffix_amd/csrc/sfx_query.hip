@@ -105,28 +105,30 @@ k_query_batch(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __re
 }
 
 // ---- bucket directory of the resident index ---------------------------------
-// dir[c] = first rank whose suffix's first k symbols (dense symbol codes of `bits` bits, zero-padded
-// past the end of the text) are >= c, for every k-symbol code c, plus dir[2^(k*bits)] = n: the bucket
-// structure the build's initial sort works with, kept next to the suffix array.  A query first looks
-// its own first k symbols up -- one read instead of the ~ k*bits top levels of the binary search, and
-// no probe at all for queries of <= k symbols or with a byte the text does not contain.
+// dir[c] = first rank whose suffix's first `dbits` bits of dense symbol codes (`bits` bits per symbol,
+// zero-padded past the end of the text) are >= c, for every dbits-bit prefix c, plus dir[2^dbits] = n:
+// the bucket structure the build's initial sort works with, kept next to the suffix array -- about one
+// bucket per four suffixes (dbits = log2 n - 2, at most 28: 1 GiB of directory for 10^9 suffixes; HBM is
+// what this machine has plenty of).  A query looks its own first dbits bits up -- two adjacent reads
+// instead of the ~ dbits top levels of the binary search, and no probe at all for queries of <= kfull
+// symbols or with a byte the text does not contain.  k = symbols a key touches (the last one partly).
 struct DirParams {
     const uint32_t* dir;
     const uint16_t* lut;        // byte -> symbol code + 1, 0 = byte does not occur in the text
-    int bits, k;
+    int bits, k, dbits;
 };
 __device__ __forceinline__ uint32_t dir_code_of_suffix(const uint8_t* __restrict__ text, uint64_t n, uint64_t s,
-                                                       const uint16_t* __restrict__ lut, int bits, int k)
+                                                       const uint16_t* __restrict__ lut, int bits, int k, int dbits)
 {
-    uint32_t c = 0;
-    for (int j = 0; j < k; j++) c = (c << bits) | (s + j < n ? (uint32_t)lut[text[s + j]] - 1u : 0u);
-    return c;
+    uint64_t c = 0;
+    for (int j = 0; j < k; j++) c = (c << bits) | (s + j < n ? (uint64_t)lut[text[s + j]] - 1u : 0u);
+    return (uint32_t)(c >> (k * bits - dbits));
 }
 // dir[code of rank r] = r wherever the code changes (dir pre-filled with 0xFFFFFFFF); bad[0] counts
 // suffix-array entries >= n (from_parts hands the engine an unchecked table, :105-119)
 __global__ void __launch_bounds__(kBlock)
 k_dir_mark(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, const uint16_t* __restrict__ lut,
-           int bits, int k, uint32_t* __restrict__ dir, unsigned long long* __restrict__ bad)
+           int bits, int k, int dbits, uint32_t* __restrict__ dir, unsigned long long* __restrict__ bad)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const unsigned lane = lane_id();
@@ -137,11 +139,11 @@ k_dir_mark(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restr
         const bool ok = s < n;
         if (live && !ok) atomicAdd(bad, 1ull);
         if (!ok) s = 0;
-        const uint32_t c = live ? dir_code_of_suffix(text, n, s, lut, bits, k) : 0u;
+        const uint32_t c = live ? dir_code_of_suffix(text, n, s, lut, bits, k, dbits) : 0u;
         uint32_t cp = __shfl_up(c, 1u);
         if (lane == 0 && live && r > 0) {
             const uint64_t sp = sa[r - 1];
-            cp = sp < n ? dir_code_of_suffix(text, n, sp, lut, bits, k) : 0u;
+            cp = sp < n ? dir_code_of_suffix(text, n, sp, lut, bits, k, dbits) : 0u;
         }
         if (live && (r == 0 || c != cp)) dir[c] = (uint32_t)r;
     }
@@ -168,7 +170,7 @@ k_dir_block_min(const uint32_t* __restrict__ dir, uint64_t entries, uint32_t* __
         bmin[blockIdx.x] = a;
     }
 }
-__global__ void k_dir_scan_mins(uint32_t* __restrict__ bmin, uint64_t nb)      // one thread: nb <= 4097
+__global__ void k_dir_scan_mins(uint32_t* __restrict__ bmin, uint64_t nb)      // one thread: nb <= 65537
 {
     if (threadIdx.x || blockIdx.x) return;
     uint32_t run = 0xFFFFFFFFu;
@@ -210,18 +212,23 @@ k_query_batch_dir(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* 
         const uint64_t m = qoff[qi + 1] - qoff[qi];
         uint64_t start = 0, end = 0;
         if (n != 0 && m != 0) {                                       // :228-229
+            const int kfull = dp.dbits / dp.bits;                     // symbols wholly inside a directory key
             const int L = m < (uint64_t)dp.k ? (int)m : dp.k;
-            uint32_t c = 0;
+            uint64_t c = 0;
             bool absent = false;
             for (int j = 0; j < L; j++) {
                 const uint32_t sym = dp.lut[q[j]];
                 absent |= sym == 0u;
-                c = (c << dp.bits) | (sym - 1u);
+                c = (c << dp.bits) | (uint64_t)(sym - 1u);
             }
             if (!absent) {
-                const int rest = dp.bits * (dp.k - L);
-                uint64_t lo = dp.dir[(uint64_t)c << rest], hi = dp.dir[((uint64_t)c + 1) << rest];
-                if (m <= (uint64_t)dp.k) {
+                // the first min(L * bits, dbits) bits of the query's code stream select the bucket range
+                const int have = L * dp.bits;
+                uint64_t c_lo, c_hi;
+                if (have >= dp.dbits) { c_lo = c >> (have - dp.dbits); c_hi = c_lo + 1; }
+                else { c_lo = c << (dp.dbits - have); c_hi = (c + 1) << (dp.dbits - have); }
+                uint64_t lo = dp.dir[c_lo], hi = dp.dir[c_hi];
+                if (m <= (uint64_t)kfull) {
                     // every suffix in these buckets starts with q, except suffixes shorter than q whose
                     // zero padding imitates q's tail: they are the first entries of the first bucket
                     while (lo < hi && n - (uint64_t)sa[lo] < m) lo++;
@@ -263,16 +270,15 @@ k_query_batch_dir(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* 
     }
 }
 
-// symbols per directory key: k * bits <= 24 and about n / 4 buckets at most
-int dir_shape(uint64_t n, int bits, int* k_out, uint64_t* entries_out)
+// directory key width: about n / 4 buckets, at most 2^28 (1 GiB of u32); k = symbols a key touches
+int dir_shape(uint64_t n, int bits, int* k_out, int* dbits_out, uint64_t* entries_out)
 {
-    int budget = bits_for(n) - 2;
-    if (budget > 24) budget = 24;
-    int k = budget / bits;
-    if (k < 1) k = 1;
-    while (k > 1 && k * bits > 24) k--;
-    *k_out = k;
-    *entries_out = (1ull << (k * bits)) + 1;
+    int dbits = bits_for(n) - 2;
+    if (dbits > 28) dbits = 28;
+    if (dbits < bits) dbits = bits;
+    *dbits_out = dbits;
+    *k_out = (dbits + bits - 1) / bits;
+    *entries_out = (1ull << dbits) + 1;
     return SFX_OK;
 }
 uint64_t dir_scratch_words(uint64_t entries) { return (entries + kDirTile - 1) / kDirTile + 8; }
@@ -280,7 +286,7 @@ uint64_t dir_scratch_words(uint64_t entries) { return (entries + kDirTile - 1) /
 // d_lut256 (256 u16: byte -> code + 1) and d_dir (entries u32) are filled; d_scratch: dir_scratch_words(entries) u32
 // + 8 bytes.  *bad_out = suffix-array entries >= n (the table is not usable then).
 int dir_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint16_t* host_lut256, int bits, int k,
-                  uint64_t entries, uint16_t* d_lut256, uint32_t* d_dir, uint32_t* d_scratch, hipStream_t st,
+                  int dbits, uint64_t entries, uint16_t* d_lut256, uint32_t* d_dir, uint32_t* d_scratch, hipStream_t st,
                   uint64_t* bad_out)
 {
     unsigned long long* bad = reinterpret_cast<unsigned long long*>(d_scratch);
@@ -289,7 +295,7 @@ int dir_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const
     SFX_HIP(hipMemsetAsync(d_dir, 0xFF, entries * sizeof(uint32_t), st));
     SFX_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned long long), st));
     const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
-    SFX_LAUNCH("dir_mark", (double)n * 12, k_dir_mark, grid, kBlock, st, d_text, n, d_sa, d_lut256, bits, k, d_dir, bad);
+    SFX_LAUNCH("dir_mark", (double)n * 12, k_dir_mark, grid, kBlock, st, d_text, n, d_sa, d_lut256, bits, k, dbits, d_dir, bad);
     const uint32_t n32 = (uint32_t)n;
     SFX_HIP(hipMemcpyAsync(d_dir + (entries - 1), &n32, sizeof(n32), hipMemcpyHostToDevice, st));
     const uint64_t nb = (entries + kDirTile - 1) / kDirTile;
@@ -303,15 +309,15 @@ int dir_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const
 }
 
 int query_batch_dir_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint32_t* d_dir,
-                        const uint16_t* d_lut256, int bits, int k, const uint8_t* d_q, const uint64_t* d_qoff, uint64_t nq,
+                        const uint16_t* d_lut256, int bits, int k, int dbits, const uint8_t* d_q, const uint64_t* d_qoff, uint64_t nq,
                         uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st)
 {
     if (nq == 0) return SFX_OK;
     if (!d_qoff || (n && (!d_text || !d_sa || !d_dir || !d_lut256))) return SFX_ERR_ARG;
     const unsigned grid = (unsigned)dmin<uint64_t>((nq + kBlock - 1) / kBlock, kMaxGrid);
     // one directory read, then 2 * log2(bucket) probes of 12 bytes: ~ half of the undirected search
-    const double probes = 1.0 + (double)dmax(2, 2 * (bits_for(n ? n : 1) - bits * k));
-    DirParams dp = {d_dir, d_lut256, bits, k};
+    const double probes = 1.0 + (double)dmax(2, 2 * (bits_for(n ? n : 1) - dbits));
+    DirParams dp = {d_dir, d_lut256, bits, k, dbits};
     SFX_LAUNCH("query_batch_dir", (double)nq * probes * 12.0, k_query_batch_dir, grid, kBlock, st, d_text, n, d_sa, dp,
                d_q, d_qoff, nq, d_start, d_end, d_found, d_any);
     return SFX_OK;
