@@ -118,6 +118,27 @@ int sfx_query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa,
                         uint32_t* d_start, uint32_t* d_end, uint8_t* d_found,
                         uint32_t* d_any, void* stream);
 
+/* ---- suffix-tree topology from SA + LCP (suffix_tree/src/lib.rs:392-505 `to_suffix_tree`), flat ------
+ * The internal nodes of the suffix tree are the lcp-intervals of the LCP array; the reference finds them
+ * with a serial stack sweep, the engine with nearest-smaller-value searches over a min-pyramid.  For every
+ * BOUNDARY p in [0, n) (between ranks p - 1 and p; value lcp[p]) the call writes
+ *   lb[p], rb[p]   the rank range of the node the boundary belongs to (its string depth is lcp[p]);
+ *   node[p]        that node's id = its leftmost boundary with that depth (0 = the root: [0, n-1], depth 0,
+ *                  to which every boundary with lcp[p] == 0 belongs);
+ *   parent[p]      the id of that node's parent (UINT32_MAX for the root's own entry p = 0);
+ * and for every RANK r:  leaf_parent[r] = id of the node the leaf of suffix sa[r] hangs under.
+ * Node k's edge label is text[sa[lb[k]] + depth(parent) .. sa[lb[k]] + depth(k)); children are the nodes /
+ * leaves whose parent is k -- the same tree as `to_suffix_tree`, as arrays.  All device pointers, n u32 each. */
+uint64_t sfx_lcp_intervals_workspace_bytes(uint64_t n);
+int sfx_lcp_intervals_dev(const uint32_t* d_lcp, uint64_t n, uint32_t* d_lb, uint32_t* d_rb, uint32_t* d_node,
+                          uint32_t* d_parent, uint32_t* d_leaf_parent, void* d_workspace, uint64_t workspace_bytes,
+                          void* stream);
+/* ---- generalized suffix array (README.md:60-74): documents concatenated with a separator byte into one
+ * text, one SuffixTable over it; a match position is mapped back to (document, offset) by a binary search
+ * over the sorted document start offsets.  doc / offset may be NULL to skip. */
+int sfx_doc_lookup_dev(const uint32_t* d_positions, uint64_t count, const uint64_t* d_doc_starts, uint64_t ndocs,
+                       uint32_t* d_doc, uint32_t* d_offset, void* stream);
+
 /* ---- range-partitioned construction (multi-GPU, one rank per GPU) ----------- */
 /* Every rank holds the whole text in HBM (all-gathered over RCCL) and owns the
  * text shard [shard_begin, shard_end).

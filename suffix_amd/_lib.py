@@ -64,6 +64,9 @@ ABI = [
     ("sfx_positions_batch", _int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     ("sfx_contains_batch", _int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     ("sfx_query_batch_dev", _int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    ("sfx_lcp_intervals_workspace_bytes", _u64, [_u64]),
+    ("sfx_lcp_intervals_dev", _int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp]),
+    ("sfx_doc_lookup_dev", _int, [_vp, _u64, _vp, _u64, _vp, _vp, _vp]),
     ("sfx_byte_histogram_dev", _int, [_vp, _u64, _u64, _vp, _vp]),
     ("sfx_key_histogram_dev", _int, [_vp, _u64, _u64, _u64, _vp, _int, _vp, _vp]),
     ("sfx_sa_range_workspace_bytes", _u64, [_u64, _u64]),

@@ -528,6 +528,21 @@ int sfx_contains_batch(const sfx_index* ix, const uint8_t* qbytes, const uint64_
     return query_host(ix, qbytes, qoff, nq, nullptr, nullptr, found_out, any_out);
 }
 
+// ---- suffix-tree topology, generalized suffix array -------------------------------------------
+uint64_t sfx_lcp_intervals_workspace_bytes(uint64_t n) { return lcp_intervals_workspace_bytes(n); }
+int sfx_lcp_intervals_dev(const uint32_t* d_lcp, uint64_t n, uint32_t* d_lb, uint32_t* d_rb, uint32_t* d_node,
+                          uint32_t* d_parent, uint32_t* d_leaf_parent, void* d_workspace, uint64_t workspace_bytes,
+                          void* stream)
+{
+    return lcp_intervals_dev(d_lcp, n, d_lb, d_rb, d_node, d_parent, d_leaf_parent, d_workspace, workspace_bytes,
+                             (hipStream_t)stream);
+}
+int sfx_doc_lookup_dev(const uint32_t* d_positions, uint64_t count, const uint64_t* d_doc_starts, uint64_t ndocs,
+                       uint32_t* d_doc, uint32_t* d_offset, void* stream)
+{
+    return doc_lookup_dev(d_positions, count, d_doc_starts, ndocs, d_doc, d_offset, (hipStream_t)stream);
+}
+
 // ---- partitioned build ---------------------------------------------------------------------
 int sfx_byte_histogram_dev(const uint8_t* d_text, uint64_t shard_begin, uint64_t shard_end,
                            uint64_t* d_bins256, void* stream)

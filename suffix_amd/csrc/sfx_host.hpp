@@ -286,6 +286,13 @@ int build_sa_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint64_t* d_
 int pack_text_dev(const uint8_t* d_text, uint64_t count, const uint64_t* d_byte_bins, uint8_t* d_lut256,
                   uint32_t* d_words, uint64_t n_words, hipStream_t st);
 
+// suffix-tree topology / generalized suffix array (sfx_tree.hip)
+uint64_t lcp_intervals_workspace_bytes(uint64_t n);
+int lcp_intervals_dev(const uint32_t* d_lcp, uint64_t n, uint32_t* d_lb, uint32_t* d_rb, uint32_t* d_node, uint32_t* d_parent,
+                      uint32_t* d_leaf_parent, void* ws, uint64_t ws_bytes, hipStream_t st);
+int doc_lookup_dev(const uint32_t* d_pos, uint64_t count, const uint64_t* d_starts, uint64_t ndocs, uint32_t* d_doc,
+                   uint32_t* d_offset, hipStream_t st);
+
 sfx_build_stats& tls_build_stats();
 
 }  // namespace sfx

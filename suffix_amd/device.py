@@ -156,6 +156,34 @@ class DeviceIndex:
     __del__ = close
 
 
+def lcp_intervals(lcp, engine=None):
+    """Suffix-tree topology as flat arrays from the LCP array (uint32 in int32 storage, on any device the
+    engine runs on): -> dict(lb, rb, node, parent, leaf_parent), see include/suffix_hip.h."""
+    eng = engine or default_engine()
+    n = lcp.numel()
+    dev = lcp.device
+    out = {k: torch.empty(n, dtype=torch.int32, device=dev) for k in ("lb", "rb", "node", "parent", "leaf_parent")}
+    ws = torch.empty(int(eng.lib.sfx_lcp_intervals_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    with _on(lcp):
+        eng.check(eng.lib.sfx_lcp_intervals_dev(_p(lcp), n, _p(out["lb"]), _p(out["rb"]), _p(out["node"]), _p(out["parent"]),
+                                                _p(out["leaf_parent"]), _p(ws), ws.numel(), _stream_ptr(lcp)),
+                  "sfx_lcp_intervals_dev")
+    return out
+
+
+def doc_lookup(positions, doc_starts, engine=None):
+    """Generalized suffix array: text positions (uint32 in int32 storage) -> (document index, offset inside it);
+    doc_starts = sorted int64 start offsets of the documents inside the concatenated text."""
+    eng = engine or default_engine()
+    cnt = positions.numel()
+    doc = torch.empty(cnt, dtype=torch.int32, device=positions.device)
+    off = torch.empty(cnt, dtype=torch.int32, device=positions.device)
+    with _on(positions):
+        eng.check(eng.lib.sfx_doc_lookup_dev(_p(positions), cnt, _p(doc_starts), doc_starts.numel(), _p(doc), _p(off),
+                                             _stream_ptr(positions)), "sfx_doc_lookup_dev")
+    return doc, off
+
+
 def widen_u64(sa32, engine=None):
     """u32 index tensor (int32 storage) -> int64 tensor holding the same indices (config 4)."""
     eng = engine or default_engine()

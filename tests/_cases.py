@@ -281,6 +281,97 @@ def directory_queries(eng, orc, device="cpu", scale=1):
         pass
 
 
+def _stack_sweep_tree(lcp):
+    """Restatement of the reference's serial sweep (suffix_tree/src/lib.rs:392-505): walk the ranks left to
+    right keeping the stack of open ancestors (the path to the last leaf); an lcp value below the top closes
+    nodes, one above it opens a new internal node.  Returns, per closed node, (depth, lb, rb, parent_depth,
+    parent_lb) and per leaf its parent's (depth, lb).  A node is identified by (depth, lb)."""
+    n = len(lcp)
+    nodes, leaf_parent = {}, [None] * n
+    stack = [(0, 0)]                                    # (depth, lb) of open nodes; the root is never closed here
+    rb_of = {}
+    for r in range(n + 1):
+        cur = int(lcp[r]) if r < n else 0
+        lb = r - 1 if r else 0
+        # the leaf r-1 hangs under the deeper of its two boundaries; decided when boundary r is seen
+        while stack[-1][0] > cur:
+            d, l = stack.pop()
+            rb_of[(d, l)] = r - 1
+            lb = l
+            parent = stack[-1] if stack[-1][0] >= cur else (cur, l)
+            nodes[(d, l)] = parent
+        if stack[-1][0] < cur:
+            stack.append((cur, lb))
+        if r < n:
+            pass
+    # leaf parents: deeper neighbouring boundary; resolve to the enclosing node (depth, lb) by scanning
+    return nodes, rb_of
+
+
+def suffix_tree_topology(eng, orc, device="cpu", scale=1):
+    """sfx_lcp_intervals_dev against the definition (nearest smaller values, brute force) and against the
+    node set of the reference's stack sweep; sfx_doc_lookup_dev against numpy."""
+    import torch
+
+    from suffix_amd import device as sdev
+    rng = np.random.default_rng(21)
+    texts = [b"banana", b"mississippi", b"a" * 70, b"ab" * 40 + b"a", _gen.fibonacci_string(10), b"x",
+             _gen.dna(700 * scale, seed=3).tobytes(), _gen.english_like(900 * scale).tobytes(),
+             _gen.uniform_bytes(500 * scale, 3, 4, base=97).tobytes(), bytes(rng.integers(0, 256, 300 * scale, dtype=np.uint8))]
+    for text in texts:
+        n = len(text)
+        sa = orc.sais(text)
+        lcp = orc.lcp_kasai(text, sa)
+        t = sdev.lcp_intervals(torch.from_numpy(lcp.view(np.int32).copy()).to(device), engine=eng)
+        got = {k: v.cpu().numpy().view(np.uint32).astype(np.int64) for k, v in t.items()}
+        L = lcp.astype(np.int64)
+        exp_nodes = set()
+        for p in range(n):
+            v = L[p]
+            if p == 0 or v == 0:
+                assert (got["lb"][p], got["rb"][p], got["node"][p]) == (0, n - 1, 0)
+                continue
+            l = p - 1
+            while L[l] >= v:
+                l -= 1
+            r = p + 1
+            while r < n and L[r] >= v:
+                r += 1
+            node = l + 1
+            while L[node] > v:
+                node += 1
+            assert (got["lb"][p], got["rb"][p], got["node"][p]) == (l, r - 1, node), (p, text[:20])
+            vl, vr = L[l], (L[r] if r < n else 0)
+            assert got["parent"][p] == (got["node"][l] if vl >= vr else got["node"][r]), p
+            exp_nodes.add((int(v), l, r - 1))
+            # every suffix of the interval shares exactly `depth` symbols
+            a, b = int(sa[l]), int(sa[r - 1])
+            assert text[a:a + v] == text[b:b + v] and (a + v == n or b + v == n or text[a + v] != text[b + v])
+        for r in range(n):
+            dl, dr = L[r], (L[r + 1] if r + 1 < n else 0)
+            assert got["leaf_parent"][r] == (got["node"][r] if dl >= dr else got["node"][r + 1])
+        assert got["parent"][0] == 0xFFFFFFFF
+        # the same internal nodes as the reference's sweep builds
+        nodes, rb_of = _stack_sweep_tree(lcp)
+        sweep = {(d, l, rb_of[(d, l)]) for (d, l) in nodes}
+        assert sweep == exp_nodes, (len(sweep), len(exp_nodes), text[:20])
+    # generalized suffix array: positions -> (document, offset)
+    docs = [b"alpha beta", b"", b"gamma", b"delta epsilon zeta"]
+    starts, blob = [], b""
+    for dd in docs:
+        starts.append(len(blob))
+        blob += dd + b"\x00"
+    st = SuffixTable(blob, engine=eng)
+    pos = torch.from_numpy(st.table().view(np.int32).copy()).to(device)
+    d, off = sdev.doc_lookup(pos, torch.tensor(starts, dtype=torch.int64).to(device), engine=eng)
+    exp_d = np.searchsorted(np.array(starts), st.table().astype(np.int64), side="right") - 1
+    assert np.array_equal(d.cpu().numpy(), exp_d) and np.array_equal(off.cpu().numpy(), st.table().astype(np.int64) - np.array(starts)[exp_d])
+    hits = st.positions("eta")                            # "beta", "zeta": documents 0 and 3
+    dh, _ = sdev.doc_lookup(torch.from_numpy(hits.view(np.int32).copy()).to(device),
+                            torch.tensor(starts, dtype=torch.int64).to(device), engine=eng)
+    assert sorted(dh.cpu().numpy().tolist()) == [0, 3]
+
+
 def range_slices(eng, orc, text, nranges, device="cpu", packed=False, top_bits=14):
     """The range-partitioned build driven for `nranges` virtual ranks in one process: every
     range [lo, hi) of the planned key bins is built on its own and the slices must

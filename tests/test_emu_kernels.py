@@ -73,6 +73,10 @@ def test_index_directory_queries(emu, oracle):
     _cases.directory_queries(emu, oracle)
 
 
+def test_suffix_tree_topology_and_doc_lookup(emu, oracle):
+    _cases.suffix_tree_topology(emu, oracle)
+
+
 def test_fused_sa_lcp(emu, oracle):
     _cases.fused_lcp_tails(emu, oracle, iters=30)
 

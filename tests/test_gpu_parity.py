@@ -58,6 +58,10 @@ def test_index_directory_queries(eng, oracle):
     _cases.directory_queries(eng, oracle, device="cuda", scale=20)
 
 
+def test_suffix_tree_topology_and_doc_lookup(eng, oracle):
+    _cases.suffix_tree_topology(eng, oracle, device="cuda", scale=3)
+
+
 def test_fused_sa_lcp(eng, oracle):
     _cases.fused_lcp_tails(eng, oracle, iters=40, scale=50)
 
