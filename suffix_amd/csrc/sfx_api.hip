@@ -187,6 +187,10 @@ struct sfx_index {
     uint16_t* d_lut = nullptr;      // 256 entries: byte -> symbol code + 1, 0 = byte absent from the text
     int bits = 0, k = 0, dbits = 0;
     uint64_t entries = 0;
+    // prefix-key B+tree (sfx_query.hip): 8.6 n bytes; when it cannot be allocated the directory alone serves
+    uint64_t* d_tree = nullptr;
+    uint64_t tree_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int tree_levels = 0;
 };
 
 namespace sfx {
@@ -213,7 +217,17 @@ static int index_build_directory(sfx_index* ix, hipStream_t st)
     rc = dir_build_dev(ix->d_text, ix->n, ix->d_sa, lut, ix->bits, ix->k, ix->dbits, ix->entries, ix->d_lut, ix->d_dir, scratch, st, &bad);
     (void)hipFree(scratch);
     if (rc != SFX_OK) return rc;
-    return bad ? SFX_ERR_ARG : SFX_OK;
+    if (bad) return SFX_ERR_ARG;
+    // SFX_INDEX_TREE=0 (development): directory only
+    static const bool want_tree = [] { const char* e = getenv("SFX_INDEX_TREE"); return !e || atoi(e) != 0; }();
+    if (want_tree && hipMalloc((void**)&ix->d_tree, key_tree_words(ix->n) * sizeof(uint64_t)) == hipSuccess) {
+        rc = key_tree_build_dev(ix->d_text, ix->n, ix->d_sa, ix->d_tree, ix->tree_off, &ix->tree_levels, st);
+        if (rc != SFX_OK) return rc;
+    } else {
+        ix->d_tree = nullptr;
+        (void)hipGetLastError();
+    }
+    return SFX_OK;
 }
 }  // namespace sfx
 
@@ -435,6 +449,9 @@ int sfx_index_query_dev(const sfx_index* ix, const uint8_t* d_qbytes, const uint
     if (ix->n == 0 || !ix->d_dir)
         return query_batch_dev(ix->d_text, ix->n, ix->d_sa, ix->n, d_qbytes, d_qoff, nq, d_start, d_end, d_found, d_any,
                                (hipStream_t)stream);
+    if (ix->d_tree)
+        return query_batch_tree_dev(ix->d_text, ix->n, ix->d_sa, ix->d_tree, ix->tree_off, ix->tree_levels, d_qbytes, d_qoff, nq,
+                                    d_start, d_end, d_found, d_any, (hipStream_t)stream);
     return query_batch_dir_dev(ix->d_text, ix->n, ix->d_sa, ix->d_dir, ix->d_lut, ix->bits, ix->k, ix->dbits, d_qbytes, d_qoff, nq,
                                d_start, d_end, d_found, d_any, (hipStream_t)stream);
 }
@@ -447,6 +464,7 @@ void sfx_index_destroy(sfx_index* ix)
         if (ix->d_sa) (void)hipFree(ix->d_sa);
     }
     if (ix->d_dir) (void)hipFree(ix->d_dir);
+    if (ix->d_tree) (void)hipFree(ix->d_tree);
     if (ix->d_lut) (void)hipFree(ix->d_lut);
     delete ix;
 }

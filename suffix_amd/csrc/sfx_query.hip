@@ -323,6 +323,189 @@ int query_batch_dir_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa,
     return SFX_OK;
 }
 
+// ---- prefix-key B+tree of the resident index ------------------------------------------------------
+// What a query pays for in a binary search over the suffix array is not the ~30 probes but the last ~12 of
+// them: the top levels' SA entries and text lines are shared by all queries and sit in L2, the bottom
+// levels are two random 128-byte lines per probe (SA entry, then text).  The index therefore keeps, for
+// every rank, the first 8 bytes of its suffix as a big-endian integer (zero-padded past the end of the text)
+// -- the leaves of a static 16-ary B+tree whose inner levels hold the last key of every block of 16.  One
+// node = one 128-byte line; a search reads one line per level (8 levels at n = 10^9, the top five cached)
+// and never touches the text unless the query is longer than 8 bytes AND shares its first 8 bytes with
+// several suffixes.  Order: for zero-padded keys A, B of byte strings a, b, A < B implies a < b (a proper
+// prefix sorts first, padding is the smallest byte), so the ranks whose key lies in [q padded with 0x00,
+// q padded with 0xFF] contain every suffix that starts with q, and for |q| <= 8 nothing else except
+// suffixes shorter than q, which come first in that range.  8 n bytes of HBM + 7 % for the inner levels.
+constexpr int kTreeFan = 16;
+constexpr int kTreeMaxLevels = 9;                        // 16^8 = 2^32
+struct KeyTree {
+    const uint64_t* lvl[kTreeMaxLevels];                 // lvl[0] = leaves, each level padded with ~0 to whole nodes
+    uint64_t len[kTreeMaxLevels];                        // real entries per level
+    int levels;
+    uint64_t n;
+};
+__device__ __forceinline__ uint64_t be64_of_suffix(const uint8_t* __restrict__ text, uint64_t n, uint64_t s)
+{
+    uint64_t k = 0;
+    if (s + 8 <= n) {
+        __builtin_memcpy(&k, text + s, 8);
+        return __builtin_bswap64(k);
+    }
+    for (unsigned j = 0; j < 8; j++) k = (k << 8) | (s + j < n ? (uint64_t)text[s + j] : 0ull);
+    return k;
+}
+__global__ void __launch_bounds__(kBlock)
+k_tree_leaves(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint64_t* __restrict__ leaves)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) {
+        const uint64_t sfx = sa[r];
+        leaves[r] = sfx < n ? be64_of_suffix(text, n, sfx) : ~0ull;      // (an invalid table is refused elsewhere)
+    }
+}
+__global__ void __launch_bounds__(kBlock)
+k_tree_level(const uint64_t* __restrict__ below, uint64_t len_below, uint64_t* __restrict__ out, uint64_t len_out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < len_out; j += stride)
+        out[j] = below[dmin<uint64_t>(j * kTreeFan + kTreeFan - 1, len_below - 1)];       // last key of block j
+}
+// first rank whose key is >= q (upper = false) or > q (upper = true)
+__device__ __forceinline__ uint64_t tree_bound(const KeyTree& t, uint64_t q, bool upper)
+{
+    uint64_t pos = 0;
+    for (int l = t.levels - 1; l >= 0; l--) {
+        const ulonglong2* node = reinterpret_cast<const ulonglong2*>(t.lvl[l] + pos * kTreeFan);
+        unsigned c = 0;
+#pragma unroll
+        for (int i = 0; i < kTreeFan / 2; i++) {
+            const ulonglong2 kk = node[i];
+            c += upper ? (kk.x <= q) : (kk.x < q);
+            c += upper ? (kk.y <= q) : (kk.y < q);
+        }
+        pos = pos * kTreeFan + c;
+        if (pos >= t.len[l]) return t.n;                      // beyond the last key of this level: q is above every suffix
+    }
+    return pos;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_query_batch_tree(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, KeyTree tree,
+                   const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, uint64_t nq,
+                   uint32_t* __restrict__ start_out, uint32_t* __restrict__ end_out,
+                   uint8_t* __restrict__ found_out, uint32_t* __restrict__ any_out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t qi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; qi < nq; qi += stride) {
+        const uint8_t* q = qbytes + qoff[qi];
+        const uint64_t m = qoff[qi + 1] - qoff[qi];
+        uint64_t start = 0, end = 0;
+        if (n != 0 && m != 0) {                                       // :228-229
+            uint64_t klo = 0, khi = 0;
+            for (unsigned j = 0; j < 8; j++) {
+                const bool in = j < m;
+                klo = (klo << 8) | (in ? (uint64_t)q[j] : 0ull);
+                khi = (khi << 8) | (in ? (uint64_t)q[j] : 0xFFull);
+            }
+            uint64_t lo = tree_bound(tree, klo, false), hi = tree_bound(tree, khi, true);
+            if (lo < hi) {
+                if (m <= 8) {
+                    // every rank in [lo, hi) starts with q, except suffixes shorter than q whose padding imitates
+                    // q's zero bytes: they are the first entries of the range
+                    while (lo < hi && n - (uint64_t)sa[lo] < m) lo++;
+                    start = lo;
+                    end = hi;
+                } else {
+                    const uint64_t top = hi;                          // the ranks that share q's first 8 bytes
+                    while (lo < hi) {                                 // :244-246 among them
+                        const uint64_t mid = (lo + hi) >> 1;
+                        if (query_le_suffix(q, m, text, n, sa[mid])) hi = mid; else lo = mid + 1;
+                    }
+                    start = lo;
+                    uint64_t cnt = 0;                                 // :247-250, bounded by `top`
+                    if (start < top && suffix_starts_with(q, m, text, n, sa[start])) {
+                        cnt = 1;
+                        uint64_t step = 1;
+                        while (start + cnt - 1 + step < top && suffix_starts_with(q, m, text, n, sa[start + cnt - 1 + step])) {
+                            cnt += step;
+                            step <<= 1;
+                        }
+                        lo = start + cnt;
+                        hi = dmin<uint64_t>(top, start + cnt - 1 + step);
+                        while (lo < hi) {
+                            const uint64_t mid = (lo + hi) >> 1;
+                            if (!suffix_starts_with(q, m, text, n, sa[mid])) hi = mid; else lo = mid + 1;
+                        }
+                        cnt = lo - start;
+                    }
+                    end = start + cnt;
+                }
+            }
+        }
+        const bool found = end > start;
+        if (!found) start = end = 0;
+        if (start_out) start_out[qi] = (uint32_t)start;
+        if (end_out) end_out[qi] = (uint32_t)end;
+        if (found_out) found_out[qi] = found ? 1 : 0;
+        if (any_out) any_out[qi] = found ? sa[start] : 0xFFFFFFFFu;
+    }
+}
+
+// words (u64) of one allocation that holds all levels, each padded to whole nodes plus one spare node
+uint64_t key_tree_words(uint64_t n)
+{
+    uint64_t words = 0, len = n;
+    for (int l = 0; l < kTreeMaxLevels; l++) {
+        words += (len + kTreeFan - 1) / kTreeFan * kTreeFan + kTreeFan;
+        if (len <= (uint64_t)kTreeFan) break;
+        len = (len + kTreeFan - 1) / kTreeFan;
+    }
+    return words;
+}
+// d_tree: key_tree_words(n) u64.  level_offsets_out[l] = word offset of level l, *levels_out = count.
+int key_tree_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint64_t* d_tree, uint64_t* level_offsets_out,
+                       int* levels_out, hipStream_t st)
+{
+    SFX_HIP(hipMemsetAsync(d_tree, 0xFF, key_tree_words(n) * sizeof(uint64_t), st));       // padding keys = max
+    const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
+    SFX_LAUNCH("tree_leaves", (double)n * 20, k_tree_leaves, grid, kBlock, st, d_text, n, d_sa, d_tree);
+    uint64_t off = 0, len = n;
+    int l = 0;
+    level_offsets_out[0] = 0;
+    while (len > (uint64_t)kTreeFan && l + 1 < kTreeMaxLevels) {
+        const uint64_t next_off = off + (len + kTreeFan - 1) / kTreeFan * kTreeFan + kTreeFan;
+        const uint64_t next_len = (len + kTreeFan - 1) / kTreeFan;
+        const unsigned g = (unsigned)dmin<uint64_t>((next_len + kBlock - 1) / kBlock, kMaxGrid);
+        SFX_LAUNCH("tree_level", (double)next_len * 16, k_tree_level, g, kBlock, st, (const uint64_t*)(d_tree + off), len,
+                   d_tree + next_off, next_len);
+        off = next_off;
+        len = next_len;
+        level_offsets_out[++l] = off;
+    }
+    *levels_out = l + 1;
+    return SFX_OK;
+}
+int query_batch_tree_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint64_t* d_tree,
+                         const uint64_t* level_offsets, int levels, const uint8_t* d_q, const uint64_t* d_qoff, uint64_t nq,
+                         uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st)
+{
+    if (nq == 0) return SFX_OK;
+    if (!d_qoff || !d_tree || levels < 1 || levels > kTreeMaxLevels) return SFX_ERR_ARG;
+    KeyTree t;
+    uint64_t len = n;
+    for (int l = 0; l < kTreeMaxLevels; l++) {
+        t.lvl[l] = l < levels ? d_tree + level_offsets[l] : nullptr;
+        t.len[l] = l < levels ? len : 0;
+        len = (len + kTreeFan - 1) / kTreeFan;
+    }
+    t.levels = levels;
+    t.n = n;
+    const unsigned grid = (unsigned)dmin<uint64_t>((nq + kBlock - 1) / kBlock, kMaxGrid);
+    // two descents of one 128-byte node per level, a few probes of 2 lines beyond 8 bytes
+    SFX_LAUNCH("query_batch_tree", (double)nq * (2.0 * levels * 128 + 4 * 256), k_query_batch_tree, grid, kBlock, st, d_text, n,
+               d_sa, t, d_q, d_qoff, nq, d_start, d_end, d_found, d_any);
+    return SFX_OK;
+}
+
 // sa_len == n: the whole suffix array.  sa_len < n: a contiguous SLICE of it (one rank of
 // the range-partitioned index); start/end are then positions inside the slice.
 int query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, uint64_t sa_len, const uint8_t* d_q,

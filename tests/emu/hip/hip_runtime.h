@@ -34,6 +34,7 @@ struct dim3 {
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) ulonglong2 { unsigned long long x, y; };
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };

@@ -61,6 +61,9 @@ if os.environ.get("SFX_LCP_DIRECT_MIN"):
     assert k == ["lcp_sample", "phi_scatter", "plcp", "lcp_gather"], k
     k = lcp_kernels(texts[4])                          # cap reached: Phi/PLCP redoes the array
     assert "lcp_windows_packed" in k and k[-3:] == ["phi_scatter", "plcp", "lcp_gather"], k
+if os.environ.get("SFX_INDEX_TREE"):
+    import _cases
+    _cases.directory_queries(eng, oracle)
 print("OK")
 """
 
@@ -76,6 +79,7 @@ VARIANTS = {
     "small-tiles-small-segments": {"SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
     "small-tiles-key64-multi-tile": {"SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "3", "SFX_SEG_SMALL": "1"},
     "key64": {"SFX_FORCE_KEY64": "1"},
+    "index-directory-only": {"SFX_INDEX_TREE": "0"},
     "tile-1024x4-pair32": {"SFX_TILE_GEOM": "1", "SFX_TILE_PAIR": "32"},
     "tile-512x8": {"SFX_TILE_GEOM": "2"},
     "tile-512x4-key64": {"SFX_TILE_GEOM": "3", "SFX_FORCE_KEY64": "1"},
