@@ -243,14 +243,20 @@ k_query_batch_dir(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* 
                     start = lo;
                     uint64_t cnt = 0;                                 // :247-250 as in k_query_batch, bounded by the bucket
                     if (start < top && suffix_starts_with(q, m, text, n, sa[start])) {
+                        // gallop while the interval may still be short (<= 15 matches: 4 probes), then bisect what is
+                        // left of the range -- queries drawn from a natural-language text match 10^5 suffixes on
+                        // average, where galloping all the way costs 2 log2(#matches) probes and bisecting log2(range)
                         cnt = 1;
                         uint64_t step = 1;
-                        while (start + cnt - 1 + step < top && suffix_starts_with(q, m, text, n, sa[start + cnt - 1 + step])) {
+                        bool more = true;
+                        while (step <= 8) {
+                            more = start + cnt - 1 + step < top && suffix_starts_with(q, m, text, n, sa[start + cnt - 1 + step]);
+                            if (!more) break;
                             cnt += step;
                             step <<= 1;
                         }
                         lo = start + cnt;
-                        hi = dmin<uint64_t>(top, start + cnt - 1 + step);
+                        hi = more ? top : dmin<uint64_t>(top, start + cnt - 1 + step);
                         while (lo < hi) {
                             const uint64_t mid = (lo + hi) >> 1;
                             if (!suffix_starts_with(q, m, text, n, sa[mid])) hi = mid; else lo = mid + 1;
@@ -423,14 +429,20 @@ k_query_batch_tree(const uint8_t* __restrict__ text, uint64_t n, const uint32_t*
                     start = lo;
                     uint64_t cnt = 0;                                 // :247-250, bounded by `top`
                     if (start < top && suffix_starts_with(q, m, text, n, sa[start])) {
+                        // gallop while the interval may still be short (<= 15 matches: 4 probes), then bisect what is
+                        // left of the range -- queries drawn from a natural-language text match 10^5 suffixes on
+                        // average, where galloping all the way costs 2 log2(#matches) probes and bisecting log2(range)
                         cnt = 1;
                         uint64_t step = 1;
-                        while (start + cnt - 1 + step < top && suffix_starts_with(q, m, text, n, sa[start + cnt - 1 + step])) {
+                        bool more = true;
+                        while (step <= 8) {
+                            more = start + cnt - 1 + step < top && suffix_starts_with(q, m, text, n, sa[start + cnt - 1 + step]);
+                            if (!more) break;
                             cnt += step;
                             step <<= 1;
                         }
                         lo = start + cnt;
-                        hi = dmin<uint64_t>(top, start + cnt - 1 + step);
+                        hi = more ? top : dmin<uint64_t>(top, start + cnt - 1 + step);
                         while (lo < hi) {
                             const uint64_t mid = (lo + hi) >> 1;
                             if (!suffix_starts_with(q, m, text, n, sa[mid])) hi = mid; else lo = mid + 1;

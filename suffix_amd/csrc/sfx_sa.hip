@@ -1422,7 +1422,9 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
     int rounds = 0;
     while (m > 0) {
         if (++rounds > kMaxTextOnlyRounds + 80) return SFX_ERR_INTERNAL;
-        if (rank_mode && n - 1 + h > 0xFFFFFFFFull)              // key2 = rank + h would not fit 32 bits
+        // SFX_FORCE_COMPOSITE=1 is a test hook: take the fallback at once (it is otherwise only reachable beyond 2^31 bytes)
+        static const bool force_composite = [] { const char* e = getenv("SFX_FORCE_COMPOSITE"); return e && atoi(e) != 0; }();
+        if (rank_mode && (n - 1 + h > 0xFFFFFFFFull || force_composite))   // key2 = rank + h would not fit 32 bits
             return refine_composite(pt, cpk, b, sa, isa, 0, S_cur, V_cur, m, m, st, stats, h);
         uint32_t* V_next = (V_cur == b.VA) ? b.VB : b.VA;
         uint32_t* S_next = (S_cur == b.S0) ? b.S1 : b.S0;

@@ -184,10 +184,11 @@ def doc_lookup(positions, doc_starts, engine=None):
     return doc, off
 
 
-def widen_u64(sa32, engine=None):
+def widen_u64(sa32, out=None, engine=None):
     """u32 index tensor (int32 storage) -> int64 tensor holding the same indices (config 4)."""
     eng = engine or default_engine()
-    out = torch.empty(sa32.numel(), dtype=torch.int64, device=sa32.device)
+    if out is None:
+        out = torch.empty(sa32.numel(), dtype=torch.int64, device=sa32.device)
     with _on(sa32):
         eng.check(eng.lib.sfx_widen_u32_to_u64_dev(_p(sa32), sa32.numel(), _p(out), _stream_ptr(sa32)),
                   "sfx_widen_u32_to_u64_dev")

@@ -80,6 +80,8 @@ VARIANTS = {
     "small-tiles-key64-multi-tile": {"SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "3", "SFX_SEG_SMALL": "1"},
     "key64": {"SFX_FORCE_KEY64": "1"},
     "index-directory-only": {"SFX_INDEX_TREE": "0"},
+    # rank rounds through round 1's composite-key sort (the fallback for key2 = rank + h beyond 32 bits)
+    "composite-rank-rounds": {"SFX_FORCE_COMPOSITE": "1"},
     "tile-1024x4-pair32": {"SFX_TILE_GEOM": "1", "SFX_TILE_PAIR": "32"},
     "tile-512x8": {"SFX_TILE_GEOM": "2"},
     "tile-512x4-key64": {"SFX_TILE_GEOM": "3", "SFX_FORCE_KEY64": "1"},
