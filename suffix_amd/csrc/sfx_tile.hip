@@ -393,7 +393,7 @@ static bool tile_small()
 // at pair 32 -- small workgroups hide the gather latency better and leave fewer members to the radix passes
 static int tile_geom()
 {
-    static const int v = [] { const char* e = getenv("SFX_TILE_GEOM"); int x = e ? atoi(e) : 3; return x >= 0 && x <= 3 ? x : 3; }();
+    static const int v = [] { const char* e = getenv("SFX_TILE_GEOM"); int x = e ? atoi(e) : 3; return x >= 0 && x <= 5 ? x : 3; }();
     return v;
 }
 static int tile_pair()
@@ -430,6 +430,8 @@ static int tile_round_impl(const KeyFn& keyfn, const TileRound& r, uint64_t m, h
         if (g == 1) SFX_TRY(SFX_TILE(16, 4));
         else if (g == 2) SFX_TRY(SFX_TILE(8, 8));
         else if (g == 3) SFX_TRY(SFX_TILE(8, 4));
+        else if (g == 4) SFX_TRY(SFX_TILE(4, 4));
+        else if (g == 5) SFX_TRY(SFX_TILE(4, 2));
         else SFX_TRY(SFX_TILE(16, 8));
 #undef SFX_TILE
     }
