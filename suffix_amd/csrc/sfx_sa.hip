@@ -797,7 +797,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         for (int b = 0; b < SUB; b++) {
             const uint64_t ib = i0 + (uint64_t)b * kGroupItems;
             const unsigned v8 = (valid >> (8 * b)) & 0xFFu, h8 = (head >> (8 * b)) & 0xFFu, k8 = (keepm >> (8 * b)) & 0xFFu;
-            if (k8 || ((isa || !sa_in_place) && v8)) {           // (all-singleton groups have nothing to write in place)
+            if (k8 || ((isa || sa_in_place != 1) && v8)) {       // (all-singleton groups have nothing to write in place)
                 // gathers first (all in flight together), stores after: one memory round trip per group
                 uint32_t slot[kGroupItems], suffix[kGroupItems], head_slot[kGroupItems], back[kGroupItems];
 #pragma unroll
@@ -808,14 +808,16 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                     const uint32_t my_head = run_head - 1u;
                     back[j] = (uint32_t)i - my_head;             // distance to the bucket head (all kept in between)
                     slot[j] = (v && S) ? S[i] : (uint32_t)i;
-                    suffix[j] = (v && (!sa_in_place || keep || isa)) ? V[i] : 0u;
+                    suffix[j] = (v && (sa_in_place != 1 || keep || isa)) ? V[i] : 0u;
                     head_slot[j] = (v && S && (isa || (keep && R_next))) ? S[my_head] : my_head;
                 }
 #pragma unroll
                 for (int j = 0; j < kGroupItems; j++) {
                     if ((v8 >> j) & 1u) {
                         const bool keep = (k8 >> j) & 1u;
-                        if (!sa_in_place) sa[slot[j]] = suffix[j];
+                        // sa_in_place: 0 = every element goes to its slot; 1 = V is the SA; 2 = only the elements that
+                        // resolve now (the members of unresolved buckets would be rewritten every round)
+                        if (sa_in_place == 0 || (sa_in_place == 2 && !keep)) sa[slot[j]] = suffix[j];
                         if (isa) {
                             // large texts: (suffix, rank) pairs out in stream order, scattered afterwards
                             // through a partitioning pass (scatter_pairs_u32) instead of n random writes
@@ -983,6 +985,12 @@ k_iota(uint32_t* __restrict__ out, uint64_t n)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) out[r] = (uint32_t)r;
+}
+__global__ void __launch_bounds__(kBlock)
+k_scatter_by_slot(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ slot, uint64_t m, uint32_t* __restrict__ sa)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < m; q += stride) sa[slot[q]] = suf[q];
 }
 __global__ void __launch_bounds__(kBlock)
 k_head_slots(const uint32_t* __restrict__ slot, const uint32_t* __restrict__ gid, uint64_t m, uint32_t* __restrict__ H)
@@ -1159,9 +1167,10 @@ static int round_totals(const KeyT* K, uint64_t m, SaBuffers& b, hipStream_t st,
 template <class KeyT>
 static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint64_t m, SaBuffers& b,
                        uint32_t* sa, uint32_t* isa, uint32_t* S_next, uint32_t* V_next,
-                       uint32_t* R_next, hipStream_t st, bool sa_in_place, uint64_t n, sfx_build_stats& stats,
+                       uint32_t* R_next, hipStream_t st, int sa_mode, uint64_t n, sfx_build_stats& stats,
                        uint64_t kept)
 {
+    const bool sa_in_place = sa_mode == 1;
     // the sorted keys K sit in one of K0/K1 (for 32-bit keys: in its first half); the other
     // one is free for the (suffix, rank) pairs, and K's own buffer is free once this kernel is done
     uint64_t* pairs = nullptr;
@@ -1182,7 +1191,7 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
     else
         SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, 1>), ch.blocks, kBlock, st, K, V, S, m,
                    ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
-                   b.G, R_next, sa_in_place ? 1 : 0, pairs, (const uint16_t*)b.F);
+                   b.G, R_next, sa_mode, pairs, (const uint16_t*)b.F);
     if (pairs) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, m, n, isa, b.hist, st, &stats));
     return SFX_OK;
 }
@@ -1322,10 +1331,13 @@ static bool small_groups_pay(uint64_t m, uint64_t groups) { return m > 0 && grou
 static int build_ranks(SaBuffers& b, const uint32_t* sa, uint64_t n, const uint32_t* V_act, const uint32_t* S_act,
                        uint64_t m_act, uint32_t* isa, hipStream_t st, sfx_build_stats& stats)
 {
-    (void)V_act;
     const unsigned g1 = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
     const unsigned g2 = (unsigned)dmin<uint64_t>((m_act + kBlock - 1) / kBlock, kMaxGrid);
     uint32_t* H = isa_scratch_h(b);
+    // the rounds only write resolved suffixes to the array: the members of unresolved buckets go in now, in
+    // list order (any order inside a bucket will do: all members of a bucket get the same rank)
+    if (m_act) SFX_LAUNCH("rank_active_slots", (double)m_act * 12, k_scatter_by_slot, g2, kBlock, st, V_act, S_act, m_act,
+                          const_cast<uint32_t*>(sa));
     SFX_LAUNCH("rank_iota", (double)n * 4, k_iota, g1, kBlock, st, H, n);
     if (m_act) SFX_LAUNCH("rank_head_slots", (double)m_act * 16, k_head_slots, g2, kBlock, st, S_act, b.G, m_act, H);
     if (n >= partitioned_scatter_min()) {
@@ -1382,7 +1394,7 @@ static int refine_composite(const PackedText& pt, int cpk, SaBuffers& b, uint32_
         SFX_TRY(round_totals<uint64_t>(Kr, m, b, st, &kept, &kept_groups));
         const bool full_text_round = isa && text_round;
         SFX_TRY(round_apply<uint64_t>(Kr, Vr, S_cur, m, b, sa, (isa && !text_round) ? isa : nullptr,
-                                      S_next, V_next, full_text_round ? b.R : nullptr, st, false, n, stats, kept));
+                                      S_next, V_next, full_text_round ? b.R : nullptr, st, 0, n, stats, kept));
         h = text_round ? h + (uint64_t)spw : h * 2;
         if (full_text_round && --text_rounds == 0 && kept > 0)
             SFX_TRY(build_ranks(b, sa, n, V_next, S_next, kept, isa, st, stats));
@@ -1452,8 +1464,10 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         uint32_t host_totals[2] = {0, 0};
         SFX_TRY(read_back(host_totals, b.totals, sizeof(host_totals), st));
         const uint64_t kept = host_totals[0], kept_groups = host_totals[1];
+        // (SA slots are written when a suffix resolves; the members of still-unresolved buckets only if ranks
+        // have to be built from the array: build_ranks below)
         SFX_TRY(round_apply<uint64_t>(b.K0, V_cur, S_cur, m, b, sa, rank_mode ? isa : nullptr, S_next, V_next, nullptr,
-                                      st, false, n, stats, kept));
+                                      st, 2, n, stats, kept));
         h = rank_mode ? h * 2 : h + (uint64_t)wsym;
         stats.rounds++;
         if (rank_mode) stats.rank_rounds++; else stats.text_rounds++;
@@ -1525,7 +1539,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups, fuse));
     stats.active_after_initial = kept;
     // no rank array yet: its n-element scatter is only paid if the text rounds stall (refine)
-    SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place, pt.n, stats,
+    SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place ? 1 : 0, pt.n, stats,
                               kept));
     uint32_t* S_cur = b.S0;
     if (small_groups_pay(kept, groups))
