@@ -167,12 +167,14 @@ struct SegSort {
     uint64_t status_words;
     uint32_t* counters;
 };
-uint32_t seg_tile_elems();
-int segmented_layout(const SegSort& q, uint32_t nseg, hipStream_t st);
+uint32_t seg_tile_elems(bool kv);
+int segmented_layout(const SegSort& q, uint32_t nseg, bool kv, hipStream_t st);
 // one entry of the tile table (32 bytes): list positions [begin, begin + count) of one segment
 struct SegTileHost { uint32_t begin, count, seg_start, info, mseg, pad[3]; };
 int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg, uint64_t nlarge, uint32_t* V,
                        uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit);
+int segmented_sort_kv64(uint64_t* K0, uint32_t* V0, uint64_t* K1, uint32_t* V1, int npass, const SegSort& q, uint32_t nseg,
+                        uint64_t nlarge, uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit);
 // target[idx] = val for m (idx << 32 | val) pairs, idx < n: one partitioning pass on the top
 // bits of idx, then a scatter whose writes stay inside a cache-sized window of `target`.
 // `tmp` is m u64 of scratch, `radix_scratch` as for the sorts.  Pays for 4n >> Infinity Cache.
@@ -207,8 +209,9 @@ struct LcpEmit {
     uint32_t h;                 // symbols the members of a bucket share
     uint32_t n;
     int rank_mode;
-    int field_bits;             // width of the symbol field of a text key2
+    int field_bits;             // width of the symbol field of a 32-bit text key2
     uint32_t inv_bits;          // ceil(65536 / bits)
+    int field_bits64;           // ... of a 64-bit text key2 (flag in bit 63)
 };
 constexpr uint32_t kLcpBoundFlag = 0x80000000u;
 __device__ __forceinline__ uint32_t lcp_from_key2(const LcpEmit& L, uint32_t ka, uint32_t kb, uint32_t sa, uint32_t sb)
@@ -218,6 +221,15 @@ __device__ __forceinline__ uint32_t lcp_from_key2(const LcpEmit& L, uint32_t ka,
     if (!(ka & kb & 0x80000000u)) return cap;            // one of them ends before offset h: the shorter is a prefix
     const uint32_t x = ka ^ kb;                          // (!= 0: different classes)
     const uint32_t lz = (uint32_t)__clz((int)x) - (32u - (uint32_t)L.field_bits);
+    const uint32_t v = L.h + ((lz * L.inv_bits) >> 16);
+    return v < cap ? v : cap;
+}
+__device__ __forceinline__ uint32_t lcp_from_key2_64(const LcpEmit& L, uint64_t ka, uint64_t kb, uint32_t sa, uint32_t sb)
+{
+    const uint32_t la = L.n - sa, lb = L.n - sb, cap = la < lb ? la : lb;
+    if (!((ka & kb) >> 63)) return cap;
+    const uint64_t x = ka ^ kb;
+    const uint32_t lz = (uint32_t)__clzll((long long)x) - (64u - (uint32_t)L.field_bits64);
     const uint32_t v = L.h + ((lz * L.inv_bits) >> 16);
     return v < cap ? v : cap;
 }
@@ -231,12 +243,18 @@ struct TileRound {
     uint32_t* block_counts;       // kMaxGrid
     uint32_t* totals;
     unsigned long long* counters; // 2
-    uint64_t* EA; uint64_t* EB;   // large buckets: m u64 each (key2 << 32 | suffix at the list positions, ping-pong)
+    uint64_t* EA; uint64_t* EB;   // large buckets: m u64 each (key2 << 32 | suffix at the list positions, ping-pong;
+                                  // 64-bit text keys: the key arrays, values ping-pong between V and V_other)
+    uint32_t* V_other;
     SegSort seg;                  // scratch of the segmented sort
 };
 int tile_round_text(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
                     sfx_build_stats* stats);
 LcpEmit make_lcp_emit(uint32_t* lcp, const uint32_t* S, const PackedText& pt, uint64_t h, bool rank_mode);
+// text round on 64-bit keys: text_key64_symbols(pt) symbols per round
+int text_key64_symbols(const PackedText& pt);
+int tile_round_text64(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
+                      sfx_build_stats* stats);
 // (needs n - 1 + h < 2^32: key2 = rank + h)
 int tile_round_rank(const uint32_t* isa, uint64_t n, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
                     sfx_build_stats* stats);

@@ -364,15 +364,15 @@ struct SegTile {
 struct SegArgs {
     const SegTile* tiles;
     const uint32_t* ntiles;     // device-side count (made by k_seg_layout: no host round trip)
-    const uint32_t* segexcl;    // [mseg][4][256]: elements of the segment with a smaller digit, per pass
-    int pass;
+    const uint32_t* segexcl;    // [mseg][npass][256]: elements of the segment with a smaller digit, per pass
+    int pass, npass;
 };
 
 template <class Src, class Dst, int KPT, bool ONESWEEP, bool RANK_ATOMIC, int NW, bool SEG = false>
 __global__ void __launch_bounds__(NW * kWave, SFX_RADIX_MIN_WAVES)
 k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t chunk,
              const uint32_t* __restrict__ hist, const uint32_t* __restrict__ digit_total,
-             uint32_t* __restrict__ status, uint32_t* __restrict__ ticket, SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0})
+             uint32_t* __restrict__ status, uint32_t* __restrict__ ticket, SegArgs seg = SegArgs{nullptr, nullptr, nullptr, 0, 0})
 {
     constexpr bool HAS_VAL = Src::kHasVal;
     constexpr int kThreads = NW * kWave;
@@ -436,7 +436,7 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
                 seq_first = d.info & 1u;
                 seg_single = d.info & 2u;
                 seg_start = d.seg_start;
-                if (owner && !seg_single) my_head = d.seg_start + seg.segexcl[((uint64_t)d.mseg * 4 + seg.pass) * kRadix + tid];
+                if (owner && !seg_single) my_head = d.seg_start + seg.segexcl[((uint64_t)d.mseg * seg.npass + seg.pass) * kRadix + tid];
                 tile_no = d.info >> 2;                              // status words are indexed by the dense multi-tile index
             }
         } else {
@@ -829,36 +829,35 @@ k_seg_layout(const uint2* __restrict__ segs, uint32_t nseg, uint32_t tile_elems,
                                 {nt, size, 0u}};
     }
 }
-// digit counts of the four passes for every tile of a multi-tile segment: tilehist[mt][4][256]
+// digit counts of every pass for every tile of a multi-tile segment: tilehist[mt][npass][256]
+// (digit p of an element = bits [shift0 + 8p, shift0 + 8p + 8) of its 64-bit key word)
+constexpr int kSegMaxPasses = 8;
 __global__ void __launch_bounds__(kBlock)
 k_seg_hist(const uint64_t* __restrict__ E, const SegTile* __restrict__ tiles, const uint32_t* __restrict__ ntiles,
-           uint32_t* __restrict__ tilehist)
+           uint32_t* __restrict__ tilehist, int npass, int shift0)
 {
-    __shared__ uint32_t h[4][kRadix];
+    __shared__ uint32_t h[kSegMaxPasses][kRadix];
     const unsigned tid = threadIdx.x;
     const uint32_t nt = *ntiles;
     for (uint32_t t = blockIdx.x; t < nt; t += gridDim.x) {
         const SegTile d = tiles[t];
         if (d.info & 2u) continue;
-        for (int p = 0; p < 4; p++) h[p][tid] = 0;
+        for (int p = 0; p < npass; p++) h[p][tid] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < d.count; i += kBlock) {
-            const uint32_t key = (uint32_t)(E[(uint64_t)d.begin + i] >> 32);
-            atomicAdd(&h[0][key & 255u], 1u);
-            atomicAdd(&h[1][(key >> 8) & 255u], 1u);
-            atomicAdd(&h[2][(key >> 16) & 255u], 1u);
-            atomicAdd(&h[3][key >> 24], 1u);
+            const uint64_t key = E[(uint64_t)d.begin + i] >> shift0;
+            for (int p = 0; p < npass; p++) atomicAdd(&h[p][(unsigned)(key >> (8 * p)) & 255u], 1u);
         }
         __syncthreads();
-        uint32_t* out = tilehist + (uint64_t)(d.info >> 2) * 4 * kRadix;
-        for (int p = 0; p < 4; p++) out[p * kRadix + tid] = h[p][tid];
+        uint32_t* out = tilehist + (uint64_t)(d.info >> 2) * npass * kRadix;
+        for (int p = 0; p < npass; p++) out[p * kRadix + tid] = h[p][tid];
         __syncthreads();
     }
 }
 // per multi-tile segment and pass: elements of the segment with a smaller digit
 __global__ void __launch_bounds__(kBlock)
 k_seg_scan(const SegTile* __restrict__ tiles, const uint32_t* __restrict__ ntiles, const uint32_t* __restrict__ tilehist,
-           uint32_t* __restrict__ segexcl)
+           uint32_t* __restrict__ segexcl, int npass)
 {
     __shared__ uint32_t part[kWavesPerBlock];
     const unsigned tid = threadIdx.x;
@@ -867,12 +866,12 @@ k_seg_scan(const SegTile* __restrict__ tiles, const uint32_t* __restrict__ ntile
         const SegTile d = tiles[t];
         if ((d.info & 3u) != 1u) continue;                         // first tile of a multi-tile segment
         const uint32_t mt0 = d.info >> 2, cnt = d.pad[0];
-        for (int p = 0; p < 4; p++) {
+        for (int p = 0; p < npass; p++) {
             uint32_t tot = 0;
-            for (uint32_t j = 0; j < cnt; j++) tot += tilehist[((uint64_t)(mt0 + j) * 4 + p) * kRadix + tid];
+            for (uint32_t j = 0; j < cnt; j++) tot += tilehist[((uint64_t)(mt0 + j) * npass + p) * kRadix + tid];
             uint32_t total;
             const uint32_t ex = block_scan_add_excl(tot, part, total);
-            segexcl[((uint64_t)d.mseg * 4 + p) * kRadix + tid] = ex;
+            segexcl[((uint64_t)d.mseg * npass + p) * kRadix + tid] = ex;
         }
     }
 }
@@ -901,7 +900,32 @@ k_seg_finish(const uint64_t* __restrict__ E, const SegTile* __restrict__ tiles, 
     }
 }
 
-uint32_t seg_tile_elems() { return seg_small() ? kSegSmallNW * kWave * kSegSmallKPT : kSegNW * kWave * kSegKPT; }
+// 64-bit text keys (K = key2, V = suffix, sorted in place as key / value arrays): flags and fused LCP
+__global__ void __launch_bounds__(kBlock)
+k_seg_finish64(const uint64_t* __restrict__ K, const uint32_t* __restrict__ V, const SegTile* __restrict__ tiles,
+               const uint32_t* __restrict__ ntiles, uint8_t* __restrict__ F8, LcpEmit emit)
+{
+    const uint32_t nt = *ntiles;
+    for (uint32_t t = blockIdx.x; t < nt; t += gridDim.x) {
+        const SegTile d = tiles[t];
+        const uint64_t seg_end = (uint64_t)d.seg_start + d.pad[1];
+        for (uint32_t i = threadIdx.x; i < d.count; i += kBlock) {
+            const uint64_t p = (uint64_t)d.begin + i;
+            const uint64_t key = K[p];
+            const bool head = p == d.seg_start || K[p - 1] != key;
+            const bool last = p + 1 == seg_end || K[p + 1] != key;
+            F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
+            if (emit.lcp && head && p != d.seg_start) emit.lcp[emit.S[p]] = lcp_from_key2_64(emit, K[p - 1], key, V[p - 1], V[p]);
+        }
+    }
+}
+
+// tile of the segmented sort: E64 elements (rank rounds) or 64-bit keys + values (text rounds)
+uint32_t seg_tile_elems(bool kv)
+{
+    if (seg_small()) return kv ? 8 * kWave * 9 : kSegSmallNW * kWave * kSegSmallKPT;       // (4608 / 4096 elements)
+    return kv ? 16 * kWave * 9 : kSegNW * kWave * kSegKPT;
+}
 
 template <int KPT, int NW>
 static int seg_passes(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t* status, uint64_t status_words, hipStream_t st,
@@ -909,7 +933,7 @@ static int seg_passes(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t* stat
 {
     for (int p = 0; p < 4; p++) {
         SFX_HIP(hipMemsetAsync(status, 0, status_words * sizeof(uint32_t), st));
-        SegArgs sa = {reinterpret_cast<const SegTile*>(q.tiles), q.counters, q.segexcl, p};
+        SegArgs sa = {reinterpret_cast<const SegTile*>(q.tiles), q.counters, q.segexcl, p, 4};
         const uint64_t* src = (p & 1) ? B : A;
         uint64_t* dst = (p & 1) ? A : B;
         SFX_LAUNCH("seg_radix_pass", algo, (k_radix_pass<SrcE64, DstE64, KPT, true, true, NW, true>), kMaxGrid / 4, NW * kWave, st,
@@ -918,14 +942,28 @@ static int seg_passes(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t* stat
     }
     return SFX_OK;
 }
+template <int KPT, int NW>
+static int seg_passes_kv(uint64_t* K0, uint32_t* V0, uint64_t* K1, uint32_t* V1, const SegSort& q, uint32_t* status,
+                         uint64_t status_words, hipStream_t st, double algo, int npass)
+{
+    for (int p = 0; p < npass; p++) {
+        SFX_HIP(hipMemsetAsync(status, 0, status_words * sizeof(uint32_t), st));
+        SegArgs sa = {reinterpret_cast<const SegTile*>(q.tiles), q.counters, q.segexcl, p, npass};
+        const bool odd = p & 1;
+        SFX_LAUNCH("seg_radix_pass_kv", algo, (k_radix_pass<SrcKV, DstKV, KPT, true, true, NW, true>), kMaxGrid / 4, NW * kWave, st,
+                   SrcKV{odd ? K1 : K0, odd ? V1 : V0}, DstKV{odd ? K0 : K1, odd ? V0 : V1}, (uint64_t)0, 8 * p, 255u, (uint64_t)0,
+                   (const uint32_t*)nullptr, (const uint32_t*)nullptr, status, q.counters + 4 + p, sa);
+    }
+    return SFX_OK;
+}
 
 // tile table of the segments q.segs[0, nseg) (device side; the tile count stays on the device)
-int segmented_layout(const SegSort& q, uint32_t nseg, hipStream_t st)
+int segmented_layout(const SegSort& q, uint32_t nseg, bool kv, hipStream_t st)
 {
     if (nseg == 0) return SFX_OK;
     SFX_HIP(hipMemsetAsync(q.counters, 0, 16 * sizeof(uint32_t), st));
     SFX_LAUNCH("seg_layout", (double)nseg * 24, k_seg_layout, (nseg + kBlock - 1) / kBlock, kBlock, st,
-               reinterpret_cast<const uint2*>(q.segs), nseg, seg_tile_elems(), reinterpret_cast<SegTile*>(q.tiles), q.counters);
+               reinterpret_cast<const uint2*>(q.segs), nseg, seg_tile_elems(kv), reinterpret_cast<SegTile*>(q.tiles), q.counters);
     return SFX_OK;
 }
 
@@ -936,12 +974,12 @@ int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg
                        uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit)
 {
     if (nseg == 0) return SFX_OK;
-    const uint32_t te = seg_tile_elems();
+    const uint32_t te = seg_tile_elems(false);
     const unsigned grid = (unsigned)dmin<uint64_t>(nlarge / te + nseg, kMaxGrid);
     SFX_LAUNCH("seg_hist", (double)nlarge * 8, k_seg_hist, grid, kBlock, st, A, reinterpret_cast<const SegTile*>(q.tiles),
-               q.counters, q.tilehist);
+               q.counters, q.tilehist, 4, 32);
     SFX_LAUNCH("seg_scan", 0.0, k_seg_scan, grid, kBlock, st, reinterpret_cast<const SegTile*>(q.tiles), q.counters,
-               q.tilehist, q.segexcl);
+               q.tilehist, q.segexcl, 4);
     const uint64_t status_words = (2 * (nlarge / te) + 2) * kRadix;
     if (status_words > q.status_words) return SFX_ERR_WORKSPACE;
     if (seg_small()) SFX_TRY((seg_passes<kSegSmallKPT, kSegSmallNW>(A, B, q, q.status, status_words, st, (double)nlarge * 16)));
@@ -949,6 +987,29 @@ int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg
     SFX_LAUNCH("seg_finish", (double)nlarge * 13, k_seg_finish, grid, kBlock, st, A, reinterpret_cast<const SegTile*>(q.tiles),
                q.counters, V, F8, emit);
     if (stats) { stats->radix_passes += 4; stats->elements_sorted += 4 * nlarge; }
+    return SFX_OK;
+}
+
+// The same for 64-bit keys: K0[p] = key2, V0[p] = suffix at the positions of the segments, (K1, V1) the
+// ping-pong buffers; key bits [0, 8 * npass) are sorted (npass even: the result is back in K0 / V0).
+int segmented_sort_kv64(uint64_t* K0, uint32_t* V0, uint64_t* K1, uint32_t* V1, int npass, const SegSort& q, uint32_t nseg,
+                        uint64_t nlarge, uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit)
+{
+    if (nseg == 0) return SFX_OK;
+    if (npass < 2 || npass > kSegMaxPasses || (npass & 1)) return SFX_ERR_INTERNAL;
+    const uint32_t te = seg_tile_elems(true);
+    const unsigned grid = (unsigned)dmin<uint64_t>(nlarge / te + nseg, kMaxGrid);
+    SFX_LAUNCH("seg_hist", (double)nlarge * 8, k_seg_hist, grid, kBlock, st, K0, reinterpret_cast<const SegTile*>(q.tiles),
+               q.counters, q.tilehist, npass, 0);
+    SFX_LAUNCH("seg_scan", 0.0, k_seg_scan, grid, kBlock, st, reinterpret_cast<const SegTile*>(q.tiles), q.counters,
+               q.tilehist, q.segexcl, npass);
+    const uint64_t status_words = (2 * (nlarge / te) + 2) * kRadix;
+    if (status_words > q.status_words) return SFX_ERR_WORKSPACE;
+    if (seg_small()) SFX_TRY((seg_passes_kv<9, 8>(K0, V0, K1, V1, q, q.status, status_words, st, (double)nlarge * 24, npass)));
+    else SFX_TRY((seg_passes_kv<9, 16>(K0, V0, K1, V1, q, q.status, status_words, st, (double)nlarge * 24, npass)));
+    SFX_LAUNCH("seg_finish", (double)nlarge * 9, k_seg_finish64, grid, kBlock, st, (const uint64_t*)K0, (const uint32_t*)V0,
+               reinterpret_cast<const SegTile*>(q.tiles), q.counters, F8, emit);
+    if (stats) { stats->radix_passes += npass; stats->elements_sorted += (uint64_t)npass * nlarge; }
     return SFX_OK;
 }
 

@@ -1428,7 +1428,10 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
 {
     const uint64_t n = pt.n;
     uint64_t h = (uint64_t)cpk;
-    const int wsym = pt.kbits == 32 ? pt.spw - 1 : pt.spw;     // symbols of a text round (31-bit key2 + flag)
+    // symbols of a text round: 64-bit key2 (flag + up to 63 bits of symbols: half the rounds, half the key
+    // gathers); SFX_TEXT_KEY=32 (development) keeps round 2's first 32-bit keys
+    static const bool key64 = [] { const char* e = getenv("SFX_TEXT_KEY"); return !e || atoi(e) != 32; }();
+    const int wsym = key64 ? text_key64_symbols(pt) : (pt.kbits == 32 ? pt.spw - 1 : pt.spw);
     bool rank_mode = false;
     uint64_t stalled = 0;
     int rounds = 0;
@@ -1448,7 +1451,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         // scratch of the segmented sort: element ping-pong in K0 / K1; tile table and segment list in the
         // slot list of the next round (free until round_apply), per-tile digit counts in G1, per-segment
         // digit offsets in R, status words in the radix scratch
-        tr.EA = b.K0; tr.EB = b.K1;
+        tr.EA = b.K0; tr.EB = b.K1; tr.V_other = V_next;
         tr.seg.tiles = S_next;
         tr.seg.segs = S_next + (m / 4) * 3;                    // (8 B per segment, <= m / 1025 of them; tiles: 32 B each)
         tr.seg.tilehist = b.G1;
@@ -1457,6 +1460,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         tr.seg.status_words = radix_scratch_words(m) - 64;
         tr.seg.counters = b.hist;
         if (rank_mode) SFX_TRY(tile_round_rank(isa, n, h, tr, m, st, &stats));
+        else if (key64) SFX_TRY(tile_round_text64(pt, h, tr, m, st, &stats));
         else SFX_TRY(tile_round_text(pt, h, tr, m, st, &stats));
         Chunking ch = make_chunking(m, kApplyTile);
         SFX_LAUNCH("groups_scan", 0.0, k_groups_scan, 1, kBlock, st, b.part_head, b.part_keep, b.part_ghead, ch.blocks,
