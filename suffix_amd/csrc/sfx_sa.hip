@@ -1428,9 +1428,12 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
 {
     const uint64_t n = pt.n;
     uint64_t h = (uint64_t)cpk;
-    // symbols of a text round: 64-bit key2 (flag + up to 63 bits of symbols: half the rounds, half the key
-    // gathers); SFX_TEXT_KEY=32 (development) keeps round 2's first 32-bit keys
-    static const bool key64 = [] { const char* e = getenv("SFX_TEXT_KEY"); return !e || atoi(e) != 32; }();
+    // symbols of a text round: 32-bit key2 (flag + up to 31 bits of symbols).  SFX_TEXT_KEY=64 selects 64-bit
+    // keys (twice the symbols per round, half the rounds): measured on 1 GB inputs (profiles/
+    // r2_text_key64_vs_32.jsonl) 178 vs 186 ms English-like, 149 vs 144 ms on round 1's English-like input, 316 vs
+    // 282 ms UTF-8 -- a round is bound by sorting work (bits x members: 8 LDS passes / 8 segmented 24-byte
+    // passes instead of 4 + 4 over two rounds), not by its key gather, so the wider key does not pay
+    static const bool key64 = [] { const char* e = getenv("SFX_TEXT_KEY"); return e && atoi(e) == 64; }();
     const int wsym = key64 ? text_key64_symbols(pt) : (pt.kbits == 32 ? pt.spw - 1 : pt.spw);
     bool rank_mode = false;
     uint64_t stalled = 0;

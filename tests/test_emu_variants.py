@@ -79,8 +79,9 @@ VARIANTS = {
     "small-tiles-small-segments": {"SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
     "small-tiles-key64-multi-tile": {"SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "3", "SFX_SEG_SMALL": "1"},
     "key64": {"SFX_FORCE_KEY64": "1"},
-    # round 2's first text rounds: 32-bit key2 (the 64-bit form is the default)
-    "text-key32-small-tiles": {"SFX_TEXT_KEY": "32", "SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
+    # text rounds on 64-bit keys (opt-in): the 64-bit LDS sort and the key/value form of the segmented sort
+    "text-key64": {"SFX_TEXT_KEY": "64"},
+    "text-key64-small-tiles": {"SFX_TEXT_KEY": "64", "SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
     "index-directory-only": {"SFX_INDEX_TREE": "0"},
     # rank rounds through round 1's composite-key sort (the fallback for key2 = rank + h beyond 32 bits)
     "composite-rank-rounds": {"SFX_FORCE_COMPOSITE": "1"},
