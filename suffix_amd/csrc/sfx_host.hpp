@@ -292,7 +292,9 @@ int key_tree_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, 
                        int* levels_out, hipStream_t st);
 int query_batch_tree_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint64_t* d_tree,
                          const uint64_t* level_offsets, int levels, const uint8_t* d_q, const uint64_t* d_qoff, uint64_t nq,
-                         uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st);
+                         uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st,
+                         void* order_scratch);
+uint64_t query_order_scratch_bytes(uint64_t nq);
 int byte_presence_host(const uint8_t* d_text, uint64_t n, void* d_small4k, unsigned long long* host_bins256,
                        hipStream_t st);
 int build_lcp_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa_part, uint64_t count,

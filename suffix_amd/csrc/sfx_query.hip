@@ -398,10 +398,13 @@ __global__ void __launch_bounds__(kBlock)
 k_query_batch_tree(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, KeyTree tree,
                    const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, uint64_t nq,
                    uint32_t* __restrict__ start_out, uint32_t* __restrict__ end_out,
-                   uint8_t* __restrict__ found_out, uint32_t* __restrict__ any_out)
+                   uint8_t* __restrict__ found_out, uint32_t* __restrict__ any_out, const uint32_t* __restrict__ order)
 {
+    // `order` (optional): the queries sorted by their first 8 bytes -- neighbouring lanes then walk the same
+    // tree nodes and, inside a range of suffixes sharing those bytes, probe the same SA entries and text lines
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t qi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; qi < nq; qi += stride) {
+    for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < nq; slot += stride) {
+        const uint64_t qi = order ? (uint64_t)order[slot] : slot;
         const uint8_t* q = qbytes + qoff[qi];
         const uint64_t m = qoff[qi + 1] - qoff[qi];
         uint64_t start = 0, end = 0;
@@ -462,6 +465,22 @@ k_query_batch_tree(const uint8_t* __restrict__ text, uint64_t n, const uint32_t*
     }
 }
 
+// (first 8 bytes of query k, big-endian, zero-padded) for the ordering above
+__global__ void __launch_bounds__(kBlock)
+k_query_keys(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, uint64_t nq, uint64_t* __restrict__ keys,
+             uint32_t* __restrict__ idx)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < nq; k += stride) {
+        const uint8_t* q = qbytes + qoff[k];
+        const uint64_t m = qoff[k + 1] - qoff[k];
+        uint64_t key = 0;
+        for (unsigned j = 0; j < 8; j++) key = (key << 8) | (j < m ? (uint64_t)q[j] : 0ull);
+        keys[k] = key;
+        idx[k] = (uint32_t)k;
+    }
+}
+
 // words (u64) of one allocation that holds all levels, each padded to whole nodes plus one spare node
 uint64_t key_tree_words(uint64_t n)
 {
@@ -496,9 +515,14 @@ int key_tree_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, 
     *levels_out = l + 1;
     return SFX_OK;
 }
+// scratch of the query ordering: 2 * nq u64 + 2 * nq u32 + radix_scratch_words(nq) u32
+uint64_t query_order_scratch_bytes(uint64_t nq)
+{
+    return 2 * nq * sizeof(uint64_t) + 2 * nq * sizeof(uint32_t) + radix_scratch_words(nq) * sizeof(uint32_t) + 1024;
+}
 int query_batch_tree_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint64_t* d_tree,
                          const uint64_t* level_offsets, int levels, const uint8_t* d_q, const uint64_t* d_qoff, uint64_t nq,
-                         uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st)
+                         uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st, void* order_scratch)
 {
     if (nq == 0) return SFX_OK;
     if (!d_qoff || !d_tree || levels < 1 || levels > kTreeMaxLevels) return SFX_ERR_ARG;
@@ -512,9 +536,24 @@ int query_batch_tree_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa
     t.levels = levels;
     t.n = n;
     const unsigned grid = (unsigned)dmin<uint64_t>((nq + kBlock - 1) / kBlock, kMaxGrid);
+    const uint32_t* order = nullptr;
+    if (order_scratch && nq >= 4096 && nq <= 0xFFFFFFFFull) {
+        // sort (first 8 bytes, query number): 8 passes over 12-byte elements of a small array
+        char* w = reinterpret_cast<char*>(order_scratch);
+        uint64_t* k0 = reinterpret_cast<uint64_t*>(w);
+        uint64_t* k1 = k0 + nq;
+        uint32_t* v0 = reinterpret_cast<uint32_t*>(k1 + nq);
+        uint32_t* v1 = v0 + nq;
+        uint32_t* scr = v1 + nq;
+        scr = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(scr) + 255) & ~uintptr_t(255));
+        SFX_LAUNCH("query_keys", (double)nq * 28, k_query_keys, grid, kBlock, st, d_q, d_qoff, nq, k0, v0);
+        int in1 = 0;
+        SFX_TRY(radix_sort_kv64(k0, v0, k1, v1, nq, 0, 64, scr, st, &in1, nullptr, nullptr));
+        order = in1 ? v1 : v0;
+    }
     // two descents of one 128-byte node per level, a few probes of 2 lines beyond 8 bytes
     SFX_LAUNCH("query_batch_tree", (double)nq * (2.0 * levels * 128 + 4 * 256), k_query_batch_tree, grid, kBlock, st, d_text, n,
-               d_sa, t, d_q, d_qoff, nq, d_start, d_end, d_found, d_any);
+               d_sa, t, d_q, d_qoff, nq, d_start, d_end, d_found, d_any, order);
     return SFX_OK;
 }
 
