@@ -117,7 +117,12 @@ def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
     in which the complete arrays were compared element by element with the oracle
     (profiles/r2_fullsize_full_oracle.jsonl) -- so no 3-minute CPU oracle inside the bench."""
     import hashlib
-    spec = {"c3": ("config 3: %d B English-like ASCII (SURVEY 8d), SA + LCP", _gen.english_like),
+    import _gen_r1
+    spec = {"c3r1": ("config 3 on ROUND 1's input (PCG64 word stream, mean LCP 13.4: the input round 1's 217 ms / 4.61 GB/s was "
+                     "measured on): %d B, SA + LCP", _gen_r1.english_like),
+            "c5r1": ("config 5 on ROUND 1's input (uniformly drawn code points, mean LCP 6.9: round 1's 131 ms): %d B, SA + LCP",
+                     _gen_r1.utf8_mixed),
+            "c3": ("config 3: %d B English-like ASCII (SURVEY 8d), SA + LCP", _gen.english_like),
             "c5": ("config 5: %d B UTF-8 mixed-script (SURVEY 8d), SA + LCP + 10^6 positions()", _gen.utf8_mixed),
             "dup": ("high-LCP: %d B near-duplicate documents (16 x 1 MiB, one substitution per ~400 B), SA + LCP",
                     _gen.near_duplicates)}[key]
@@ -238,10 +243,13 @@ def main():
                     help="also launch the known-byte-count copy / run-scatter micro-benchmarks once, so a "
                          "rocprofv3 --pmc pass of this command can calibrate FETCH_SIZE / WRITE_SIZE")
     ap.add_argument("--no-microbench", action="store_true", help="skip the scatter/gather roofline probes")
-    ap.add_argument("--configs", default="c3,c5,dup",
+    ap.add_argument("--configs", default="c3,c5,dup,c3r1,c5r1",
                     help="full-size BASELINE configs reported next to the headline at N = 1 (c3 = 1 GB English-like "
-                         "SA + LCP, c5 = 1 GB UTF-8 + 10^6 positions(), dup = 1 GB near-duplicate documents); "
+                         "SA + LCP, c5 = 1 GB UTF-8 + 10^6 positions(), dup = 1 GB near-duplicate documents, c3r1 / c5r1 = "
+                         "configs 3 / 5 on round 1's easier inputs, for a like-for-like comparison with round 1 -- their "
+                         "numpy generators take ~1 min each, so they are skipped once the run is past --config-budget seconds); "
                          "'' = none")
+    ap.add_argument("--config-budget", type=float, default=150.0)
     ap.add_argument("--config-size", type=int, default=1_000_000_000)
     args = ap.parse_args()
 
@@ -545,7 +553,11 @@ def main():
         except (OSError, ValueError):
             pass
         configs = []
+        t_cfg0 = time.perf_counter()
         for key in [k for k in args.configs.split(",") if k]:
+            if key.endswith("r1") and time.perf_counter() - t_cfg0 > args.config_budget:
+                configs.append({"config": key, "skipped": "time budget of the default run (--config-budget)"})
+                continue
             try:
                 configs.append(fullsize_config(torch, eng, sdev, _gen, key, args.config_size, pins, dev))
             except Exception as exc:                    # a failing extra must not cost the headline its line
