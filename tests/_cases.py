@@ -207,6 +207,36 @@ def small_buckets(eng, orc, scale=1):
     assert eng.build_stats()["rounds"] > 0
 
 
+def random_medium_sweep(eng, orc, iters=40, max_len=200_000, seed=77):
+    """Random texts of random length, alphabet and repeat structure (planted copies, periodic stretches, runs of
+    the smallest symbol at the end), each through new(), lcp_lens(), the fused entry and a few queries -- the
+    sizes at which refinement rounds, LDS bucket sorts and the segmented sort all take part."""
+    rng = np.random.default_rng(seed)
+    for it in range(iters):
+        n = int(rng.integers(1, max_len))
+        sigma = int(rng.choice([2, 3, 4, 5, 16, 20, 64, 66, 130, 256]))
+        body = rng.integers(0, sigma, n, dtype=np.uint8)
+        if sigma < 200:
+            body = body + np.uint8(rng.integers(0, 256 - sigma))
+        t = bytearray(body.tobytes())
+        kind = it % 5
+        if kind == 1 and n > 50:                               # planted copies of random stretches
+            for _ in range(int(rng.integers(1, 6))):
+                a = int(rng.integers(0, n - 20)); ln = int(rng.integers(10, min(5000, n - a)))
+                t += t[a:a + ln]
+        elif kind == 2 and n > 10:                             # a long periodic stretch
+            per = bytes(t[:int(rng.integers(1, 8))])
+            t += per * int(rng.integers(10, 3000))
+        elif kind == 3:                                        # ends in a run of the smallest symbol
+            t += bytes([min(t)]) * int(rng.integers(1, 200))
+        elif kind == 4 and n > 100:                            # few distinct "words"
+            words = [bytes(t[i:i + int(rng.integers(2, 9))]) for i in rng.integers(0, n - 10, 12)]
+            t = bytearray(b" ".join(words[int(k)] for k in rng.integers(0, 12, n // 4)))
+        t = bytes(t)
+        qs = [t[int(a):int(a) + int(rng.integers(1, 12))] for a in rng.integers(0, len(t), 4)] + [b"\x00", t[-3:]]
+        check_text(eng, orc, t, queries=qs)
+
+
 def fused_lcp_tails(eng, orc, iters=40, scale=1):
     """sfx_build_sa_lcp_u32 on texts whose initial key sort separates most suffixes (the LCP of those
     pairs is read off the sorted keys) and whose END is made of the smallest symbol: suffixes shorter

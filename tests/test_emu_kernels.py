@@ -77,6 +77,10 @@ def test_suffix_tree_topology_and_doc_lookup(emu, oracle):
     _cases.suffix_tree_topology(emu, oracle)
 
 
+def test_random_medium_sweep(emu, oracle):
+    _cases.random_medium_sweep(emu, oracle, iters=15, max_len=6000, seed=5)
+
+
 def test_fused_sa_lcp(emu, oracle):
     _cases.fused_lcp_tails(emu, oracle, iters=30)
 

@@ -54,6 +54,10 @@ def test_generated_medium(eng, oracle):
     _cases.generated(eng, oracle, n_dna=3_000_000, n_text=1_500_000)
 
 
+def test_random_medium_sweep(eng, oracle):
+    _cases.random_medium_sweep(eng, oracle, iters=60, max_len=300_000)
+
+
 def test_index_directory_queries(eng, oracle):
     _cases.directory_queries(eng, oracle, device="cuda", scale=20)
 
