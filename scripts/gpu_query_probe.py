@@ -31,10 +31,16 @@ sets["text_bytes_len12"] = substrings(12)
 sets["text_bytes_len32"] = substrings(32)
 rb = rng.integers(0, 256, nq * 12, dtype=np.uint8)
 sets["random_bytes_len12"] = (rb, np.arange(0, (nq + 1) * 12, 12, dtype=np.int64))
+only = os.environ.get("PROBE_SETS")
+if only:
+    sets = {k: v for k, v in sets.items() if k in only.split(",")}
 for name, (b, o) in sets.items():
     d_b, d_o = torch.from_numpy(np.ascontiguousarray(b)).to(dev), torch.from_numpy(o).to(dev)
     rec = {"set": name}
-    for label, fn in (("undirected", lambda: sdev.query_batch(text, sa, d_b, d_o)), ("index", lambda: ix.query(d_b, d_o))):
+    legs = (("undirected", lambda: sdev.query_batch(text, sa, d_b, d_o)), ("index", lambda: ix.query(d_b, d_o)))
+    if os.environ.get("PROBE_INDEX_ONLY"):
+        legs = legs[1:]
+    for label, fn in legs:
         fn(); torch.cuda.synchronize()
         eng.profile(True); eng.profile_reset()
         t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); wall = time.perf_counter() - t0

@@ -454,13 +454,14 @@ int sfx_index_query_dev(const sfx_index* ix, const uint8_t* d_qbytes, const uint
         // neighbouring lanes share tree nodes and probes.  Measured on config 5's 10^6 queries: the search kernel
         // 1.39 -> 1.23 ms, the 8-pass sort of the (key, query) pairs 0.24 ms -- not worth it, off by default
         static const bool want_order = [] { const char* e = getenv("SFX_QUERY_ORDER"); return e && atoi(e) != 0; }();
-        // per-thread scratch, kept across calls (no allocation, no synchronisation on the hot path); work queued on
-        // another stream may still be using it when the thread switches streams: drain that one first
-        struct OrderScratch { void* p = nullptr; uint64_t bytes = 0; hipStream_t last = nullptr; bool used = false; };
-        thread_local OrderScratch sc;
+        // per-thread scratch (the list of queries that go on to phase 2; the ordering), kept across calls (no
+        // allocation, no synchronisation on the hot path); work queued on another stream may still be using it
+        // when the thread switches streams: drain that one first.  Without it the batch is answered in one phase.
+        struct QueryScratch { void* p = nullptr; uint64_t bytes = 0; hipStream_t last = nullptr; bool used = false; };
+        thread_local QueryScratch sc;
         void* os = nullptr;
-        if (want_order && nq >= 4096) {
-            const uint64_t need = query_order_scratch_bytes(nq);
+        if (nq >= query_two_phase_min()) {
+            const uint64_t need = query_scratch_bytes(nq, want_order);
             if (sc.used && sc.last != (hipStream_t)stream) (void)hipStreamSynchronize(sc.last);
             if (sc.bytes < need) {
                 if (sc.p) { (void)hipStreamSynchronize(sc.last); (void)hipFree(sc.p); sc.p = nullptr; sc.bytes = 0; }
@@ -469,7 +470,8 @@ int sfx_index_query_dev(const sfx_index* ix, const uint8_t* d_qbytes, const uint
             if (sc.p) { os = sc.p; sc.last = (hipStream_t)stream; sc.used = true; }
         }
         return query_batch_tree_dev(ix->d_text, ix->n, ix->d_sa, ix->d_tree, ix->tree_off, ix->tree_levels, d_qbytes, d_qoff, nq,
-                                    d_start, d_end, d_found, d_any, (hipStream_t)stream, os);
+                                    d_start, d_end, d_found, d_any, (hipStream_t)stream, os, want_order, ix->d_dir, ix->d_lut, ix->bits,
+                                    ix->k, ix->dbits);
     }
     return query_batch_dir_dev(ix->d_text, ix->n, ix->d_sa, ix->d_dir, ix->d_lut, ix->bits, ix->k, ix->dbits, d_qbytes, d_qoff, nq,
                                d_start, d_end, d_found, d_any, (hipStream_t)stream);

@@ -293,8 +293,9 @@ int key_tree_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, 
 int query_batch_tree_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint64_t* d_tree,
                          const uint64_t* level_offsets, int levels, const uint8_t* d_q, const uint64_t* d_qoff, uint64_t nq,
                          uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st,
-                         void* order_scratch);
-uint64_t query_order_scratch_bytes(uint64_t nq);
+                         void* scratch, bool ordered, const uint32_t* d_dir, const uint16_t* d_lut256, int bits, int k, int dbits);
+uint64_t query_scratch_bytes(uint64_t nq, bool ordered);
+uint64_t query_two_phase_min();
 int byte_presence_host(const uint8_t* d_text, uint64_t n, void* d_small4k, unsigned long long* host_bins256,
                        hipStream_t st);
 int build_lcp_range_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa_part, uint64_t count,

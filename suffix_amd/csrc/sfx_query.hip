@@ -9,6 +9,8 @@
 // contains(q) == (end > start); any_position(q) returns table[start] -- the
 // reference documents the choice as arbitrary (:261-262).
 // Algorithmic bytes per query: 2*ceil(log2 n) probes x (4 B SA entry + compared bytes).
+#include <stdlib.h>
+
 #include "sfx_host.hpp"
 
 namespace sfx {
@@ -333,15 +335,19 @@ int query_batch_dir_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa,
 // What a query pays for in a binary search over the suffix array is not the ~30 probes but the last ~12 of
 // them: the top levels' SA entries and text lines are shared by all queries and sit in L2, the bottom
 // levels are two random 128-byte lines per probe (SA entry, then text).  The index therefore keeps, for
-// every rank, the first 8 bytes of its suffix as a big-endian integer (zero-padded past the end of the text)
-// -- the leaves of a static 16-ary B+tree whose inner levels hold the last key of every block of 16.  One
-// node = one 128-byte line; a search reads one line per level (8 levels at n = 10^9, the top five cached)
-// and never touches the text unless the query is longer than 8 bytes AND shares its first 8 bytes with
-// several suffixes.  Order: for zero-padded keys A, B of byte strings a, b, A < B implies a < b (a proper
-// prefix sorts first, padding is the smallest byte), so the ranks whose key lies in [q padded with 0x00,
-// q padded with 0xFF] contain every suffix that starts with q, and for |q| <= 8 nothing else except
-// suffixes shorter than q, which come first in that range.  8 n bytes of HBM + 7 % for the inner levels.
-constexpr int kTreeFan = 16;
+// every rank, the first 16 bytes of its suffix as two big-endian integers (zero-padded past the end of the
+// text) -- the leaves of a static 16-ary B+tree whose inner levels hold the last key of every block of 16.
+// One node = two adjacent 128-byte lines: the 16 first halves, then the 16 second halves; a search reads the
+// first line of one node per level (8 levels at n = 10^9, the top five cached) and the second line only where
+// a first half ties with the query's (inside a run of suffixes that share 8 bytes: the bottom levels of a
+// query longer than 8 bytes).  The text is touched only when the query is longer than 16 bytes AND shares
+// its first 16 bytes with several suffixes.  Order: for zero-padded keys A, B of byte strings a, b, A < B
+// implies a < b (a proper prefix sorts first, padding is the smallest byte), so the ranks whose key lies in
+// [q padded with 0x00, q padded with 0xFF] contain every suffix that starts with q, and for |q| <= 16 nothing
+// else except suffixes shorter than q, which come first in that range.  16 n bytes of HBM + 7 % for the
+// inner levels (17 GB at n = 10^9: HBM is what this machine has plenty of).
+constexpr int kTreeFan = 16;                           // (the shifts by 4 below are log2 of it)
+constexpr int kTreeNodeWords = 2 * kTreeFan;             // [16 first halves][16 second halves]
 constexpr int kTreeMaxLevels = 9;                        // 16^8 = 2^32
 struct KeyTree {
     const uint64_t* lvl[kTreeMaxLevels];                 // lvl[0] = leaves, each level padded with ~0 to whole nodes
@@ -359,109 +365,309 @@ __device__ __forceinline__ uint64_t be64_of_suffix(const uint8_t* __restrict__ t
     for (unsigned j = 0; j < 8; j++) k = (k << 8) | (s + j < n ? (uint64_t)text[s + j] : 0ull);
     return k;
 }
+// entry e of a level lives in node e / 16, slot e % 16
+__device__ __forceinline__ uint64_t tree_slot(uint64_t e) { return (e / kTreeFan) * kTreeNodeWords + (e % kTreeFan); }
 __global__ void __launch_bounds__(kBlock)
 k_tree_leaves(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint64_t* __restrict__ leaves)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) {
         const uint64_t sfx = sa[r];
-        leaves[r] = sfx < n ? be64_of_suffix(text, n, sfx) : ~0ull;      // (an invalid table is refused elsewhere)
+        const uint64_t w = tree_slot(r);
+        leaves[w] = sfx < n ? be64_of_suffix(text, n, sfx) : ~0ull;      // (an invalid table is refused elsewhere)
+        leaves[w + kTreeFan] = sfx < n ? be64_of_suffix(text, n, sfx + 8) : ~0ull;
     }
 }
 __global__ void __launch_bounds__(kBlock)
 k_tree_level(const uint64_t* __restrict__ below, uint64_t len_below, uint64_t* __restrict__ out, uint64_t len_out)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < len_out; j += stride)
-        out[j] = below[dmin<uint64_t>(j * kTreeFan + kTreeFan - 1, len_below - 1)];       // last key of block j
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < len_out; j += stride) {
+        const uint64_t src = tree_slot(dmin<uint64_t>(j * kTreeFan + kTreeFan - 1, len_below - 1));   // last key of block j
+        const uint64_t dst = tree_slot(j);
+        out[dst] = below[src];
+        out[dst + kTreeFan] = below[src + kTreeFan];
+    }
 }
-// first rank whose key is >= q (upper = false) or > q (upper = true)
-__device__ __forceinline__ uint64_t tree_bound(const KeyTree& t, uint64_t q, bool upper)
+// One node against two search keys at once: ca = #keys < (a1, a2), cb = #keys <= (b1, b2); `want_a` / `want_b` switch
+// a side off.  The first line is read once for both sides, the second one only if a side has ties to break.
+__device__ __forceinline__ void node_counts(const uint64_t* __restrict__ np, uint64_t a1, uint64_t a2, uint64_t b1, uint64_t b2,
+                                            bool want_a, bool want_b, unsigned& ca, unsigned& cb)
 {
-    uint64_t pos = 0;
-    for (int l = t.levels - 1; l >= 0; l--) {
-        const ulonglong2* node = reinterpret_cast<const ulonglong2*>(t.lvl[l] + pos * kTreeFan);
-        unsigned c = 0;
+    const ulonglong2* node = reinterpret_cast<const ulonglong2*>(np);
+    unsigned below_a = 0, ties_a = 0, below_b = 0, ties_b = 0;
+#pragma unroll
+    for (int i = 0; i < kTreeFan / 2; i++) {
+        const ulonglong2 kk = node[i];
+        below_a += (kk.x < a1) + (kk.y < a1);
+        ties_a += (kk.x == a1) + (kk.y == a1);
+        below_b += (kk.x < b1) + (kk.y < b1);
+        ties_b += (kk.x == b1) + (kk.y == b1);
+    }
+    ca = below_a;
+    cb = below_b;
+    // the ties are slots [below, below + ties) of the node: their second halves decide
+    const bool need_a = want_a && ties_a && a2 != 0ull;               // (no second half is < 0)
+    const bool need_b = want_b && ties_b && b2 != ~0ull;
+    if (ties_b && b2 == ~0ull) cb += ties_b;                          // (every second half is <= ~0)
+    if (need_a || need_b) {
 #pragma unroll
         for (int i = 0; i < kTreeFan / 2; i++) {
-            const ulonglong2 kk = node[i];
-            c += upper ? (kk.x <= q) : (kk.x < q);
-            c += upper ? (kk.y <= q) : (kk.y < q);
+            const ulonglong2 kk = node[kTreeFan / 2 + i];
+            const unsigned a0 = 2u * i - below_a, b0 = 2u * i - below_b;      // (unsigned: slots before the ties wrap)
+            if (need_a) ca += ((a0 < ties_a) & (kk.x < a2)) + ((a0 + 1u < ties_a) & (kk.y < a2));
+            if (need_b) cb += ((b0 < ties_b) & (kk.x <= b2)) + ((b0 + 1u < ties_b) & (kk.y <= b2));
         }
-        pos = pos * kTreeFan + c;
-        if (pos >= t.len[l]) return t.n;                      // beyond the last key of this level: q is above every suffix
     }
-    return pos;
+}
+// lo = first rank whose 16-byte key is >= klo, hi = first rank whose key is > khi (klo <= khi).  Both descents start
+// at node `pos` of level `top` (the root: levels - 1, 0), whose ranks must include both answers (or end at them),
+// and share every node until their paths part -- for a query that matches a handful of suffixes, at the leaf.
+__device__ __forceinline__ void tree_bounds(const KeyTree& t, const uint64_t (&klo)[2], const uint64_t (&khi)[2], int top,
+                                            uint64_t pos, uint64_t& lo, uint64_t& hi)
+{
+    uint64_t plo = pos, phi = pos;
+    bool lo_out = false, hi_out = false;                              // beyond the last key of a level: the answer is n
+    for (int l = top; l >= 0 && !(lo_out && hi_out); l--) {
+        // (two node visits per level at most, whatever mixture of shared and parted paths a wave holds)
+        unsigned ca = 0, cb = 0, dummy;
+        const bool shared = plo == phi && !lo_out && !hi_out;
+        if (!lo_out) node_counts(t.lvl[l] + plo * kTreeNodeWords, klo[0], klo[1], khi[0], khi[1], true, shared, ca, cb);
+        if (!hi_out && !shared) node_counts(t.lvl[l] + phi * kTreeNodeWords, klo[0], klo[1], khi[0], khi[1], false, true, dummy, cb);
+        if (!lo_out) { plo = plo * kTreeFan + ca; lo_out = plo >= t.len[l]; }
+        if (!hi_out) { phi = phi * kTreeFan + cb; hi_out = phi >= t.len[l]; }
+    }
+    lo = lo_out ? t.n : plo;
+    hi = hi_out ? t.n : phi;
 }
 
-__global__ void __launch_bounds__(kBlock)
+// A query longer than the tree's 16-byte keys, inside [lo, hi) = the ranks that share its first 16 bytes:
+// ONE bisection until a probe lands on a suffix that starts with q (or the range is empty: no match), then
+// the two ends are searched on either side of that rank -- a bounded gallop (the interval is usually short
+// against the range), then a bisection of what is left.  About log2(range) + 2 log2(#matches) probes of two
+// lines (SA entry, text) where separate searches for start (:244-246) and end (:247-250) take 2 log2(range).
+// Comparisons skip the 16 bytes the keys have settled; the query's next 32 bytes are held in registers as
+// big-endian words (a probe then reads the table entry and the text, never the query).
+constexpr uint64_t kTreeKeyBytes = 16;
+constexpr int kQueryWords = 4;
+// 8 bytes of p[0..len) at offset k as a big-endian integer, zero-padded past len
+__device__ __forceinline__ uint64_t be64_at(const uint8_t* __restrict__ p, uint64_t k, uint64_t len)
+{
+    uint64_t v = 0;
+    if (k + 8 <= len) {
+        __builtin_memcpy(&v, p + k, 8);
+        return __builtin_bswap64(v);
+    }
+    for (unsigned j = 0; j < 8; j++) v = (v << 8) | (k + j < len ? (uint64_t)p[k + j] : 0ull);
+    return v;
+}
+struct LongQueryKey {
+    uint64_t w[kQueryWords];                                          // bytes [16 + 8 i, 24 + 8 i) of the query
+    const uint8_t* q;
+    uint64_t m;
+};
+__device__ __forceinline__ LongQueryKey long_query_key(const uint8_t* __restrict__ q, uint64_t m)
+{
+    LongQueryKey k;
+#pragma unroll
+    for (int i = 0; i < kQueryWords; i++) k.w[i] = be64_at(q, kTreeKeyBytes + 8u * i, m);
+    k.q = q;
+    k.m = m;
+    return k;
+}
+// three-way comparison of q with the suffix at s on bytes [16, min(m, n - s)): <0 q smaller, >0 q larger, 0 equal there
+__device__ __forceinline__ int compare_beyond_keys(const LongQueryKey& key, const uint8_t* __restrict__ text, uint64_t n, uint64_t s)
+{
+    const uint64_t len = n - s, lim = key.m < len ? key.m : len;
+    const uint8_t* tp = text + s;
+#pragma unroll
+    for (int i = 0; i < kQueryWords; i++) {
+        const uint64_t k = kTreeKeyBytes + 8u * i;
+        if (k >= lim) return 0;
+        uint64_t x = key.w[i], y = be64_at(tp, k, len);
+        if (lim - k < 8) {
+            const uint64_t mask = ~0ull << (8u * (8u - (unsigned)(lim - k)));
+            x &= mask;
+            y &= mask;
+        }
+        if (x != y) return x < y ? -1 : 1;
+    }
+    for (uint64_t k = kTreeKeyBytes + 8u * kQueryWords; k < lim; k += 8) {      // (queries of more than 48 bytes)
+        uint64_t x = be64_at(key.q, k, key.m), y = be64_at(tp, k, len);
+        if (lim - k < 8) {
+            const uint64_t mask = ~0ull << (8u * (8u - (unsigned)(lim - k)));
+            x &= mask;
+            y &= mask;
+        }
+        if (x != y) return x < y ? -1 : 1;
+    }
+    return 0;
+}
+// The three searches as ONE loop with one probe site (phase 0: the bisection for a match, 1 / 2: gallop and
+// bisection for the start, 3 / 4: the same for the end): lanes in different phases still probe together.
+__device__ __forceinline__ void long_query_interval(const uint8_t* __restrict__ q, uint64_t m, const uint8_t* __restrict__ text,
+                                                    uint64_t n, const uint32_t* __restrict__ sa, uint64_t lo, uint64_t hi,
+                                                    uint64_t& start, uint64_t& end)
+{
+    const LongQueryKey key = long_query_key(q, m);
+    start = end = 0;
+    uint64_t a = lo, b = hi, hit = 0, top = hi, step = 1;
+    int phase = 0;
+    for (;;) {
+        uint64_t r = 0;
+        bool probe = false;
+        while (!probe && phase < 5) {                                 // settle which rank to probe next
+            if (phase == 0) {                                         // ranks < a are smaller than q, ranks >= b larger and no match
+                if (a < b) { r = (a + b) >> 1; probe = true; } else phase = 6;              // (6: no match at all)
+            } else if (phase == 1) {                                  // the first match lies in [a, b], b is a match
+                if (step <= 8 && b > a) { r = b - a > step ? b - step : a; probe = true; } else phase = 2;
+            } else if (phase == 2) {
+                if (a < b) { r = (a + b) >> 1; probe = true; }
+                else { start = b; a = hit + 1; b = top; step = 1; phase = 3; }
+            } else if (phase == 3) {                                  // the end lies in [a, b], everything in [hit, a) matches
+                if (step <= 8 && a < b) { r = b - a > step ? a + step - 1 : b - 1; probe = true; } else phase = 4;
+            } else {
+                if (a < b) { r = (a + b) >> 1; probe = true; } else { end = a; phase = 5; }
+            }
+        }
+        if (!probe) break;
+        const uint64_t s = sa[r];
+        const int c = compare_beyond_keys(key, text, n, s);
+        const bool match = c == 0 && n - s >= m;                      // (a suffix that is a proper prefix of q sorts before q)
+        if (phase == 0) {
+            if (c < 0) b = r;
+            else if (!match) a = r + 1;
+            else { hit = r; top = b; b = r; step = 1; phase = 1; }
+        } else if (phase == 1) {
+            if (match) { b = r; step <<= 1; } else { a = r + 1; phase = 2; }
+        } else if (phase == 2) {
+            if (match) b = r; else a = r + 1;
+        } else if (phase == 3) {
+            if (match) { a = r + 1; step <<= 1; } else { b = r; phase = 4; }
+        } else {
+            if (match) a = r + 1; else b = r;
+        }
+    }
+    if (phase == 6) start = end = 0;
+}
+__device__ __forceinline__ void query_write(uint64_t qi, uint64_t start, uint64_t end, const uint32_t* __restrict__ sa,
+                                            uint32_t* __restrict__ start_out, uint32_t* __restrict__ end_out,
+                                            uint8_t* __restrict__ found_out, uint32_t* __restrict__ any_out)
+{
+    const bool found = end > start;
+    if (!found) start = end = 0;
+    if (start_out) start_out[qi] = (uint32_t)start;
+    if (end_out) end_out[qi] = (uint32_t)end;
+    if (found_out) found_out[qi] = found ? 1 : 0;
+    if (any_out) any_out[qi] = found ? sa[start] : 0xFFFFFFFFu;
+}
+
+// Phase 1: the two descents of every query; queries of <= 16 bytes (and misses) are answered here.  The others
+// cost ten times as many lines; with `work` they are appended to a list (query, lo, hi) for phase 2, so that a
+// wave never idles 60 lanes while 4 of them bisect on the text; without it they are finished in place.
+struct LongQuery { uint32_t qi, lo, hi; };
+// (6 waves per SIMD: measured the same as 8, which spills)
+__global__ void __launch_bounds__(kBlock, 6)
 k_query_batch_tree(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, KeyTree tree,
                    const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, uint64_t nq,
                    uint32_t* __restrict__ start_out, uint32_t* __restrict__ end_out,
-                   uint8_t* __restrict__ found_out, uint32_t* __restrict__ any_out, const uint32_t* __restrict__ order)
+                   uint8_t* __restrict__ found_out, uint32_t* __restrict__ any_out, const uint32_t* __restrict__ order,
+                   LongQuery* __restrict__ work, uint32_t* __restrict__ work_count, DirParams dp)
 {
     // `order` (optional): the queries sorted by their first 8 bytes -- neighbouring lanes then walk the same
     // tree nodes and, inside a range of suffixes sharing those bytes, probe the same SA entries and text lines
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t slot = (uint64_t)blockIdx.x * kBlock + threadIdx.x; slot < nq; slot += stride) {
-        const uint64_t qi = order ? (uint64_t)order[slot] : slot;
-        const uint8_t* q = qbytes + qoff[qi];
-        const uint64_t m = qoff[qi + 1] - qoff[qi];
+    const unsigned lane = lane_id();
+    for (uint64_t base = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); base < nq; base += stride) {
+        const uint64_t slot = base + lane;
+        const bool live = slot < nq;
+        const uint64_t qi = live ? (order ? (uint64_t)order[slot] : slot) : 0;
+        const uint8_t* q = qbytes + (live ? qoff[qi] : 0);
+        const uint64_t m = live ? qoff[qi + 1] - qoff[qi] : 0;
         uint64_t start = 0, end = 0;
+        bool later = false;
+        uint64_t lo = 0, hi = 0;
         if (n != 0 && m != 0) {                                       // :228-229
-            uint64_t klo = 0, khi = 0;
-            for (unsigned j = 0; j < 8; j++) {
-                const bool in = j < m;
-                klo = (klo << 8) | (in ? (uint64_t)q[j] : 0ull);
-                khi = (khi << 8) | (in ? (uint64_t)q[j] : 0xFFull);
+            // the query's first 16 bytes as the two ends of its key range: padded with 0x00 and with 0xFF
+            uint64_t klo[2], khi[2];
+            klo[0] = be64_at(q, 0, m);
+            klo[1] = be64_at(q, 8, m);
+            khi[0] = klo[0] | (m < 8 ? ~0ull >> (8u * (unsigned)m) : 0ull);
+            khi[1] = klo[1] | (m < 16 ? (m <= 8 ? ~0ull : ~0ull >> (8u * (unsigned)(m - 8))) : 0ull);
+            // The bucket directory first (dp.dir, optional): the ranks [d_lo, d_hi) whose first symbols have q's code
+            // prefix contain both answers, so the descents start at the lowest node that spans them instead of the
+            // root -- the top levels are cached, but every node visited is 8 loads of 64 different lines per wave.
+            int top = tree.levels - 1;
+            uint64_t node = 0;
+            bool none = false;
+            if (dp.dir) {
+                const int L = m < (uint64_t)dp.k ? (int)m : dp.k;
+                uint64_t c = 0;
+                for (int j = 0; j < L; j++) {                         // (L <= 16: the bytes are in the key)
+                    const uint32_t sym = dp.lut[(unsigned)(klo[j >> 3] >> (56 - 8 * (j & 7))) & 0xFFu];
+                    none |= sym == 0u;                                // a byte the text does not contain
+                    c = (c << dp.bits) | (uint64_t)(sym - 1u);
+                }
+                if (!none) {
+                    const int have = L * dp.bits;
+                    uint64_t c_lo, c_hi;
+                    if (have >= dp.dbits) { c_lo = c >> (have - dp.dbits); c_hi = c_lo + 1; }
+                    else { c_lo = c << (dp.dbits - have); c_hi = (c + 1) << (dp.dbits - have); }
+                    const uint64_t d_lo = dp.dir[c_lo], d_hi = dp.dir[c_hi];
+                    none = d_lo >= d_hi;
+                    for (int l = 0; l < tree.levels - 1; l++) {       // the lowest node [p F^(l+1), (p+1) F^(l+1)] with both ends inside
+                        const int sh = 4 * (l + 1);
+                        const uint64_t p = d_lo >> sh;
+                        if (d_hi <= ((p + 1) << sh)) { top = l; node = p; break; }
+                    }
+                }
             }
-            uint64_t lo = tree_bound(tree, klo, false), hi = tree_bound(tree, khi, true);
+            if (!none) tree_bounds(tree, klo, khi, top, node, lo, hi);
             if (lo < hi) {
-                if (m <= 8) {
+                if (m <= kTreeKeyBytes) {
                     // every rank in [lo, hi) starts with q, except suffixes shorter than q whose padding imitates
-                    // q's zero bytes: they are the first entries of the range
-                    while (lo < hi && n - (uint64_t)sa[lo] < m) lo++;
+                    // q's zero bytes (q ends in 0x00 then): they are the first entries of the range
+                    if (q[m - 1] == 0)
+                        while (lo < hi && n - (uint64_t)sa[lo] < m) lo++;
                     start = lo;
                     end = hi;
+                } else if (work) {
+                    later = true;
                 } else {
-                    const uint64_t top = hi;                          // the ranks that share q's first 8 bytes
-                    while (lo < hi) {                                 // :244-246 among them
-                        const uint64_t mid = (lo + hi) >> 1;
-                        if (query_le_suffix(q, m, text, n, sa[mid])) hi = mid; else lo = mid + 1;
-                    }
-                    start = lo;
-                    uint64_t cnt = 0;                                 // :247-250, bounded by `top`
-                    if (start < top && suffix_starts_with(q, m, text, n, sa[start])) {
-                        // gallop while the interval may still be short (<= 15 matches: 4 probes), then bisect what is
-                        // left of the range -- queries drawn from a natural-language text match 10^5 suffixes on
-                        // average, where galloping all the way costs 2 log2(#matches) probes and bisecting log2(range)
-                        cnt = 1;
-                        uint64_t step = 1;
-                        bool more = true;
-                        while (step <= 8) {
-                            more = start + cnt - 1 + step < top && suffix_starts_with(q, m, text, n, sa[start + cnt - 1 + step]);
-                            if (!more) break;
-                            cnt += step;
-                            step <<= 1;
-                        }
-                        lo = start + cnt;
-                        hi = more ? top : dmin<uint64_t>(top, start + cnt - 1 + step);
-                        while (lo < hi) {
-                            const uint64_t mid = (lo + hi) >> 1;
-                            if (!suffix_starts_with(q, m, text, n, sa[mid])) hi = mid; else lo = mid + 1;
-                        }
-                        cnt = lo - start;
-                    }
-                    end = start + cnt;
+                    long_query_interval(q, m, text, n, sa, lo, hi, start, end);
                 }
             }
         }
-        const bool found = end > start;
-        if (!found) start = end = 0;
-        if (start_out) start_out[qi] = (uint32_t)start;
-        if (end_out) end_out[qi] = (uint32_t)end;
-        if (found_out) found_out[qi] = found ? 1 : 0;
-        if (any_out) any_out[qi] = found ? sa[start] : 0xFFFFFFFFu;
+        if (work) {                                                   // (uniform: every lane of the wave is here)
+            const unsigned long long votes = __ballot(later);
+            if (votes) {
+                const int leader = __ffsll((long long)votes) - 1;
+                uint32_t at = 0;
+                if ((int)lane == leader) at = atomicAdd(work_count, (uint32_t)__popcll(votes));
+                at = __shfl(at, leader);
+                if (later) work[at + lanes_below(votes)] = LongQuery{(uint32_t)qi, (uint32_t)lo, (uint32_t)hi};
+            }
+        }
+        if (live && !later) query_write(qi, start, end, sa, start_out, end_out, found_out, any_out);
+    }
+}
+// Phase 2: the listed queries, one per lane, every lane busy.
+__global__ void __launch_bounds__(kBlock, 8)
+k_query_tree_long(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa,
+                  const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff,
+                  const LongQuery* __restrict__ work, const uint32_t* __restrict__ work_count,
+                  uint32_t* __restrict__ start_out, uint32_t* __restrict__ end_out,
+                  uint8_t* __restrict__ found_out, uint32_t* __restrict__ any_out)
+{
+    const uint64_t count = *work_count;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < count; k += stride) {
+        const LongQuery w = work[k];
+        const uint8_t* q = qbytes + qoff[w.qi];
+        const uint64_t m = qoff[w.qi + 1] - qoff[w.qi];
+        uint64_t start, end;
+        long_query_interval(q, m, text, n, sa, w.lo, w.hi, start, end);
+        query_write(w.qi, start, end, sa, start_out, end_out, found_out, any_out);
     }
 }
 
@@ -486,7 +692,7 @@ uint64_t key_tree_words(uint64_t n)
 {
     uint64_t words = 0, len = n;
     for (int l = 0; l < kTreeMaxLevels; l++) {
-        words += (len + kTreeFan - 1) / kTreeFan * kTreeFan + kTreeFan;
+        words += ((len + kTreeFan - 1) / kTreeFan + 1) * kTreeNodeWords;
         if (len <= (uint64_t)kTreeFan) break;
         len = (len + kTreeFan - 1) / kTreeFan;
     }
@@ -498,15 +704,15 @@ int key_tree_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, 
 {
     SFX_HIP(hipMemsetAsync(d_tree, 0xFF, key_tree_words(n) * sizeof(uint64_t), st));       // padding keys = max
     const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
-    SFX_LAUNCH("tree_leaves", (double)n * 20, k_tree_leaves, grid, kBlock, st, d_text, n, d_sa, d_tree);
+    SFX_LAUNCH("tree_leaves", (double)n * 36, k_tree_leaves, grid, kBlock, st, d_text, n, d_sa, d_tree);
     uint64_t off = 0, len = n;
     int l = 0;
     level_offsets_out[0] = 0;
     while (len > (uint64_t)kTreeFan && l + 1 < kTreeMaxLevels) {
-        const uint64_t next_off = off + (len + kTreeFan - 1) / kTreeFan * kTreeFan + kTreeFan;
+        const uint64_t next_off = off + ((len + kTreeFan - 1) / kTreeFan + 1) * kTreeNodeWords;
         const uint64_t next_len = (len + kTreeFan - 1) / kTreeFan;
         const unsigned g = (unsigned)dmin<uint64_t>((next_len + kBlock - 1) / kBlock, kMaxGrid);
-        SFX_LAUNCH("tree_level", (double)next_len * 16, k_tree_level, g, kBlock, st, (const uint64_t*)(d_tree + off), len,
+        SFX_LAUNCH("tree_level", (double)next_len * 32, k_tree_level, g, kBlock, st, (const uint64_t*)(d_tree + off), len,
                    d_tree + next_off, next_len);
         off = next_off;
         len = next_len;
@@ -515,14 +721,28 @@ int key_tree_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, 
     *levels_out = l + 1;
     return SFX_OK;
 }
-// scratch of the query ordering: 2 * nq u64 + 2 * nq u32 + radix_scratch_words(nq) u32
-uint64_t query_order_scratch_bytes(uint64_t nq)
+// scratch of a batch: the list of phase 2 (a counter, then nq entries); with `ordered`, behind it the query
+// ordering: 2 * nq u64 + 2 * nq u32 + radix_scratch_words(nq) u32
+// smaller batches are finished in place (one launch); SFX_QUERY_PHASE_MIN (tests) moves the threshold
+uint64_t query_two_phase_min()
 {
-    return 2 * nq * sizeof(uint64_t) + 2 * nq * sizeof(uint32_t) + radix_scratch_words(nq) * sizeof(uint32_t) + 1024;
+    static const uint64_t v = [] {
+        const char* e = getenv("SFX_QUERY_PHASE_MIN");
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)4096;
+    }();
+    return v;
+}
+static uint64_t query_work_bytes(uint64_t nq) { return (256 + nq * sizeof(LongQuery) + 255) & ~uint64_t(255); }
+uint64_t query_scratch_bytes(uint64_t nq, bool ordered)
+{
+    uint64_t b = query_work_bytes(nq);
+    if (ordered) b += 2 * nq * sizeof(uint64_t) + 2 * nq * sizeof(uint32_t) + radix_scratch_words(nq) * sizeof(uint32_t) + 1024;
+    return b;
 }
 int query_batch_tree_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, const uint64_t* d_tree,
                          const uint64_t* level_offsets, int levels, const uint8_t* d_q, const uint64_t* d_qoff, uint64_t nq,
-                         uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st, void* order_scratch)
+                         uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, hipStream_t st, void* scratch,
+                         bool ordered, const uint32_t* d_dir, const uint16_t* d_lut256, int bits, int k, int dbits)
 {
     if (nq == 0) return SFX_OK;
     if (!d_qoff || !d_tree || levels < 1 || levels > kTreeMaxLevels) return SFX_ERR_ARG;
@@ -536,10 +756,17 @@ int query_batch_tree_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa
     t.levels = levels;
     t.n = n;
     const unsigned grid = (unsigned)dmin<uint64_t>((nq + kBlock - 1) / kBlock, kMaxGrid);
+    // the directory narrows the descents when its key lies inside the tree's 16 bytes (always, except for 1-bit symbols)
+    static const bool want_dir = [] { const char* e = getenv("SFX_TREE_DIR"); return !e || atoi(e) != 0; }();
+    DirParams dp = {want_dir && d_lut256 && k <= (int)kTreeKeyBytes ? d_dir : nullptr, d_lut256, bits, k, dbits};
     const uint32_t* order = nullptr;
-    if (order_scratch && nq >= 4096 && nq <= 0xFFFFFFFFull) {
+    const bool two_phase = scratch && nq >= query_two_phase_min() && nq <= 0xFFFFFFFFull;
+    uint32_t* work_count = two_phase ? reinterpret_cast<uint32_t*>(scratch) : nullptr;
+    LongQuery* work = two_phase ? reinterpret_cast<LongQuery*>(reinterpret_cast<char*>(scratch) + 256) : nullptr;
+    if (two_phase) SFX_HIP(hipMemsetAsync(work_count, 0, sizeof(uint32_t), st));
+    if (two_phase && ordered) {
         // sort (first 8 bytes, query number): 8 passes over 12-byte elements of a small array
-        char* w = reinterpret_cast<char*>(order_scratch);
+        char* w = reinterpret_cast<char*>(scratch) + query_work_bytes(nq);
         uint64_t* k0 = reinterpret_cast<uint64_t*>(w);
         uint64_t* k1 = k0 + nq;
         uint32_t* v0 = reinterpret_cast<uint32_t*>(k1 + nq);
@@ -551,9 +778,13 @@ int query_batch_tree_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa
         SFX_TRY(radix_sort_kv64(k0, v0, k1, v1, nq, 0, 64, scr, st, &in1, nullptr, nullptr));
         order = in1 ? v1 : v0;
     }
-    // two descents of one 128-byte node per level, a few probes of 2 lines beyond 8 bytes
-    SFX_LAUNCH("query_batch_tree", (double)nq * (2.0 * levels * 128 + 4 * 256), k_query_batch_tree, grid, kBlock, st, d_text, n,
-               d_sa, t, d_q, d_qoff, nq, d_start, d_end, d_found, d_any, order);
+    // two descents of one 128-byte line per level (a second one at the bottom levels of queries longer than 8
+    // bytes), a few probes of 2 lines beyond 16 bytes
+    SFX_LAUNCH("query_batch_tree", (double)nq * (2.0 * (levels + 3) * 128 + 2 * 256), k_query_batch_tree, grid, kBlock, st, d_text, n,
+               d_sa, t, d_q, d_qoff, nq, d_start, d_end, d_found, d_any, order, work, work_count, dp);
+    if (two_phase)
+        SFX_LAUNCH("query_tree_long", (double)nq * 0.4 * 40 * 256, k_query_tree_long, grid, kBlock, st, d_text, n, d_sa, d_q,
+                   d_qoff, (const LongQuery*)work, (const uint32_t*)work_count, d_start, d_end, d_found, d_any);
     return SFX_OK;
 }
 

@@ -6,7 +6,7 @@ same C ABI.  Not part of the pytest suite (several minutes); run by hand after k
     make -C tests/emu asan
     LD_PRELOAD=$(gcc -print-file-name=libasan.so) \\
     ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 \\
-    SFX_LCP_DIRECT_MIN=8 python tests/asan_check.py            # add SFX_PARTITION_MIN=1 SFX_MAX_GRID=3 for the variants
+    SFX_LCP_DIRECT_MIN=8 python tests/asan_check.py            # add SFX_PARTITION_MIN=1 SFX_MAX_GRID=3 SFX_QUERY_PHASE_MIN=1 for the variants
 """
 import os
 import sys
@@ -42,3 +42,8 @@ for nr in (1, 3, 11):
     _cases.range_slices(eng, oracle, _gen.english_like(2503).tobytes(), nr)
     _cases.range_slices(eng, oracle, b"ab" * 150 + b"b", nr)
 print("ranges ok")
+_cases.directory_queries(eng, oracle)              # resident index: directory, 16-byte key tree, both query phases
+print("index queries ok")
+_cases.suffix_tree_topology(eng, oracle)
+_cases.fused_lcp_tails(eng, oracle, iters=6)
+print("tree + fused lcp ok")

@@ -61,7 +61,7 @@ if os.environ.get("SFX_LCP_DIRECT_MIN"):
     assert k == ["lcp_sample", "phi_scatter", "plcp", "lcp_gather"], k
     k = lcp_kernels(texts[4])                          # cap reached: Phi/PLCP redoes the array
     assert "lcp_windows_packed" in k and k[-3:] == ["phi_scatter", "plcp", "lcp_gather"], k
-if os.environ.get("SFX_INDEX_TREE"):
+if os.environ.get("SFX_INDEX_TREE") or os.environ.get("SFX_QUERY_PHASE_MIN"):
     import _cases
     _cases.directory_queries(eng, oracle)
 print("OK")
@@ -83,6 +83,10 @@ VARIANTS = {
     "text-key64": {"SFX_TEXT_KEY": "64"},
     "text-key64-small-tiles": {"SFX_TEXT_KEY": "64", "SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
     "index-directory-only": {"SFX_INDEX_TREE": "0"},
+    # queries longer than the tree's keys listed for a second launch (batches of >= 4096 by default), with and
+    # without the (opt-in) ordering of the batch
+    "index-two-phase-queries": {"SFX_QUERY_PHASE_MIN": "1"},
+    "index-two-phase-ordered": {"SFX_QUERY_PHASE_MIN": "1", "SFX_QUERY_ORDER": "1"},
     # rank rounds through round 1's composite-key sort (the fallback for key2 = rank + h beyond 32 bits)
     "composite-rank-rounds": {"SFX_FORCE_COMPOSITE": "1"},
     "tile-1024x4-pair32": {"SFX_TILE_GEOM": "1", "SFX_TILE_PAIR": "32"},
