@@ -206,9 +206,9 @@ def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
                           # 2 * ceil(log2 n) probes * (4 B SA entry + ~8 compared bytes) = 720 B per query
                           "roofline": {"algo_bytes_per_query": 720, "achieved_GB/s": round(720 * 1e6 / t_q / 1e9, 1),
                                        "note": "SURVEY's per-query figure for the undirected search.  What bounds a query is random 128-byte "
-                                               "line fetches: the index answers queries of <= 8 bytes (and misses) from ~16 tree nodes; longer "
-                                               "queries drawn from the text share their first 8 bytes with ~10^5 suffixes and still bisect "
-                                               "that range on the text (DESIGN.md 6)"},
+                                               "line fetches: the index answers queries of <= 16 bytes (and misses) from the nodes of a B+tree "
+                                               "over 16-byte prefix keys, entered below the bucket directory; longer queries bisect the ranks "
+                                               "that share their first 16 bytes on the text, in a second launch of their own (DESIGN.md 6)"},
                           "sha256_start_end": hashlib.sha256(memoryview(torch.stack([s, e]).cpu().numpy())).hexdigest()}
         ix.close()
     pin = (pins or {}).get(key, {}).get(str(n))

@@ -92,10 +92,13 @@ typedef struct sfx_index sfx_index;
  * a memory-safe panic there, so the engine must not read out of bounds either).  The index also holds a
  * BUCKET DIRECTORY: for every prefix of dbits bits of dense symbol codes (dbits = log2 n - 2, at most 28:
  * about one bucket per four suffixes, n bytes of HBM) the first rank whose suffix is not smaller -- a query
- * looks its own first dbits bits up and binary-searches only inside that bucket. */
+ * looks its own first dbits bits up and searches only inside that bucket -- and, memory permitting (17 n
+ * bytes), a static 16-ary B+TREE over the first 16 bytes of every suffix in table order: a query of <= 16
+ * bytes is answered from its nodes alone, a longer one bisects the ranks that share its first 16 bytes.
+ * Batches of >= 4096 queries keep a per-thread scratch list (12 bytes per query) between calls. */
 int sfx_index_create(const uint8_t* text, uint64_t n, const uint32_t* sa, sfx_index** out);
 /* the same over text and suffix array that already live in HBM (borrowed, not copied: keep them alive and
- * unchanged while the index exists); only the directory is built.  Queries with device buffers: */
+ * unchanged while the index exists); only the directory and the tree are built.  Queries with device buffers: */
 int sfx_index_create_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, void* stream, sfx_index** out);
 int sfx_index_query_dev(const sfx_index* ix, const uint8_t* d_qbytes, const uint64_t* d_qoff, uint64_t nq,
                         uint32_t* d_start, uint32_t* d_end, uint8_t* d_found, uint32_t* d_any, void* stream);
