@@ -214,24 +214,32 @@ struct LcpEmit {
     int field_bits64;           // ... of a 64-bit text key2 (flag in bit 63)
 };
 constexpr uint32_t kLcpBoundFlag = 0x80000000u;
+// LCP of a class head (suffix sb, key kb) with the member of the preceding class that stands in front of it NOW
+// (suffix sa, key ka).  All members of that class share ka, so the symbols the keys have in common are the same
+// whichever of them ends up in front of sb -- except that the key of a suffix ending inside it is zero-padded and
+// may imitate the smallest symbol: when that is what sa is (n - sa < common prefix of the keys), the value depends
+// on which member the class's own resolution puts last, and the pair is left pending (decided on the text once
+// the suffix array is final).  sb's own length caps the value for good.
 __device__ __forceinline__ uint32_t lcp_from_key2(const LcpEmit& L, uint32_t ka, uint32_t kb, uint32_t sa, uint32_t sb)
 {
     if (L.rank_mode) return kLcpBoundFlag | L.h;
-    const uint32_t la = L.n - sa, lb = L.n - sb, cap = la < lb ? la : lb;
-    if (!(ka & kb & 0x80000000u)) return cap;            // one of them ends before offset h: the shorter is a prefix
+    const uint32_t la = L.n - sa, lb = L.n - sb;
+    if (!(ka & kb & 0x80000000u)) return la < lb ? la : lb;   // one of them ends before offset h (a class of its own): the shorter is a prefix
     const uint32_t x = ka ^ kb;                          // (!= 0: different classes)
     const uint32_t lz = (uint32_t)__clz((int)x) - (32u - (uint32_t)L.field_bits);
     const uint32_t v = L.h + ((lz * L.inv_bits) >> 16);
-    return v < cap ? v : cap;
+    if (v > la) return kLcpBoundFlag | L.h;
+    return v < lb ? v : lb;
 }
 __device__ __forceinline__ uint32_t lcp_from_key2_64(const LcpEmit& L, uint64_t ka, uint64_t kb, uint32_t sa, uint32_t sb)
 {
-    const uint32_t la = L.n - sa, lb = L.n - sb, cap = la < lb ? la : lb;
-    if (!((ka & kb) >> 63)) return cap;
+    const uint32_t la = L.n - sa, lb = L.n - sb;
+    if (!((ka & kb) >> 63)) return la < lb ? la : lb;
     const uint64_t x = ka ^ kb;
     const uint32_t lz = (uint32_t)__clzll((long long)x) - (64u - (uint32_t)L.field_bits64);
     const uint32_t v = L.h + ((lz * L.inv_bits) >> 16);
-    return v < cap ? v : cap;
+    if (v > la) return kLcpBoundFlag | L.h;
+    return v < lb ? v : lb;
 }
 struct TileRound {
     LcpEmit emit;
