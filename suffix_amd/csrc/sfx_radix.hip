@@ -542,6 +542,210 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
     }
 }
 
+// ---- hybrid initial sort: two device-wide passes on the top 16 key bits, the rest in LDS ----------
+// An LSD sort moves every element once per 8 key bits through the CU write path (0.41 of HBM peak, §9 of
+// DESIGN.md).  When the text is large enough that the 65536 sub-buckets of the top 16 key bits hold a few
+// thousand suffixes each, and none more than an LDS tile, two passes suffice: the top two digits are sorted
+// device-wide (LSD order: bits [hi-16, hi-8), then [hi-8, hi) -- after them the array is ordered by its top
+// 16 bits, stably), then every sub-bucket is sorted by its remaining low bits inside LDS by one workgroup and
+// written out sequentially (k_bucket_sort): the same stable LSD ranking, 2 digits deep, with no scatter.
+// Sub-bucket boundaries and the digit totals of the two passes come from one 65536-bin histogram of the top
+// 16 bits of every suffix's key, counted from the packed text in two sweeps of 32768 LDS counters.
+constexpr int kH16Bins = 1 << 16;
+constexpr int kH16Words = kH16Bins / 2;                              // two 16-bit counters per LDS word
+constexpr int kH16Threads = 1024;
+// One sweep over the workgroup's stretch of the text with 16-bit counters (128 KiB of LDS).  A counter can only
+// wrap when a sub-bucket holds >= 65536 suffixes of this stretch alone -- far beyond what the LDS sort accepts;
+// a wrap changes the sum of all counters by -65535 (low half: its carry lands in the high half) or -65536 (high
+// half), never by 0 in any combination, so the host detects it from the total (!= m) and takes the other route.
+__global__ void __launch_bounds__(kH16Threads)
+k_hist16_text(PackedText t, int drop, uint64_t words_per_block, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[kH16Words];                                 // 128 KiB
+    const unsigned tid = threadIdx.x;
+    const uint64_t nwords = (t.n + (uint64_t)t.spw - 1) / (uint64_t)t.spw;
+    const uint64_t qb = (uint64_t)blockIdx.x * words_per_block;
+    const uint64_t qe = dmin<uint64_t>(nwords, qb + words_per_block);
+    const uint64_t mask = (1ull << t.kbits) - 1ull;
+    for (unsigned i = tid; i < (unsigned)kH16Words; i += kH16Threads) h[i] = 0;
+    __syncthreads();
+    for (uint64_t q = qb + tid; q < qe; q += kH16Threads) {
+        // the spw keys that start in word q, from the two words they span (as packed_key32)
+        const uint64_t both = ((uint64_t)t.words[q] << t.kbits) | (uint64_t)t.words[q + 1];
+        const uint64_t j0 = q * (uint64_t)t.spw;
+        for (int o = 0; o < t.spw; o++) {
+            if (j0 + (uint64_t)o >= t.n) break;
+            const uint32_t key = (uint32_t)((both >> ((unsigned)(t.spw - o) * (unsigned)t.bits)) & mask);
+            const uint32_t top = key >> drop;
+            atomicAdd(&h[top >> 1], (top & 1u) ? 65536u : 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* out = partial + (uint64_t)blockIdx.x * kH16Words;
+    for (unsigned i = tid; i < (unsigned)kH16Words; i += kH16Threads) out[i] = h[i];
+}
+// bin totals; workgroup j owns the 256 bins whose high digit is j: totals_hi[j] = their sum
+__global__ void __launch_bounds__(kBlock)
+k_hist16_reduce(const uint32_t* __restrict__ partial, unsigned nblocks, uint32_t* __restrict__ bins,
+                uint32_t* __restrict__ totals_hi, uint32_t* __restrict__ max_bin)
+{
+    __shared__ uint32_t part[kWavesPerBlock];
+    const unsigned b = blockIdx.x * kBlock + threadIdx.x;
+    const unsigned sh = (b & 1u) * 16u;
+    uint32_t c = 0;
+    for (unsigned g = 0; g < nblocks; g++) c += (partial[(uint64_t)g * kH16Words + (b >> 1)] >> sh) & 0xFFFFu;
+    bins[b] = c;
+    uint32_t mx = c;
+    for (int d = 32; d >= 1; d >>= 1) mx = dmax(mx, __shfl_xor(mx, d));
+    if (lane_id() == 0) atomicMax(max_bin, mx);
+    uint32_t total;
+    (void)block_scan_add_excl(c, part, total);
+    if (threadIdx.x == 0) totals_hi[blockIdx.x] = total;
+}
+// totals_lo[d] = sum over the high digits of bin (j, d); bins[b] -> first position of sub-bucket b (in place),
+// bins[65536] = m
+__global__ void __launch_bounds__(kH16Threads)
+k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uint32_t* __restrict__ total_out)
+{
+    __shared__ uint32_t part[kH16Threads / kWave];
+    __shared__ uint32_t lo[4][kRadix];
+    constexpr int kPer = kH16Bins / kH16Threads;
+    const unsigned tid = threadIdx.x;
+    {
+        // thread (q, d): the bins (j, d) with j = q mod 4
+        const unsigned d = tid & 255u, q = tid >> 8;
+        uint32_t t = 0;
+        for (unsigned j = q; j < (unsigned)kRadix; j += 4) t += bins[j * kRadix + d];
+        lo[q][d] = t;
+    }
+    uint32_t v[kPer], sum = 0;
+    for (int j = 0; j < kPer; j++) { v[j] = bins[tid * kPer + j]; sum += v[j]; }
+    // exclusive scan of one value per thread over 16 waves
+    const uint32_t incl = wave_scan_add(sum);
+    if (lane_id() == 63) part[wave_id()] = incl;
+    __syncthreads();
+    if (tid < (unsigned)kRadix) totals_lo[tid] = lo[0][tid] + lo[1][tid] + lo[2][tid] + lo[3][tid];
+    uint32_t base = 0;
+    for (unsigned k = 0; k < wave_id(); k++) base += part[k];
+    uint32_t run = base + incl - sum;
+    for (int j = 0; j < kPer; j++) { bins[tid * kPer + j] = run; run += v[j]; }
+    if (tid == kH16Threads - 1) { bins[kH16Bins] = run; total_out[0] = run; }
+}
+
+// One workgroup per sub-bucket [bstart[b], bstart[b + 1]) of X (sorted by its top 16 key bits): LSD sort by key
+// bits [0, low_bits) in LDS -- digit A = bits [0, 8), digit B = bits [8, low_bits) -- then keys and suffixes
+// leave as two sequential runs.  A bucket of `size` elements is spread evenly: wave w owns the 64 * kpt
+// consecutive elements from w * 64 * kpt, kpt = ceil(size / (64 NW)), so (wave, round, lane) order is memory
+// order and the ranking is stable.  Padding (~0) carries the largest digit and stays behind the real elements.
+template <int NW, int KPT>
+__global__ void __launch_bounds__(NW * kWave)
+k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstart, uint32_t nbuckets, int low_bits,
+              uint32_t* __restrict__ K, uint32_t* __restrict__ V)
+{
+    constexpr int kThreads = NW * kWave;
+    constexpr uint32_t kCap = kThreads * KPT;
+    static_assert(kWave * KPT >= kRadix, "the match masks must fit the staging buffer");
+    __shared__ struct {
+        uint32_t cnt[NW][kRadix];
+        uint32_t part[2][NW];
+        uint64_t stage[NW * kWave * KPT];
+    } s;
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const unsigned long long mybit = 1ull << lane;
+    const bool owner = tid < (unsigned)kRadix;
+    unsigned long long* const my_flags = reinterpret_cast<unsigned long long*>(s.stage) + w * kRadix;
+    unsigned par = 0;
+    if (owner) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0u;
+    }
+    __syncthreads();
+    // Two sub-buckets ahead: the bounds of bucket b + 2 G and the elements of bucket b + G are requested before
+    // bucket b is sorted, so that a workgroup always has a bucket of HBM reads in flight.
+    auto bounds = [&](uint32_t b, uint32_t& begin, uint32_t& size) {
+        begin = 0; size = 0;
+        if (b < nbuckets) { begin = bstart[b]; size = bstart[b + 1] - begin; }
+        if (size > kCap) size = 0;                                               // (oversized: the caller took the other route)
+    };
+    uint64_t nkey[KPT];
+    auto fetch = [&](uint32_t begin, uint32_t size) {
+        const unsigned per = ((size + kThreads - 1) / kThreads) * kWave;
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            const unsigned idx = w * per + r * kWave + lane;
+            nkey[r] = ((unsigned)(r * kWave) < per && idx < size) ? X[(uint64_t)begin + idx] : ~0ull;
+        }
+    };
+    uint32_t b = blockIdx.x, begin, size, begin1, size1;
+    bounds(b, begin, size);
+    bounds(b + gridDim.x, begin1, size1);
+    fetch(begin, size);
+    for (; b < nbuckets; b += gridDim.x) {
+        uint64_t key[KPT];
+        uint32_t pos[KPT];
+#pragma unroll
+        for (int r = 0; r < KPT; r++) key[r] = nkey[r];
+        uint32_t begin2, size2;
+        bounds(b + 2 * gridDim.x, begin2, size2);
+        fetch(begin1, size1);
+        const unsigned kpt = (size + kThreads - 1) / kThreads;                  // rounds in use, <= KPT
+        const unsigned per = kpt * kWave;
+        for (int pass = 0; pass < 2 && size > 1; pass++) {
+            const int shift = 32 + 8 * pass;
+            const int nb = pass == 0 ? (low_bits < 8 ? low_bits : 8) : low_bits - 8;
+            if (nb <= 0) break;
+            const unsigned mask = (1u << nb) - 1u;
+#pragma unroll
+            for (int k = 0; k < kRadix / kWave; k++) my_flags[k * kWave + lane] = 0ull;
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < KPT; r++)
+                if ((unsigned)r < kpt) pos[r] = rank_round<true>(digit_of(key[r], shift, mask), my_flags, s.cnt[w], mybit);
+            __syncthreads();
+            {
+                uint32_t c[NW], tile_count = 0;
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    c[k] = owner ? s.cnt[k][tid] : 0u;
+                    tile_count += c[k];
+                }
+                const uint32_t ex = block_scan_excl_1b<NW>(tile_count, s.part, par);
+                if (owner) {
+                    uint32_t run = ex;
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        s.cnt[k][tid] = run;
+                        run += c[k];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < KPT; r++)
+                if ((unsigned)r < kpt) s.stage[pos[r] + s.cnt[w][digit_of(key[r], shift, mask)]] = key[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < KPT; r++)
+                if ((unsigned)r < kpt) key[r] = s.stage[w * per + r * kWave + lane];
+            if (owner) {
+#pragma unroll
+                for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0u;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            const unsigned idx = w * per + r * kWave + lane;
+            if ((unsigned)r < kpt && idx < size) {
+                K[(uint64_t)begin + idx] = (uint32_t)(key[r] >> 32);
+                V[(uint64_t)begin + idx] = (uint32_t)key[r];
+            }
+        }
+        begin = begin1; size = size1;
+        begin1 = begin2; size1 = size2;
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------
 // Tuning knobs (development only; read once per process):
 //   SFX_RADIX_SWEEP  1 = one-sweep (default), 0 = chunked
@@ -687,6 +891,74 @@ static bool use_sweep(uint64_t m, int npass)
     return radix_tuning().sweep && m < (1ull << 30) && npass <= kMaxPasses;
 }
 
+// The hybrid route of a text-fed E64 sort with split output (see k_bucket_sort).  Applies to texts between
+// 3 * 2^24 and 2^28 suffixes whose key has at least 24 bits (below, a sub-bucket is too small to keep a workgroup
+// busy: 50 MB of DNA runs the same either way; 100 MB 1.92 against 2.24 ms, 200 MB 3.84 against 4.63); gives way
+// (returns 0 in *done) when a sub-bucket of the top 16 bits is larger than an LDS tile of 4096 -- skewed texts keep
+// the four-pass sort.
+//   SFX_HYBRID=0 switches it off; SFX_HYBRID_MIN=<suffixes> (tests) moves the lower bound; SFX_HYBRID_CAP=<elements>
+//   (tests) lowers the largest sub-bucket accepted.
+constexpr int kBucketNW = 4, kBucketKPT = 16;                 // the largest geometry: sub-buckets of up to 4096 suffixes
+static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, const RadixScratch& scr,
+                                hipStream_t st, sfx_build_stats* stats, const PackedText& text, uint32_t* split_v,
+                                uint32_t** split_k_out, bool* done)
+{
+    *done = false;
+    static const int enabled = [] { const char* e = getenv("SFX_HYBRID"); return e ? atoi(e) : 1; }();
+    static const uint64_t min_m = [] { const char* e = getenv("SFX_HYBRID_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (3ull << 24); }();
+    static const uint32_t cap = [] {
+        const char* e = getenv("SFX_HYBRID_CAP");
+        const uint32_t full = kBucketNW * kWave * kBucketKPT;
+        const uint32_t v = e ? (uint32_t)atoi(e) : full;
+        return v >= 1 && v < full ? v : full;
+    }();
+    const int key_bits = bit_hi - bit_lo;
+    if (!enabled || bit_lo != 32 || key_bits != text.kbits || key_bits < 24 || m != text.n || m < min_m || m > (1ull << 28))
+        return SFX_OK;
+    const int low_bits = key_bits - 16;
+    uint32_t* bins = scr.partial;                              // 65537 u32: counts, then sub-bucket starts
+    uint32_t* max_bin = scr.partial + kH16Bins + 64;
+    uint32_t* partial = reinterpret_cast<uint32_t*>(e1);       // [workgroups][65536]: e1 is idle until the second pass
+    const uint64_t nwords = (m + (uint64_t)text.spw - 1) / (uint64_t)text.spw;
+    const uint64_t room = m * sizeof(uint64_t) / (kH16Words * sizeof(uint32_t));     // partial histograms that fit e1
+    if (room == 0) return SFX_OK;
+    Chunking ch = make_chunking(nwords, kH16Threads, (unsigned)dmin<uint64_t>(room, 256));
+    SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
+    SFX_HIP(hipMemsetAsync(max_bin, 0, 2 * sizeof(uint32_t), st));
+    SFX_LAUNCH("radix_hist16_text", (double)m * text.bits / 8.0, k_hist16_text, ch.blocks, kH16Threads, st, text, low_bits,
+               ch.tiles_per_block * kH16Threads, partial);
+    SFX_LAUNCH("radix_hist16_reduce", (double)ch.blocks * kH16Words * 4, k_hist16_reduce, kH16Bins / kBlock, kBlock, st,
+               (const uint32_t*)partial, ch.blocks, bins, scr.totals + kRadix, max_bin);
+    SFX_LAUNCH("radix_hist16_scan", (double)kH16Bins * 8, k_hist16_scan, 1, kH16Threads, st, bins, scr.totals, max_bin + 1);
+    uint32_t host_stat[2] = {0, 0};                            // largest sub-bucket, sum of all of them
+    SFX_TRY(read_back(host_stat, max_bin, sizeof(host_stat), st));
+    const uint32_t host_max = host_stat[0];
+    // a sub-bucket does not fit an LDS tile, or a 16-bit counter wrapped: four passes
+    if (host_max > cap || (uint64_t)host_stat[1] != m) return SFX_OK;
+    const bool sweep = true;
+    SrcText32 tsrc = {text};
+    SFX_TRY(run_pass("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), tsrc, DstE64{e0}, m, bit_hi - 16, 255u, scr, 0,
+                     sweep, st));
+    SFX_TRY(run_pass("radix_scatter_u32", (double)m * 16.0, SrcE64{e0}, DstE64{e1}, m, bit_hi - 8, 255u, scr, 1, sweep, st));
+    uint32_t* split_k = reinterpret_cast<uint32_t*>(e0);
+    // geometry by the largest sub-bucket: 256 threads x 8 (8 workgroups per CU) is the fastest, measured on 100 MB
+    // of DNA 0.55 ms against 0.63 (256 x 16) and 0.80 (512 x 8; 512 x 16 did not pay at all); SFX_HYBRID_GEOM=1
+    // forces the larger one (tests)
+    static const int force_geom = [] { const char* e = getenv("SFX_HYBRID_GEOM"); return e ? atoi(e) : -1; }();
+    const int geom = (host_max <= 2048 && force_geom != 1) ? 0 : 1;
+    const unsigned grid = (unsigned)dmin<uint64_t>(kH16Bins, (uint64_t)grid_cap() * 2);
+#define SFX_BUCKET_SORT(NW, KPT)                                                                                          \
+    SFX_LAUNCH("bucket_sort_lds", (double)m * 16.0, (k_bucket_sort<NW, KPT>), grid, NW * kWave, st, (const uint64_t*)e1,  \
+               (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, split_k, split_v)
+    if (geom == 0) SFX_BUCKET_SORT(4, 8);             // (the 8-ballot ranking instead of the LDS match masks: 0.64 against 0.56 ms)
+    else SFX_BUCKET_SORT(kBucketNW, kBucketKPT);
+#undef SFX_BUCKET_SORT
+    if (split_k_out) *split_k_out = split_k;
+    if (stats) { stats->radix_passes += 2; stats->elements_sorted += 2 * m; }
+    *done = true;
+    return SFX_OK;
+}
+
 // E64 sort on element bits [bit_lo, bit_hi).  With `text` the first pass computes element i
 // from the packed text (e0 need not hold anything).  With `split_v` the last pass writes
 // the suffix halves to split_v and the key halves to a u32 array carved from whichever of
@@ -710,6 +982,11 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
     const int npass = radix_pass_count(bit_lo, bit_hi);
     const bool sweep = use_sweep(m, npass);
     RadixScratch scr(scratch, m);
+    if (sweep && text && split_v && npass >= 3) {
+        bool done = false;
+        SFX_TRY(hybrid_sort_e64_text(e0, e1, m, bit_lo, bit_hi, scr, st, stats, *text, split_v, split_k_out, &done));
+        if (done) return SFX_OK;
+    }
     SrcText32 tsrc = {text ? *text : PackedText{nullptr, 0, 0, 1, 0, 1.0}};
     if (sweep && hist_blocks && !text) {
         // the producer of e0 counted the digits (radix_e64_presort_hist): only the row sums are left

@@ -6,6 +6,7 @@ environment variables are read once per process, so every variant runs in a subp
   SFX_LCP_DIRECT_MIN                     sampled choice between direct and Phi/PLCP LCP, cap + fallback
   SFX_TILE_SMALL / SFX_FORCE_KEY64       small LDS windows of the refinement rounds; 64-bit initial keys
   SFX_SEG_SMALL                          small tiles in the segmented sort of the large buckets
+  SFX_HYBRID_MIN / _GEOM / _CAP          hybrid initial sort (two device-wide passes + LDS sort of the sub-buckets)
 Every run compares SA and LCP with the oracle on a few texts that exercise the path."""
 import os
 import subprocess
@@ -39,6 +40,24 @@ if os.environ.get("SFX_LCP_DIRECT_MIN"):
         body = rng.integers(0, sigma, 12000, dtype=np.uint8) + 97
         rep = body[1000:1000 + 90 + 40 * sigma].tobytes()
         texts.append(body.tobytes() + rep + b"a" + rep)
+if os.environ.get("SFX_HYBRID_MIN"):
+    # keys of 32 bits (sigma 2, 4, 16) and of 30 bits (sigma 5: 14 low bits, second LDS digit of 6 bits); a text
+    # whose two largest sub-buckets wrap the 16-bit counters of the histogram (detected from the total: four passes)
+    texts += [_gen.uniform_bytes(30000, 5, 2, base=65).tobytes(), _gen.uniform_bytes(30000, 16, 3, base=65).tobytes(),
+              _gen.uniform_bytes(40000, 2, 4, base=65).tobytes(), b"AC" * 70000 + _gen.dna(3000, seed=5).tobytes()]
+    from suffix_amd import device as sdev
+    for t in texts[:1]:                                 # the fused SA + LCP entry over the same initial sort
+        import torch
+        d = torch.frombuffer(bytearray(t), dtype=torch.uint8)
+        sa, lcp = sdev.build_sa_lcp(d, engine=eng)
+        exp = oracle.sais(t)
+        assert np.array_equal(sa.numpy().view(np.uint32), exp) and np.array_equal(lcp.numpy().view(np.uint32), oracle.lcp_kasai(t, exp))
+    eng.profile(True); eng.profile_reset()
+    SuffixTable(texts[0], engine=eng).table()
+    names = [r["name"] for r in eng.profile_report()]
+    eng.profile(False)
+    want = int(os.environ.get("SFX_HYBRID_CAP", "100000")) > 1000
+    assert ("bucket_sort_lds" in names) == want, names
 for t in texts:
     st = SuffixTable(t, engine=eng)
     exp = oracle.sais(t)
@@ -82,6 +101,10 @@ VARIANTS = {
     # text rounds on 64-bit keys (opt-in): the 64-bit LDS sort and the key/value form of the segmented sort
     "text-key64": {"SFX_TEXT_KEY": "64"},
     "text-key64-small-tiles": {"SFX_TEXT_KEY": "64", "SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
+    # hybrid initial sort forced on small inputs; the larger LDS geometries; a cap that sends every text the other way
+    "hybrid-initial-sort": {"SFX_HYBRID_MIN": "1"},
+    "hybrid-initial-sort-multi-tile": {"SFX_HYBRID_MIN": "1", "SFX_MAX_GRID": "3", "SFX_HYBRID_GEOM": "1"},
+    "hybrid-initial-sort-cap": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_CAP": "3"},
     "index-directory-only": {"SFX_INDEX_TREE": "0"},
     # queries longer than the tree's keys listed for a second launch (batches of >= 4096 by default), with and
     # without the (opt-in) ordering of the batch

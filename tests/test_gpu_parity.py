@@ -97,6 +97,31 @@ def test_dna_20mb_full_compare(eng, oracle):
     assert stats["sigma"] == 4 and stats["key_bits"] == 32 and stats["symbols_per_key"] == 16
 
 
+def test_hybrid_initial_sort_56mb(eng, oracle):
+    """>= 3 * 2^24 suffixes with a 32-bit key: two device-wide passes on the top 16 key bits, the 65536 sub-buckets
+    sorted in LDS (k_bucket_sort); a skewed text whose largest sub-bucket does not fit takes the four-pass sort.
+    Complete SA and LCP against the oracle for both, and the fused SA + LCP entry."""
+    import torch
+    from suffix_amd import device as sdev
+    n = 56_000_000
+    rng = np.random.default_rng(12)
+    uniform = _gen.dna(n, seed=31)
+    skewed = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, size=n, p=[0.55, 0.05, 0.05, 0.35])]
+    for host, lds in ((uniform, True), (skewed, False)):
+        text = torch.from_numpy(np.ascontiguousarray(host)).cuda()
+        eng.profile(True); eng.profile_reset()
+        sa = sdev.build_sa(text)
+        torch.cuda.synchronize()
+        names = {r["name"] for r in eng.profile_report()}
+        eng.profile(False)
+        assert "radix_hist16_text" in names and ("bucket_sort_lds" in names) == lds, names
+        exp = oracle.sais(host.tobytes())
+        assert np.array_equal(sa.cpu().numpy().view(np.uint32), exp)
+        sa2, lcp2 = sdev.build_sa_lcp(text)
+        assert np.array_equal(sa2.cpu().numpy().view(np.uint32), exp)
+        assert np.array_equal(lcp2.cpu().numpy().view(np.uint32), oracle.lcp_kasai(host.tobytes(), exp))
+
+
 def test_device_resident_100mb_properties(eng):
     """BASELINE config 2 at full size, checked through size-independent properties."""
     import sys, os
