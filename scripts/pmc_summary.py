@@ -26,7 +26,8 @@ NAMES = [("k_radix_pass<sfx::SrcE64", "radix_scatter_u32"), ("k_radix_pass<sfx::
          ("k_groups_reduce", "groups_reduce"), ("k_radix_hist_all<sfx::SrcText32", "radix_hist_all_text_u32"),
          ("k_pack_text", "pack_text"), ("k_small_groups", "small_groups"), ("k_byte_presence", "byte_presence"),
          ("k_tile_sort", "tile_sort"), ("k_seg_gather", "seg_gather"), ("k_lcp_windows_packed", "lcp_windows_packed"),
-         ("k_lcp_pending", "lcp_pending")]
+         ("k_lcp_pending", "lcp_pending"), ("k_bucket_sort", "bucket_sort_lds"), ("k_hist16_text", "radix_hist16_text"),
+         ("k_hist16_reduce", "radix_hist16_reduce")]
 
 acc = defaultdict(lambda: [0.0, 0])
 for d in args:
