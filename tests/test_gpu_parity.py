@@ -122,6 +122,32 @@ def test_hybrid_initial_sort_56mb(eng, oracle):
         assert np.array_equal(lcp2.cpu().numpy().view(np.uint32), oracle.lcp_kasai(host.tobytes(), exp))
 
 
+@pytest.mark.parametrize("sigma", [2, 5, 16])
+def test_hybrid_initial_sort_other_alphabets(eng, sigma):
+    """The hybrid route on keys of 32 one-bit symbols and 8 four-bit symbols, 56 * 10^6 suffixes each, through the
+    size-independent property gate; the fused SA + LCP entry gives the same arrays.  Five symbols (3 bits, 10 per
+    word) do not separate 56 * 10^6 suffixes in a 32-bit key: that text takes 64-bit keys and never sees the hybrid
+    route (30-bit keys, whose LDS digits have 8 + 6 bits, are covered on the emulator)."""
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from suffix_amd import device as sdev
+    text = torch.from_numpy(_gen.uniform_bytes(56_000_000, sigma, 40 + sigma, base=65)).cuda()
+    eng.profile(True); eng.profile_reset()
+    sa = sdev.build_sa(text)
+    torch.cuda.synchronize()
+    names = {r["name"] for r in eng.profile_report()}
+    eng.profile(False)
+    # (a binary text repeats inside 32 symbols all the time, but its top-16-bit sub-buckets are as even as any)
+    assert ("radix_hist16_text" in names) == (sigma != 5) and ("bucket_sort_lds" in names) == (sigma != 5), names
+    ok, how = bench.verify_sa_on_device(torch, sdev, text, sa)
+    assert ok, how
+    sa2, lcp2 = sdev.build_sa_lcp(text)
+    assert torch.equal(sa2, sa)
+    assert torch.equal(lcp2, sdev.build_lcp(text, sa))
+
+
 def test_device_resident_100mb_properties(eng):
     """BASELINE config 2 at full size, checked through size-independent properties."""
     import sys, os
