@@ -389,53 +389,109 @@ k_tree_level(const uint64_t* __restrict__ below, uint64_t len_below, uint64_t* _
         out[dst + kTreeFan] = below[src + kTreeFan];
     }
 }
-// One node against two search keys at once: ca = #keys < (a1, a2), cb = #keys <= (b1, b2); `want_a` / `want_b` switch
-// a side off.  The first line is read once for both sides, the second one only if a side has ties to break.
-__device__ __forceinline__ void node_counts(const uint64_t* __restrict__ np, uint64_t a1, uint64_t a2, uint64_t b1, uint64_t b2,
-                                            bool want_a, bool want_b, unsigned& ca, unsigned& cb)
+// ---- the descents of a wave's 64 queries, node lines fetched cooperatively ---------------------------
+// A lane that reads its own node needs 8 loads of 16 bytes, and every one of them is 64 different lines to the
+// wave: 8 x 64 tag lookups per level in the CU's L1, which is what a batch of short queries was bound by
+// (profiles/r2_query_pmc.txt: 153 L1 accesses per query at 60 % of one per cycle, 10 HBM lines per query).
+// Here lanes 8 j' .. 8 j' + 7 of load i fetch the line of query 8 i + j' together -- one line per 8 lanes, 64
+// lookups per level instead of 512 -- into an LDS row of the wave; then every lane reads its own row back.
+// Rows are 144 bytes apart (9 x 16): a wave's 16-byte reads of 64 rows fall on distinct banks.
+constexpr int kCoopRow = 9;
+struct CoopSmem {
+    ulonglong2 rows[kWavesPerBlock][kWave][kCoopRow];
+    uint64_t addr[kWavesPerBlock][kWave];
+};
+// np: this lane's node line (16 u64), or nullptr; kk: its 16 keys (zeros for nullptr).  Every lane of the wave calls.
+__device__ __forceinline__ void coop_load_line(CoopSmem& s, const uint64_t* np, ulonglong2 (&kk)[kTreeFan / 2])
 {
-    const ulonglong2* node = reinterpret_cast<const ulonglong2*>(np);
-    unsigned below_a = 0, ties_a = 0, below_b = 0, ties_b = 0;
+    const unsigned w = wave_id(), lane = lane_id();
+    s.addr[w][lane] = reinterpret_cast<uint64_t>(np);
+    wave_sync();
+    ulonglong2 v[kTreeFan / 2];
 #pragma unroll
     for (int i = 0; i < kTreeFan / 2; i++) {
-        const ulonglong2 kk = node[i];
-        below_a += (kk.x < a1) + (kk.y < a1);
-        ties_a += (kk.x == a1) + (kk.y == a1);
-        below_b += (kk.x < b1) + (kk.y < b1);
-        ties_b += (kk.x == b1) + (kk.y == b1);
+        const uint64_t a = s.addr[w][8 * i + (lane >> 3)];
+        v[i] = a ? reinterpret_cast<const ulonglong2*>(a)[lane & 7u] : ulonglong2{0ull, 0ull};
     }
-    ca = below_a;
-    cb = below_b;
-    // the ties are slots [below, below + ties) of the node: their second halves decide
-    const bool need_a = want_a && ties_a && a2 != 0ull;               // (no second half is < 0)
-    const bool need_b = want_b && ties_b && b2 != ~0ull;
-    if (ties_b && b2 == ~0ull) cb += ties_b;                          // (every second half is <= ~0)
-    if (need_a || need_b) {
 #pragma unroll
-        for (int i = 0; i < kTreeFan / 2; i++) {
-            const ulonglong2 kk = node[kTreeFan / 2 + i];
-            const unsigned a0 = 2u * i - below_a, b0 = 2u * i - below_b;      // (unsigned: slots before the ties wrap)
-            if (need_a) ca += ((a0 < ties_a) & (kk.x < a2)) + ((a0 + 1u < ties_a) & (kk.y < a2));
-            if (need_b) cb += ((b0 < ties_b) & (kk.x <= b2)) + ((b0 + 1u < ties_b) & (kk.y <= b2));
-        }
+    for (int i = 0; i < kTreeFan / 2; i++) s.rows[w][8 * i + (lane >> 3)][lane & 7u] = v[i];
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < kTreeFan / 2; k++) kk[k] = s.rows[w][lane][k];
+    wave_sync();                                              // (the next call overwrites the rows)
+}
+// first halves of a node against q1: #keys below, #keys equal
+__device__ __forceinline__ void count_first(const ulonglong2 (&kk)[kTreeFan / 2], uint64_t q1, unsigned& below, unsigned& ties)
+{
+    below = 0;
+    ties = 0;
+#pragma unroll
+    for (int i = 0; i < kTreeFan / 2; i++) {
+        below += (kk[i].x < q1) + (kk[i].y < q1);
+        ties += (kk[i].x == q1) + (kk[i].y == q1);
     }
 }
-// lo = first rank whose 16-byte key is >= klo, hi = first rank whose key is > khi (klo <= khi).  Both descents start
-// at node `pos` of level `top` (the root: levels - 1, 0), whose ranks must include both answers (or end at them),
-// and share every node until their paths part -- for a query that matches a handful of suffixes, at the leaf.
-__device__ __forceinline__ void tree_bounds(const KeyTree& t, const uint64_t (&klo)[2], const uint64_t (&khi)[2], int top,
-                                            uint64_t pos, uint64_t& lo, uint64_t& hi)
+// second halves of the tying slots [below, below + ties): how many are < q2 (upper: <= q2)
+__device__ __forceinline__ unsigned count_second(const ulonglong2 (&kk)[kTreeFan / 2], uint64_t q2, bool upper, unsigned below,
+                                                 unsigned ties)
+{
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < kTreeFan / 2; i++) {
+        const unsigned s0 = 2u * i - below;                           // (unsigned: slots before the ties wrap)
+        c += ((s0 < ties) & (upper ? (kk[i].x <= q2) : (kk[i].x < q2))) + ((s0 + 1u < ties) & (upper ? (kk[i].y <= q2) : (kk[i].y < q2)));
+    }
+    return c;
+}
+// lo = first rank whose 16-byte key is >= klo, hi = first rank whose key is > khi (klo <= khi), for the query of
+// every lane of the wave (`act`: this lane has one).  A lane's two descents start at node `pos` of level `top`
+// (the root: levels - 1, 0), whose ranks must include both answers (or end at them), and share every node until
+// their paths part -- for a query that matches a handful of suffixes, at the leaf.  Per level the wave makes one
+// cooperative fetch for the lower (and shared) descents, one for the parted upper ones if there are any, and one
+// more each for the second halves where first halves tie.
+__device__ __forceinline__ void tree_bounds_wave(CoopSmem& s, const KeyTree& t, const uint64_t (&klo)[2], const uint64_t (&khi)[2],
+                                                 bool act, int top, uint64_t pos, uint64_t& lo, uint64_t& hi)
 {
     uint64_t plo = pos, phi = pos;
-    bool lo_out = false, hi_out = false;                              // beyond the last key of a level: the answer is n
-    for (int l = top; l >= 0 && !(lo_out && hi_out); l--) {
-        // (two node visits per level at most, whatever mixture of shared and parted paths a wave holds)
-        unsigned ca = 0, cb = 0, dummy;
-        const bool shared = plo == phi && !lo_out && !hi_out;
-        if (!lo_out) node_counts(t.lvl[l] + plo * kTreeNodeWords, klo[0], klo[1], khi[0], khi[1], true, shared, ca, cb);
-        if (!hi_out && !shared) node_counts(t.lvl[l] + phi * kTreeNodeWords, klo[0], klo[1], khi[0], khi[1], false, true, dummy, cb);
-        if (!lo_out) { plo = plo * kTreeFan + ca; lo_out = plo >= t.len[l]; }
-        if (!hi_out) { phi = phi * kTreeFan + cb; hi_out = phi >= t.len[l]; }
+    bool lo_out = !act, hi_out = !act;                                // beyond the last key of a level: the answer is n
+    int lmax = act ? top : -1;
+    for (int d = 32; d >= 1; d >>= 1) lmax = dmax(lmax, __shfl_xor(lmax, d));
+    ulonglong2 kk[kTreeFan / 2];
+    for (int l = lmax; l >= 0; l--) {
+        const bool on = act && l <= top;                              // this lane's descents have started
+        const bool shared = on && !lo_out && !hi_out && plo == phi;
+        const bool act_a = on && !lo_out;
+        const uint64_t* np_a = act_a ? t.lvl[l] + plo * kTreeNodeWords : nullptr;
+        unsigned ca = 0, cb = 0, below_b = 0, ties_a = 0, ties_b = 0;
+        coop_load_line(s, np_a, kk);
+        count_first(kk, klo[0], ca, ties_a);
+        if (shared) { count_first(kk, khi[0], below_b, ties_b); cb = below_b; }
+        const bool need_a = act_a && ties_a && klo[1] != 0ull;        // (no second half is < 0)
+        bool need_b = shared && ties_b && khi[1] != ~0ull;
+        if (shared && ties_b && khi[1] == ~0ull) cb += ties_b;        // (every second half is <= ~0)
+        if (__any(need_a || need_b)) {
+            const unsigned below_a = ca;
+            coop_load_line(s, (need_a || need_b) ? np_a + kTreeFan : nullptr, kk);
+            if (need_a) ca += count_second(kk, klo[1], false, below_a, ties_a);
+            if (need_b) cb += count_second(kk, khi[1], true, below_b, ties_b);
+        }
+        const bool act_b = on && !hi_out && !shared;                  // the upper descent on its own path
+        if (__any(act_b)) {
+            const uint64_t* np_b = act_b ? t.lvl[l] + phi * kTreeNodeWords : nullptr;
+            coop_load_line(s, np_b, kk);
+            if (act_b) {
+                count_first(kk, khi[0], below_b, ties_b);
+                cb = below_b;
+                if (ties_b && khi[1] == ~0ull) cb += ties_b;
+            }
+            need_b = act_b && ties_b && khi[1] != ~0ull;
+            if (__any(need_b)) {
+                coop_load_line(s, need_b ? np_b + kTreeFan : nullptr, kk);
+                if (need_b) cb += count_second(kk, khi[1], true, below_b, ties_b);
+            }
+        }
+        if (act_a) { plo = plo * kTreeFan + ca; lo_out = plo >= t.len[l]; }
+        if (on && !hi_out) { phi = phi * kTreeFan + cb; hi_out = phi >= t.len[l]; }
     }
     lo = lo_out ? t.n : plo;
     hi = hi_out ? t.n : phi;
@@ -576,6 +632,7 @@ k_query_batch_tree(const uint8_t* __restrict__ text, uint64_t n, const uint32_t*
 {
     // `order` (optional): the queries sorted by their first 8 bytes -- neighbouring lanes then walk the same
     // tree nodes and, inside a range of suffixes sharing those bytes, probe the same SA entries and text lines
+    __shared__ CoopSmem coop;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const unsigned lane = lane_id();
     for (uint64_t base = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); base < nq; base += stride) {
@@ -587,19 +644,20 @@ k_query_batch_tree(const uint8_t* __restrict__ text, uint64_t n, const uint32_t*
         uint64_t start = 0, end = 0;
         bool later = false;
         uint64_t lo = 0, hi = 0;
+        uint64_t klo[2] = {0, 0}, khi[2] = {0, 0};
+        int top = tree.levels - 1;
+        uint64_t node = 0;
+        bool none = true;                                             // no descent: empty text / query, or the directory says no
         if (n != 0 && m != 0) {                                       // :228-229
             // the query's first 16 bytes as the two ends of its key range: padded with 0x00 and with 0xFF
-            uint64_t klo[2], khi[2];
+            none = false;
             klo[0] = be64_at(q, 0, m);
             klo[1] = be64_at(q, 8, m);
             khi[0] = klo[0] | (m < 8 ? ~0ull >> (8u * (unsigned)m) : 0ull);
             khi[1] = klo[1] | (m < 16 ? (m <= 8 ? ~0ull : ~0ull >> (8u * (unsigned)(m - 8))) : 0ull);
             // The bucket directory first (dp.dir, optional): the ranks [d_lo, d_hi) whose first symbols have q's code
             // prefix contain both answers, so the descents start at the lowest node that spans them instead of the
-            // root -- the top levels are cached, but every node visited is 8 loads of 64 different lines per wave.
-            int top = tree.levels - 1;
-            uint64_t node = 0;
-            bool none = false;
+            // root.
             if (dp.dir) {
                 const int L = m < (uint64_t)dp.k ? (int)m : dp.k;
                 uint64_t c = 0;
@@ -622,7 +680,9 @@ k_query_batch_tree(const uint8_t* __restrict__ text, uint64_t n, const uint32_t*
                     }
                 }
             }
-            if (!none) tree_bounds(tree, klo, khi, top, node, lo, hi);
+        }
+        tree_bounds_wave(coop, tree, klo, khi, !none, top, node, lo, hi);          // (every lane of the wave takes part)
+        if (!none) {
             if (lo < hi) {
                 if (m <= kTreeKeyBytes) {
                     // every rank in [lo, hi) starts with q, except suffixes shorter than q whose padding imitates
