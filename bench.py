@@ -184,21 +184,27 @@ def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
     if key == "c5":
         qb, off = _gen.queries(host, 1_000_000)
         d_qb, d_off = torch.from_numpy(qb).to(dev), torch.from_numpy(off).to(dev)
+        # (both forms: one untimed call, then the mean of 5 batches of 10^6 queries issued back to back)
+        q_reps = 5
         sdev.query_batch(text, sa, d_qb, d_off); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        s0, e0, f0, a0 = sdev.query_batch(text, sa, d_qb, d_off); torch.cuda.synchronize()
-        t_plain = time.perf_counter() - t0
-        # the resident index: text + SA stay in HBM, plus a B+tree over the first 8 bytes of every suffix (and the
-        # bucket directory as the fallback structure)
+        for _ in range(q_reps):
+            s0, e0, f0, a0 = sdev.query_batch(text, sa, d_qb, d_off)
+        torch.cuda.synchronize()
+        t_plain = (time.perf_counter() - t0) / q_reps
+        # the resident index: text + SA stay in HBM, plus a B+tree over the first 16 bytes of every suffix and the
+        # bucket directory (the tree's entry point, and the fallback structure)
         t0 = time.perf_counter()
         ix = sdev.DeviceIndex(text, sa); torch.cuda.synchronize()
         t_ix = time.perf_counter() - t0
         ix.query(d_qb, d_off); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        s, e, f, a = ix.query(d_qb, d_off); torch.cuda.synchronize()
-        t_q = time.perf_counter() - t0
+        for _ in range(q_reps):
+            s, e, f, a = ix.query(d_qb, d_off)
+        torch.cuda.synchronize()
+        t_q = (time.perf_counter() - t0) / q_reps
         nbytes = int(off[-1])
-        rec["queries"] = {"count": 1_000_000, "ms": round(t_q * 1e3, 3), "Mqueries/s": round(1.0 / t_q, 1),
+        rec["queries"] = {"count": 1_000_000, "batches_timed": q_reps, "ms": round(t_q * 1e3, 3), "Mqueries/s": round(1.0 / t_q, 1),
                           "undirected_binary_search": {"ms": round(t_plain * 1e3, 3), "Mqueries/s": round(1.0 / t_plain, 1)},
                           "index_build_ms": round(t_ix * 1e3, 2),
                           "same_answers_as_undirected": bool(torch.equal(s, s0) and torch.equal(e, e0) and torch.equal(f, f0)),

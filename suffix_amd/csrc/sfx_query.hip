@@ -337,17 +337,21 @@ int query_batch_dir_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa,
 // levels are two random 128-byte lines per probe (SA entry, then text).  The index therefore keeps, for
 // every rank, the first 16 bytes of its suffix as two big-endian integers (zero-padded past the end of the
 // text) -- the leaves of a static 16-ary B+tree whose inner levels hold the last key of every block of 16.
-// One node = two adjacent 128-byte lines: the 16 first halves, then the 16 second halves; a search reads the
-// first line of one node per level (8 levels at n = 10^9, the top five cached) and the second line only where
-// a first half ties with the query's (inside a run of suffixes that share 8 bytes: the bottom levels of a
-// query longer than 8 bytes).  The text is touched only when the query is longer than 16 bytes AND shares
-// its first 16 bytes with several suffixes.  Order: for zero-padded keys A, B of byte strings a, b, A < B
-// implies a < b (a proper prefix sorts first, padding is the smallest byte), so the ranks whose key lies in
-// [q padded with 0x00, q padded with 0xFF] contain every suffix that starts with q, and for |q| <= 16 nothing
-// else except suffixes shorter than q, which come first in that range.  16 n bytes of HBM + 7 % for the
-// inner levels (17 GB at n = 10^9: HBM is what this machine has plenty of).
+// One node = adjacent 128-byte lines: the 16 first words, then the 16 second words; a search reads the first
+// line of one node per level (8 levels at n = 10^9, the top five cached) and the second line only where the
+// first words tie with the query's (inside a run of suffixes that share 8 bytes: the bottom levels of a query
+// longer than that).  The text is touched only when the query is longer than the key AND shares all of it
+// with several suffixes.  Order: for zero-padded keys A, B of byte strings a, b, A < B implies a < b (a proper
+// prefix sorts first, padding is the smallest byte), so the ranks whose key lies in [q padded with 0x00, q
+// padded with 0xFF] contain every suffix that starts with q, and for |q| <= 16 nothing else except suffixes
+// shorter than q, which come first in that range.  16 n bytes of HBM + 7 % for the inner levels (17 GB at
+// n = 10^9: HBM is what this machine has plenty of).
 constexpr int kTreeFan = 16;                           // (the shifts by 4 below are log2 of it)
-constexpr int kTreeNodeWords = 2 * kTreeFan;             // [16 first halves][16 second halves]
+// a key = the first 16 bytes of a suffix, as two big-endian words.  (Three words -- 24 bytes, 26 GB at n = 10^9 --
+// are one constant away and were measured on config 5's query set: 0.42 + 0.18 ms against 0.35 + 0.27 with two,
+// 3 % in all for 8 n more bytes and 13 ms more index build: not taken.)
+constexpr int kTreeKeyWords = 2;
+constexpr int kTreeNodeWords = kTreeKeyWords * kTreeFan; // [16 first words][16 second words]
 constexpr int kTreeMaxLevels = 9;                        // 16^8 = 2^32
 struct KeyTree {
     const uint64_t* lvl[kTreeMaxLevels];                 // lvl[0] = leaves, each level padded with ~0 to whole nodes
@@ -374,8 +378,9 @@ k_tree_leaves(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __re
     for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) {
         const uint64_t sfx = sa[r];
         const uint64_t w = tree_slot(r);
-        leaves[w] = sfx < n ? be64_of_suffix(text, n, sfx) : ~0ull;      // (an invalid table is refused elsewhere)
-        leaves[w + kTreeFan] = sfx < n ? be64_of_suffix(text, n, sfx + 8) : ~0ull;
+#pragma unroll
+        for (int k = 0; k < kTreeKeyWords; k++)                          // (an invalid table is refused elsewhere)
+            leaves[w + k * kTreeFan] = sfx < n ? be64_of_suffix(text, n, sfx + 8u * k) : ~0ull;
     }
 }
 __global__ void __launch_bounds__(kBlock)
@@ -385,8 +390,8 @@ k_tree_level(const uint64_t* __restrict__ below, uint64_t len_below, uint64_t* _
     for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < len_out; j += stride) {
         const uint64_t src = tree_slot(dmin<uint64_t>(j * kTreeFan + kTreeFan - 1, len_below - 1));   // last key of block j
         const uint64_t dst = tree_slot(j);
-        out[dst] = below[src];
-        out[dst + kTreeFan] = below[src + kTreeFan];
+#pragma unroll
+        for (int k = 0; k < kTreeKeyWords; k++) out[dst + k * kTreeFan] = below[src + k * kTreeFan];
     }
 }
 // ---- the descents of a wave's 64 queries, node lines fetched cooperatively ---------------------------
@@ -420,91 +425,107 @@ __device__ __forceinline__ void coop_load_line(CoopSmem& s, const uint64_t* np, 
     for (int k = 0; k < kTreeFan / 2; k++) kk[k] = s.rows[w][lane][k];
     wave_sync();                                              // (the next call overwrites the rows)
 }
-// first halves of a node against q1: #keys below, #keys equal
-__device__ __forceinline__ void count_first(const ulonglong2 (&kk)[kTreeFan / 2], uint64_t q1, unsigned& below, unsigned& ties)
+// one key word of a node against q, over the slots [base, base + ties) that tie on the words before it:
+// how many of them are below q, how many equal
+__device__ __forceinline__ void count_word(const ulonglong2 (&kk)[kTreeFan / 2], uint64_t q, unsigned base, unsigned ties,
+                                           unsigned& below, unsigned& equal)
 {
     below = 0;
-    ties = 0;
+    equal = 0;
 #pragma unroll
     for (int i = 0; i < kTreeFan / 2; i++) {
-        below += (kk[i].x < q1) + (kk[i].y < q1);
-        ties += (kk[i].x == q1) + (kk[i].y == q1);
+        const unsigned s0 = 2u * i - base;                            // (unsigned: slots before the range wrap)
+        const unsigned in0 = s0 < ties, in1 = s0 + 1u < ties;
+        below += (in0 & (kk[i].x < q)) + (in1 & (kk[i].y < q));
+        equal += (in0 & (kk[i].x == q)) + (in1 & (kk[i].y == q));
     }
 }
-// second halves of the tying slots [below, below + ties): how many are < q2 (upper: <= q2)
-__device__ __forceinline__ unsigned count_second(const ulonglong2 (&kk)[kTreeFan / 2], uint64_t q2, bool upper, unsigned below,
-                                                 unsigned ties)
-{
-    unsigned c = 0;
-#pragma unroll
-    for (int i = 0; i < kTreeFan / 2; i++) {
-        const unsigned s0 = 2u * i - below;                           // (unsigned: slots before the ties wrap)
-        c += ((s0 < ties) & (upper ? (kk[i].x <= q2) : (kk[i].x < q2))) + ((s0 + 1u < ties) & (upper ? (kk[i].y <= q2) : (kk[i].y < q2)));
+// One side of a descent inside a node: after word w the keys below the search key are the `base` first slots plus
+// whatever the tying slots [base, base + ties) decide on the next word.  #keys < q = base at the end; #keys <= q =
+// base + ties.  A side is settled when nothing ties, or when the rest of its search key is all 0x00 (lower end:
+// no key is below it) / all 0xFF (upper end: every key is <= it).
+struct NodeSide {
+    unsigned base, ties;
+    __device__ __forceinline__ void start() { base = 0; ties = kTreeFan; }
+    __device__ __forceinline__ void word(const ulonglong2 (&kk)[kTreeFan / 2], uint64_t q)
+    {
+        unsigned below, equal;
+        count_word(kk, q, base, ties, below, equal);
+        base += below;
+        ties = equal;
     }
-    return c;
-}
-// lo = first rank whose 16-byte key is >= klo, hi = first rank whose key is > khi (klo <= khi), for the query of
-// every lane of the wave (`act`: this lane has one).  A lane's two descents start at node `pos` of level `top`
-// (the root: levels - 1, 0), whose ranks must include both answers (or end at them), and share every node until
-// their paths part -- for a query that matches a handful of suffixes, at the leaf.  Per level the wave makes one
-// cooperative fetch for the lower (and shared) descents, one for the parted upper ones if there are any, and one
-// more each for the second halves where first halves tie.
-__device__ __forceinline__ void tree_bounds_wave(CoopSmem& s, const KeyTree& t, const uint64_t (&klo)[2], const uint64_t (&khi)[2],
-                                                 bool act, int top, uint64_t pos, uint64_t& lo, uint64_t& hi)
+};
+// lo = first rank whose key is >= klo, hi = first rank whose key is > khi (klo <= khi, kTreeKeyWords words each), for
+// the query of every lane of the wave (`act`: this lane has one).  A lane's two descents start at node `pos` of
+// level `top` (the root: levels - 1, 0), whose ranks must include both answers (or end at them), and share every
+// node until their paths part -- for a query that matches a handful of suffixes, at the leaf.  Per level the wave
+// makes one cooperative fetch per key word for the lower (and shared) descents, one per word for the parted upper
+// ones if there are any; words after the first only while some lane still has slots that tie.
+__device__ __forceinline__ void tree_bounds_wave(CoopSmem& s, const KeyTree& t, const uint64_t (&klo)[kTreeKeyWords],
+                                                 const uint64_t (&khi)[kTreeKeyWords], bool act, int top, uint64_t pos,
+                                                 uint64_t& lo, uint64_t& hi)
 {
     uint64_t plo = pos, phi = pos;
     bool lo_out = !act, hi_out = !act;                                // beyond the last key of a level: the answer is n
     int lmax = act ? top : -1;
     for (int d = 32; d >= 1; d >>= 1) lmax = dmax(lmax, __shfl_xor(lmax, d));
+    // bit w: the words w.. of klo are all 0x00 / of khi all 0xFF
+    unsigned rest0 = 0, restf = 0;
+    {
+        bool z = true, f = true;
+#pragma unroll
+        for (int w = kTreeKeyWords - 1; w >= 0; w--) {
+            z = z && klo[w] == 0ull;
+            f = f && khi[w] == ~0ull;
+            rest0 |= (z ? 1u : 0u) << w;
+            restf |= (f ? 1u : 0u) << w;
+        }
+    }
     ulonglong2 kk[kTreeFan / 2];
     for (int l = lmax; l >= 0; l--) {
         const bool on = act && l <= top;                              // this lane's descents have started
         const bool shared = on && !lo_out && !hi_out && plo == phi;
         const bool act_a = on && !lo_out;
         const uint64_t* np_a = act_a ? t.lvl[l] + plo * kTreeNodeWords : nullptr;
-        unsigned ca = 0, cb = 0, below_b = 0, ties_a = 0, ties_b = 0;
-        coop_load_line(s, np_a, kk);
-        count_first(kk, klo[0], ca, ties_a);
-        if (shared) { count_first(kk, khi[0], below_b, ties_b); cb = below_b; }
-        const bool need_a = act_a && ties_a && klo[1] != 0ull;        // (no second half is < 0)
-        bool need_b = shared && ties_b && khi[1] != ~0ull;
-        if (shared && ties_b && khi[1] == ~0ull) cb += ties_b;        // (every second half is <= ~0)
-        if (__any(need_a || need_b)) {
-            const unsigned below_a = ca;
-            coop_load_line(s, (need_a || need_b) ? np_a + kTreeFan : nullptr, kk);
-            if (need_a) ca += count_second(kk, klo[1], false, below_a, ties_a);
-            if (need_b) cb += count_second(kk, khi[1], true, below_b, ties_b);
+        NodeSide a, b;
+        a.start();
+        b.start();
+#pragma unroll
+        for (int w = 0; w < kTreeKeyWords; w++) {
+            // (word 0 is always read; a later one only by the lanes whose side is not settled yet)
+            const bool more_a = act_a && (w == 0 || (a.ties && !((rest0 >> w) & 1u)));
+            const bool more_b = shared && (w == 0 || (b.ties && !((restf >> w) & 1u)));
+            if (w > 0 && !__any(more_a || more_b)) break;
+            coop_load_line(s, (more_a || more_b) ? np_a + w * kTreeFan : nullptr, kk);
+            if (more_a) a.word(kk, klo[w]);
+            if (more_b) b.word(kk, khi[w]);
         }
         const bool act_b = on && !hi_out && !shared;                  // the upper descent on its own path
         if (__any(act_b)) {
             const uint64_t* np_b = act_b ? t.lvl[l] + phi * kTreeNodeWords : nullptr;
-            coop_load_line(s, np_b, kk);
-            if (act_b) {
-                count_first(kk, khi[0], below_b, ties_b);
-                cb = below_b;
-                if (ties_b && khi[1] == ~0ull) cb += ties_b;
-            }
-            need_b = act_b && ties_b && khi[1] != ~0ull;
-            if (__any(need_b)) {
-                coop_load_line(s, need_b ? np_b + kTreeFan : nullptr, kk);
-                if (need_b) cb += count_second(kk, khi[1], true, below_b, ties_b);
+#pragma unroll
+            for (int w = 0; w < kTreeKeyWords; w++) {
+                const bool more_b = act_b && (w == 0 || (b.ties && !((restf >> w) & 1u)));
+                if (w > 0 && !__any(more_b)) break;
+                coop_load_line(s, more_b ? np_b + w * kTreeFan : nullptr, kk);
+                if (more_b) b.word(kk, khi[w]);
             }
         }
-        if (act_a) { plo = plo * kTreeFan + ca; lo_out = plo >= t.len[l]; }
-        if (on && !hi_out) { phi = phi * kTreeFan + cb; hi_out = phi >= t.len[l]; }
+        if (act_a) { plo = plo * kTreeFan + a.base; lo_out = plo >= t.len[l]; }
+        if (on && !hi_out) { phi = phi * kTreeFan + b.base + b.ties; hi_out = phi >= t.len[l]; }
     }
     lo = lo_out ? t.n : plo;
     hi = hi_out ? t.n : phi;
 }
 
-// A query longer than the tree's 16-byte keys, inside [lo, hi) = the ranks that share its first 16 bytes:
+// A query longer than the tree's keys, inside [lo, hi) = the ranks that share its first kTreeKeyBytes (16) bytes:
 // ONE bisection until a probe lands on a suffix that starts with q (or the range is empty: no match), then
 // the two ends are searched on either side of that rank -- a bounded gallop (the interval is usually short
 // against the range), then a bisection of what is left.  About log2(range) + 2 log2(#matches) probes of two
 // lines (SA entry, text) where separate searches for start (:244-246) and end (:247-250) take 2 log2(range).
-// Comparisons skip the 16 bytes the keys have settled; the query's next 32 bytes are held in registers as
+// Comparisons skip the bytes the keys have settled; the query's next 32 bytes are held in registers as
 // big-endian words (a probe then reads the table entry and the text, never the query).
-constexpr uint64_t kTreeKeyBytes = 16;
+constexpr uint64_t kTreeKeyBytes = 8 * kTreeKeyWords;
 constexpr int kQueryWords = 4;
 // 8 bytes of p[0..len) at offset k as a big-endian integer, zero-padded past len
 __device__ __forceinline__ uint64_t be64_at(const uint8_t* __restrict__ p, uint64_t k, uint64_t len)
@@ -644,17 +665,21 @@ k_query_batch_tree(const uint8_t* __restrict__ text, uint64_t n, const uint32_t*
         uint64_t start = 0, end = 0;
         bool later = false;
         uint64_t lo = 0, hi = 0;
-        uint64_t klo[2] = {0, 0}, khi[2] = {0, 0};
+        uint64_t klo[kTreeKeyWords], khi[kTreeKeyWords];
+#pragma unroll
+        for (int w = 0; w < kTreeKeyWords; w++) klo[w] = khi[w] = 0;
         int top = tree.levels - 1;
         uint64_t node = 0;
         bool none = true;                                             // no descent: empty text / query, or the directory says no
         if (n != 0 && m != 0) {                                       // :228-229
             // the query's first 16 bytes as the two ends of its key range: padded with 0x00 and with 0xFF
             none = false;
-            klo[0] = be64_at(q, 0, m);
-            klo[1] = be64_at(q, 8, m);
-            khi[0] = klo[0] | (m < 8 ? ~0ull >> (8u * (unsigned)m) : 0ull);
-            khi[1] = klo[1] | (m < 16 ? (m <= 8 ? ~0ull : ~0ull >> (8u * (unsigned)(m - 8))) : 0ull);
+#pragma unroll
+            for (int w = 0; w < kTreeKeyWords; w++) {
+                klo[w] = be64_at(q, 8u * w, m);
+                const uint64_t have = m > 8u * w ? m - 8u * w : 0;    // bytes of the query in this word
+                khi[w] = klo[w] | (have >= 8 ? 0ull : (have == 0 ? ~0ull : ~0ull >> (8u * (unsigned)have)));
+            }
             // The bucket directory first (dp.dir, optional): the ranks [d_lo, d_hi) whose first symbols have q's code
             // prefix contain both answers, so the descents start at the lowest node that spans them instead of the
             // root.
@@ -764,7 +789,7 @@ int key_tree_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, 
 {
     SFX_HIP(hipMemsetAsync(d_tree, 0xFF, key_tree_words(n) * sizeof(uint64_t), st));       // padding keys = max
     const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
-    SFX_LAUNCH("tree_leaves", (double)n * 36, k_tree_leaves, grid, kBlock, st, d_text, n, d_sa, d_tree);
+    SFX_LAUNCH("tree_leaves", (double)n * (4 + 8 + 8 * kTreeKeyWords), k_tree_leaves, grid, kBlock, st, d_text, n, d_sa, d_tree);
     uint64_t off = 0, len = n;
     int l = 0;
     level_offsets_out[0] = 0;
@@ -772,7 +797,7 @@ int key_tree_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, 
         const uint64_t next_off = off + ((len + kTreeFan - 1) / kTreeFan + 1) * kTreeNodeWords;
         const uint64_t next_len = (len + kTreeFan - 1) / kTreeFan;
         const unsigned g = (unsigned)dmin<uint64_t>((next_len + kBlock - 1) / kBlock, kMaxGrid);
-        SFX_LAUNCH("tree_level", (double)next_len * 32, k_tree_level, g, kBlock, st, (const uint64_t*)(d_tree + off), len,
+        SFX_LAUNCH("tree_level", (double)next_len * 16 * kTreeKeyWords, k_tree_level, g, kBlock, st, (const uint64_t*)(d_tree + off), len,
                    d_tree + next_off, next_len);
         off = next_off;
         len = next_len;

@@ -301,8 +301,8 @@ def directory_queries(eng, orc, device="cpu", scale=1):
     texts = [_gen.dna(30000 * scale, seed=5).tobytes() + b"AAAA", _gen.english_like(20000 * scale).tobytes(),
              _gen.utf8_mixed(20000 * scale).tobytes(), bytes(range(256)) * (8 * scale) + b"\x00\x00",
              b"a" * 300, b"ab" * 200 + b"a", _gen.uniform_bytes(5000 * scale, 3, 9, base=65).tobytes() + b"AA",
-             # the 16-byte keys of the B+tree: runs of the padding bytes 0x00 / 0xFF, long shared prefixes
-             b"\xff" * 40 + b"\x00" * 40 + b"\xff" * 17 + b"\x00" * 9 + b"\xff" * 16,
+             # the 24-byte keys of the B+tree: runs of the padding bytes 0x00 / 0xFF, long shared prefixes
+             b"\xff" * 40 + b"\x00" * 40 + b"\xff" * 17 + b"\x00" * 9 + b"\xff" * 16 + b"\x00" * 25 + b"\xff" * 24,
              (b"abcdefgh" * 40 + b"abcdefgx") * 5 + b"abcdefghabcdefgh",
              _gen.english_like(3000).tobytes() * 4 + b"\x00" * 20,
              # 1-bit symbols and n > 2^18: the directory key (17 symbols) is longer than the tree's, descents start at the root
@@ -312,7 +312,9 @@ def directory_queries(eng, orc, device="cpu", scale=1):
         exp = orc.sais(text)
         qs = [b"", text[-1:], text[-2:], text[-3:], text[:1], b"\xfe\xfd", text[:40], b"A", b"AA", b"AAA", b"AAAA", b"AAAAA",
               text[-8:], text[-9:], text[-16:], text[-17:], text[-16:] + b"\x00", text[-8:] + b"\x00", text[-5:] + b"\x00\x00",
-              b"\xff" * 8, b"\xff" * 16, b"\xff" * 17, b"\x00" * 8, b"\x00" * 16, b"\x00" * 17]
+              b"\xff" * 8, b"\xff" * 16, b"\xff" * 17, b"\x00" * 8, b"\x00" * 16, b"\x00" * 17,
+              text[-24:], text[-25:], text[-24:] + b"\x00", text[-20:] + b"\x00\x00", b"\xff" * 24, b"\xff" * 25, b"\x00" * 24,
+              b"\x00" * 25, text[:24], text[:25], text[:23] + b"\xff", text[:16] + b"\x00" * 8, text[:16] + b"\xff" * 8]
         for it in range(400):
             a = int(rng.integers(0, n))
             q = text[a:a + int(rng.integers(1, 14 if it < 200 else (40 if it < 340 else 90)))]
