@@ -637,6 +637,16 @@ k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uin
 // leave as two sequential runs.  A bucket of `size` elements is spread evenly: wave w owns the 64 * kpt
 // consecutive elements from w * 64 * kpt, kpt = ceil(size / (64 NW)), so (wave, round, lane) order is memory
 // order and the ranking is stable.  Padding (~0) carries the largest digit and stays behind the real elements.
+//
+// Fast path (`pairs`, taken when no group below holds more than kPairLimit elements -- always, on keys that are
+// spread evenly): the elements are GROUPED by the top 10 of their low key bits with one returning LDS atomic each
+// (the order inside a group does not matter yet), and an element's final place is its group's start plus the
+// number of group members that are smaller -- a couple of LDS reads against a group of 1-4.  An element is a whole
+// 64-bit word (key << 32 | suffix), all different, so "smaller" is a total order and ties in the key come out in
+// suffix order, exactly as the stable LSD rounds leave them.  No match masks, no wave-level round trips.
+constexpr uint32_t kPairLimit = 32;
+constexpr int kGroupBits = 10;
+constexpr int kGroups = 1 << kGroupBits;
 template <int NW, int KPT>
 __global__ void __launch_bounds__(NW * kWave)
 k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstart, uint32_t nbuckets, int low_bits,
@@ -645,14 +655,18 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
     constexpr int kThreads = NW * kWave;
     constexpr uint32_t kCap = kThreads * KPT;
     static_assert(kWave * KPT >= kRadix, "the match masks must fit the staging buffer");
+    static_assert(NW * kRadix >= kGroups && kGroups % (NW * kWave) == 0, "the group counts of the fast path live in cnt");
     __shared__ struct {
-        uint32_t cnt[NW][kRadix];
+        uint32_t cnt[NW][kRadix];                                   // LSD rounds: per-wave digit counts; fast path: the group counts
+        uint32_t gstart[kGroups];
         uint32_t part[2][NW];
+        uint32_t big;
         uint64_t stage[NW * kWave * KPT];
     } s;
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const unsigned long long mybit = 1ull << lane;
     const bool owner = tid < (unsigned)kRadix;
+    if (tid == 0) s.big = 0u;
     unsigned long long* const my_flags = reinterpret_cast<unsigned long long*>(s.stage) + w * kRadix;
     unsigned par = 0;
     if (owner) {
@@ -690,7 +704,57 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
         fetch(begin1, size1);
         const unsigned kpt = (size + kThreads - 1) / kThreads;                  // rounds in use, <= KPT
         const unsigned per = kpt * kWave;
-        for (int pass = 0; pass < 2 && size > 1; pass++) {
+        bool pairs = false;
+        if (size > 1) {
+            // group by the top bits of the low key part: place inside the group from a returning atomic, group starts by a scan
+            const int gbits = low_bits < kGroupBits ? low_bits : kGroupBits;
+            const int gshift = 32 + low_bits - gbits;
+            const unsigned gmask = (1u << gbits) - 1u;
+            uint32_t* const gcount = &s.cnt[0][0];
+#pragma unroll
+            for (int r = 0; r < KPT; r++)
+                if ((unsigned)r < kpt && w * per + r * kWave + lane < size) pos[r] = atomicAdd(&gcount[digit_of(key[r], gshift, gmask)], 1u);
+            __syncthreads();
+            constexpr int kPerThread = kGroups / kThreads;                      // consecutive groups per thread
+            uint32_t c[kPerThread], sum = 0, most = 0;
+#pragma unroll
+            for (int k = 0; k < kPerThread; k++) {
+                c[k] = gcount[tid * kPerThread + k];
+                sum += c[k];
+                most = dmax(most, c[k]);
+            }
+            uint32_t run = block_scan_excl_1b<NW>(sum, s.part, par);
+#pragma unroll
+            for (int k = 0; k < kPerThread; k++) {
+                s.gstart[tid * kPerThread + k] = run;
+                run += c[k];
+            }
+            if (most > kPairLimit) s.big = 1u;
+            __syncthreads();
+            pairs = s.big == 0u;
+            if (pairs) {
+#pragma unroll
+                for (int r = 0; r < KPT; r++)
+                    if ((unsigned)r < kpt && w * per + r * kWave + lane < size)
+                        s.stage[s.gstart[digit_of(key[r], gshift, gmask)] + pos[r]] = key[r];
+                __syncthreads();
+                for (unsigned q = tid; q < size; q += kThreads) {
+                    const uint64_t e = s.stage[q];
+                    const unsigned d = digit_of(e, gshift, gmask);
+                    const unsigned gb = s.gstart[d], ge = gb + gcount[d];
+                    unsigned rank = 0;
+                    for (unsigned j = gb; j < ge; j++) rank += s.stage[j] < e ? 1u : 0u;
+                    K[(uint64_t)begin + gb + rank] = (uint32_t)(e >> 32);
+                    V[(uint64_t)begin + gb + rank] = (uint32_t)e;
+                }
+            }
+            __syncthreads();                                                    // (stage and the counts are read to the end)
+#pragma unroll
+            for (int k = 0; k < kPerThread; k++) gcount[tid * kPerThread + k] = 0u;
+            if (tid == 0) s.big = 0u;
+            __syncthreads();
+        }
+        for (int pass = 0; pass < 2 && size > 1 && !pairs; pass++) {
             const int shift = 32 + 8 * pass;
             const int nb = pass == 0 ? (low_bits < 8 ? low_bits : 8) : low_bits - 8;
             if (nb <= 0) break;
@@ -736,7 +800,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
             const unsigned idx = w * per + r * kWave + lane;
-            if ((unsigned)r < kpt && idx < size) {
+            if ((unsigned)r < kpt && idx < size && !pairs) {
                 K[(uint64_t)begin + idx] = (uint32_t)(key[r] >> 32);
                 V[(uint64_t)begin + idx] = (uint32_t)key[r];
             }
@@ -893,7 +957,7 @@ static bool use_sweep(uint64_t m, int npass)
 
 // The hybrid route of a text-fed E64 sort with split output (see k_bucket_sort).  Applies to texts between
 // 3 * 2^24 and 2^28 suffixes whose key has at least 24 bits (below, a sub-bucket is too small to keep a workgroup
-// busy: 50 MB of DNA runs the same either way; 100 MB 1.92 against 2.24 ms, 200 MB 3.84 against 4.63); gives way
+// busy: 50 MB of DNA runs the same either way; 100 MB 1.78 against 2.24 ms, 200 MB 3.88 against 4.63); gives way
 // (returns 0 in *done) when a sub-bucket of the top 16 bits is larger than an LDS tile of 4096 -- skewed texts keep
 // the four-pass sort.
 //   SFX_HYBRID=0 switches it off; SFX_HYBRID_MIN=<suffixes> (tests) moves the lower bound; SFX_HYBRID_CAP=<elements>
@@ -942,8 +1006,8 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     SFX_TRY(run_pass("radix_scatter_u32", (double)m * 16.0, SrcE64{e0}, DstE64{e1}, m, bit_hi - 8, 255u, scr, 1, sweep, st));
     uint32_t* split_k = reinterpret_cast<uint32_t*>(e0);
     // geometry by the largest sub-bucket: 256 threads x 8 (8 workgroups per CU) is the fastest, measured on 100 MB
-    // of DNA 0.55 ms against 0.63 (256 x 16) and 0.80 (512 x 8; 512 x 16 did not pay at all); SFX_HYBRID_GEOM=1
-    // forces the larger one (tests)
+    // of DNA with the LSD rounds 0.55 ms against 0.63 (256 x 16) and 0.80 (512 x 8; 512 x 16 did not pay at all),
+    // 0.39 with the grouped all-pairs path; SFX_HYBRID_GEOM=1 forces the larger one (tests)
     static const int force_geom = [] { const char* e = getenv("SFX_HYBRID_GEOM"); return e ? atoi(e) : -1; }();
     const int geom = (host_max <= 2048 && force_geom != 1) ? 0 : 1;
     const unsigned grid = (unsigned)dmin<uint64_t>(kH16Bins, (uint64_t)grid_cap() * 2);

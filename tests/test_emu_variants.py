@@ -43,6 +43,11 @@ if os.environ.get("SFX_LCP_DIRECT_MIN"):
 if os.environ.get("SFX_HYBRID_MIN"):
     # keys of 32 bits (sigma 2, 4, 16) and of 30 bits (sigma 5: 14 low bits, second LDS digit of 6 bits); a text
     # whose two largest sub-buckets wrap the 16-bit counters of the histogram (detected from the total: four passes)
+    # four 8-symbol blocks, each followed by 8 random symbols: a few sub-buckets of ~900 suffixes whose low 16 key
+    # bits are spread out (the grouped all-pairs path of the LDS sort), next to sub-buckets of one or two
+    rngh = np.random.default_rng(5)
+    blocks = [bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for _ in range(4)]
+    texts.append(b"".join(blocks[int(k)] + bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for k in rngh.integers(0, 4, 3600)))
     texts += [_gen.uniform_bytes(30000, 5, 2, base=65).tobytes(), _gen.uniform_bytes(30000, 16, 3, base=65).tobytes(),
               _gen.uniform_bytes(40000, 2, 4, base=65).tobytes(), b"AC" * 70000 + _gen.dna(3000, seed=5).tobytes()]
     from suffix_amd import device as sdev
