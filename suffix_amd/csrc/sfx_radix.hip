@@ -658,7 +658,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
     static_assert(NW * kRadix >= kGroups && kGroups % (NW * kWave) == 0, "the group counts of the fast path live in cnt");
     __shared__ struct {
         uint32_t cnt[NW][kRadix];                                   // LSD rounds: per-wave digit counts; fast path: the group counts
-        uint32_t gstart[kGroups];
+        uint16_t gstart[kGroups];                                   // (sub-buckets hold at most 4096 elements)
         uint32_t part[2][NW];
         uint32_t big;
         uint64_t stage[NW * kWave * KPT];
@@ -726,7 +726,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
             uint32_t run = block_scan_excl_1b<NW>(sum, s.part, par);
 #pragma unroll
             for (int k = 0; k < kPerThread; k++) {
-                s.gstart[tid * kPerThread + k] = run;
+                s.gstart[tid * kPerThread + k] = (uint16_t)run;
                 run += c[k];
             }
             if (most > kPairLimit) s.big = 1u;
