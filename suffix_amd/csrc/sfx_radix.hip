@@ -956,8 +956,9 @@ static bool use_sweep(uint64_t m, int npass)
 }
 
 // The hybrid route of a text-fed E64 sort with split output (see k_bucket_sort).  Applies to texts between
-// 3 * 2^24 and 2^28 suffixes whose key has at least 24 bits (below, a sub-bucket is too small to keep a workgroup
-// busy: 50 MB of DNA runs the same either way; 100 MB 1.78 against 2.24 ms, 200 MB 3.88 against 4.63); gives way
+// 2^25 and 2^28 suffixes whose key has at least 24 bits (below, a sub-bucket is too small to keep a workgroup
+// busy: 20 MB of DNA 0.63 against 0.59 ms, 34 MB 0.82 against 0.88, 50 MB 1.04 against 1.23, 100 MB 1.78 against
+// 2.24, 200 MB 3.88 against 4.63); gives way
 // (returns 0 in *done) when a sub-bucket of the top 16 bits is larger than an LDS tile of 4096 -- skewed texts keep
 // the four-pass sort.
 //   SFX_HYBRID=0 switches it off; SFX_HYBRID_MIN=<suffixes> (tests) moves the lower bound; SFX_HYBRID_CAP=<elements>
@@ -969,7 +970,7 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
 {
     *done = false;
     static const int enabled = [] { const char* e = getenv("SFX_HYBRID"); return e ? atoi(e) : 1; }();
-    static const uint64_t min_m = [] { const char* e = getenv("SFX_HYBRID_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (3ull << 24); }();
+    static const uint64_t min_m = [] { const char* e = getenv("SFX_HYBRID_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 25); }();
     static const uint32_t cap = [] {
         const char* e = getenv("SFX_HYBRID_CAP");
         const uint32_t full = kBucketNW * kWave * kBucketKPT;
