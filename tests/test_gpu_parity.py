@@ -98,7 +98,7 @@ def test_dna_20mb_full_compare(eng, oracle):
 
 
 def test_hybrid_initial_sort_56mb(eng, oracle):
-    """>= 3 * 2^24 suffixes with a 32-bit key: two device-wide passes on the top 16 key bits, the 65536 sub-buckets
+    """>= 2^25 suffixes with a 32-bit key: two device-wide passes on the top 16 key bits, the 65536 sub-buckets
     sorted in LDS (k_bucket_sort); a skewed text whose largest sub-bucket does not fit takes the four-pass sort.
     Complete SA and LCP against the oracle for both, and the fused SA + LCP entry."""
     import torch
