@@ -168,7 +168,8 @@ struct SegSort {
     uint32_t* counters;
 };
 uint32_t seg_tile_elems(bool kv);
-int segmented_layout(const SegSort& q, uint32_t nseg, bool kv, hipStream_t st);
+// segments of at most skip_upto members are left out of the table (someone else sorts them)
+int segmented_layout(const SegSort& q, uint32_t nseg, bool kv, hipStream_t st, uint32_t skip_upto = 0);
 // one entry of the tile table (32 bytes): list positions [begin, begin + count) of one segment
 struct SegTileHost { uint32_t begin, count, seg_start, info, mseg, pad[3]; };
 int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg, uint64_t nlarge, uint32_t* V,

@@ -1152,12 +1152,13 @@ static bool seg_small()
 // counters: [0] tiles, [1] tiles of multi-tile segments, [2] multi-tile segments
 __global__ void __launch_bounds__(kBlock)
 k_seg_layout(const uint2* __restrict__ segs, uint32_t nseg, uint32_t tile_elems, SegTile* __restrict__ tiles,
-             uint32_t* __restrict__ counters)
+             uint32_t* __restrict__ counters, uint32_t skip_upto)
 {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= nseg) return;
     const uint32_t start = segs[k].x, size = segs[k].y;
     const uint32_t nt = (size + tile_elems - 1) / tile_elems;
+    if (size <= skip_upto) return;                                    // (sorted inside LDS by k_seg_single, sfx_tile.hip)
     const uint32_t t0 = atomicAdd(&counters[0], nt);
     if (nt == 1) {
         tiles[t0] = SegTile{start, size, start, 3u, 0u, {1u, size, 0u}};
@@ -1300,12 +1301,13 @@ static int seg_passes_kv(uint64_t* K0, uint32_t* V0, uint64_t* K1, uint32_t* V1,
 }
 
 // tile table of the segments q.segs[0, nseg) (device side; the tile count stays on the device)
-int segmented_layout(const SegSort& q, uint32_t nseg, bool kv, hipStream_t st)
+int segmented_layout(const SegSort& q, uint32_t nseg, bool kv, hipStream_t st, uint32_t skip_upto)
 {
     if (nseg == 0) return SFX_OK;
     SFX_HIP(hipMemsetAsync(q.counters, 0, 16 * sizeof(uint32_t), st));
     SFX_LAUNCH("seg_layout", (double)nseg * 24, k_seg_layout, (nseg + kBlock - 1) / kBlock, kBlock, st,
-               reinterpret_cast<const uint2*>(q.segs), nseg, seg_tile_elems(kv), reinterpret_cast<SegTile*>(q.tiles), q.counters);
+               reinterpret_cast<const uint2*>(q.segs), nseg, seg_tile_elems(kv), reinterpret_cast<SegTile*>(q.tiles), q.counters,
+               skip_upto);
     return SFX_OK;
 }
 

@@ -622,6 +622,121 @@ k_seg_gather(KeyFn keyfn, const uint32_t* __restrict__ V, const SegTileHost* __r
     }
 }
 
+// ---- large buckets that fit one tile: sorted inside LDS ------------------------------------------
+// A bucket of 1025 .. 11264 members went through the segmented sort like any other: key2 gathered into an
+// 8-byte element (one write), four device-wide passes of 16 bytes, flags and suffixes read back -- ~85 bytes per
+// member and round although the whole bucket fits a workgroup's LDS.  Here one workgroup takes the bucket:
+// suffixes in, key2 gathered, four stable LSD rounds on key2 in LDS (the tile engine of the radix pass: match-mask
+// ranking, block scan of the digit counts, reorder through the staging buffer), suffixes + flag bytes (+ fused LCP)
+// out: 13 bytes per member and round plus the gather.  Members are spread evenly over the waves (wave w owns
+// the 64 * kpt consecutive members from w * 64 * kpt, kpt = ceil(size / threads)), so (wave, round, lane) order is
+// list order and the sort is stable.  segs: the (start, size) list of the round; a workgroup takes the segments
+// whose size lies in (lo, hi].
+template <int NW, int KPT, class KeyFn>
+__global__ void __launch_bounds__(NW * kWave)
+k_seg_single(KeyFn keyfn, const uint2* __restrict__ segs, uint32_t nseg, uint32_t lo, uint32_t hi, uint32_t* __restrict__ V,
+             uint8_t* __restrict__ F8, LcpEmit emit)
+{
+    constexpr int kThreads = NW * kWave;
+    static_assert(kWave * KPT >= kRadixDev, "the match masks must fit the staging buffer");
+    static_assert(kThreads >= kRadixDev, "thread d owns digit d");
+    __shared__ struct {
+        uint32_t cnt[NW][kRadixDev];
+        uint32_t part[2][NW];
+        uint64_t stage[NW * kWave * KPT + 2];                         // (+ sentinel slots on either side of the sorted bucket)
+    } s;
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const unsigned long long mybit = 1ull << lane;
+    const bool owner = tid < (unsigned)kRadixDev;
+    uint64_t* const stage = s.stage + 1;
+    unsigned long long* const my_flags = reinterpret_cast<unsigned long long*>(stage) + w * kRadixDev;
+    unsigned par = 0;
+    if (owner) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t g = blockIdx.x; g < nseg; g += gridDim.x) {
+        const uint32_t begin = segs[g].x, size = segs[g].y;
+        if (size <= lo || size > hi) continue;                        // (uniform: the whole workgroup skips)
+        const unsigned kpt = (size + kThreads - 1) / kThreads;        // rounds in use, <= KPT
+        const unsigned per = kpt * kWave;
+        uint64_t key[KPT];
+        uint32_t pos[KPT];
+        {
+            uint32_t suf[KPT];
+#pragma unroll
+            for (int r = 0; r < KPT; r++) {
+                const unsigned idx = w * per + r * kWave + lane;
+                suf[r] = ((unsigned)r < kpt && idx < size) ? V[(uint64_t)begin + idx] : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < KPT; r++) {                           // (the gathers of all rounds in flight together)
+                const unsigned idx = w * per + r * kWave + lane;
+                key[r] = ((unsigned)r < kpt && idx < size) ? (((uint64_t)keyfn(suf[r]) << 32) | (uint64_t)suf[r]) : ~0ull;
+            }
+        }
+        for (int shift = 32; shift < 64; shift += 8) {
+#pragma unroll
+            for (int k = 0; k < kRadixDev / kWave; k++) my_flags[k * kWave + lane] = 0ull;
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < KPT; r++)
+                if ((unsigned)r < kpt) pos[r] = rank_round<true>((unsigned)(key[r] >> shift) & 255u, my_flags, s.cnt[w], mybit);
+            __syncthreads();
+            {
+                uint32_t c[NW], tile_count = 0;
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    c[k] = owner ? s.cnt[k][tid] : 0u;
+                    tile_count += c[k];
+                }
+                const uint32_t ex = block_scan_excl_1b<NW>(tile_count, s.part, par);
+                if (owner) {
+                    uint32_t run = ex;
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        s.cnt[k][tid] = run;
+                        run += c[k];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < KPT; r++)
+                if ((unsigned)r < kpt) stage[pos[r] + s.cnt[w][(unsigned)(key[r] >> shift) & 255u]] = key[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < KPT; r++)
+                if ((unsigned)r < kpt) key[r] = stage[w * per + r * kWave + lane];
+            if (owner) {
+#pragma unroll
+                for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0u;
+            }
+            __syncthreads();                                          // (the padding, key2 = ~0, is behind the members: slots >= size)
+        }
+        // stage[0, size) = the bucket in key2 order; flags and fused LCP from the neighbours in LDS
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            const unsigned idx = w * per + r * kWave + lane;
+            if ((unsigned)r < kpt && idx < size) {
+                const uint64_t e = key[r];
+                const uint32_t k2 = (uint32_t)(e >> 32);
+                const bool head = idx == 0 || (uint32_t)(stage[idx - 1] >> 32) != k2;
+                const bool last = idx + 1 == size || (uint32_t)(stage[idx + 1] >> 32) != k2;
+                const uint64_t p = (uint64_t)begin + idx;
+                V[p] = (uint32_t)e;
+                F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
+                if (emit.lcp && head && idx != 0) {                   // split from its predecessor in this round
+                    const uint64_t ep = stage[idx - 1];
+                    emit.lcp[emit.S[p]] = lcp_from_key2(emit, (uint32_t)(ep >> 32), k2, (uint32_t)ep, (uint32_t)e);
+                }
+            }
+        }
+        __syncthreads();                                              // (stage is read to the end before the next bucket's masks)
+    }
+}
+
 // ---- flag bytes -> flag words + partials (the role of k_groups_reduce after a key sort) ----
 __global__ void __launch_bounds__(kBlock)
 k_flags_reduce(const uint8_t* __restrict__ F8, uint64_t m, uint64_t chunk, uint32_t* __restrict__ part_head,
@@ -729,8 +844,27 @@ static int tile_round_impl(const KeyFn& keyfn, const TileRound& r, uint64_t m, h
     if ((nlarge == 0) != (nseg == 0)) return SFX_ERR_INTERNAL;
     if (stats) stats->tile_sorted += host[0];
     if (nseg > 0) {
-        SFX_TRY(segmented_layout(r.seg, nseg, false, st));
-        const unsigned grid = (unsigned)dmin<uint64_t>(nlarge / seg_tile_elems(false) + nseg, kMaxGrid);
+        // buckets that fit one tile of the segmented sort are sorted inside LDS by one workgroup each (SFX_SEG_SINGLE=0:
+        // development, everything through the segmented passes)
+        static const bool singles = [] { const char* e = getenv("SFX_SEG_SINGLE"); return !e || atoi(e) != 0; }();
+        const uint32_t te = seg_tile_elems(false);
+        // three size classes: 256 threads x 16, 1024 x 11 (one tile of the segmented sort), 1024 x 16 (the LDS holds no more);
+        // with the small tiles of the tests (4096) only the first
+        const uint32_t top = !singles ? 0u : (te > 4096u ? 16384u : 4096u);
+        if (singles) {
+            const uint2* segs = reinterpret_cast<const uint2*>(r.seg.segs);
+            const unsigned grid = (unsigned)dmin<uint64_t>(nseg, (uint64_t)grid_cap() * 2);
+            SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<4, 16, KeyFn>), grid, 4 * kWave, st, keyfn, segs, nseg, 0u, 4096u,
+                       r.V, r.F8, r.emit);
+            if (top > 4096u) {
+                SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<16, 11, KeyFn>), dmin(grid, grid_cap()), 16 * kWave, st,
+                           keyfn, segs, nseg, 4096u, 11264u, r.V, r.F8, r.emit);
+                SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<16, 16, KeyFn>), dmin(grid, grid_cap()), 16 * kWave, st,
+                           keyfn, segs, nseg, 11264u, top, r.V, r.F8, r.emit);
+            }
+        }
+        SFX_TRY(segmented_layout(r.seg, nseg, false, st, top));
+        const unsigned grid = (unsigned)dmin<uint64_t>(nlarge / te + nseg, kMaxGrid);
         SFX_LAUNCH("seg_gather", (double)nlarge * 16, (k_seg_gather<KeyFn>), grid, kBlock, st, keyfn, (const uint32_t*)r.V,
                    reinterpret_cast<const SegTileHost*>(r.seg.tiles), (const uint32_t*)r.seg.counters, r.EA);
         SFX_TRY(segmented_sort_e64(r.EA, r.EB, r.seg, nseg, nlarge, r.V, r.F8, st, stats, r.emit));
