@@ -584,32 +584,38 @@ k_hist16_text(PackedText t, int drop, uint64_t words_per_block, uint32_t* __rest
     uint32_t* out = partial + (uint64_t)blockIdx.x * kH16Words;
     for (unsigned i = tid; i < (unsigned)kH16Words; i += kH16Threads) out[i] = h[i];
 }
-// bin totals; workgroup j owns the 256 bins whose high digit is j: totals_hi[j] = their sum
+// bins[b] += the counts of a slice of the workgroups' partial histograms: workgroup x + 64 y takes the 1024 bins
+// from 1024 x (2 KB of every partial, one 8-byte load per thread) and the partials y, y + split, ...
+constexpr int kH16ReduceBins = 1024;
+constexpr unsigned kH16ReduceSplit = 8;
 __global__ void __launch_bounds__(kBlock)
-k_hist16_reduce(const uint32_t* __restrict__ partial, unsigned nblocks, uint32_t* __restrict__ bins,
-                uint32_t* __restrict__ totals_hi, uint32_t* __restrict__ max_bin)
+k_hist16_reduce(const uint32_t* __restrict__ partial, unsigned nblocks, uint32_t* __restrict__ bins)
 {
-    __shared__ uint32_t part[kWavesPerBlock];
-    const unsigned b = blockIdx.x * kBlock + threadIdx.x;
-    const unsigned sh = (b & 1u) * 16u;
-    uint32_t c = 0;
-    for (unsigned g = 0; g < nblocks; g++) c += (partial[(uint64_t)g * kH16Words + (b >> 1)] >> sh) & 0xFFFFu;
-    bins[b] = c;
-    uint32_t mx = c;
-    for (int d = 32; d >= 1; d >>= 1) mx = dmax(mx, __shfl_xor(mx, d));
-    if (lane_id() == 0) atomicMax(max_bin, mx);
-    uint32_t total;
-    (void)block_scan_add_excl(c, part, total);
-    if (threadIdx.x == 0) totals_hi[blockIdx.x] = total;
+    const unsigned bx = blockIdx.x % (kH16Bins / kH16ReduceBins), by = blockIdx.x / (kH16Bins / kH16ReduceBins);
+    const unsigned w0 = bx * (kH16ReduceBins / 2) + threadIdx.x * 2;              // this thread's two counter words = 4 bins
+    uint32_t c[4] = {0, 0, 0, 0};
+    for (unsigned g = by; g < nblocks; g += kH16ReduceSplit) {
+        const uint2 v = *reinterpret_cast<const uint2*>(partial + (uint64_t)g * kH16Words + w0);
+        c[0] += v.x & 0xFFFFu;
+        c[1] += v.x >> 16;
+        c[2] += v.y & 0xFFFFu;
+        c[3] += v.y >> 16;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (c[k]) atomicAdd(&bins[2 * w0 + k], c[k]);
 }
-// totals_lo[d] = sum over the high digits of bin (j, d); bins[b] -> first position of sub-bucket b (in place),
-// bins[65536] = m
+// totals_lo[d] = sum over the high digits of bin (j, d), totals_hi[j] = sum over the low digits; the largest bin and
+// the sum of all; bins[b] -> first position of sub-bucket b (in place), bins[65536] = m
 __global__ void __launch_bounds__(kH16Threads)
-k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uint32_t* __restrict__ total_out)
+k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uint32_t* __restrict__ totals_hi,
+              uint32_t* __restrict__ stat_out)
 {
     __shared__ uint32_t part[kH16Threads / kWave];
+    __shared__ uint32_t pmax[kH16Threads / kWave];
     __shared__ uint32_t lo[4][kRadix];
-    constexpr int kPer = kH16Bins / kH16Threads;
+    __shared__ uint32_t tsum[kH16Threads];
+    constexpr int kPer = kH16Bins / kH16Threads;                       // 64 consecutive bins per thread: a quarter of a high digit
     const unsigned tid = threadIdx.x;
     {
         // thread (q, d): the bins (j, d) with j = q mod 4
@@ -618,18 +624,29 @@ k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uin
         for (unsigned j = q; j < (unsigned)kRadix; j += 4) t += bins[j * kRadix + d];
         lo[q][d] = t;
     }
-    uint32_t v[kPer], sum = 0;
-    for (int j = 0; j < kPer; j++) { v[j] = bins[tid * kPer + j]; sum += v[j]; }
+    uint32_t v[kPer], sum = 0, most = 0;
+    for (int j = 0; j < kPer; j++) { v[j] = bins[tid * kPer + j]; sum += v[j]; most = dmax(most, v[j]); }
+    tsum[tid] = sum;
+    for (int d = 32; d >= 1; d >>= 1) most = dmax(most, __shfl_xor(most, d));
     // exclusive scan of one value per thread over 16 waves
     const uint32_t incl = wave_scan_add(sum);
     if (lane_id() == 63) part[wave_id()] = incl;
+    if (lane_id() == 0) pmax[wave_id()] = most;
     __syncthreads();
-    if (tid < (unsigned)kRadix) totals_lo[tid] = lo[0][tid] + lo[1][tid] + lo[2][tid] + lo[3][tid];
+    if (tid < (unsigned)kRadix) {
+        totals_lo[tid] = lo[0][tid] + lo[1][tid] + lo[2][tid] + lo[3][tid];
+        totals_hi[tid] = tsum[4 * tid] + tsum[4 * tid + 1] + tsum[4 * tid + 2] + tsum[4 * tid + 3];
+    }
     uint32_t base = 0;
     for (unsigned k = 0; k < wave_id(); k++) base += part[k];
     uint32_t run = base + incl - sum;
     for (int j = 0; j < kPer; j++) { bins[tid * kPer + j] = run; run += v[j]; }
-    if (tid == kH16Threads - 1) { bins[kH16Bins] = run; total_out[0] = run; }
+    if (tid == kH16Threads - 1) { bins[kH16Bins] = run; stat_out[1] = run; }
+    if (tid == 0) {
+        uint32_t mx = 0;
+        for (unsigned k = 0; k < (unsigned)(kH16Threads / kWave); k++) mx = dmax(mx, pmax[k]);
+        stat_out[0] = mx;
+    }
 }
 
 // One workgroup per sub-bucket [bstart[b], bstart[b + 1]) of X (sorted by its top 16 key bits): LSD sort by key
@@ -989,12 +1006,13 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     if (room == 0) return SFX_OK;
     Chunking ch = make_chunking(nwords, kH16Threads, (unsigned)dmin<uint64_t>(room, 256));
     SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
-    SFX_HIP(hipMemsetAsync(max_bin, 0, 2 * sizeof(uint32_t), st));
+    SFX_HIP(hipMemsetAsync(bins, 0, (kH16Bins + 64 + 2) * sizeof(uint32_t), st));         // (the counts and max_bin[0..1])
     SFX_LAUNCH("radix_hist16_text", (double)m * text.bits / 8.0, k_hist16_text, ch.blocks, kH16Threads, st, text, low_bits,
                ch.tiles_per_block * kH16Threads, partial);
-    SFX_LAUNCH("radix_hist16_reduce", (double)ch.blocks * kH16Words * 4, k_hist16_reduce, kH16Bins / kBlock, kBlock, st,
-               (const uint32_t*)partial, ch.blocks, bins, scr.totals + kRadix, max_bin);
-    SFX_LAUNCH("radix_hist16_scan", (double)kH16Bins * 8, k_hist16_scan, 1, kH16Threads, st, bins, scr.totals, max_bin + 1);
+    SFX_LAUNCH("radix_hist16_reduce", (double)ch.blocks * kH16Words * 4, k_hist16_reduce, (kH16Bins / kH16ReduceBins) * kH16ReduceSplit, kBlock, st,
+               (const uint32_t*)partial, ch.blocks, bins);
+    SFX_LAUNCH("radix_hist16_scan", (double)kH16Bins * 8, k_hist16_scan, 1, kH16Threads, st, bins, scr.totals, scr.totals + kRadix,
+               max_bin);
     uint32_t host_stat[2] = {0, 0};                            // largest sub-bucket, sum of all of them
     SFX_TRY(read_back(host_stat, max_bin, sizeof(host_stat), st));
     const uint32_t host_max = host_stat[0];
