@@ -174,7 +174,11 @@ __device__ __forceinline__ uint32_t packed_key32(const PackedText& t, uint64_t p
 {
     const uint64_t q = packed_word_index(t, p);
     const unsigned off = (unsigned)(p - q * (uint64_t)t.spw);
-    const uint64_t both = ((uint64_t)t.words[q] << t.kbits) | (uint64_t)t.words[q + 1];
+    // (the two words as ONE 8-byte load: a gather is 64 different lines to the wave, and every load instruction
+    // looks each of them up in the L1 again)
+    uint64_t pair;
+    __builtin_memcpy(&pair, t.words + q, 8);
+    const uint64_t both = ((pair & 0xFFFFFFFFull) << t.kbits) | (pair >> 32);
     const uint64_t mask = (1ull << t.kbits) - 1ull;
     return (uint32_t)((both >> (((unsigned)t.spw - off) * (unsigned)t.bits)) & mask);
 }
@@ -183,7 +187,9 @@ __device__ __forceinline__ uint64_t packed_key64(const PackedText& t, uint64_t p
 {
     const uint64_t q = packed_word_index(t, p);
     const unsigned off = (unsigned)(p - q * (uint64_t)t.spw);
-    const uint64_t w0 = t.words[q], w1 = t.words[q + 1], w2 = t.words[q + 2];
+    struct { uint32_t w[3]; } three;                                  // (one 12-byte load)
+    __builtin_memcpy(&three, t.words + q, 12);
+    const uint64_t w0 = three.w[0], w1 = three.w[1], w2 = three.w[2];
     const uint64_t mask = (1ull << t.kbits) - 1ull;
     const unsigned sh = ((unsigned)t.spw - off) * (unsigned)t.bits;
     const uint64_t a = (((w0 << t.kbits) | w1) >> sh) & mask;
