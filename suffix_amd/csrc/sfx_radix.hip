@@ -606,13 +606,18 @@ k_hist16_reduce(const uint32_t* __restrict__ partial, unsigned nblocks, uint32_t
         if (c[k]) atomicAdd(&bins[2 * w0 + k], c[k]);
 }
 // totals_lo[d] = sum over the high digits of bin (j, d), totals_hi[j] = sum over the low digits; the largest bin and
-// the sum of all; bins[b] -> first position of sub-bucket b (in place), bins[65536] = m
+// the sum of all; bins[b] -> first position of sub-bucket b (in place), bins[65536] = m.  Sub-buckets of more than
+// `cap` suffixes go on a list (bin, start, size, offset among the listed ones): stat_out = {largest bin, sum of all
+// bins, listed sub-buckets, their suffixes, suffixes in sub-buckets of more than `fast`}.
+struct OversizeEntry { uint32_t bin, start, size, off; };
+constexpr uint32_t kOversizeMax = 16384;
 __global__ void __launch_bounds__(kH16Threads)
 k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uint32_t* __restrict__ totals_hi,
-              uint32_t* __restrict__ stat_out)
+              uint32_t* __restrict__ stat_out, uint32_t cap, uint32_t fast, OversizeEntry* __restrict__ over)
 {
     __shared__ uint32_t part[kH16Threads / kWave];
     __shared__ uint32_t pmax[kH16Threads / kWave];
+    __shared__ uint64_t pover[kH16Threads / kWave];
     __shared__ uint32_t lo[4][kRadix];
     __shared__ uint32_t tsum[kH16Threads];
     constexpr int kPer = kH16Bins / kH16Threads;                       // 64 consecutive bins per thread: a quarter of a high digit
@@ -624,13 +629,22 @@ k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uin
         for (unsigned j = q; j < (unsigned)kRadix; j += 4) t += bins[j * kRadix + d];
         lo[q][d] = t;
     }
-    uint32_t v[kPer], sum = 0, most = 0;
-    for (int j = 0; j < kPer; j++) { v[j] = bins[tid * kPer + j]; sum += v[j]; most = dmax(most, v[j]); }
+    uint32_t v[kPer], sum = 0, most = 0, slow = 0;
+    uint64_t ov = 0;                                                  // listed sub-buckets << 32 | their suffixes
+    for (int j = 0; j < kPer; j++) {
+        v[j] = bins[tid * kPer + j];
+        sum += v[j];
+        most = dmax(most, v[j]);
+        if (v[j] > cap) ov += (1ull << 32) | (uint64_t)v[j];
+        if (v[j] > fast) slow += v[j];
+    }
+    if (slow) atomicAdd(&stat_out[4], slow);                          // (stat_out is zeroed by the caller)
     tsum[tid] = sum;
     for (int d = 32; d >= 1; d >>= 1) most = dmax(most, __shfl_xor(most, d));
-    // exclusive scan of one value per thread over 16 waves
+    // exclusive scans of one value per thread over 16 waves
     const uint32_t incl = wave_scan_add(sum);
-    if (lane_id() == 63) part[wave_id()] = incl;
+    const uint64_t ov_incl = wave_scan_add(ov);
+    if (lane_id() == 63) { part[wave_id()] = incl; pover[wave_id()] = ov_incl; }
     if (lane_id() == 0) pmax[wave_id()] = most;
     __syncthreads();
     if (tid < (unsigned)kRadix) {
@@ -638,18 +652,64 @@ k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uin
         totals_hi[tid] = tsum[4 * tid] + tsum[4 * tid + 1] + tsum[4 * tid + 2] + tsum[4 * tid + 3];
     }
     uint32_t base = 0;
-    for (unsigned k = 0; k < wave_id(); k++) base += part[k];
+    uint64_t ov_base = 0;
+    for (unsigned k = 0; k < wave_id(); k++) { base += part[k]; ov_base += pover[k]; }
     uint32_t run = base + incl - sum;
-    for (int j = 0; j < kPer; j++) { bins[tid * kPer + j] = run; run += v[j]; }
-    if (tid == kH16Threads - 1) { bins[kH16Bins] = run; stat_out[1] = run; }
+    uint64_t ov_run = ov_base + ov_incl - ov;
+    for (int j = 0; j < kPer; j++) {
+        bins[tid * kPer + j] = run;
+        if (v[j] > cap) {
+            const uint32_t at = (uint32_t)(ov_run >> 32);
+            if (at < kOversizeMax) over[at] = OversizeEntry{tid * kPer + (unsigned)j, run, v[j], (uint32_t)ov_run};
+            ov_run += (1ull << 32) | (uint64_t)v[j];
+        }
+        run += v[j];
+    }
+    if (tid == kH16Threads - 1) {
+        bins[kH16Bins] = run;
+        stat_out[1] = run;
+        stat_out[2] = (uint32_t)(ov_run >> 32);
+        stat_out[3] = (uint32_t)ov_run;
+    }
     if (tid == 0) {
         uint32_t mx = 0;
         for (unsigned k = 0; k < (unsigned)(kH16Threads / kWave); k++) mx = dmax(mx, pmax[k]);
         stat_out[0] = mx;
     }
 }
+// The listed sub-buckets, gathered into one array with (list index, low key bits) as the key -- sorted by the
+// device-wide sort as ONE array, they come back in place, sub-bucket by sub-bucket, in key order.
+__global__ void __launch_bounds__(kBlock)
+k_oversize_gather(const uint64_t* __restrict__ X, const OversizeEntry* __restrict__ over, uint32_t nover, int low_bits,
+                  uint64_t* __restrict__ T)
+{
+    const uint32_t lmask = (uint32_t)((1ull << low_bits) - 1ull);
+    for (uint32_t j = blockIdx.x; j < nover; j += gridDim.x) {
+        const OversizeEntry e = over[j];
+        for (uint32_t i = threadIdx.x; i < e.size; i += kBlock) {
+            const uint64_t x = X[(uint64_t)e.start + i];
+            const uint32_t key = (j << low_bits) | ((uint32_t)(x >> 32) & lmask);
+            T[(uint64_t)e.off + i] = ((uint64_t)key << 32) | (x & 0xFFFFFFFFull);
+        }
+    }
+}
+__global__ void __launch_bounds__(kBlock)
+k_oversize_return(const uint64_t* __restrict__ T, const OversizeEntry* __restrict__ over, uint32_t nover, int low_bits,
+                  uint32_t* __restrict__ K, uint32_t* __restrict__ V)
+{
+    const uint32_t lmask = (uint32_t)((1ull << low_bits) - 1ull);
+    for (uint32_t j = blockIdx.x; j < nover; j += gridDim.x) {
+        const OversizeEntry e = over[j];
+        for (uint32_t i = threadIdx.x; i < e.size; i += kBlock) {
+            const uint64_t x = T[(uint64_t)e.off + i];
+            K[(uint64_t)e.start + i] = (e.bin << low_bits) | ((uint32_t)(x >> 32) & lmask);
+            V[(uint64_t)e.start + i] = (uint32_t)x;
+        }
+    }
+}
 
-// One workgroup per sub-bucket [bstart[b], bstart[b + 1]) of X (sorted by its top 16 key bits): LSD sort by key
+// One workgroup per sub-bucket [bstart[b], bstart[b + 1]) of X (sorted by its top 16 key bits) whose size lies in
+// (lo, hi] -- three launches cover three size classes with three geometries: LSD sort by key
 // bits [0, low_bits) in LDS -- digit A = bits [0, 8), digit B = bits [8, low_bits) -- then keys and suffixes
 // leave as two sequential runs.  A bucket of `size` elements is spread evenly: wave w owns the 64 * kpt
 // consecutive elements from w * 64 * kpt, kpt = ceil(size / (64 NW)), so (wave, round, lane) order is memory
@@ -667,7 +727,7 @@ constexpr int kGroups = 1 << kGroupBits;
 template <int NW, int KPT>
 __global__ void __launch_bounds__(NW * kWave)
 k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstart, uint32_t nbuckets, int low_bits,
-              uint32_t* __restrict__ K, uint32_t* __restrict__ V)
+              uint32_t lo, uint32_t hi, uint32_t* __restrict__ K, uint32_t* __restrict__ V)
 {
     constexpr int kThreads = NW * kWave;
     constexpr uint32_t kCap = kThreads * KPT;
@@ -696,7 +756,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
     auto bounds = [&](uint32_t b, uint32_t& begin, uint32_t& size) {
         begin = 0; size = 0;
         if (b < nbuckets) { begin = bstart[b]; size = bstart[b + 1] - begin; }
-        if (size > kCap) size = 0;                                               // (oversized: the caller took the other route)
+        if (size <= lo || size > hi || size > kCap) size = 0;                    // (another size class, or sorted device-wide: k_oversize_*)
     };
     uint64_t nkey[KPT];
     auto fetch = [&](uint32_t begin, uint32_t size) {
@@ -975,12 +1035,14 @@ static bool use_sweep(uint64_t m, int npass)
 // The hybrid route of a text-fed E64 sort with split output (see k_bucket_sort).  Applies to texts between
 // 2^25 and 2^28 suffixes whose key has at least 24 bits (below, a sub-bucket is too small to keep a workgroup
 // busy: 20 MB of DNA 0.63 against 0.59 ms, 34 MB 0.82 against 0.88, 50 MB 1.04 against 1.23, 100 MB 1.78 against
-// 2.24, 200 MB 3.88 against 4.63); gives way
-// (returns 0 in *done) when a sub-bucket of the top 16 bits is larger than an LDS tile of 4096 -- skewed texts keep
-// the four-pass sort.
+// 2.24, 200 MB 3.88 against 4.63).  Sub-buckets of more than 16384 suffixes (skewed composition, repeats) do not
+// fit the LDS: they are gathered into one array keyed by (list index, low key bits), sorted by the ordinary
+// device-wide passes as ONE array and copied back.  The route is for evenly spread keys with a few outliers: when
+// more than 1/64 of the suffixes sit in sub-buckets above 4096 (or a 16-bit counter wrapped) it gives way (returns
+// 0 in *done) and the text keeps the four-pass sort.
 //   SFX_HYBRID=0 switches it off; SFX_HYBRID_MIN=<suffixes> (tests) moves the lower bound; SFX_HYBRID_CAP=<elements>
-//   (tests) lowers the largest sub-bucket accepted.
-constexpr int kBucketNW = 4, kBucketKPT = 16;                 // the largest geometry: sub-buckets of up to 4096 suffixes
+//   (tests) lowers the size from which a sub-bucket counts as oversized.
+constexpr int kBucketNW = 16, kBucketKPT = 16;                // the largest geometry: sub-buckets of up to 16384 suffixes
 static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, const RadixScratch& scr,
                                 hipStream_t st, sfx_build_stats* stats, const PackedText& text, uint32_t* split_v,
                                 uint32_t** split_k_out, bool* done)
@@ -998,44 +1060,75 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     if (!enabled || bit_lo != 32 || key_bits != text.kbits || key_bits < 24 || m != text.n || m < min_m || m > (1ull << 28))
         return SFX_OK;
     const int low_bits = key_bits - 16;
-    uint32_t* bins = scr.partial;                              // 65537 u32: counts, then sub-bucket starts
-    uint32_t* max_bin = scr.partial + kH16Bins + 64;
+    // counts / sub-bucket starts, statistics and the oversize list sit at the END of the histogram scratch: the
+    // device-wide sort of the oversized sub-buckets (<= 4 passes) uses its first half
+    constexpr uint64_t kReserve = 1u << 18;
+    uint32_t* bins = scr.partial + ((uint64_t)kMaxPasses * kRadix * kHistAllGrid - kReserve);     // 65537 u32
+    uint32_t* stat = bins + kH16Bins + 64;                     // largest sub-bucket, sum of all, oversized ones, their suffixes
+    OversizeEntry* over = reinterpret_cast<OversizeEntry*>(bins + kH16Bins + 128);
+    static_assert(kH16Bins + 128 + 4 * kOversizeMax <= kReserve, "the reserve holds bins, statistics and the oversize list");
     uint32_t* partial = reinterpret_cast<uint32_t*>(e1);       // [workgroups][65536]: e1 is idle until the second pass
     const uint64_t nwords = (m + (uint64_t)text.spw - 1) / (uint64_t)text.spw;
     const uint64_t room = m * sizeof(uint64_t) / (kH16Words * sizeof(uint32_t));     // partial histograms that fit e1
     if (room == 0) return SFX_OK;
     Chunking ch = make_chunking(nwords, kH16Threads, (unsigned)dmin<uint64_t>(room, 256));
     SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
-    SFX_HIP(hipMemsetAsync(bins, 0, (kH16Bins + 64 + 2) * sizeof(uint32_t), st));         // (the counts and max_bin[0..1])
+    SFX_HIP(hipMemsetAsync(bins, 0, (kH16Bins + 128) * sizeof(uint32_t), st));             // (the counts and the statistics)
     SFX_LAUNCH("radix_hist16_text", (double)m * text.bits / 8.0, k_hist16_text, ch.blocks, kH16Threads, st, text, low_bits,
                ch.tiles_per_block * kH16Threads, partial);
     SFX_LAUNCH("radix_hist16_reduce", (double)ch.blocks * kH16Words * 4, k_hist16_reduce, (kH16Bins / kH16ReduceBins) * kH16ReduceSplit, kBlock, st,
                (const uint32_t*)partial, ch.blocks, bins);
     SFX_LAUNCH("radix_hist16_scan", (double)kH16Bins * 8, k_hist16_scan, 1, kH16Threads, st, bins, scr.totals, scr.totals + kRadix,
-               max_bin);
-    uint32_t host_stat[2] = {0, 0};                            // largest sub-bucket, sum of all of them
-    SFX_TRY(read_back(host_stat, max_bin, sizeof(host_stat), st));
-    const uint32_t host_max = host_stat[0];
-    // a sub-bucket does not fit an LDS tile, or a 16-bit counter wrapped: four passes
-    if (host_max > cap || (uint64_t)host_stat[1] != m) return SFX_OK;
+               stat, cap, dmin(cap, 4096u), over);
+    uint32_t host_stat[5] = {0, 0, 0, 0, 0};
+    SFX_TRY(read_back(host_stat, stat, sizeof(host_stat), st));
+    const uint32_t host_max = host_stat[0], nover = host_stat[2];
+    const uint64_t nlarge = host_stat[3], nslow = host_stat[4];
+    // A 16-bit counter wrapped, or more than 1/64 of the text sits in sub-buckets of more than 4096 suffixes: four
+    // passes.  (Measured on 100 MB over {A, C, G, T} drawn 32/18/18/32 %: 15 % of the suffixes in sub-buckets of 4097 ..
+    // 16384 -- one workgroup per CU sorts them at 50 ps per suffix, five times the price of two device-wide passes --
+    // and 3.3 ms against 2.5; the device-wide sort of the oversized ones is latency-bound, ~0.3 ms however few they are.
+    // The route pays on evenly spread keys and tolerates a few outliers: repeats in an otherwise random-like text.)
+    if ((uint64_t)host_stat[1] != m || nover > kOversizeMax || nslow * 64 > m) return SFX_OK;
+    if (nover && (m + 1) / 2 + 32 + 2 * (nlarge + 32) > m) return SFX_OK;       // (tiny inputs of the tests: no room behind the keys)
     const bool sweep = true;
     SrcText32 tsrc = {text};
     SFX_TRY(run_pass("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), tsrc, DstE64{e0}, m, bit_hi - 16, 255u, scr, 0,
                      sweep, st));
     SFX_TRY(run_pass("radix_scatter_u32", (double)m * 16.0, SrcE64{e0}, DstE64{e1}, m, bit_hi - 8, 255u, scr, 1, sweep, st));
-    uint32_t* split_k = reinterpret_cast<uint32_t*>(e0);
-    // geometry by the largest sub-bucket: 256 threads x 8 (8 workgroups per CU) is the fastest, measured on 100 MB
-    // of DNA with the LSD rounds 0.55 ms against 0.63 (256 x 16) and 0.80 (512 x 8; 512 x 16 did not pay at all),
-    // 0.39 with the grouped all-pairs path; SFX_HYBRID_GEOM=1 forces the larger one (tests)
+    uint32_t* split_k = reinterpret_cast<uint32_t*>(e0);       // (the first half of e0; the oversized sub-buckets are sorted in the second)
+    const uint64_t* over_sorted = nullptr;
+    if (nover) {
+        uint64_t* T = e0 + (((m + 1) / 2 + 31) & ~uint64_t(31));       // (behind the m u32 keys of split_k)
+        uint64_t* T2 = T + ((nlarge + 31) & ~uint64_t(31));
+        const unsigned g = (unsigned)dmin<uint64_t>(nover, kMaxGrid);
+        SFX_LAUNCH("oversize_gather", (double)nlarge * 16, k_oversize_gather, g, kBlock, st, (const uint64_t*)e1, (const OversizeEntry*)over,
+                   nover, low_bits, T);
+        int in1 = 0;
+        SFX_TRY(radix_sort_e64(T, T2, nlarge, 32, 32 + low_bits + bits_for(nover > 1 ? nover - 1 : 1), scr.partial, st, &in1, stats,
+                               nullptr, nullptr, nullptr, 0));
+        over_sorted = in1 ? T2 : T;
+    }
+    // three size classes, three geometries: 256 threads x 8 (8 workgroups per CU) is the fastest -- measured on 100 MB
+    // of DNA with the LSD rounds 0.55 ms against 0.63 (256 x 16) and 0.80 (512 x 8), 0.39 with the grouped all-pairs
+    // path -- and takes the sub-buckets of up to 2048 suffixes; 256 x 16 those up to 4096; 1024 x 16 those up to 16384
+    // (what the LDS holds).  SFX_HYBRID_GEOM=1 / 2 (tests) gives everything to the second / third.
     static const int force_geom = [] { const char* e = getenv("SFX_HYBRID_GEOM"); return e ? atoi(e) : -1; }();
-    const int geom = (host_max <= 2048 && force_geom != 1) ? 0 : 1;
+    const uint32_t top = dmin(host_max, cap);                  // the largest sub-bucket the LDS sort takes
+    const uint32_t c1 = force_geom >= 1 ? 0u : dmin(2048u, cap), c2 = force_geom == 2 ? c1 : dmin(4096u, cap);
     const unsigned grid = (unsigned)dmin<uint64_t>(kH16Bins, (uint64_t)grid_cap() * 2);
-#define SFX_BUCKET_SORT(NW, KPT)                                                                                          \
-    SFX_LAUNCH("bucket_sort_lds", (double)m * 16.0, (k_bucket_sort<NW, KPT>), grid, NW * kWave, st, (const uint64_t*)e1,  \
-               (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, split_k, split_v)
-    if (geom == 0) SFX_BUCKET_SORT(4, 8);             // (the 8-ballot ranking instead of the LDS match masks: 0.64 against 0.56 ms)
-    else SFX_BUCKET_SORT(kBucketNW, kBucketKPT);
+#define SFX_BUCKET_SORT(NW, KPT, LO, HI, GRID)                                                                              \
+    SFX_LAUNCH("bucket_sort_lds", (double)m * 16.0, (k_bucket_sort<NW, KPT>), GRID, NW * kWave, st, (const uint64_t*)e1,    \
+               (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, (uint32_t)(LO), (uint32_t)(HI), split_k, split_v)
+    if (c1 > 0) SFX_BUCKET_SORT(4, 8, 0u, c1, grid);
+    if (c2 > c1 && top > c1) SFX_BUCKET_SORT(4, 16, c1, c2, grid);
+    if (cap > c2 && top > c2) SFX_BUCKET_SORT(16, 16, c2, cap, dmin(grid, grid_cap()));
 #undef SFX_BUCKET_SORT
+    if (nover) {
+        const unsigned g = (unsigned)dmin<uint64_t>(nover, kMaxGrid);
+        SFX_LAUNCH("oversize_return", (double)nlarge * 16, k_oversize_return, g, kBlock, st, over_sorted, (const OversizeEntry*)over, nover,
+                   low_bits, split_k, split_v);
+    }
     if (split_k_out) *split_k_out = split_k;
     if (stats) { stats->radix_passes += 2; stats->elements_sorted += 2 * m; }
     *done = true;

@@ -78,7 +78,7 @@ def test_suffix_tree_topology_and_doc_lookup(emu, oracle):
 
 
 def test_random_medium_sweep(emu, oracle):
-    _cases.random_medium_sweep(emu, oracle, iters=15, max_len=6000, seed=5)
+    _cases.random_medium_sweep(emu, oracle, iters=10, max_len=6000, seed=5)
 
 
 def test_fused_sa_lcp(emu, oracle):

@@ -41,15 +41,16 @@ if os.environ.get("SFX_LCP_DIRECT_MIN"):
         rep = body[1000:1000 + 90 + 40 * sigma].tobytes()
         texts.append(body.tobytes() + rep + b"a" + rep)
 if os.environ.get("SFX_HYBRID_MIN"):
-    # keys of 32 bits (sigma 2, 4, 16) and of 30 bits (sigma 5: 14 low bits, second LDS digit of 6 bits); a text
-    # whose two largest sub-buckets wrap the 16-bit counters of the histogram (detected from the total: four passes)
+    # keys of 32 bits (sigma 2, 4, 16) and of 30 bits (sigma 5: 14 low bits, second LDS digit of 6 bits).  (A wrapped
+    # 16-bit counter of the histogram needs 65536 equal prefixes in one workgroup's stretch: tests/test_gpu_parity.py
+    # and tests/asan_check.py.)
     # four 8-symbol blocks, each followed by 8 random symbols: a few sub-buckets of ~900 suffixes whose low 16 key
     # bits are spread out (the grouped all-pairs path of the LDS sort), next to sub-buckets of one or two
     rngh = np.random.default_rng(5)
     blocks = [bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for _ in range(4)]
     texts.append(b"".join(blocks[int(k)] + bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for k in rngh.integers(0, 4, 3600)))
     texts += [_gen.uniform_bytes(30000, 5, 2, base=65).tobytes(), _gen.uniform_bytes(30000, 16, 3, base=65).tobytes(),
-              _gen.uniform_bytes(40000, 2, 4, base=65).tobytes(), b"AC" * 70000 + _gen.dna(3000, seed=5).tobytes()]
+              _gen.uniform_bytes(40000, 2, 4, base=65).tobytes()]
     from suffix_amd import device as sdev
     for t in texts[:1]:                                 # the fused SA + LCP entry over the same initial sort
         import torch
@@ -57,17 +58,35 @@ if os.environ.get("SFX_HYBRID_MIN"):
         sa, lcp = sdev.build_sa_lcp(d, engine=eng)
         exp = oracle.sais(t)
         assert np.array_equal(sa.numpy().view(np.uint32), exp) and np.array_equal(lcp.numpy().view(np.uint32), oracle.lcp_kasai(t, exp))
-    eng.profile(True); eng.profile_reset()
-    SuffixTable(texts[0], engine=eng).table()
-    names = [r["name"] for r in eng.profile_report()]
-    eng.profile(False)
-    want = int(os.environ.get("SFX_HYBRID_CAP", "100000")) > 1000
-    assert ("bucket_sort_lds" in names) == want, names
+    # which route the first text takes (random DNA: no sub-bucket above a handful) and a text with three planted
+    # sub-buckets of ~130 suffixes (oversized under SFX_HYBRID_CAP=100: gathered, sorted device-wide, copied back)
+    planted = _gen.dna(70000, seed=3).tobytes() + b"".join(
+        blocks[int(k)] + bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for k in rngh.integers(0, 3, 400))
+    texts.append(planted)
+    def kernels_of(t):
+        eng.profile(True); eng.profile_reset()
+        SuffixTable(t, engine=eng).table()
+        names = [r["name"] for r in eng.profile_report()]
+        eng.profile(False)
+        return names
+    cap = int(os.environ.get("SFX_HYBRID_CAP", "100000"))
+    names = kernels_of(texts[0])
+    # (cap 3: 6 % of that text sits in sub-buckets of more than 3 suffixes -- above the 1/64 the route tolerates)
+    assert ("bucket_sort_lds" in names) == (cap > 10) and "oversize_gather" not in names, names
+    names = kernels_of(planted)                                       # 0.5 % of it in the three planted sub-buckets
+    assert ("bucket_sort_lds" in names) == (cap > 10) and ("oversize_gather" in names) == (10 < cap < 400), names
+    # most of the suffixes in oversized sub-buckets: the four-pass sort
+    skewed = np.frombuffer(b"ACGT", dtype=np.uint8)[rngh.choice(4, size=30000, p=[0.85, 0.05, 0.05, 0.05])].tobytes()
+    texts.append(skewed)
+    if cap < 400:
+        names = kernels_of(skewed)
+        assert "radix_hist16_text" in names and "bucket_sort_lds" not in names, names
 for t in texts:
     st = SuffixTable(t, engine=eng)
     exp = oracle.sais(t)
     assert np.array_equal(st.table(), exp), ("SA", len(t))
-    assert np.array_equal(st.lcp_lens(), oracle.lcp_quadratic(t, exp)), ("LCP", len(t))
+    want = oracle.lcp_kasai(t, exp) if len(t) > 50000 else oracle.lcp_quadratic(t, exp)     # (quadratic: hopeless on long periodic texts)
+    assert np.array_equal(st.lcp_lens(), want), ("LCP", len(t))
 if os.environ.get("SFX_LCP_DIRECT_MIN"):
     def lcp_kernels(t):
         st = SuffixTable(t, engine=eng)
@@ -106,10 +125,11 @@ VARIANTS = {
     # text rounds on 64-bit keys (opt-in): the 64-bit LDS sort and the key/value form of the segmented sort
     "text-key64": {"SFX_TEXT_KEY": "64"},
     "text-key64-small-tiles": {"SFX_TEXT_KEY": "64", "SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
-    # hybrid initial sort forced on small inputs; the larger LDS geometries; a cap that sends every text the other way
+    # hybrid initial sort forced on small inputs
     "hybrid-initial-sort": {"SFX_HYBRID_MIN": "1"},
-    "hybrid-initial-sort-multi-tile": {"SFX_HYBRID_MIN": "1", "SFX_MAX_GRID": "3", "SFX_HYBRID_GEOM": "1"},
-    "hybrid-initial-sort-cap": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_CAP": "3"},
+    # a few oversized sub-buckets (gathered, sorted device-wide, copied back), the 256 x 16 geometry, several sub-buckets
+    # per workgroup
+    "hybrid-initial-sort-oversized": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_CAP": "100", "SFX_MAX_GRID": "3", "SFX_HYBRID_GEOM": "1"},
     "index-directory-only": {"SFX_INDEX_TREE": "0"},
     # queries longer than the tree's keys listed for a second launch (batches of >= 4096 by default), with and
     # without the (opt-in) ordering of the batch

@@ -99,27 +99,37 @@ def test_dna_20mb_full_compare(eng, oracle):
 
 def test_hybrid_initial_sort_56mb(eng, oracle):
     """>= 2^25 suffixes with a 32-bit key: two device-wide passes on the top 16 key bits, the 65536 sub-buckets
-    sorted in LDS (k_bucket_sort); a skewed text whose largest sub-bucket does not fit takes the four-pass sort.
-    Complete SA and LCP against the oracle for both, and the fused SA + LCP entry."""
+    sorted in LDS (k_bucket_sort).  The same text with 20000 copies of one 16-mer planted has nine sub-buckets of
+    20000 suffixes (above what the LDS holds: gathered, sorted device-wide, copied back) and four of 5000 (the
+    1024-thread geometry); a skewed text has most of its suffixes in such sub-buckets and takes the four-pass sort,
+    and so does a text with a run that wraps two 16-bit counters of the histogram (noticed in its total).
+    Complete SA and LCP against the oracle for all three, through the separate entries and the fused SA + LCP entry."""
     import torch
     from suffix_amd import device as sdev
     n = 56_000_000
     rng = np.random.default_rng(12)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
     uniform = _gen.dna(n, seed=31)
-    skewed = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, size=n, p=[0.55, 0.05, 0.05, 0.35])]
-    for host, lds in ((uniform, True), (skewed, False)):
+    planted = uniform.copy()
+    block = np.concatenate([np.tile(letters[rng.integers(0, 4, 16)], (20000, 1)), letters[rng.integers(0, 4, (20000, 16))]], axis=1)
+    planted[1_000_000:1_000_000 + block.size] = block.reshape(-1)
+    skewed = letters[rng.choice(4, size=n, p=[0.55, 0.05, 0.05, 0.35])]
+    wrapped = uniform.copy()                                       # 70000 x "AC": two 16-bit counters of one workgroup's histogram wrap
+    wrapped[30_000_000:30_140_000] = np.tile(np.frombuffer(b"AC", dtype=np.uint8), 70000)
+    for host, lds, over in ((uniform, True, False), (planted, True, True), (skewed, False, False), (wrapped, False, False)):
         text = torch.from_numpy(np.ascontiguousarray(host)).cuda()
         eng.profile(True); eng.profile_reset()
         sa = sdev.build_sa(text)
         torch.cuda.synchronize()
         names = {r["name"] for r in eng.profile_report()}
         eng.profile(False)
-        assert "radix_hist16_text" in names and ("bucket_sort_lds" in names) == lds, names
+        assert "radix_hist16_text" in names and ("bucket_sort_lds" in names) == lds and ("oversize_gather" in names) == over, names
         exp = oracle.sais(host.tobytes())
         assert np.array_equal(sa.cpu().numpy().view(np.uint32), exp)
         sa2, lcp2 = sdev.build_sa_lcp(text)
         assert np.array_equal(sa2.cpu().numpy().view(np.uint32), exp)
         assert np.array_equal(lcp2.cpu().numpy().view(np.uint32), oracle.lcp_kasai(host.tobytes(), exp))
+        del text, sa, sa2, lcp2
 
 
 @pytest.mark.parametrize("sigma", [2, 5, 16])
