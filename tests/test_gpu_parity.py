@@ -114,8 +114,8 @@ def test_hybrid_initial_sort_56mb(eng, oracle):
     block = np.concatenate([np.tile(letters[rng.integers(0, 4, 16)], (20000, 1)), letters[rng.integers(0, 4, (20000, 16))]], axis=1)
     planted[1_000_000:1_000_000 + block.size] = block.reshape(-1)
     skewed = letters[rng.choice(4, size=n, p=[0.55, 0.05, 0.05, 0.35])]
-    wrapped = uniform.copy()                                       # 70000 x "AC": two 16-bit counters of one workgroup's histogram wrap
-    wrapped[30_000_000:30_140_000] = np.tile(np.frombuffer(b"AC", dtype=np.uint8), 70000)
+    wrapped = uniform.copy()                                       # 250000 x "AC": longer than two of the histogram's stretches (229376
+    wrapped[30_000_000:30_500_000] = np.tile(np.frombuffer(b"AC", dtype=np.uint8), 250000)   # positions): two 16-bit counters of a workgroup wrap
     for host, lds, over in ((uniform, True, False), (planted, True, True), (skewed, False, False), (wrapped, False, False)):
         text = torch.from_numpy(np.ascontiguousarray(host)).cuda()
         eng.profile(True); eng.profile_reset()
