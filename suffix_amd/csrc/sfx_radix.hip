@@ -629,14 +629,15 @@ k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uin
         for (unsigned j = q; j < (unsigned)kRadix; j += 4) t += bins[j * kRadix + d];
         lo[q][d] = t;
     }
-    uint32_t v[kPer], sum = 0, most = 0, slow = 0;
+    // (the 64 counts are read twice rather than kept: 1024 threads leave 128 registers each)
+    uint32_t sum = 0, most = 0, slow = 0;
     uint64_t ov = 0;                                                  // listed sub-buckets << 32 | their suffixes
     for (int j = 0; j < kPer; j++) {
-        v[j] = bins[tid * kPer + j];
-        sum += v[j];
-        most = dmax(most, v[j]);
-        if (v[j] > cap) ov += (1ull << 32) | (uint64_t)v[j];
-        if (v[j] > fast) slow += v[j];
+        const uint32_t v = bins[tid * kPer + j];
+        sum += v;
+        most = dmax(most, v);
+        if (v > cap) ov += (1ull << 32) | (uint64_t)v;
+        if (v > fast) slow += v;
     }
     if (slow) atomicAdd(&stat_out[4], slow);                          // (stat_out is zeroed by the caller)
     tsum[tid] = sum;
@@ -657,13 +658,14 @@ k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uin
     uint32_t run = base + incl - sum;
     uint64_t ov_run = ov_base + ov_incl - ov;
     for (int j = 0; j < kPer; j++) {
+        const uint32_t v = bins[tid * kPer + j];
         bins[tid * kPer + j] = run;
-        if (v[j] > cap) {
+        if (v > cap) {
             const uint32_t at = (uint32_t)(ov_run >> 32);
-            if (at < kOversizeMax) over[at] = OversizeEntry{tid * kPer + (unsigned)j, run, v[j], (uint32_t)ov_run};
-            ov_run += (1ull << 32) | (uint64_t)v[j];
+            if (at < kOversizeMax) over[at] = OversizeEntry{tid * kPer + (unsigned)j, run, v, (uint32_t)ov_run};
+            ov_run += (1ull << 32) | (uint64_t)v;
         }
-        run += v[j];
+        run += v;
     }
     if (tid == kH16Threads - 1) {
         bins[kH16Bins] = run;
