@@ -605,19 +605,17 @@ k_hist16_reduce(const uint32_t* __restrict__ partial, unsigned nblocks, uint32_t
     for (int k = 0; k < 4; k++)
         if (c[k]) atomicAdd(&bins[2 * w0 + k], c[k]);
 }
-// totals_lo[d] = sum over the high digits of bin (j, d), totals_hi[j] = sum over the low digits; the largest bin and
-// the sum of all; bins[b] -> first position of sub-bucket b (in place), bins[65536] = m.  Sub-buckets of more than
-// `cap` suffixes go on a list (bin, start, size, offset among the listed ones): stat_out = {largest bin, sum of all
-// bins, listed sub-buckets, their suffixes, suffixes in sub-buckets of more than `fast`}.
+// totals_lo[d] = sum over the high digits of bin (j, d), totals_hi[j] = sum over the low digits; bins[b] -> first
+// position of sub-bucket b (in place), bins[65536] = m.  stat_out (zeroed by the caller) = {largest bin, sum of all
+// bins, sub-buckets of more than `cap` suffixes, their suffixes, suffixes in sub-buckets of more than `fast`}.
 struct OversizeEntry { uint32_t bin, start, size, off; };
 constexpr uint32_t kOversizeMax = 16384;
 __global__ void __launch_bounds__(kH16Threads)
 k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uint32_t* __restrict__ totals_hi,
-              uint32_t* __restrict__ stat_out, uint32_t cap, uint32_t fast, OversizeEntry* __restrict__ over)
+              uint32_t* __restrict__ stat_out, uint32_t cap, uint32_t fast)
 {
     __shared__ uint32_t part[kH16Threads / kWave];
     __shared__ uint32_t pmax[kH16Threads / kWave];
-    __shared__ uint64_t pover[kH16Threads / kWave];
     __shared__ uint32_t lo[4][kRadix];
     __shared__ uint32_t tsum[kH16Threads];
     constexpr int kPer = kH16Bins / kH16Threads;                       // 64 consecutive bins per thread: a quarter of a high digit
@@ -629,23 +627,24 @@ k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uin
         for (unsigned j = q; j < (unsigned)kRadix; j += 4) t += bins[j * kRadix + d];
         lo[q][d] = t;
     }
-    // (the 64 counts are read twice rather than kept: 1024 threads leave 128 registers each)
-    uint32_t sum = 0, most = 0, slow = 0;
-    uint64_t ov = 0;                                                  // listed sub-buckets << 32 | their suffixes
-    for (int j = 0; j < kPer; j++) {
-        const uint32_t v = bins[tid * kPer + j];
-        sum += v;
-        most = dmax(most, v);
-        if (v > cap) ov += (1ull << 32) | (uint64_t)v;
-        if (v > fast) slow += v;
+    uint32_t v[kPer], sum = 0, most = 0;
+    {
+        uint32_t slow = 0, nover = 0, sover = 0;
+        for (int j = 0; j < kPer; j++) {
+            v[j] = bins[tid * kPer + j];
+            sum += v[j];
+            most = dmax(most, v[j]);
+            if (v[j] > fast) slow += v[j];
+            if (v[j] > cap) { nover++; sover += v[j]; }
+        }
+        if (slow) atomicAdd(&stat_out[4], slow);
+        if (nover) { atomicAdd(&stat_out[2], nover); atomicAdd(&stat_out[3], sover); }
     }
-    if (slow) atomicAdd(&stat_out[4], slow);                          // (stat_out is zeroed by the caller)
     tsum[tid] = sum;
     for (int d = 32; d >= 1; d >>= 1) most = dmax(most, __shfl_xor(most, d));
-    // exclusive scans of one value per thread over 16 waves
+    // exclusive scan of one value per thread over 16 waves
     const uint32_t incl = wave_scan_add(sum);
-    const uint64_t ov_incl = wave_scan_add(ov);
-    if (lane_id() == 63) { part[wave_id()] = incl; pover[wave_id()] = ov_incl; }
+    if (lane_id() == 63) part[wave_id()] = incl;
     if (lane_id() == 0) pmax[wave_id()] = most;
     __syncthreads();
     if (tid < (unsigned)kRadix) {
@@ -653,30 +652,41 @@ k_hist16_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ totals_lo, uin
         totals_hi[tid] = tsum[4 * tid] + tsum[4 * tid + 1] + tsum[4 * tid + 2] + tsum[4 * tid + 3];
     }
     uint32_t base = 0;
-    uint64_t ov_base = 0;
-    for (unsigned k = 0; k < wave_id(); k++) { base += part[k]; ov_base += pover[k]; }
+    for (unsigned k = 0; k < wave_id(); k++) base += part[k];
     uint32_t run = base + incl - sum;
-    uint64_t ov_run = ov_base + ov_incl - ov;
-    for (int j = 0; j < kPer; j++) {
-        const uint32_t v = bins[tid * kPer + j];
-        bins[tid * kPer + j] = run;
-        if (v > cap) {
-            const uint32_t at = (uint32_t)(ov_run >> 32);
-            if (at < kOversizeMax) over[at] = OversizeEntry{tid * kPer + (unsigned)j, run, v, (uint32_t)ov_run};
-            ov_run += (1ull << 32) | (uint64_t)v;
-        }
-        run += v;
-    }
-    if (tid == kH16Threads - 1) {
-        bins[kH16Bins] = run;
-        stat_out[1] = run;
-        stat_out[2] = (uint32_t)(ov_run >> 32);
-        stat_out[3] = (uint32_t)ov_run;
-    }
+    for (int j = 0; j < kPer; j++) { bins[tid * kPer + j] = run; run += v[j]; }
+    if (tid == kH16Threads - 1) { bins[kH16Bins] = run; stat_out[1] = run; }
     if (tid == 0) {
         uint32_t mx = 0;
         for (unsigned k = 0; k < (unsigned)(kH16Threads / kWave); k++) mx = dmax(mx, pmax[k]);
         stat_out[0] = mx;
+    }
+}
+// (only when there are any:) the list of the sub-buckets of more than `cap` suffixes, in bin order, from the starts
+__global__ void __launch_bounds__(kH16Threads)
+k_hist16_oversize(const uint32_t* __restrict__ bstart, uint32_t cap, OversizeEntry* __restrict__ over)
+{
+    __shared__ uint64_t pover[kH16Threads / kWave];
+    constexpr int kPer = kH16Bins / kH16Threads;
+    const unsigned tid = threadIdx.x;
+    uint64_t ov = 0;                                                  // listed sub-buckets << 32 | their suffixes
+    for (int j = 0; j < kPer; j++) {
+        const uint32_t b = tid * kPer + j, v = bstart[b + 1] - bstart[b];
+        if (v > cap) ov += (1ull << 32) | (uint64_t)v;
+    }
+    const uint64_t incl = wave_scan_add(ov);
+    if (lane_id() == 63) pover[wave_id()] = incl;
+    __syncthreads();
+    uint64_t run = incl - ov;
+    for (unsigned k = 0; k < wave_id(); k++) run += pover[k];
+    if (ov == 0) return;
+    for (int j = 0; j < kPer; j++) {
+        const uint32_t b = tid * kPer + j, start = bstart[b], v = bstart[b + 1] - start;
+        if (v > cap) {
+            const uint32_t at = (uint32_t)(run >> 32);
+            if (at < kOversizeMax) over[at] = OversizeEntry{b, start, v, (uint32_t)run};
+            run += (1ull << 32) | (uint64_t)v;
+        }
     }
 }
 // The listed sub-buckets, gathered into one array with (list index, low key bits) as the key -- sorted by the
@@ -1081,7 +1091,7 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     SFX_LAUNCH("radix_hist16_reduce", (double)ch.blocks * kH16Words * 4, k_hist16_reduce, (kH16Bins / kH16ReduceBins) * kH16ReduceSplit, kBlock, st,
                (const uint32_t*)partial, ch.blocks, bins);
     SFX_LAUNCH("radix_hist16_scan", (double)kH16Bins * 8, k_hist16_scan, 1, kH16Threads, st, bins, scr.totals, scr.totals + kRadix,
-               stat, cap, dmin(cap, 4096u), over);
+               stat, cap, dmin(cap, 4096u));
     uint32_t host_stat[5] = {0, 0, 0, 0, 0};
     SFX_TRY(read_back(host_stat, stat, sizeof(host_stat), st));
     const uint32_t host_max = host_stat[0], nover = host_stat[2];
@@ -1101,6 +1111,7 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     uint32_t* split_k = reinterpret_cast<uint32_t*>(e0);       // (the first half of e0; the oversized sub-buckets are sorted in the second)
     const uint64_t* over_sorted = nullptr;
     if (nover) {
+        SFX_LAUNCH("radix_hist16_oversize", (double)kH16Bins * 8, k_hist16_oversize, 1, kH16Threads, st, (const uint32_t*)bins, cap, over);
         uint64_t* T = e0 + (((m + 1) / 2 + 31) & ~uint64_t(31));       // (behind the m u32 keys of split_k)
         uint64_t* T2 = T + ((nlarge + 31) & ~uint64_t(31));
         const unsigned g = (unsigned)dmin<uint64_t>(nover, kMaxGrid);
