@@ -254,6 +254,14 @@ k_window_fix(PackedText t, uint32_t* __restrict__ totals)
     for (int p = 0; p < 4; p++) totals[p * kRadix + tid] = wcount - sub[p][tid];
 }
 
+// The same W from the hybrid route's histogram of 16-bit key prefixes when that route gives way: totals[256 + x] holds
+// the count of the 8-bit windows x at the positions [0, n); the 3 * 8/bits positions past the end see only padding.
+__global__ void __launch_bounds__(kBlock)
+k_window_from_hist16(uint32_t* __restrict__ totals, uint32_t tail_positions)
+{
+    totals[threadIdx.x] = totals[kRadix + threadIdx.x] + (threadIdx.x == 0 ? tail_positions : 0u);
+}
+
 // one workgroup per row: exclusive scan of the row in place, row total -> row_total.
 __global__ void __launch_bounds__(kBlock)
 k_radix_scan(uint32_t* __restrict__ hist, unsigned nblocks, uint32_t* __restrict__ row_total)
@@ -1057,9 +1065,10 @@ static bool use_sweep(uint64_t m, int npass)
 constexpr int kBucketNW = 16, kBucketKPT = 16;                // the largest geometry: sub-buckets of up to 16384 suffixes
 static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, const RadixScratch& scr,
                                 hipStream_t st, sfx_build_stats* stats, const PackedText& text, uint32_t* split_v,
-                                uint32_t** split_k_out, bool* done)
+                                uint32_t** split_k_out, bool* done, bool* windows_ready)
 {
     *done = false;
+    *windows_ready = false;
     static const int enabled = [] { const char* e = getenv("SFX_HYBRID"); return e ? atoi(e) : 1; }();
     static const uint64_t min_m = [] { const char* e = getenv("SFX_HYBRID_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 25); }();
     static const uint32_t cap = [] {
@@ -1101,8 +1110,20 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     // 16384 -- one workgroup per CU sorts them at 50 ps per suffix, five times the price of two device-wide passes --
     // and 3.3 ms against 2.5; the device-wide sort of the oversized ones is latency-bound, ~0.3 ms however few they are.
     // The route pays on evenly spread keys and tolerates a few outliers: repeats in an otherwise random-like text.)
-    if ((uint64_t)host_stat[1] != m || nover > kOversizeMax || nslow * 64 > m) return SFX_OK;
-    if (nover && (m + 1) / 2 + 32 + 2 * (nlarge + 32) > m) return SFX_OK;       // (tiny inputs of the tests: no room behind the keys)
+    const bool give_way = nover > kOversizeMax || nslow * 64 > m ||
+                          (nover && (m + 1) / 2 + 32 + 2 * (nlarge + 32) > m);   // (tiny inputs of the tests: no room behind the keys)
+    if ((uint64_t)host_stat[1] != m) return SFX_OK;
+    if (give_way) {
+        // the four-pass sort takes its digit totals from this histogram when its digits are whole symbols
+        // (prepare_sweep_windows would count the 8-bit windows again)
+        if (text.kbits == 32 && (8 % text.bits) == 0 && bit_hi == 64) {
+            SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
+            SFX_LAUNCH("radix_window_from_hist16", 0.0, k_window_from_hist16, 1, kBlock, st, scr.totals, (uint32_t)(3 * (8 / text.bits)));
+            SFX_LAUNCH("radix_window_fix", 0.0, k_window_fix, 1, kBlock, st, text, scr.totals);
+            *windows_ready = true;
+        }
+        return SFX_OK;
+    }
     const bool sweep = true;
     SrcText32 tsrc = {text};
     SFX_TRY(run_pass("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), tsrc, DstE64{e0}, m, bit_hi - 16, 255u, scr, 0,
@@ -1171,9 +1192,10 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
     const int npass = radix_pass_count(bit_lo, bit_hi);
     const bool sweep = use_sweep(m, npass);
     RadixScratch scr(scratch, m);
+    bool windows_ready = false;                                  // the digit totals of all passes are in place already
     if (sweep && text && split_v && npass >= 3) {
         bool done = false;
-        SFX_TRY(hybrid_sort_e64_text(e0, e1, m, bit_lo, bit_hi, scr, st, stats, *text, split_v, split_k_out, &done));
+        SFX_TRY(hybrid_sort_e64_text(e0, e1, m, bit_lo, bit_hi, scr, st, stats, *text, split_v, split_k_out, &done, &windows_ready));
         if (done) return SFX_OK;
     }
     SrcText32 tsrc = {text ? *text : PackedText{nullptr, 0, 0, 1, 0, 1.0}};
@@ -1183,6 +1205,8 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
         SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
         SFX_LAUNCH("radix_scan", (double)npass * kRadix * hist_blocks * 8, k_radix_scan, npass * kRadix, kBlock, st,
                    scr.partial, hist_blocks, scr.totals);
+    } else if (sweep && windows_ready) {
+        // (hybrid_sort_e64_text gave way and left the totals)
     } else if (sweep) {
         if (window_hist_applies(text, m, bit_lo, bit_hi)) SFX_TRY(prepare_sweep_windows(*text, scr, st));
         else if (text) SFX_TRY(prepare_sweep("radix_hist_all_text_u32", (double)m * text->bits / 8.0, tsrc, m, bit_lo, bit_hi, npass, scr, st));
