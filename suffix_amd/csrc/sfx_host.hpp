@@ -180,7 +180,11 @@ int segmented_sort_kv64(uint64_t* K0, uint32_t* V0, uint64_t* K1, uint32_t* V1, 
 // bits of idx, then a scatter whose writes stay inside a cache-sized window of `target`.
 // `tmp` is m u64 of scratch, `radix_scratch` as for the sorts.  Pays for 4n >> Infinity Cache.
 int scatter_pairs_u32(uint64_t* pairs, uint64_t* tmp, uint64_t m, uint64_t n, uint32_t* target,
-                      uint32_t* radix_scratch, hipStream_t st, sfx_build_stats* stats);
+                      uint32_t* radix_scratch, hipStream_t st, sfx_build_stats* stats, unsigned hist_blocks = 0);
+// the producer of the pairs may count the digits of the partitioning passes itself: bits [*lo_out, *nb_out) of the
+// suffix index, 8 per pass, into radix_scratch[(pass * 256 + digit) * workgroups + workgroup]; returns how many
+// workgroups at most (0: do not, the sort counts for itself)
+unsigned scatter_pairs_presort_hist(uint64_t m, uint64_t n, int* lo_out, int* nb_out);
 // from 2^27 entries (a 512 MB target) up; SFX_PARTITION_MIN=<entries> is a test hook
 inline uint64_t partitioned_scatter_min()
 {

@@ -1179,6 +1179,24 @@ unsigned radix_e64_presort_hist(uint64_t m, int bit_lo, int bit_hi)
     if (m == 0 || bit_hi <= bit_lo || m > 0xFFFFFFFFull) return 0;
     return use_sweep(m, radix_pass_count(bit_lo, bit_hi)) ? kHistAllGrid : 0u;
 }
+// the bits of the suffix index that scatter_pairs_u32 partitions by, and how many producer workgroups may count
+// them (0: the sort counts for itself)
+static int scatter_part_bits()
+{
+    static const int v = [] { const char* e = getenv("SFX_PARTITION_BITS"); int x = e ? atoi(e) : 24; return x >= 8 && x <= 24 ? x : 24; }();
+    return v;
+}
+unsigned scatter_pairs_presort_hist(uint64_t m, uint64_t n, int* lo_out, int* nb_out)
+{
+    const int nb = bits_for(n > 1 ? n - 1 : 1);
+    const int lo = nb > scatter_part_bits() ? nb - scatter_part_bits() : 0;
+    *lo_out = lo;
+    *nb_out = nb;
+    if (m == 0 || m > 0xFFFFFFFFull) return 0;
+    const int npass = radix_pass_count(32 + lo, 32 + nb);
+    if (!use_sweep(m, npass)) return 0;
+    return (unsigned)((uint64_t)kMaxPasses * kHistAllGrid / (unsigned)npass);   // [npass][256][workgroups] fits the partials
+}
 
 int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, uint32_t* scratch, hipStream_t st,
                    int* result_in_1, sfx_build_stats* stats, const PackedText* text, uint32_t* split_v,
@@ -1201,7 +1219,7 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
     SrcText32 tsrc = {text ? *text : PackedText{nullptr, 0, 0, 1, 0, 1.0}};
     if (sweep && hist_blocks && !text) {
         // the producer of e0 counted the digits (radix_e64_presort_hist): only the row sums are left
-        if (hist_blocks > kHistAllGrid) return SFX_ERR_INTERNAL;
+        if ((uint64_t)hist_blocks * (unsigned)npass > (uint64_t)kMaxPasses * kHistAllGrid) return SFX_ERR_INTERNAL;
         SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
         SFX_LAUNCH("radix_scan", (double)npass * kRadix * hist_blocks * 8, k_radix_scan, npass * kRadix, kBlock, st,
                    scr.partial, hist_blocks, scr.totals);
@@ -1529,17 +1547,18 @@ k_scatter_pairs(const uint64_t* __restrict__ pairs, uint64_t m, uint32_t* __rest
 }
 
 int scatter_pairs_u32(uint64_t* pairs, uint64_t* tmp, uint64_t m, uint64_t n, uint32_t* target,
-                      uint32_t* radix_scratch, hipStream_t st, sfx_build_stats* stats)
+                      uint32_t* radix_scratch, hipStream_t st, sfx_build_stats* stats, unsigned hist_blocks)
 {
     if (m == 0) return SFX_OK;
     const int nb = bits_for(n > 1 ? n - 1 : 1);
     // measured at n = 10^9 (ms, sort + scatter): direct scatter 44; 8 bits 50; 12 bits 52; 16 bits 37;
     // 20 bits (3 passes, 4 KB windows) 34; 24 bits (still 3 passes, 256-byte windows: the writes
     // coalesce into whole lines) 26
-    static const int part_bits = [] { const char* e = getenv("SFX_PARTITION_BITS"); int v = e ? atoi(e) : 24; return v >= 8 && v <= 24 ? v : 24; }();
+    const int part_bits = scatter_part_bits();
     const int lo = nb > part_bits ? nb - part_bits : 0;
     int in1 = 0;
-    SFX_TRY(radix_sort_e64(pairs, tmp, m, 32 + lo, 32 + nb, radix_scratch, st, &in1, stats, nullptr, nullptr, nullptr));
+    // (hist_blocks: the producer of the pairs counted the digits, scatter_pairs_presort_hist)
+    SFX_TRY(radix_sort_e64(pairs, tmp, m, 32 + lo, 32 + nb, radix_scratch, st, &in1, stats, nullptr, nullptr, nullptr, hist_blocks));
     const uint64_t* src = in1 ? tmp : pairs;
     unsigned grid = (unsigned)dmin<uint64_t>((m + kBlock - 1) / kBlock, kMaxGrid);
     SFX_LAUNCH("scatter_pairs", (double)m * 12, k_scatter_pairs, grid, kBlock, st, src, m, target);

@@ -713,10 +713,19 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                uint32_t* __restrict__ isa, uint32_t* __restrict__ S_next,
                uint32_t* __restrict__ V_next, uint32_t* __restrict__ G_next,
                uint32_t* __restrict__ R_next, int sa_in_place, uint64_t* __restrict__ rank_pairs,
-               const uint16_t* __restrict__ flags_in)
+               const uint16_t* __restrict__ flags_in, uint32_t* __restrict__ pair_hist, int pair_lo, int pair_nb)
 {
     __shared__ uint32_t part_m[2][kWavesPerBlock], part_a[2][kWavesPerBlock];
+    // pair_hist (with rank_pairs): digit counts of the passes that partition the pairs by suffix index (bits [pair_lo,
+    // pair_nb), 8 per pass, at most 3) -- counted here, where the pairs are made, instead of by a pass over them
+    constexpr int kPairPasses = 3;
+    __shared__ uint32_t ph[SUB == 1 ? kWavesPerBlock : 1][kPairPasses][kRadixDev];
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int pair_passes = pair_hist ? (pair_nb - pair_lo + 7) / 8 : 0;
+    if (SUB == 1 && pair_hist) {
+        for (unsigned i = tid; i < (unsigned)(kWavesPerBlock * kPairPasses * kRadixDev); i += kBlock) (&ph[0][0][0])[i] = 0u;
+        __syncthreads();
+    }
     uint64_t begin = (uint64_t)blockIdx.x * chunk;
     uint64_t end = begin + chunk;
     if (end > m) end = m;
@@ -821,8 +830,18 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                         if (isa) {
                             // large texts: (suffix, rank) pairs out in stream order, scattered afterwards
                             // through a partitioning pass (scatter_pairs_u32) instead of n random writes
-                            if (rank_pairs) rank_pairs[ib + j] = ((uint64_t)suffix[j] << 32) | (uint64_t)head_slot[j];
-                            else isa[suffix[j]] = head_slot[j];
+                            if (rank_pairs) {
+                                rank_pairs[ib + j] = ((uint64_t)suffix[j] << 32) | (uint64_t)head_slot[j];
+                                if (SUB == 1 && pair_hist) {
+#pragma unroll
+                                    for (int p = 0; p < kPairPasses; p++) {
+                                        const int sh = pair_lo + 8 * p, nbits = pair_nb - sh < 8 ? pair_nb - sh : 8;
+                                        if (p < pair_passes) atomicAdd(&ph[w][p][(suffix[j] >> sh) & ((1u << nbits) - 1u)], 1u);
+                                    }
+                                }
+                            } else {
+                                isa[suffix[j]] = head_slot[j];
+                            }
                         }
                         if (keep) {
                             if (R_next) R_next[run_keep] = head_slot[j];
@@ -839,6 +858,15 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         }
         c_head = dmax(c_head, tot_m);
         c_keep += tot_a;
+    }
+    if (SUB == 1 && pair_hist) {
+        __syncthreads();
+        for (int p = 0; p < pair_passes; p++) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int k = 0; k < kWavesPerBlock; k++) c += ph[k][p][tid];
+            pair_hist[((uint64_t)p * kRadixDev + tid) * gridDim.x + blockIdx.x] = c;
+        }
     }
 }
 
@@ -1181,18 +1209,26 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
         pairs_tmp = k_in_0 ? b.K0 : b.K1;
     }
     Chunking ch = make_chunking(m, kApplyTile);
+    // the digit counts of the passes that partition the pairs are taken where the pairs are made
+    uint32_t* pair_hist = nullptr;
+    int pair_lo = 0, pair_nb = 0;
+    unsigned pair_blocks = 0;
+    if (pairs) {
+        const unsigned most = scatter_pairs_presort_hist(m, n, &pair_lo, &pair_nb);
+        if (most && ch.blocks <= most && (pair_nb - pair_lo + 7) / 8 <= 3) { pair_hist = b.hist; pair_blocks = ch.blocks; }
+    }
     const char* name = sizeof(KeyT) == 4 ? "groups_apply_u32" : "groups_apply_u64";
     const double algo = (double)m * (0.25 + (sa_in_place ? 0 : 8) + (isa ? 4 : 0) + (S ? 4 : 0));
     uint32_t* sa_arg = sa_in_place ? (uint32_t*)nullptr /* V is the SA */ : sa;
     if (sa_in_place && !isa && kept * kSparseApplyDivisor <= m)
         SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, kApplySub>), ch.blocks, kBlock, st, K, V, S, m,
                    ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
-                   b.G, R_next, 1, pairs, (const uint16_t*)b.F);
+                   b.G, R_next, 1, pairs, (const uint16_t*)b.F, (uint32_t*)nullptr, 0, 0);
     else
         SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, 1>), ch.blocks, kBlock, st, K, V, S, m,
                    ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
-                   b.G, R_next, sa_mode, pairs, (const uint16_t*)b.F);
-    if (pairs) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, m, n, isa, b.hist, st, &stats));
+                   b.G, R_next, sa_mode, pairs, (const uint16_t*)b.F, pair_hist, pair_lo, pair_nb);
+    if (pairs) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, m, n, isa, b.hist, st, &stats, pair_blocks));
     return SFX_OK;
 }
 
