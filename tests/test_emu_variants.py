@@ -49,8 +49,8 @@ if os.environ.get("SFX_HYBRID_MIN"):
     rngh = np.random.default_rng(5)
     blocks = [bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for _ in range(4)]
     texts.append(b"".join(blocks[int(k)] + bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for k in rngh.integers(0, 4, 3600)))
-    texts += [_gen.uniform_bytes(30000, 5, 2, base=65).tobytes(), _gen.uniform_bytes(30000, 16, 3, base=65).tobytes(),
-              _gen.uniform_bytes(40000, 2, 4, base=65).tobytes()]
+    texts += [_gen.uniform_bytes(20000, 5, 2, base=65).tobytes(), _gen.uniform_bytes(20000, 16, 3, base=65).tobytes(),
+              _gen.uniform_bytes(25000, 2, 4, base=65).tobytes()]
     from suffix_amd import device as sdev
     for t in texts[:1]:                                 # the fused SA + LCP entry over the same initial sort
         import torch
