@@ -6,7 +6,7 @@ same C ABI.  Not part of the pytest suite (several minutes); run by hand after k
     make -C tests/emu asan
     LD_PRELOAD=$(gcc -print-file-name=libasan.so) \\
     ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 \\
-    SFX_LCP_DIRECT_MIN=8 python tests/asan_check.py            # add SFX_PARTITION_MIN=1 SFX_MAX_GRID=3 SFX_QUERY_PHASE_MIN=1 for the variants
+    SFX_LCP_DIRECT_MIN=8 python tests/asan_check.py            # variants: add SFX_PARTITION_MIN=1 SFX_MAX_GRID=3 SFX_QUERY_PHASE_MIN=1 SFX_HYBRID_MIN=1 [SFX_HYBRID_CAP=100]
 """
 import os
 import sys
@@ -53,3 +53,14 @@ print("index queries ok")
 _cases.suffix_tree_topology(eng, oracle)
 _cases.fused_lcp_tails(eng, oracle, iters=6)
 print("tree + fused lcp ok")
+# large buckets of the refinement rounds: the three LDS size classes of k_seg_single (2000, 5000 and 12000 copies of
+# one word) and, with SFX_PARTITION_MIN=1, rank rounds whose pair histogram is counted inside groups_apply
+rng = np.random.default_rng(4)
+def planted(copies, alphabet, wlen, tail):
+    w = bytes(rng.choice(list(alphabet), wlen).tolist())
+    return b"".join(w + bytes(rng.choice(list(alphabet), tail).tolist()) for _ in range(copies))
+for t in (planted(5000, b"ACGT", 16, 20) + planted(2000, b"ACGT", 16, 24), planted(12000, b"ACGT", 16, 12),
+          b"AAAAAAAAAAAAAAAAAAAAAAAC" * 600 + _gen.english_like(15000, seed=3).tobytes() * 3):
+    st = SuffixTable(t, engine=eng)
+    assert np.array_equal(st.table(), oracle.sais(t))
+print("large buckets + rank rounds ok")
