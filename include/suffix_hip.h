@@ -246,6 +246,7 @@ typedef struct {
     uint64_t large_sorted;    /* elements of buckets too large for LDS, summed over rounds        */
     uint32_t text_rounds;     /* refinement rounds keyed by text symbols                          */
     uint32_t rank_rounds;     /* refinement rounds keyed by ranks (prefix doubling)               */
+    uint64_t deep_gathers;    /* 64-bit key gathers of the deep text rounds (one random line each) */
 } sfx_build_stats;
 void sfx_last_build_stats(sfx_build_stats* out);
 

@@ -32,7 +32,8 @@ class BuildStats(ctypes.Structure):
                 ("symbols_per_key", _u32), ("rounds", _u32), ("reserved", _u32),
                 ("active_after_initial", _u64), ("radix_passes", _u64),
                 ("elements_sorted", _u64), ("small_bucket_resolved", _u64),
-                ("tile_sorted", _u64), ("large_sorted", _u64), ("text_rounds", _u32), ("rank_rounds", _u32)]
+                ("tile_sorted", _u64), ("large_sorted", _u64), ("text_rounds", _u32), ("rank_rounds", _u32),
+                ("deep_gathers", _u64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}

@@ -219,7 +219,7 @@ static int index_build_directory(sfx_index* ix, hipStream_t st)
     if (rc != SFX_OK) return rc;
     if (bad) return SFX_ERR_ARG;
     // SFX_INDEX_TREE=0 (development): directory only
-    static const bool want_tree = [] { const char* e = getenv("SFX_INDEX_TREE"); return !e || atoi(e) != 0; }();
+    static const bool want_tree = [] { const char* e = dev_env("SFX_INDEX_TREE"); return !e || atoi(e) != 0; }();
     if (want_tree && hipMalloc((void**)&ix->d_tree, key_tree_words(ix->n) * sizeof(uint64_t)) == hipSuccess) {
         rc = key_tree_build_dev(ix->d_text, ix->n, ix->d_sa, ix->d_tree, ix->tree_off, &ix->tree_levels, st);
         if (rc != SFX_OK) return rc;
@@ -453,7 +453,7 @@ int sfx_index_query_dev(const sfx_index* ix, const uint8_t* d_qbytes, const uint
         // SFX_QUERY_ORDER=1 (development): answer large batches in the order of their first 8 bytes, so that
         // neighbouring lanes share tree nodes and probes.  Measured on config 5's 10^6 queries: the search kernel
         // 1.39 -> 1.23 ms, the 8-pass sort of the (key, query) pairs 0.24 ms -- not worth it, off by default
-        static const bool want_order = [] { const char* e = getenv("SFX_QUERY_ORDER"); return e && atoi(e) != 0; }();
+        static const bool want_order = [] { const char* e = dev_env("SFX_QUERY_ORDER"); return e && atoi(e) != 0; }();
         // per-thread scratch (the list of queries that go on to phase 2; the ordering), kept across calls (no
         // allocation, no synchronisation on the hot path); work queued on another stream may still be using it
         // when the thread switches streams: drain that one first.  Without it the batch is answered in one phase.

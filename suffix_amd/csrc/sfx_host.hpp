@@ -55,6 +55,16 @@ struct ArenaSizer {
     template <class T> void take(uint64_t count) { used += (count * sizeof(T) + 255) & ~uint64_t(255); }
 };
 
+// ---- development hooks -----------------------------------------------------------
+// The SFX_* environment knobs (small tiles for the emulator, A/B switches for lab runs) exist only in builds
+// made with -DSFX_DEV_HOOKS: the kernel-logic emulator (tests/emu) and libsuffix_hip_dev.so (`make dev`).
+// The shipped libsuffix_hip.so reads no environment variable: its routes depend on (alphabet, n) alone.
+#ifdef SFX_DEV_HOOKS
+inline const char* dev_env(const char* name) { return getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#endif
+
 // ---- launch geometry -----------------------------------------------------------
 // Streaming kernels use a fixed-size grid of persistent workgroups, each owning a
 // contiguous chunk (256 CUs x 8 resident 256-thread workgroups = 2048), so
@@ -73,7 +83,7 @@ struct Chunking {
 inline unsigned grid_cap()
 {
     static const unsigned cap = [] {
-        const char* e = getenv("SFX_MAX_GRID");
+        const char* e = dev_env("SFX_MAX_GRID");
         int v = e ? atoi(e) : 0;
         return (v >= 1 && v <= (int)kMaxGrid) ? (unsigned)v : kMaxGrid;
     }();
@@ -173,7 +183,8 @@ int segmented_layout(const SegSort& q, uint32_t nseg, bool kv, hipStream_t st, u
 // one entry of the tile table (32 bytes): list positions [begin, begin + count) of one segment
 struct SegTileHost { uint32_t begin, count, seg_start, info, mseg, pad[3]; };
 int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg, uint64_t nlarge, uint32_t* V,
-                       uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit);
+                       uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit, uint16_t* Hd = nullptr,
+                       uint32_t wsym = 0);
 int segmented_sort_kv64(uint64_t* K0, uint32_t* V0, uint64_t* K1, uint32_t* V1, int npass, const SegSort& q, uint32_t nseg,
                         uint64_t nlarge, uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit);
 // target[idx] = val for m (idx << 32 | val) pairs, idx < n: one partitioning pass on the top
@@ -189,7 +200,7 @@ unsigned scatter_pairs_presort_hist(uint64_t m, uint64_t n, int* lo_out, int* nb
 inline uint64_t partitioned_scatter_min()
 {
     static const uint64_t v = [] {
-        const char* e = getenv("SFX_PARTITION_MIN");
+        const char* e = dev_env("SFX_PARTITION_MIN");
         long long x = e ? atoll(e) : 0;
         return x > 0 ? (uint64_t)x : (1ull << 27);
     }();
@@ -225,16 +236,21 @@ constexpr uint32_t kLcpBoundFlag = 0x80000000u;
 // may imitate the smallest symbol: when that is what sa is (n - sa < common prefix of the keys), the value depends
 // on which member the class's own resolution puts last, and the pair is left pending (decided on the text once
 // the suffix array is final).  sb's own length caps the value for good.
-__device__ __forceinline__ uint32_t lcp_from_key2(const LcpEmit& L, uint32_t ka, uint32_t kb, uint32_t sa, uint32_t sb)
+// (depth: symbols the two suffixes' bucket shares -- L.h in a rank round, the bucket's own in a deep text round)
+__device__ __forceinline__ uint32_t lcp_from_key2_at(const LcpEmit& L, uint32_t depth, uint32_t ka, uint32_t kb, uint32_t sa, uint32_t sb)
 {
     if (L.rank_mode) return kLcpBoundFlag | L.h;
     const uint32_t la = L.n - sa, lb = L.n - sb;
     if (!(ka & kb & 0x80000000u)) return la < lb ? la : lb;   // one of them ends before offset h (a class of its own): the shorter is a prefix
     const uint32_t x = ka ^ kb;                          // (!= 0: different classes)
     const uint32_t lz = (uint32_t)__clz((int)x) - (32u - (uint32_t)L.field_bits);
-    const uint32_t v = L.h + ((lz * L.inv_bits) >> 16);
-    if (v > la) return kLcpBoundFlag | L.h;
+    const uint32_t v = depth + ((lz * L.inv_bits) >> 16);
+    if (v > la) return kLcpBoundFlag | depth;
     return v < lb ? v : lb;
+}
+__device__ __forceinline__ uint32_t lcp_from_key2(const LcpEmit& L, uint32_t ka, uint32_t kb, uint32_t sa, uint32_t sb)
+{
+    return lcp_from_key2_at(L, L.h, ka, kb, sa, sb);
 }
 __device__ __forceinline__ uint32_t lcp_from_key2_64(const LcpEmit& L, uint64_t ka, uint64_t kb, uint32_t sa, uint32_t sb)
 {
@@ -246,16 +262,20 @@ __device__ __forceinline__ uint32_t lcp_from_key2_64(const LcpEmit& L, uint64_t 
     if (v > la) return kLcpBoundFlag | L.h;
     return v < lb ? v : lb;
 }
+constexpr unsigned kDeepSlotWords = 1024 * 8;
 struct TileRound {
     LcpEmit emit;
     const uint32_t* G;
     uint32_t* V;
     uint8_t* F8;                  // m bytes (+ 8), scratch
+    uint16_t* Hd;                 // deep text rounds: symbols the members of p's bucket share, per list position (in / out)
+    uint32_t wsym;                // ... and what a split by the large-bucket path adds to it (text_round_symbols)
     uint16_t* F;
     uint32_t* part_head; uint32_t* part_keep; uint32_t* part_ghead;
     uint32_t* block_counts;       // kMaxGrid
     uint32_t* totals;
-    unsigned long long* counters; // 2
+    unsigned long long* counters; // 4
+    unsigned long long* deep_slots; // kDeepSlotWords: per-wave-class counter lines of the deep text rounds
     uint64_t* EA; uint64_t* EB;   // large buckets: m u64 each (key2 << 32 | suffix at the list positions, ping-pong;
                                   // 64-bit text keys: the key arrays, values ping-pong between V and V_other)
     uint32_t* V_other;
@@ -264,6 +284,11 @@ struct TileRound {
 int tile_round_text(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
                     sfx_build_stats* stats);
 LcpEmit make_lcp_emit(uint32_t* lcp, const uint32_t* S, const PackedText& pt, uint64_t h, bool rank_mode);
+// deep text round (sfx_tile.hip): buckets of a few hundred members are finished inside one wave, each from its own
+// depth r.Hd (deep_text_symbols(pt) symbols per gather); larger ones are split by their next text_round_symbols(pt) symbols
+int deep_text_symbols(const PackedText& pt);
+inline int text_round_symbols(const PackedText& pt) { return pt.kbits == 32 ? pt.spw - 1 : pt.spw; }
+int deep_round_text(const PackedText& pt, const TileRound& r, uint64_t m, hipStream_t st, sfx_build_stats* stats);
 // text round on 64-bit keys: text_key64_symbols(pt) symbols per round
 int text_key64_symbols(const PackedText& pt);
 int tile_round_text64(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,

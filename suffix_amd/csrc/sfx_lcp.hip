@@ -466,7 +466,7 @@ int widen_u32_to_u64_dev(const uint32_t* d_in, uint64_t count, uint64_t* d_out, 
 static uint64_t direct_lcp_min()
 {
     static const uint64_t v = [] {
-        const char* e = getenv("SFX_LCP_DIRECT_MIN");
+        const char* e = dev_env("SFX_LCP_DIRECT_MIN");
         long long x = e ? atoll(e) : 0;
         return x >= 8 ? (uint64_t)x : kDirectMinN;              // (the counters borrow 16 bytes of the 4n Phi array)
     }();

@@ -812,7 +812,7 @@ int key_tree_build_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, 
 uint64_t query_two_phase_min()
 {
     static const uint64_t v = [] {
-        const char* e = getenv("SFX_QUERY_PHASE_MIN");
+        const char* e = dev_env("SFX_QUERY_PHASE_MIN");
         return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)4096;
     }();
     return v;
@@ -842,7 +842,7 @@ int query_batch_tree_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa
     t.n = n;
     const unsigned grid = (unsigned)dmin<uint64_t>((nq + kBlock - 1) / kBlock, kMaxGrid);
     // the directory narrows the descents when its key lies inside the tree's 16 bytes (always, except for 1-bit symbols)
-    static const bool want_dir = [] { const char* e = getenv("SFX_TREE_DIR"); return !e || atoi(e) != 0; }();
+    static const bool want_dir = [] { const char* e = dev_env("SFX_TREE_DIR"); return !e || atoi(e) != 0; }();
     DirParams dp = {want_dir && d_lut256 && k <= (int)kTreeKeyBytes ? d_dir : nullptr, d_lut256, bits, k, dbits};
     const uint32_t* order = nullptr;
     const bool two_phase = scratch && nq >= query_two_phase_min() && nq <= 0xFFFFFFFFull;

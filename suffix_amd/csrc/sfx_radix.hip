@@ -920,12 +920,12 @@ static RadixTuning radix_tuning()
     static const RadixTuning t = [] {
         RadixTuning r = {1, 11, 1, 16, 16, 9};          // measured best on MI355X (profiles/r1c_radix_variants.txt):
                                                 // 1024-thread workgroups, 8192-element tiles = 256-byte runs
-        if (const char* e = getenv("SFX_RADIX_SWEEP")) r.sweep = atoi(e) ? 1 : 0;
-        if (const char* e = getenv("SFX_RADIX_KPT")) r.kpt = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 8;
-        if (const char* e = getenv("SFX_RADIX_RANK")) r.rank = atoi(e) ? 1 : 0;
-        if (const char* e = getenv("SFX_RADIX_KPT_TEXT")) r.kpt_text = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 16;
-        if (const char* e = getenv("SFX_RADIX_KPT_KV")) r.kpt_kv = atoi(e) == 9 ? 9 : 8;
-        if (const char* e = getenv("SFX_RADIX_NW")) r.nw = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 4);
+        if (const char* e = dev_env("SFX_RADIX_SWEEP")) r.sweep = atoi(e) ? 1 : 0;
+        if (const char* e = dev_env("SFX_RADIX_KPT")) r.kpt = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 8;
+        if (const char* e = dev_env("SFX_RADIX_RANK")) r.rank = atoi(e) ? 1 : 0;
+        if (const char* e = dev_env("SFX_RADIX_KPT_TEXT")) r.kpt_text = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 16;
+        if (const char* e = dev_env("SFX_RADIX_KPT_KV")) r.kpt_kv = atoi(e) == 9 ? 9 : 8;
+        if (const char* e = dev_env("SFX_RADIX_NW")) r.nw = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 4);
         return r;
     }();
     return t;
@@ -1069,10 +1069,10 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
 {
     *done = false;
     *windows_ready = false;
-    static const int enabled = [] { const char* e = getenv("SFX_HYBRID"); return e ? atoi(e) : 1; }();
-    static const uint64_t min_m = [] { const char* e = getenv("SFX_HYBRID_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 25); }();
+    static const int enabled = [] { const char* e = dev_env("SFX_HYBRID"); return e ? atoi(e) : 1; }();
+    static const uint64_t min_m = [] { const char* e = dev_env("SFX_HYBRID_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 25); }();
     static const uint32_t cap = [] {
-        const char* e = getenv("SFX_HYBRID_CAP");
+        const char* e = dev_env("SFX_HYBRID_CAP");
         const uint32_t full = kBucketNW * kWave * kBucketKPT;
         const uint32_t v = e ? (uint32_t)atoi(e) : full;
         return v >= 1 && v < full ? v : full;
@@ -1147,7 +1147,7 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     // of DNA with the LSD rounds 0.55 ms against 0.63 (256 x 16) and 0.80 (512 x 8), 0.39 with the grouped all-pairs
     // path -- and takes the sub-buckets of up to 2048 suffixes; 256 x 16 those up to 4096; 1024 x 16 those up to 16384
     // (what the LDS holds).  SFX_HYBRID_GEOM=1 / 2 (tests) gives everything to the second / third.
-    static const int force_geom = [] { const char* e = getenv("SFX_HYBRID_GEOM"); return e ? atoi(e) : -1; }();
+    static const int force_geom = [] { const char* e = dev_env("SFX_HYBRID_GEOM"); return e ? atoi(e) : -1; }();
     const uint32_t top = dmin(host_max, cap);                  // the largest sub-bucket the LDS sort takes
     const uint32_t c1 = force_geom >= 1 ? 0u : dmin(2048u, cap), c2 = force_geom == 2 ? c1 : dmin(4096u, cap);
     const unsigned grid = (unsigned)dmin<uint64_t>(kH16Bins, (uint64_t)grid_cap() * 2);
@@ -1183,7 +1183,7 @@ unsigned radix_e64_presort_hist(uint64_t m, int bit_lo, int bit_hi)
 // them (0: the sort counts for itself)
 static int scatter_part_bits()
 {
-    static const int v = [] { const char* e = getenv("SFX_PARTITION_BITS"); int x = e ? atoi(e) : 24; return x >= 8 && x <= 24 ? x : 24; }();
+    static const int v = [] { const char* e = dev_env("SFX_PARTITION_BITS"); int x = e ? atoi(e) : 24; return x >= 8 && x <= 24 ? x : 24; }();
     return v;
 }
 unsigned scatter_pairs_presort_hist(uint64_t m, uint64_t n, int* lo_out, int* nb_out)
@@ -1312,7 +1312,7 @@ constexpr int kSegKPT = 11, kSegNW = 16;                  // the E64 geometry: 1
 constexpr int kSegSmallKPT = 16, kSegSmallNW = 4;         // SFX_SEG_SMALL=1 (tests): 4096-element tiles
 static bool seg_small()
 {
-    static const bool v = [] { const char* e = getenv("SFX_SEG_SMALL"); return e && atoi(e) != 0; }();
+    static const bool v = [] { const char* e = dev_env("SFX_SEG_SMALL"); return e && atoi(e) != 0; }();
     return v;
 }
 // counters: [0] tiles, [1] tiles of multi-tile segments, [2] multi-tile segments
@@ -1387,12 +1387,13 @@ k_seg_scan(const SegTile* __restrict__ tiles, const uint32_t* __restrict__ ntile
 // suffixes back to the list, head / singleton flags from the sorted key2 values
 __global__ void __launch_bounds__(kBlock)
 k_seg_finish(const uint64_t* __restrict__ E, const SegTile* __restrict__ tiles, const uint32_t* __restrict__ ntiles,
-             uint32_t* __restrict__ V, uint8_t* __restrict__ F8, LcpEmit emit)
+             uint32_t* __restrict__ V, uint8_t* __restrict__ F8, LcpEmit emit, uint16_t* __restrict__ Hd, uint32_t wsym)
 {
     const uint32_t nt = *ntiles;
     for (uint32_t t = blockIdx.x; t < nt; t += gridDim.x) {
         const SegTile d = tiles[t];
         const uint64_t seg_end = (uint64_t)d.seg_start + d.pad[1];
+        const uint32_t depth = d.pad[2];                              // (the bucket's depth, left by k_seg_gather)
         for (uint32_t i = threadIdx.x; i < d.count; i += kBlock) {
             const uint64_t p = (uint64_t)d.begin + i;
             const uint64_t e = E[p];
@@ -1401,9 +1402,10 @@ k_seg_finish(const uint64_t* __restrict__ E, const SegTile* __restrict__ tiles, 
             const bool last = p + 1 == seg_end || (uint32_t)(E[p + 1] >> 32) != key;
             V[p] = (uint32_t)e;
             F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
+            if (Hd) Hd[p] = (uint16_t)(depth + wsym);
             if (emit.lcp && head && p != d.seg_start) {               // split from its predecessor in this round
                 const uint64_t ep = E[p - 1];
-                emit.lcp[emit.S[p]] = lcp_from_key2(emit, (uint32_t)(ep >> 32), key, (uint32_t)ep, (uint32_t)e);
+                emit.lcp[emit.S[p]] = lcp_from_key2_at(emit, depth, (uint32_t)(ep >> 32), key, (uint32_t)ep, (uint32_t)e);
             }
         }
     }
@@ -1481,7 +1483,7 @@ int segmented_layout(const SegSort& q, uint32_t nseg, bool kv, hipStream_t st, u
 // alone; segmented_layout has run); on return V and F8 are written for those positions.  nlarge = sum of
 // the segment sizes.
 int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg, uint64_t nlarge, uint32_t* V,
-                       uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit)
+                       uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit, uint16_t* Hd, uint32_t wsym)
 {
     if (nseg == 0) return SFX_OK;
     const uint32_t te = seg_tile_elems(false);
@@ -1495,7 +1497,7 @@ int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg
     if (seg_small()) SFX_TRY((seg_passes<kSegSmallKPT, kSegSmallNW>(A, B, q, q.status, status_words, st, (double)nlarge * 16)));
     else SFX_TRY((seg_passes<kSegKPT, kSegNW>(A, B, q, q.status, status_words, st, (double)nlarge * 16)));
     SFX_LAUNCH("seg_finish", (double)nlarge * 13, k_seg_finish, grid, kBlock, st, A, reinterpret_cast<const SegTile*>(q.tiles),
-               q.counters, V, F8, emit);
+               q.counters, V, F8, emit, Hd, wsym);
     if (stats) { stats->radix_passes += 4; stats->elements_sorted += 4 * nlarge; }
     return SFX_OK;
 }

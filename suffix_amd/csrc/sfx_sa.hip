@@ -38,6 +38,7 @@
 // The same kernels serve the range-partitioned (multi-GPU) build, where a rank
 // sorts only the suffixes whose leading key bits fall in its bucket range and
 // refines with text rounds only (no ranks of foreign suffixes needed).
+#include <stdio.h>
 #include <string.h>
 
 #include "sfx_host.hpp"
@@ -713,8 +714,11 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                uint32_t* __restrict__ isa, uint32_t* __restrict__ S_next,
                uint32_t* __restrict__ V_next, uint32_t* __restrict__ G_next,
                uint32_t* __restrict__ R_next, int sa_in_place, uint64_t* __restrict__ rank_pairs,
-               const uint16_t* __restrict__ flags_in, uint32_t* __restrict__ pair_hist, int pair_lo, int pair_nb)
+               const uint16_t* __restrict__ flags_in, uint32_t* __restrict__ pair_hist, int pair_lo, int pair_nb,
+               const uint16_t* __restrict__ Hd, uint16_t* __restrict__ Hd_next, uint32_t hd_floor)
 {
+    // Hd_next (deep text rounds): the kept elements carry the depth of their bucket, at least hd_floor (what the
+    // round's large-bucket path established for the buckets it split; the deep kernel wrote larger values itself)
     __shared__ uint32_t part_m[2][kWavesPerBlock], part_a[2][kWavesPerBlock];
     // pair_hist (with rank_pairs): digit counts of the passes that partition the pairs by suffix index (bits [pair_lo,
     // pair_nb), 8 per pass, at most 3) -- counted here, where the pairs are made, instead of by a pass over them
@@ -800,6 +804,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                 S_next[pos] = slot;
                 V_next[pos] = suffix;
                 G_next[pos] = pos - ((uint32_t)i - my_head);
+                if (Hd_next) Hd_next[pos] = (uint16_t)(Hd ? dmax<uint32_t>(Hd[i], hd_floor) : hd_floor);
             }
         } else
 #pragma unroll
@@ -848,6 +853,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                             S_next[run_keep] = slot[j];
                             V_next[run_keep] = suffix[j];
                             G_next[run_keep] = run_keep - back[j];   // bucket id = position of its head in the new list
+                            if (Hd_next) Hd_next[run_keep] = (uint16_t)(Hd ? dmax<uint32_t>(Hd[ib + j], hd_floor) : hd_floor);
                             run_keep++;
                         }
                     }
@@ -978,7 +984,7 @@ __global__ void __launch_bounds__(kBlock)
 k_flag_compact(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ S, const uint32_t* __restrict__ V2,
                const uint32_t* __restrict__ G, uint64_t m, uint64_t chunk, int phase,
                uint32_t* __restrict__ block_counts, uint32_t* __restrict__ S_next, uint32_t* __restrict__ V_next,
-               uint32_t* __restrict__ G_next)
+               uint32_t* __restrict__ G_next, const uint16_t* __restrict__ Hd, uint16_t* __restrict__ Hd_next)
 {
     __shared__ uint32_t part[kWavesPerBlock];
     const unsigned tid = threadIdx.x;
@@ -997,6 +1003,7 @@ k_flag_compact(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ S
             S_next[running + ex] = S[p];
             V_next[running + ex] = V2[p];
             G_next[running + ex] = (uint32_t)(running + ex) - ((uint32_t)p - G[p]);
+            if (Hd_next) Hd_next[running + ex] = Hd[p];
         }
         running += total;
     }
@@ -1084,7 +1091,7 @@ static void choose_key(const Alphabet& a, uint64_t n, int* key_bits, int* cpk)
     int l2 = bits_for(a.sigma) - 1;                 // floor(log2 sigma), sigma >= 1
     if (l2 < 1) l2 = 1;
     // SFX_FORCE_KEY64=1 is a test hook (the 64-bit-key path on inputs small enough for the emulator)
-    static const bool force64 = [] { const char* e = getenv("SFX_FORCE_KEY64"); return e && atoi(e) != 0; }();
+    static const bool force64 = [] { const char* e = dev_env("SFX_FORCE_KEY64"); return e && atoi(e) != 0; }();
     if (!force64 && spw * l2 >= bits_for(n) + 1) { *key_bits = 32; *cpk = spw; }
     else { *key_bits = 64; *cpk = 2 * spw; }
 }
@@ -1109,7 +1116,9 @@ struct SaBuffers {
     uint32_t* G1;
     uint16_t* F;                                        // head / single bits, 16 per 8 elements
     uint8_t* F8;                                        // one flag byte per element (tile rounds)
-    unsigned long long* counters;                       // 2
+    uint16_t* Hd0; uint16_t* Hd1;                       // deep text rounds: depth of every list member's bucket, paired with S0 / S1
+    unsigned long long* counters;                       // 4
+    unsigned long long* deep_slots;                     // kDeepSlotWords
     uint32_t* block_counts;                             // kMaxGrid
     uint32_t* R;                                        // scratch (positions of the large-bucket members of a tile round)
     uint32_t* isa;
@@ -1122,6 +1131,7 @@ struct SaBuffers {
 };
 
 static inline uint32_t* isa_scratch_h(SaBuffers& b) { return b.R; }       // n + 1024 u32, free between rounds
+static inline uint16_t* hd_of(SaBuffers& b, const uint32_t* S) { return S == b.S0 ? b.Hd0 : b.Hd1; }
 
 struct SizerArena : ArenaSizer {
     template <class T> T* take(uint64_t c) { ArenaSizer::take<T>(c); return nullptr; }
@@ -1141,9 +1151,14 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint16_t* F = ar.template take<uint16_t>(cap / kGroupItems + kBlock * kApplySub);
     uint32_t* bc = ar.template take<uint32_t>(kMaxGrid);
     uint8_t* F8 = ar.template take<uint8_t>(cap + 64);
-    unsigned long long* counters = ar.template take<unsigned long long>(2);
+    unsigned long long* counters = ar.template take<unsigned long long>(4);
+    unsigned long long* deep_slots = ar.template take<unsigned long long>(kDeepSlotWords);
     uint32_t* R = ar.template take<uint32_t>(cap + 1024);
     uint32_t* isa = ar.template take<uint32_t>(isa_len);
+    // the bucket depths of the text rounds live in the rank array, which is idle until the build switches to rank
+    // rounds (and the depths are dead from then on); a slice of the partitioned build has no rank array
+    uint16_t* Hd0 = isa_len >= cap ? reinterpret_cast<uint16_t*>(isa) : ar.template take<uint16_t>(cap);
+    uint16_t* Hd1 = isa_len >= cap ? (Hd0 ? Hd0 + cap : nullptr) : ar.template take<uint16_t>(cap);
     uint32_t* packed = ar.template take<uint32_t>(packed_words(n, nullptr));
     uint32_t* hist = ar.template take<uint32_t>(radix_scratch_words(cap));
     uint32_t* ph = ar.template take<uint32_t>(kMaxGrid);
@@ -1154,7 +1169,8 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint8_t* lut = ar.template take<uint8_t>(256);
     if (b) {
         b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->G1 = G1; b->F = F; b->F8 = F8;
-        b->counters = counters; b->block_counts = bc; b->R = R;
+        b->Hd0 = Hd0; b->Hd1 = Hd1;
+        b->counters = counters; b->deep_slots = deep_slots; b->block_counts = bc; b->R = R;
         b->isa = isa; b->packed = packed; b->hist = hist; b->part_head = ph; b->part_keep = pk;
         b->part_ghead = pg; b->totals = totals; b->bins = bins; b->lut = lut;
     }
@@ -1196,7 +1212,7 @@ template <class KeyT>
 static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint64_t m, SaBuffers& b,
                        uint32_t* sa, uint32_t* isa, uint32_t* S_next, uint32_t* V_next,
                        uint32_t* R_next, hipStream_t st, int sa_mode, uint64_t n, sfx_build_stats& stats,
-                       uint64_t kept)
+                       uint64_t kept, const uint16_t* Hd = nullptr, uint16_t* Hd_next = nullptr, uint32_t hd_floor = 0)
 {
     const bool sa_in_place = sa_mode == 1;
     // the sorted keys K sit in one of K0/K1 (for 32-bit keys: in its first half); the other
@@ -1223,11 +1239,11 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
     if (sa_in_place && !isa && kept * kSparseApplyDivisor <= m)
         SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, kApplySub>), ch.blocks, kBlock, st, K, V, S, m,
                    ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
-                   b.G, R_next, 1, pairs, (const uint16_t*)b.F, (uint32_t*)nullptr, 0, 0);
+                   b.G, R_next, 1, pairs, (const uint16_t*)b.F, (uint32_t*)nullptr, 0, 0, Hd, Hd_next, hd_floor);
     else
         SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, 1>), ch.blocks, kBlock, st, K, V, S, m,
                    ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
-                   b.G, R_next, sa_mode, pairs, (const uint16_t*)b.F, pair_hist, pair_lo, pair_nb);
+                   b.G, R_next, sa_mode, pairs, (const uint16_t*)b.F, pair_hist, pair_lo, pair_nb, Hd, Hd_next, hd_floor);
     if (pairs) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, m, n, isa, b.hist, st, &stats, pair_blocks));
     return SFX_OK;
 }
@@ -1335,25 +1351,27 @@ int pack_small_alphabet(const uint8_t* d_text, uint64_t n, int max_bits, void* s
 // still unresolved.  On return the active list is (*S_cur, *V_cur, b.G) with *m elements.
 static int small_groups_pass(const PackedText& pt, uint64_t h, SaBuffers& b, uint32_t* sa, uint32_t* isa,
                              uint32_t** S_cur, uint32_t** V_cur, uint64_t* m, hipStream_t st,
-                             sfx_build_stats& stats, uint32_t* lcp = nullptr)
+                             sfx_build_stats& stats, uint32_t* lcp = nullptr, bool carry_hd = false)
 {
     const uint64_t cnt = *m;
     uint32_t* V_other = (*V_cur == b.VA) ? b.VB : b.VA;
     uint32_t* S_next = (*S_cur == b.S0) ? b.S1 : b.S0;
     uint32_t* flag = (uint32_t*)b.K0;                       // free between rounds
+    const uint16_t* Hd = carry_hd ? hd_of(b, *S_cur) : nullptr;
+    uint16_t* Hd_next = carry_hd ? hd_of(b, S_next) : nullptr;
     unsigned grid = (unsigned)dmin<uint64_t>((cnt + kBlock - 1) / kBlock, kMaxGrid);
     SFX_LAUNCH("small_groups", (double)cnt * 32, k_small_groups, grid, kBlock, st, *V_cur, *S_cur, b.G, cnt, pt, h,
                sa, isa, V_other, b.G1, flag, lcp);
     Chunking ch = make_chunking(cnt, 1024);
     const uint64_t chunk = ch.tiles_per_block * 1024;
     SFX_LAUNCH("flag_count", (double)cnt * 4, k_flag_compact, ch.blocks, kBlock, st, flag, *S_cur, V_other, b.G1, cnt,
-               chunk, 0, b.block_counts, S_next, *V_cur, b.G);
+               chunk, 0, b.block_counts, S_next, *V_cur, b.G, Hd, Hd_next);
     SFX_LAUNCH("flag_scan", 0.0, k_scan_block_counts, 1, kBlock, st, b.block_counts, ch.blocks, b.totals);
     uint32_t left = 0;
     SFX_TRY(read_back(&left, b.totals, sizeof(left), st));
     if (left > 0) {
         SFX_LAUNCH("flag_compact", (double)cnt * 4 + (double)left * 24, k_flag_compact, ch.blocks, kBlock, st, flag,
-                   *S_cur, V_other, b.G1, cnt, chunk, 1, b.block_counts, S_next, *V_cur, b.G);
+                   *S_cur, V_other, b.G1, cnt, chunk, 1, b.block_counts, S_next, *V_cur, b.G, Hd, Hd_next);
         *S_cur = S_next;                                    // V stays in *V_cur (compacted from V_other), ids in b.G
     }
     stats.small_bucket_resolved += cnt - left;
@@ -1469,15 +1487,19 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
     // r2_text_key64_vs_32.jsonl) 178 vs 186 ms English-like, 149 vs 144 ms on round 1's English-like input, 316 vs
     // 282 ms UTF-8 -- a round is bound by sorting work (bits x members: 8 LDS passes / 8 segmented 24-byte
     // passes instead of 4 + 4 over two rounds), not by its key gather, so the wider key does not pay
-    static const bool key64 = [] { const char* e = getenv("SFX_TEXT_KEY"); return e && atoi(e) == 64; }();
-    const int wsym = key64 ? text_key64_symbols(pt) : (pt.kbits == 32 ? pt.spw - 1 : pt.spw);
+    static const bool key64 = [] { const char* e = dev_env("SFX_TEXT_KEY"); return e && atoi(e) == 64; }();
+    // SFX_DEEP=0 (development): the text rounds of round 2, one list pass per text_round_symbols symbols
+    static const bool deep = [] { const char* e = dev_env("SFX_DEEP"); return !e || atoi(e) != 0; }();
+    const int wsym = (key64 && !deep) ? text_key64_symbols(pt) : text_round_symbols(pt);
     bool rank_mode = false;
     uint64_t stalled = 0;
     int rounds = 0;
+    bool any_deep = false;
+    if (m > 0) SFX_HIP(hipMemsetAsync(b.counters, 0, 4 * sizeof(unsigned long long), st));
     while (m > 0) {
         if (++rounds > kMaxTextOnlyRounds + 80) return SFX_ERR_INTERNAL;
         // SFX_FORCE_COMPOSITE=1 is a test hook: take the fallback at once (it is otherwise only reachable beyond 2^31 bytes)
-        static const bool force_composite = [] { const char* e = getenv("SFX_FORCE_COMPOSITE"); return e && atoi(e) != 0; }();
+        static const bool force_composite = [] { const char* e = dev_env("SFX_FORCE_COMPOSITE"); return e && atoi(e) != 0; }();
         if (rank_mode && (n - 1 + h > 0xFFFFFFFFull || force_composite))   // key2 = rank + h would not fit 32 bits
             return refine_composite(pt, cpk, b, sa, isa, 0, S_cur, V_cur, m, m, st, stats, h);
         uint32_t* V_next = (V_cur == b.VA) ? b.VB : b.VA;
@@ -1485,8 +1507,11 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         TileRound tr;
         tr.emit = make_lcp_emit(lcp, S_cur, pt, h, rank_mode);
         tr.G = b.G; tr.V = V_cur; tr.F8 = b.F8; tr.F = b.F;
+        const bool deep_round = deep && !rank_mode;
+        tr.Hd = deep_round ? hd_of(b, S_cur) : nullptr;
+        tr.wsym = (uint32_t)wsym;
         tr.part_head = b.part_head; tr.part_keep = b.part_keep; tr.part_ghead = b.part_ghead;
-        tr.block_counts = b.block_counts; tr.totals = b.totals; tr.counters = b.counters;
+        tr.block_counts = b.block_counts; tr.totals = b.totals; tr.counters = b.counters; tr.deep_slots = b.deep_slots;
         // scratch of the segmented sort: element ping-pong in K0 / K1; tile table and segment list in the
         // slot list of the next round (free until round_apply), per-tile digit counts in G1, per-segment
         // digit offsets in R, status words in the radix scratch
@@ -1499,6 +1524,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         tr.seg.status_words = radix_scratch_words(m) - 64;
         tr.seg.counters = b.hist;
         if (rank_mode) SFX_TRY(tile_round_rank(isa, n, h, tr, m, st, &stats));
+        else if (deep) { SFX_TRY(deep_round_text(pt, tr, m, st, &stats)); any_deep = true; }
         else if (key64) SFX_TRY(tile_round_text64(pt, h, tr, m, st, &stats));
         else SFX_TRY(tile_round_text(pt, h, tr, m, st, &stats));
         Chunking ch = make_chunking(m, kApplyTile);
@@ -1510,7 +1536,14 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         // (SA slots are written when a suffix resolves; the members of still-unresolved buckets only if ranks
         // have to be built from the array: build_ranks below)
         SFX_TRY(round_apply<uint64_t>(b.K0, V_cur, S_cur, m, b, sa, rank_mode ? isa : nullptr, S_next, V_next, nullptr,
-                                      st, 2, n, stats, kept));
+                                      st, 2, n, stats, kept, tr.Hd, deep_round ? hd_of(b, S_next) : nullptr, 0u));
+        // SFX_TRACE=1 (development): one line per round
+        static const bool trace = [] { const char* e = dev_env("SFX_TRACE"); return e && atoi(e) != 0; }();
+        if (trace)
+            fprintf(stderr, "round %d %s h=%llu m=%llu lds=%llu large=%llu kept=%llu kept_groups=%llu gathers=%llu\n", rounds,
+                    rank_mode ? "rank" : "text", (unsigned long long)h, (unsigned long long)m,
+                    (unsigned long long)stats.tile_sorted, (unsigned long long)stats.large_sorted, (unsigned long long)kept,
+                    (unsigned long long)kept_groups, (unsigned long long)stats.deep_gathers);
         h = rank_mode ? h * 2 : h + (uint64_t)wsym;
         stats.rounds++;
         if (rank_mode) stats.rank_rounds++; else stats.text_rounds++;
@@ -1518,13 +1551,15 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
             // a text round is worth another one while it keeps resolving; a stalled one costs about
             // (kept + launch overheads) against ~n for the rank array
             // SFX_SWITCH=text|rank is a development hook: never / always switch after the first round
-            static const int force = [] { const char* e = getenv("SFX_SWITCH"); return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'r' ? 2 : 0)); }();
+            static const int force = [] { const char* e = dev_env("SFX_SWITCH"); return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'r' ? 2 : 0)); }();
             if (kept * 4 > m * 3) stalled += kept + (4u << 20);
-            if (isa && force != 1 && (stalled * 2 > n || force == 2)) {
+            // (the depths of the deep rounds are 16-bit; a text that deep is a repeat anyway)
+            const bool too_deep = deep && h + 2 * (uint64_t)wsym > 60000;
+            if (isa && force != 1 && (stalled * 2 > n || force == 2 || too_deep)) {
                 // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
                 SFX_TRY(build_ranks(b, sa, n, V_next, S_next, kept, isa, st, stats));
                 rank_mode = true;
-            } else if (!isa && (stalled * 2 > n || stats.text_rounds > (uint32_t)kMaxTextOnlyRounds)) {
+            } else if (!isa && (stalled * 2 > n || stats.text_rounds > (uint32_t)kMaxTextOnlyRounds || too_deep)) {
                 // a slice of the partitioned build cannot switch (the ranks of other slices' suffixes are
                 // not here): the caller falls back to a whole-array build (suffix_amd/dist.py)
                 return SFX_ERR_NEEDS_RANKS;
@@ -1534,7 +1569,13 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         V_cur = V_next;
         m = kept;
         if (small_groups_pay(m, kept_groups))
-            SFX_TRY(small_groups_pass(pt, h, b, sa, rank_mode ? isa : nullptr, &S_cur, &V_cur, &m, st, stats, lcp));
+            SFX_TRY(small_groups_pass(pt, h, b, sa, rank_mode ? isa : nullptr, &S_cur, &V_cur, &m, st, stats, lcp,
+                                      deep && !rank_mode));
+    }
+    if (any_deep) {
+        unsigned long long g = 0;
+        SFX_TRY(read_back(&g, b.counters + 3, sizeof(g), st));
+        stats.deep_gathers = g;
     }
     return SFX_OK;
 }
@@ -1582,11 +1623,12 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups, fuse));
     stats.active_after_initial = kept;
     // no rank array yet: its n-element scatter is only paid if the text rounds stall (refine)
+    // (every bucket of the first active list shares the cpk symbols of the initial key: b.Hd0, the depths of the deep rounds)
     SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place ? 1 : 0, pt.n, stats,
-                              kept));
+                              kept, nullptr, b.Hd0, (uint32_t)cpk));
     uint32_t* S_cur = b.S0;
     if (small_groups_pay(kept, groups))
-        SFX_TRY(small_groups_pass(pt, (uint64_t)cpk, b, sa, nullptr, &S_cur, &V_next, &kept, st, stats, lcp_fuse));
+        SFX_TRY(small_groups_pass(pt, (uint64_t)cpk, b, sa, nullptr, &S_cur, &V_next, &kept, st, stats, lcp_fuse, true));
     return refine(pt, cpk, b, sa, isa, S_cur, V_next, kept, st, stats, lcp_fuse);
 }
 

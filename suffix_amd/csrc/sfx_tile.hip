@@ -33,12 +33,15 @@ struct TextKey {
     PackedText t;
     uint64_t h;
     int drop_bits;              // 32-bit packed words give up their last symbol to make room for the flag
-    __device__ __forceinline__ uint32_t operator()(uint32_t i) const
+    // (depth: symbols the members of the suffix's bucket share -- the deep text rounds keep one per bucket)
+    __device__ __forceinline__ uint32_t at(uint32_t i, uint64_t depth) const
     {
-        const uint64_t p = (uint64_t)i + h;
+        const uint64_t p = (uint64_t)i + depth;
         if (p >= t.n) return (uint32_t)(t.n - 1 - (uint64_t)i);
         return 0x80000000u | (packed_key32(t, p) >> drop_bits);
     }
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return at(i, h); }
+    __device__ __forceinline__ uint32_t depth_default() const { return (uint32_t)h; }
 };
 // text round on a 64-bit key: 1 << 63 | the next wsym64 symbols, or n-1-i
 struct TextKey64 {
@@ -62,6 +65,8 @@ struct RankKey {
         if (p >= n) return (uint32_t)(n - 1 - (uint64_t)i);
         return (uint32_t)((uint64_t)isa[p] + h);
     }
+    __device__ __forceinline__ uint32_t at(uint32_t i, uint64_t) const { return (*this)(i); }     // (rank rounds: one h for all)
+    __device__ __forceinline__ uint32_t depth_default() const { return (uint32_t)h; }
 };
 
 // ---- LDS bucket sort --------------------------------------------------------------------
@@ -602,19 +607,22 @@ k_seg_gather64(TextKey64 keyfn, const uint32_t* __restrict__ V, const SegTileHos
 // says where they are): the one gather per member that the LDS path does inside k_tile_sort
 template <class KeyFn>
 __global__ void __launch_bounds__(kBlock)
-k_seg_gather(KeyFn keyfn, const uint32_t* __restrict__ V, const SegTileHost* __restrict__ tiles,
-             const uint32_t* __restrict__ ntiles, uint64_t* __restrict__ E)
+k_seg_gather(KeyFn keyfn, const uint32_t* __restrict__ V, SegTileHost* __restrict__ tiles,
+             const uint32_t* __restrict__ ntiles, uint64_t* __restrict__ E, const uint16_t* __restrict__ Hd)
 {
     const uint32_t nt = *ntiles;
     for (uint32_t t = blockIdx.x; t < nt; t += gridDim.x) {
         const uint32_t begin = tiles[t].begin, count = tiles[t].count;
+        // the depth of the tile's bucket: kept in the tile table for k_seg_finish, which rewrites Hd
+        const uint32_t depth = Hd ? (uint32_t)Hd[tiles[t].seg_start] : keyfn.depth_default();
+        if (threadIdx.x == 0) tiles[t].pad[2] = depth;
         constexpr int U = 4;
         for (uint32_t i0 = threadIdx.x; i0 < count; i0 += U * kBlock) {
             uint32_t sfx[U], k2[U];
 #pragma unroll
             for (int u = 0; u < U; u++) sfx[u] = (i0 + u * kBlock < count) ? V[(uint64_t)begin + i0 + u * kBlock] : 0u;
 #pragma unroll
-            for (int u = 0; u < U; u++) k2[u] = (i0 + u * kBlock < count) ? keyfn(sfx[u]) : 0u;
+            for (int u = 0; u < U; u++) k2[u] = (i0 + u * kBlock < count) ? keyfn.at(sfx[u], depth) : 0u;
 #pragma unroll
             for (int u = 0; u < U; u++)
                 if (i0 + u * kBlock < count) E[(uint64_t)begin + i0 + u * kBlock] = ((uint64_t)k2[u] << 32) | (uint64_t)sfx[u];
@@ -635,7 +643,7 @@ k_seg_gather(KeyFn keyfn, const uint32_t* __restrict__ V, const SegTileHost* __r
 template <int NW, int KPT, class KeyFn>
 __global__ void __launch_bounds__(NW * kWave)
 k_seg_single(KeyFn keyfn, const uint2* __restrict__ segs, uint32_t nseg, uint32_t lo, uint32_t hi, uint32_t* __restrict__ V,
-             uint8_t* __restrict__ F8, LcpEmit emit)
+             uint8_t* __restrict__ F8, LcpEmit emit, uint16_t* __restrict__ Hd, uint32_t wsym)
 {
     constexpr int kThreads = NW * kWave;
     static_assert(kWave * KPT >= kRadixDev, "the match masks must fit the staging buffer");
@@ -661,6 +669,7 @@ k_seg_single(KeyFn keyfn, const uint2* __restrict__ segs, uint32_t nseg, uint32_
         if (size <= lo || size > hi) continue;                        // (uniform: the whole workgroup skips)
         const unsigned kpt = (size + kThreads - 1) / kThreads;        // rounds in use, <= KPT
         const unsigned per = kpt * kWave;
+        const uint32_t depth = Hd ? (uint32_t)Hd[begin] : keyfn.depth_default();    // (read before the barriers below, rewritten after them)
         uint64_t key[KPT];
         uint32_t pos[KPT];
         {
@@ -673,7 +682,7 @@ k_seg_single(KeyFn keyfn, const uint2* __restrict__ segs, uint32_t nseg, uint32_
 #pragma unroll
             for (int r = 0; r < KPT; r++) {                           // (the gathers of all rounds in flight together)
                 const unsigned idx = w * per + r * kWave + lane;
-                key[r] = ((unsigned)r < kpt && idx < size) ? (((uint64_t)keyfn(suf[r]) << 32) | (uint64_t)suf[r]) : ~0ull;
+                key[r] = ((unsigned)r < kpt && idx < size) ? (((uint64_t)keyfn.at(suf[r], depth) << 32) | (uint64_t)suf[r]) : ~0ull;
             }
         }
         for (int shift = 32; shift < 64; shift += 8) {
@@ -727,13 +736,353 @@ k_seg_single(KeyFn keyfn, const uint2* __restrict__ segs, uint32_t nseg, uint32_
                 const uint64_t p = (uint64_t)begin + idx;
                 V[p] = (uint32_t)e;
                 F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
+                if (Hd) Hd[p] = (uint16_t)(depth + wsym);
                 if (emit.lcp && head && idx != 0) {                   // split from its predecessor in this round
                     const uint64_t ep = stage[idx - 1];
-                    emit.lcp[emit.S[p]] = lcp_from_key2(emit, (uint32_t)(ep >> 32), k2, (uint32_t)ep, (uint32_t)e);
+                    emit.lcp[emit.S[p]] = lcp_from_key2_at(emit, depth, (uint32_t)(ep >> 32), k2, (uint32_t)ep, (uint32_t)e);
                 }
             }
         }
         __syncthreads();                                              // (stage is read to the end before the next bucket's masks)
+    }
+}
+
+// ---- deep text rounds: small buckets finished by one wave each ---------------------------------
+// A text round of k_tile_sort moves every unresolved suffix through a list pass (read G / V, write V / F8, flags ->
+// scan -> apply) for each 4 symbols it looks at: 2.2 G member-rounds for 0.9 G unresolved suffixes of 1 GB of
+// English-like text.  But what one round leaves of a bucket of a few hundred members is a handful of tiny
+// sub-buckets that the NEXT rounds could order without ever leaving the CU.  k_deep_wave does that: a WAVE (no
+// workgroup barrier anywhere) owns the buckets whose head lies in its stretch of H = W / 2 list positions and that
+// have at most W - H members (the W-position window then contains them), and finishes them:
+//   repeat:  every member of a still-tied sub-bucket gathers the next 64 bits of symbols (ONE random line for 8-9
+//            symbols instead of one per 4), is ranked against the other members of its sub-bucket by direct
+//            comparison (lt = keys below, eq = equal keys: its new place, the extent of its new sub-bucket and
+//            whether it is now alone all come out of the same loop), and moves there
+//   until nothing is tied, the iterations stop resolving (a repeat: left to the rank rounds), or the cap is hit.
+// Sub-buckets only ever split, so all state is per list position: suffix, start and end of the sub-bucket it
+// lies in (LDS, 16 bytes per position with the key).  Members that stay tied leave as ordinary buckets of the
+// active list with Hd = the symbols their sub-bucket is now known to share, which is where the next round picks
+// them up (a per-bucket depth: they do not have to agree with the buckets that took the large path).
+// Buckets above W - H members are announced to the large-bucket path exactly as k_tile_sort does.
+struct DeepTextKey {
+    PackedText t;
+    int shift;                  // 2 * kbits - wsym * bits (see TextKey64)
+    int wsym;                   // symbols per key
+    __device__ __forceinline__ uint64_t operator()(uint32_t i, uint32_t depth) const
+    {
+        const uint64_t p = (uint64_t)i + depth;
+        if (p >= t.n) return t.n - 1 - (uint64_t)i;
+        return (1ull << 63) | (packed_key64(t, p) >> shift);
+    }
+};
+constexpr uint32_t kDeepMaxDepth = 65000;                   // Hd is 16 bits
+
+// LCP of a class head (suffix sb, key kb) with a member of the class in front of it (suffix sa, key ka) when the
+// members of their bucket share `depth` symbols: lcp_from_key2_64 with the depth of the bucket instead of the round's
+__device__ __forceinline__ uint32_t lcp_deep(const LcpEmit& L, uint32_t depth, uint64_t ka, uint64_t kb, uint32_t sa, uint32_t sb)
+{
+    const uint32_t la = L.n - sa, lb = L.n - sb;
+    if (!((ka & kb) >> 63)) return la < lb ? la : lb;
+    const uint64_t x = ka ^ kb;
+    const uint32_t lz = (uint32_t)__clzll((long long)x) - (64u - (uint32_t)L.field_bits64);
+    const uint32_t v = depth + ((lz * L.inv_bits) >> 16);
+    if (v > la) return kLcpBoundFlag | depth;
+    return v < lb ? v : lb;
+}
+
+// One element of the wave's window during a sort: key (the 64 gathered bits), and pk = start of its sub-bucket << 16 |
+// the position it came from.  Order: sub-bucket, then key, then origin (a strict total order: ties cannot make the
+// two sides of a compare-exchange disagree).
+__device__ __forceinline__ bool deep_less(uint64_t ka, uint32_t pa, uint64_t kb, uint32_t pb)
+{
+    const uint32_t ba = pa >> 16, bb = pb >> 16;
+    return ba != bb ? ba < bb : (ka != kb ? ka < kb : pa < pb);
+}
+// Bitonic sort of the 64 * E elements of a wave, E consecutive ones per lane (element i = lane * E + e): the
+// compare-exchanges at distance < E stay inside a lane's registers, the others swap with lane ^ (distance / E).
+// No LDS, no divergence, the same ~40 instructions per element whatever the bucket sizes are.
+template <int E>
+__device__ __forceinline__ void deep_bitonic(uint64_t (&key)[E], uint32_t (&pk)[E])
+{
+    const unsigned lane = lane_id();
+#pragma unroll
+    for (int k = 2; k <= kWave * E; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= E) {
+                const unsigned lm = (unsigned)(j / E);
+                const bool asc = (lane & (unsigned)(k / E)) == 0u;          // (k >= 2 * E here: the direction is the lane's)
+                const bool keep_min = asc == ((lane & lm) == 0u);
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const uint64_t ok = __shfl_xor(key[e], (int)lm);
+                    const uint32_t op = __shfl_xor(pk[e], (int)lm);
+                    const bool mine_less = deep_less(key[e], pk[e], ok, op);
+                    if (mine_less != keep_min) { key[e] = ok; pk[e] = op; }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int f = e ^ j;
+                    if (f > e) {
+                        const bool asc = k >= E ? ((lane * (unsigned)E) & (unsigned)k) == 0u : (e & k) == 0;
+                        if (deep_less(key[f], pk[f], key[e], pk[e]) == asc) {
+                            const uint64_t tk = key[e]; key[e] = key[f]; key[f] = tk;
+                            const uint32_t tp = pk[e]; pk[e] = pk[f]; pk[f] = tp;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// counters[1] += buckets announced to the large path (the returned value is the bucket's place in `segs`); the members
+// owned and the gathers made are summed per wave into one of kDeepSlots counter lines (slots[slot * 8 + 0 / 1]: one
+// device-wide counter for millions of waves is a queue at one L2 channel -- measured: it was the whole kernel time)
+constexpr unsigned kDeepSlots = 1024;
+__global__ void __launch_bounds__(kBlock)
+k_deep_totals(const unsigned long long* __restrict__ slots, unsigned long long* __restrict__ counters, int set_owned)
+{
+    __shared__ unsigned long long part[2][kWavesPerBlock];
+    unsigned long long a = 0, b = 0;
+    for (unsigned i = threadIdx.x; i < kDeepSlots; i += kBlock) { a += slots[i * 8u]; b += slots[i * 8u + 1u]; }
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+    if (lane_id() == 0) { part[0][wave_id()] = a; part[1][wave_id()] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long x = 0, y = 0;
+        for (int w = 0; w < kWavesPerBlock; w++) { x += part[0][w]; y += part[1][w]; }
+        if (set_owned) counters[0] = x;                    // (first pass of a round: what is left is the large path's)
+        counters[3] += y;                                  // gathers of the whole build (zeroed by its first round)
+    }
+}
+template <int W>
+struct DeepSmem {
+    int32_t st[W];                                          // set-up: start (window position) of every position's bucket, -1 = not here
+    uint32_t suf[W];                                        // slot j of the compacted tied members: suffix,
+    uint16_t pos[W];                                        //   window position the slot stands for,
+    uint16_t tag[W];                                        //   slot of the first member of its sub-bucket,
+    uint16_t hd[W];                                         //   depth of its bucket when the wave took it
+};
+
+// One iteration over the cnt <= 64 * E tied members of a wave (slots [0, cnt), sub-buckets contiguous): gather the next
+// key of every member, sort the slots by (sub-bucket, key) in registers, find the new sub-buckets, write out the members
+// that are now alone (final) and compact the others to the front.  Returns the number still tied.
+template <int E, int W, bool EMIT>
+__device__ __forceinline__ unsigned deep_step(const DeepTextKey& keyfn, DeepSmem<W>& s, unsigned cnt, uint32_t it, uint64_t wbase,
+                                              uint32_t* __restrict__ V, uint8_t* __restrict__ F8, const LcpEmit& emit)
+{
+    const unsigned lane = lane_id();
+    const unsigned j0 = lane * (unsigned)E;
+    uint64_t key[E];
+    uint32_t pk[E], suf[E];
+    uint16_t pos[E], hd[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const unsigned j = j0 + (unsigned)e;
+        const bool valid = j < cnt;
+        suf[e] = valid ? s.suf[j] : 0u;
+        pos[e] = valid ? s.pos[j] : (uint16_t)0;
+        hd[e] = valid ? s.hd[j] : (uint16_t)0;
+        pk[e] = ((valid ? (uint32_t)s.tag[j] : 0xFFFFu) << 16) | j;     // (empty slots sort behind everything)
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) key[e] = j0 + (unsigned)e < cnt ? keyfn(suf[e], (uint32_t)hd[e] + it * (uint32_t)keyfn.wsym) : ~0ull;
+    deep_bitonic<E>(key, pk);
+    wave_sync();
+#pragma unroll
+    for (int e = 0; e < E; e++) suf[e] = s.suf[pk[e] & 0xFFFFu];        // the suffixes follow their elements
+    // new sub-buckets: a slot starts one where the old sub-bucket or the key changes
+    const uint64_t pkey = __shfl_up(key[E - 1], 1u);
+    const uint32_t ppk = __shfl_up(pk[E - 1], 1u);
+    const uint32_t psuf = __shfl_up(suf[E - 1], 1u);
+    unsigned nhead = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint64_t kp = e ? key[e - 1] : pkey;
+        const uint32_t pp = e ? pk[e - 1] : ppk;
+        const bool other_bucket = (e == 0 && lane == 0u) || (pp >> 16) != (pk[e] >> 16);
+        const bool hnew = other_bucket || kp != key[e] || j0 + (unsigned)e >= cnt;
+        nhead |= (hnew ? 1u : 0u) << e;
+        if (EMIT && emit.lcp && hnew && !other_bucket && j0 + (unsigned)e < cnt)    // split from the member in front of it by this key
+            emit.lcp[emit.S[wbase + pos[e]]] = lcp_deep(emit, (uint32_t)hd[e] + it * (uint32_t)keyfn.wsym, kp, key[e],
+                                                        e ? suf[e - 1] : psuf, suf[e]);
+    }
+    uint32_t ntag[E];
+    {   // first slot of every slot's sub-bucket: running maximum of the head slots
+        uint32_t run = 0, loc[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            if ((nhead >> e) & 1u) run = j0 + (unsigned)e + 1u;         // (slot + 1: 0 = none in this lane)
+            loc[e] = run;
+        }
+        const uint32_t incl = wave_scan_max(run);
+        uint32_t before = __shfl_up(incl, 1u);
+        if (lane == 0u) before = 0u;
+#pragma unroll
+        for (int e = 0; e < E; e++) ntag[e] = (loc[e] ? loc[e] : before) - 1u;
+    }
+    const unsigned nl = __shfl_down(nhead, 1u) & 1u;
+    const unsigned single = nhead & ((nhead >> 1) | ((lane == 63u ? 1u : nl) << (E - 1)));
+    unsigned keep = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        if (j0 + (unsigned)e < cnt) {
+            if ((single >> e) & 1u) {
+                const uint64_t p = wbase + pos[e];
+                V[p] = suf[e];
+                F8[p] = (uint8_t)7;                                     // first of its class | alone | finished here
+            } else {
+                keep |= 1u << e;
+            }
+        }
+    }
+    // the members still tied move to the front: whole sub-buckets, in order
+    const unsigned mine = (unsigned)__popc(keep);
+    const unsigned incl = wave_scan_add(mine);
+    const unsigned total = __shfl(incl, 63);
+    unsigned at = incl - mine;
+    wave_sync();                                                        // (every read of the old slots is done)
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        if ((keep >> e) & 1u) {
+            const unsigned j = j0 + (unsigned)e;
+            s.suf[at] = suf[e];
+            s.pos[at] = pos[e];
+            s.hd[at] = hd[e];
+            s.tag[at] = (uint16_t)(at - (j - ntag[e]));                 // (its sub-bucket moves as a whole)
+            at++;
+        }
+    }
+    wave_sync();
+    return total;
+}
+
+// The buckets of the active list (G), each from its own depth Hd; buckets above W - H members are announced to the
+// large path.  (A second pass of the same kernel over the classes the large path makes of its buckets was measured:
+// it finishes most of them a round earlier, but the large buckets stay large for as many levels as before and the
+// extra scan of the list costs what the shorter lists save -- 222 against 177 ms on 1 GB of English-like text.)
+template <int KPT, bool EMIT>
+__global__ void __launch_bounds__(kBlock)
+k_deep_wave(DeepTextKey keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* __restrict__ V, uint8_t* __restrict__ F8,
+            uint16_t* __restrict__ Hd, unsigned long long* __restrict__ counters,
+            unsigned long long* __restrict__ slots, uint2* __restrict__ segs, LcpEmit emit, int max_iter)
+{
+    constexpr int W = kWave * KPT, H = W / 2, kOwn = W - H;
+    static_assert((KPT & (KPT - 1)) == 0 && KPT >= 2 && KPT <= 8 && W <= 32768, "bitonic network up to 8 per lane; positions fit 15 bits");
+    __shared__ DeepSmem<W> smem[kWavesPerBlock];
+    DeepSmem<W>& s = smem[wave_id()];
+    const unsigned lane = lane_id();
+    const uint64_t wbase = ((uint64_t)blockIdx.x * kWavesPerBlock + wave_id()) * (uint64_t)H;
+    if (wbase >= m) return;                                 // (the whole wave)
+    const unsigned c0 = lane * (unsigned)KPT;               // the lane's positions: c0 .. c0 + KPT - 1
+    const uint64_t p0 = wbase + c0;
+
+    int32_t start[KPT];
+    unsigned headm = 0, elig = 0;                           // bit e: position c0 + e starts a bucket / may be taken
+    uint32_t g[KPT];
+    if (p0 + KPT <= m) {
+#pragma unroll
+        for (int q = 0; q < KPT / 2; q++) {
+            const uint2 v = *reinterpret_cast<const uint2*>(G + p0 + 2 * q);
+            g[2 * q] = v.x;
+            g[2 * q + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < KPT; e++) g[e] = p0 + e < m ? G[p0 + e] : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < KPT; e++) {
+        const bool in = p0 + e < m;
+        headm |= ((!in || (uint64_t)g[e] == p0 + e) ? 1u : 0u) << e;        // (the end of the list ends the last bucket)
+        elig |= (in ? 1u : 0u) << e;
+        start[e] = (in && (uint64_t)g[e] >= wbase) ? (int32_t)((uint64_t)g[e] - wbase) : -1;
+    }
+#pragma unroll
+    for (int e = 0; e < KPT; e++) s.st[c0 + e] = ((elig >> e) & 1u) ? start[e] : -2;
+    wave_sync();
+    // the head flag of the position after this lane's last one (window end: counts as a head)
+    const unsigned nxt_lane_head = __shfl_down(headm, 1u) & 1u;
+    const unsigned nexth = (headm >> 1) | ((lane == 63u ? 1u : nxt_lane_head) << (KPT - 1));   // bit e: position c0 + e + 1 is a head
+    unsigned own = 0, act = 0;
+#pragma unroll
+    for (int e = 0; e < KPT; e++) {
+        const unsigned c = c0 + (unsigned)e;
+        const uint64_t p = p0 + e;
+        // large buckets: announced by the wave in whose home their last member lies
+        if (c < (unsigned)H && p < m && ((nexth >> e) & 1u) && p - (uint64_t)g[e] + 1 > (uint64_t)kOwn) {
+            const unsigned long long k = atomicAdd(&counters[1], 1ull);
+            segs[k] = uint2{g[e], (uint32_t)(p - (uint64_t)g[e] + 1)};
+        }
+        if (((elig >> e) & 1u) && start[e] >= 0 && start[e] < H) {
+            const unsigned sc = (unsigned)start[e];
+            const bool longer = wbase + sc + kOwn < m && s.st[sc + kOwn] == start[e];      // (sc + kOwn < W)
+            if (!longer) {
+                own |= 1u << e;
+                if (!(((headm >> e) & 1u) && ((nexth >> e) & 1u))) act |= 1u << e;          // not alone in its bucket
+                else F8[p] = (uint8_t)7;                                   // (a bucket of one: nothing to do)
+            }
+        }
+    }
+    // the tied members move to slots [0, cnt): whole buckets, in list order
+    unsigned cnt;
+    {
+        const unsigned mine = (unsigned)__popc(act);
+        const unsigned incl = wave_scan_add(mine);
+        cnt = __shfl(incl, 63);
+        unsigned at = incl - mine;
+#pragma unroll
+        for (int e = 0; e < KPT; e++) {
+            if ((act >> e) & 1u) {
+                const unsigned c = c0 + (unsigned)e;
+                s.suf[at] = V[p0 + e];
+                s.pos[at] = (uint16_t)c;
+                s.hd[at] = Hd[p0 + e];
+                s.tag[at] = (uint16_t)(at - (c - (unsigned)start[e]));                      // (its bucket moves as a whole)
+                at++;
+            }
+        }
+    }
+    wave_sync();
+    auto wave_sum = [](unsigned v) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        return v;
+    };
+    unsigned n_gather = 0;
+    uint32_t it = 0;
+    while (cnt > 0 && (int)it < max_iter) {
+        {   // the depth must stay representable
+            bool over = false;
+            for (unsigned j = lane; j < cnt; j += kWave) over |= (uint32_t)s.hd[j] + (it + 1u) * (uint32_t)keyfn.wsym > kDeepMaxDepth;
+            if (__any(over)) break;
+        }
+        n_gather += cnt;
+        unsigned left;
+        if (cnt <= (unsigned)kWave) left = deep_step<1, W, EMIT>(keyfn, s, cnt, it, wbase, V, F8, emit);
+        else if (KPT >= 2 && cnt <= 2u * kWave) left = deep_step<(KPT >= 2 ? 2 : 1), W, EMIT>(keyfn, s, cnt, it, wbase, V, F8, emit);
+        else if (KPT >= 4 && cnt <= 4u * kWave) left = deep_step<(KPT >= 4 ? 4 : 1), W, EMIT>(keyfn, s, cnt, it, wbase, V, F8, emit);
+        else left = deep_step<KPT, W, EMIT>(keyfn, s, cnt, it, wbase, V, F8, emit);
+        it++;
+        const unsigned resolved = cnt - left;
+        cnt = left;
+        // a wave most of whose members stay tied is looking at a repeat: the rank rounds' job
+        if (resolved * 8u < left && left * 4u >= (unsigned)H) break;
+    }
+    // what is still tied leaves as buckets of the list, with the depth reached
+    for (unsigned j = lane; j < cnt; j += kWave) {
+        const uint64_t p = wbase + s.pos[j];
+        V[p] = s.suf[j];
+        F8[p] = (uint8_t)((s.tag[j] == j ? 1u : 0u) | 4u);
+        Hd[p] = (uint16_t)((uint32_t)s.hd[j] + it * (uint32_t)keyfn.wsym);
+    }
+    const unsigned n_own = wave_sum((unsigned)__popc(own));
+    if (lane == 0) {
+        unsigned long long* slot = slots + (size_t)((blockIdx.x * (unsigned)kWavesPerBlock + wave_id()) % kDeepSlots) * 8u;
+        if (n_own) atomicAdd(&slot[0], (unsigned long long)n_own);
+        if (n_gather) atomicAdd(&slot[1], (unsigned long long)n_gather);
     }
 }
 
@@ -784,7 +1133,7 @@ k_flags_reduce(const uint8_t* __restrict__ F8, uint64_t m, uint64_t chunk, uint3
 // inputs on the emulator cross tile boundaries and reach the large-bucket path
 static bool tile_small()
 {
-    static const bool v = [] { const char* e = getenv("SFX_TILE_SMALL"); return e && atoi(e) != 0; }();
+    static const bool v = [] { const char* e = dev_env("SFX_TILE_SMALL"); return e && atoi(e) != 0; }();
     return v;
 }
 // SFX_TILE_GEOM (development): 0 = 1024 threads x 8 (8192-element windows, one workgroup per CU),
@@ -794,12 +1143,12 @@ static bool tile_small()
 // at pair 32 -- small workgroups hide the gather latency better and leave fewer members to the radix passes
 static int tile_geom()
 {
-    static const int v = [] { const char* e = getenv("SFX_TILE_GEOM"); int x = e ? atoi(e) : 3; return x >= 0 && x <= 5 ? x : 3; }();
+    static const int v = [] { const char* e = dev_env("SFX_TILE_GEOM"); int x = e ? atoi(e) : 3; return x >= 0 && x <= 5 ? x : 3; }();
     return v;
 }
 static int tile_pair()
 {
-    static const int v = [] { const char* e = getenv("SFX_TILE_PAIR"); int x = e ? atoi(e) : kPairMaxDefault; return x == 64 ? 64 : 32; }();
+    static const int v = [] { const char* e = dev_env("SFX_TILE_PAIR"); int x = e ? atoi(e) : kPairMaxDefault; return x == 64 ? 64 : 32; }();
     return v;
 }
 
@@ -816,12 +1165,54 @@ static int launch_tile(const KeyFn& keyfn, const TileRound& r, uint64_t m, hipSt
     return SFX_OK;
 }
 
+// buckets above the LDS paths' size (announced in r.seg.segs by the tile / deep kernel): those that fit one workgroup's
+// LDS are sorted by k_seg_single, the rest by the segmented device-wide sort; V and F8 are written at their positions
+template <class KeyFn>
+static int large_phase(const KeyFn& keyfn, const TileRound& r, uint32_t nseg, uint64_t nlarge, hipStream_t st,
+                       sfx_build_stats* stats)
+{
+    if (nseg == 0) return SFX_OK;
+    // buckets that fit one tile of the segmented sort are sorted inside LDS by one workgroup each (SFX_SEG_SINGLE=0:
+    // development, everything through the segmented passes)
+    static const bool singles = [] { const char* e = dev_env("SFX_SEG_SINGLE"); return !e || atoi(e) != 0; }();
+    const uint32_t te = seg_tile_elems(false);
+    // three size classes: 256 threads x 16, 1024 x 11 (one tile of the segmented sort), 1024 x 16 (the LDS holds no more);
+    // with the small tiles of the tests (4096) only the first
+    const uint32_t top = !singles ? 0u : (te > 4096u ? 16384u : 4096u);
+    if (singles) {
+        const uint2* segs = reinterpret_cast<const uint2*>(r.seg.segs);
+        const unsigned grid = (unsigned)dmin<uint64_t>(nseg, (uint64_t)grid_cap() * 2);
+        SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<4, 16, KeyFn>), grid, 4 * kWave, st, keyfn, segs, nseg, 0u, 4096u,
+                   r.V, r.F8, r.emit, r.Hd, r.wsym);
+        if (top > 4096u) {
+            SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<16, 11, KeyFn>), dmin(grid, grid_cap()), 16 * kWave, st,
+                       keyfn, segs, nseg, 4096u, 11264u, r.V, r.F8, r.emit, r.Hd, r.wsym);
+            SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<16, 16, KeyFn>), dmin(grid, grid_cap()), 16 * kWave, st,
+                       keyfn, segs, nseg, 11264u, top, r.V, r.F8, r.emit, r.Hd, r.wsym);
+        }
+    }
+    SFX_TRY(segmented_layout(r.seg, nseg, false, st, top));
+    const unsigned grid = (unsigned)dmin<uint64_t>(nlarge / te + nseg, kMaxGrid);
+    SFX_LAUNCH("seg_gather", (double)nlarge * 16, (k_seg_gather<KeyFn>), grid, kBlock, st, keyfn, (const uint32_t*)r.V,
+               reinterpret_cast<SegTileHost*>(r.seg.tiles), (const uint32_t*)r.seg.counters, r.EA, (const uint16_t*)r.Hd);
+    SFX_TRY(segmented_sort_e64(r.EA, r.EB, r.seg, nseg, nlarge, r.V, r.F8, st, stats, r.emit, r.Hd, r.wsym));
+    if (stats) stats->large_sorted += nlarge;
+    return SFX_OK;
+}
+static int flags_phase(const TileRound& r, uint64_t m, hipStream_t st)
+{
+    Chunking ch = make_chunking(m, kFlagChunkTile);
+    SFX_LAUNCH("flags_reduce", (double)m * 1.25, k_flags_reduce, ch.blocks, kBlock, st, r.F8, m,
+               ch.tiles_per_block * kFlagChunkTile, r.part_head, r.part_keep, r.part_ghead, r.F);
+    return SFX_OK;
+}
+
 template <class KeyFn>
 static int tile_round_impl(const KeyFn& keyfn, const TileRound& r, uint64_t m, hipStream_t st, sfx_build_stats* stats)
 {
     if (m == 0) return SFX_OK;
     if (m > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
-    SFX_HIP(hipMemsetAsync(r.counters, 0, 2 * sizeof(unsigned long long), st));
+    SFX_HIP(hipMemsetAsync(r.counters, 0, 3 * sizeof(unsigned long long), st));     // ([3]: gathers of the deep rounds so far)
     uint64_t tmax = 0;
     if (tile_small()) {
         SFX_TRY((launch_tile<4, 1, 32, KeyFn>(keyfn, r, m, st, &tmax)));
@@ -843,37 +1234,69 @@ static int tile_round_impl(const KeyFn& keyfn, const TileRound& r, uint64_t m, h
     const uint32_t nseg = (uint32_t)host[1];
     if ((nlarge == 0) != (nseg == 0)) return SFX_ERR_INTERNAL;
     if (stats) stats->tile_sorted += host[0];
-    if (nseg > 0) {
-        // buckets that fit one tile of the segmented sort are sorted inside LDS by one workgroup each (SFX_SEG_SINGLE=0:
-        // development, everything through the segmented passes)
-        static const bool singles = [] { const char* e = getenv("SFX_SEG_SINGLE"); return !e || atoi(e) != 0; }();
-        const uint32_t te = seg_tile_elems(false);
-        // three size classes: 256 threads x 16, 1024 x 11 (one tile of the segmented sort), 1024 x 16 (the LDS holds no more);
-        // with the small tiles of the tests (4096) only the first
-        const uint32_t top = !singles ? 0u : (te > 4096u ? 16384u : 4096u);
-        if (singles) {
-            const uint2* segs = reinterpret_cast<const uint2*>(r.seg.segs);
-            const unsigned grid = (unsigned)dmin<uint64_t>(nseg, (uint64_t)grid_cap() * 2);
-            SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<4, 16, KeyFn>), grid, 4 * kWave, st, keyfn, segs, nseg, 0u, 4096u,
-                       r.V, r.F8, r.emit);
-            if (top > 4096u) {
-                SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<16, 11, KeyFn>), dmin(grid, grid_cap()), 16 * kWave, st,
-                           keyfn, segs, nseg, 4096u, 11264u, r.V, r.F8, r.emit);
-                SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<16, 16, KeyFn>), dmin(grid, grid_cap()), 16 * kWave, st,
-                           keyfn, segs, nseg, 11264u, top, r.V, r.F8, r.emit);
-            }
-        }
-        SFX_TRY(segmented_layout(r.seg, nseg, false, st, top));
-        const unsigned grid = (unsigned)dmin<uint64_t>(nlarge / te + nseg, kMaxGrid);
-        SFX_LAUNCH("seg_gather", (double)nlarge * 16, (k_seg_gather<KeyFn>), grid, kBlock, st, keyfn, (const uint32_t*)r.V,
-                   reinterpret_cast<const SegTileHost*>(r.seg.tiles), (const uint32_t*)r.seg.counters, r.EA);
-        SFX_TRY(segmented_sort_e64(r.EA, r.EB, r.seg, nseg, nlarge, r.V, r.F8, st, stats, r.emit));
-        if (stats) stats->large_sorted += nlarge;
-    }
-    Chunking ch = make_chunking(m, kFlagChunkTile);
-    SFX_LAUNCH("flags_reduce", (double)m * 1.25, k_flags_reduce, ch.blocks, kBlock, st, r.F8, m,
-               ch.tiles_per_block * kFlagChunkTile, r.part_head, r.part_keep, r.part_ghead, r.F);
+    SFX_TRY(large_phase(keyfn, r, nseg, nlarge, st, stats));
+    return flags_phase(r, m, st);
+}
+
+// ---- a deep text round -----------------------------------------------------------------------
+// SFX_DEEP_KPT (development): window positions per lane of k_deep_wave, 4 / 8 (default) / 16; the emulator's small-tile
+// hook selects 2 (128-position windows) so that small inputs reach the large path and the residue rules
+static int deep_kpt()
+{
+    static const int v = [] { const char* e = dev_env("SFX_DEEP_KPT"); int x = e ? atoi(e) : 4; return (x == 4 || x == 8) ? x : 4; }();
+    return v;
+}
+static int deep_max_iter()
+{
+    static const int v = [] { const char* e = dev_env("SFX_DEEP_ITERS"); int x = e ? atoi(e) : 24; return x >= 1 && x <= 4096 ? x : 24; }();
+    return v;
+}
+int deep_text_symbols(const PackedText& pt) { return text_key64_symbols(pt); }
+
+template <int KPT>
+static int launch_deep(const DeepTextKey& keyfn, const TileRound& r, uint64_t m, hipStream_t st, uint64_t* own_max)
+{
+    constexpr int W = kWave * KPT, H = W / 2;
+    *own_max = W - H;
+    const uint64_t blocks = (m + (uint64_t)H * kWavesPerBlock - 1) / ((uint64_t)H * kWavesPerBlock);
+    if (blocks > 0x7FFFFFFFull) return SFX_ERR_TOO_LARGE;
+    SFX_HIP(hipMemsetAsync(r.deep_slots, 0, (size_t)kDeepSlotWords * sizeof(unsigned long long), st));
+    // read G (+ V + Hd of what it takes), write V + F8 (+ Hd of what stays tied); the gathers are counted by the kernel
+    const double algo = (double)m * (4 + 4);
+    if (r.emit.lcp)
+        SFX_LAUNCH("deep_wave", algo, (k_deep_wave<KPT, true>), (unsigned)blocks, kBlock, st, keyfn, r.G, m, r.V, r.F8, r.Hd,
+                   r.counters, r.deep_slots, reinterpret_cast<uint2*>(r.seg.segs), r.emit, deep_max_iter());
+    else
+        SFX_LAUNCH("deep_wave", algo, (k_deep_wave<KPT, false>), (unsigned)blocks, kBlock, st, keyfn, r.G, m, r.V, r.F8, r.Hd,
+                   r.counters, r.deep_slots, reinterpret_cast<uint2*>(r.seg.segs), r.emit, deep_max_iter());
+    SFX_LAUNCH("deep_totals", 0.0, k_deep_totals, 1, kBlock, st, (const unsigned long long*)r.deep_slots, r.counters, 1);
     return SFX_OK;
+}
+
+// One text round over the active list.  Buckets of up to W / 2 members are FINISHED by k_deep_wave (every bucket carries
+// its own depth r.Hd; what stays tied leaves with a larger one).  Larger buckets are split by their next
+// text_round_symbols symbols at THEIR depth (32-bit key2, LDS / segmented sorts; their classes leave with that many more).
+// r.counters[3] accumulates the gathers.
+int deep_round_text(const PackedText& pt, const TileRound& r, uint64_t m, hipStream_t st, sfx_build_stats* stats)
+{
+    if (m == 0) return SFX_OK;
+    if (m > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    const int wsym = text_key64_symbols(pt);
+    const DeepTextKey keyfn = {pt, 2 * pt.kbits - wsym * pt.bits, wsym};
+    SFX_HIP(hipMemsetAsync(r.counters, 0, 3 * sizeof(unsigned long long), st));
+    uint64_t own_max = 0;
+    if (tile_small()) SFX_TRY(launch_deep<2>(keyfn, r, m, st, &own_max));
+    else if (deep_kpt() == 8) SFX_TRY(launch_deep<8>(keyfn, r, m, st, &own_max));
+    else SFX_TRY(launch_deep<4>(keyfn, r, m, st, &own_max));
+    unsigned long long host[2] = {0, 0};                      // members finished or refined by the waves, large buckets
+    SFX_TRY(read_back(host, r.counters, sizeof(host), st));
+    if (host[0] > m || host[1] > m / (own_max + 1)) return SFX_ERR_INTERNAL;
+    const uint64_t nlarge = m - host[0];
+    const uint32_t nseg = (uint32_t)host[1];
+    if ((nlarge == 0) != (nseg == 0)) return SFX_ERR_INTERNAL;
+    if (stats) stats->tile_sorted += host[0];
+    SFX_TRY(large_phase(TextKey{pt, 0, pt.kbits == 32 ? pt.bits : 0}, r, nseg, nlarge, st, stats));
+    return flags_phase(r, m, st);
 }
 
 int text_key64_symbols(const PackedText& pt);

@@ -81,6 +81,25 @@ if os.environ.get("SFX_HYBRID_MIN"):
     if cap < 400:
         names = kernels_of(skewed)
         assert "radix_hist16_text" in names and "bucket_sort_lds" not in names, names
+if os.environ.get("SFX_DEEP_ITERS") or os.environ.get("SFX_DEEP_KPT"):
+    # deep text rounds: buckets finished inside one wave, members that stay tied leaving with their own depth (capped
+    # iterations: every round leaves such buckets), buckets above the wave's window on the large path, fused LCP values
+    # from the keys of the iteration that splits a pair.  Repeats of 20 .. 300 symbols in 2 .. 40 copies over three alphabets.
+    rngd = np.random.default_rng(2024)
+    for sigma, n0 in ((4, 30000), (60, 20000), (200, 20000)):
+        body = rngd.integers(0, sigma, n0, dtype=np.uint8)
+        parts = [body.tobytes()]
+        for _ in range(25):
+            a = int(rngd.integers(0, n0 - 400)); ln = int(rngd.integers(20, 300)); cp = int(rngd.integers(2, 40))
+            for _ in range(cp):
+                parts.append(body[a:a + ln].tobytes() + bytes(rngd.integers(0, sigma, 3, dtype=np.uint8).tolist()))
+        texts.append(b"".join(parts))
+    texts.append(_gen.english_like(30000, seed=8).tobytes() * 2 + b"!")
+    for t in texts:
+        exp = oracle.sais(t)
+        st2, lcp2 = SuffixTable.new_with_lcp(t, engine=eng)
+        assert np.array_equal(st2.table(), exp), ("fused SA", len(t))
+        assert np.array_equal(lcp2, oracle.lcp_kasai(t, exp)), ("fused LCP", len(t))
 for t in texts:
     st = SuffixTable(t, engine=eng)
     exp = oracle.sais(t)
@@ -140,6 +159,13 @@ VARIANTS = {
     "tile-1024x4-pair32": {"SFX_TILE_GEOM": "1", "SFX_TILE_PAIR": "32"},
     "tile-512x8": {"SFX_TILE_GEOM": "2"},
     "tile-512x4-key64": {"SFX_TILE_GEOM": "3", "SFX_FORCE_KEY64": "1"},
+    # deep text rounds (k_deep_wave): one / two iterations per round (every round leaves tied members with their own
+    # depth), 128-position windows (more buckets on the large path, more waves per text), the other window sizes
+    "deep-one-iteration": {"SFX_DEEP_ITERS": "1"},
+    "deep-two-iterations-small-windows": {"SFX_DEEP_ITERS": "2", "SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
+    "deep-small-windows-key64": {"SFX_DEEP_ITERS": "24", "SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "3"},
+    "deep-256-position-windows": {"SFX_DEEP_KPT": "4"},
+    "deep-1024-position-windows": {"SFX_DEEP_KPT": "16", "SFX_DEEP_ITERS": "3"},
 }
 
 
