@@ -247,6 +247,22 @@ template <> __device__ __forceinline__ uint64_t packed_key<uint64_t>(const Packe
     return packed_key64(t, p);
 }
 
+// ---- order-preserving compressed keys ----------------------------------------------------------
+// A fixed-width key spends ceil(log2 sigma) bits on every symbol; natural-language text has 4-5 bits of
+// entropy per symbol.  An ALPHABETIC prefix code (codes ordered like the symbols, none a prefix of another:
+// Hu-Tucker / Garsia-Wachs trees) keeps the order of the strings -- two suffixes compare like the
+// concatenations of their symbols' codes -- so the key of the initial sort holds ~13 symbols of English instead
+// of 8 for one more radix pass.  The buckets then share a VARIABLE number of symbols: as many codes as fit the
+// key's kHtCodeBits code bits completely (at most kHtMaxSym).  That number is a function of those bits, so it
+// rides in the key's low kHtCountBits bits without changing the order of anything, and the bucket pass reads a
+// bucket's depth straight off its key (per-bucket depths: Hd, sfx_sa.hip).
+// ent[s], s = dense symbol code: code left-aligned in bits 31..5, length (1..27) in bits 4..0; the smallest symbol's
+// code is all zeros, so the zero padding past the end of the text reads as that symbol.
+constexpr int kHtMaxLen = 27;
+constexpr int kHtCountBits = 4;
+constexpr int kHtCodeBits = 64 - kHtCountBits;
+constexpr unsigned kHtMaxSym = (1u << kHtCountBits) - 1u;
+
 // number of bits needed to represent values in [0, v]
 __host__ __device__ inline int bits_for(uint64_t v)
 {

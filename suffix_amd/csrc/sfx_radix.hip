@@ -79,6 +79,13 @@ struct SrcKV {
     __device__ __forceinline__ uint64_t key(uint64_t i) const { return k[i]; }
     __device__ __forceinline__ uint32_t val(uint64_t i) const { return v[i]; }
 };
+struct SrcKeyIota {                 // keys in an array, value = index (the compressed keys of k_ht_keys)
+    static constexpr bool kHasVal = true;
+    static constexpr bool kFromText = false;
+    const uint64_t* k;
+    __device__ __forceinline__ uint64_t key(uint64_t i) const { return k[i]; }
+    __device__ __forceinline__ uint32_t val(uint64_t i) const { return (uint32_t)i; }
+};
 struct SrcText64 {
     static constexpr bool kHasVal = true;
     static constexpr bool kFromText = true;
@@ -1261,6 +1268,122 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
         if (stats) { stats->radix_passes++; stats->elements_sorted += m; }
     }
     *result_in_1 = (cur == e1) ? 1 : 0;
+    return SFX_OK;
+}
+
+// ---- compressed keys of a whole text ---------------------------------------------------------------
+// key of position i = the codes of symbols i, i + 1, ... (at most kHtMaxSym of them) cut to kHtCodeBits bits, then the
+// number of those symbols whose code lies completely inside (sfx_device.hpp).  A thread takes kHtRun CONSECUTIVE
+// positions and keeps the codes of the symbols ahead of it in a 128-bit buffer: the key of the next position is the
+// buffer shifted by the length of the symbol that leaves, topped up with the codes of the symbols that now fit -- about
+// two table look-ups per position instead of one per symbol and position.  A workgroup takes tiles of kHtTile
+// positions: the code table entries of the tile's symbols (+ the kHtMaxSym - 1 beyond it) go to LDS first, the keys
+// leave through LDS in coalesced order, and the digit counts of all eight radix passes are taken on the way out (the
+// role of k_radix_hist_all).
+constexpr int kHtRun = 16;
+constexpr int kHtTile = kBlock * kHtRun;                     // 4096 positions
+constexpr int kHtPad = 16;                                   // >= kHtMaxSym - 1
+__global__ void __launch_bounds__(kBlock)
+k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t tiles_per_block, int npass,
+          uint64_t* __restrict__ K, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t s_tab[256];
+    __shared__ uint32_t s_ent[kHtTile + kHtPad];
+    __shared__ uint64_t s_key[kHtTile];
+    __shared__ uint32_t h[kWavesPerBlock][kMaxPasses][kRadix];       // 32 KiB
+    const unsigned tid = threadIdx.x, w = wave_id();
+    s_tab[tid] = ent[tid];
+    for (unsigned i = tid; i < kWavesPerBlock * kMaxPasses * kRadix; i += kBlock) (&h[0][0][0])[i] = 0;
+    __syncthreads();
+    const unsigned bits = (unsigned)t.bits;
+    const uint32_t smask = (1u << bits) - 1u;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * tiles_per_block;
+    for (uint64_t tile = tile0; tile < tile0 + tiles_per_block; tile++) {
+        const uint64_t base = tile * kHtTile;
+        if (base >= m) break;
+        for (unsigned i = tid; i < (unsigned)(kHtTile + kHtPad); i += kBlock) {
+            const uint64_t p = base + i;                     // (positions past the text read as the padding's zero symbol)
+            const uint64_t q = packed_word_index(t, p);
+            const unsigned off = (unsigned)(p - q * (uint64_t)t.spw);
+            s_ent[i] = s_tab[p < t.n ? (t.words[q] >> (((unsigned)t.spw - 1u - off) * bits)) & smask : 0u];
+        }
+        __syncthreads();
+        {
+            const unsigned i0 = tid * (unsigned)kHtRun;
+            uint64_t hi = 0, lo = 0;                         // the codes of symbols [i, j), nb bits, left-aligned in hi:lo
+            unsigned nb = 0, j = i0;
+            unsigned jc = i0, nbc = 0;                       // symbols [i, jc) lie completely inside the first kHtCodeBits bits (nbc of them)
+            for (unsigned i = i0; i < i0 + (unsigned)kHtRun; i++) {
+                while (nb < (unsigned)kHtCodeBits && j < i + kHtMaxSym) {
+                    const uint32_t e = s_ent[j++];
+                    const uint64_t c = (uint64_t)(e & ~31u) << 32;
+                    const unsigned len = e & 31u;
+                    hi |= c >> nb;
+                    if (nb + len > 64u) lo |= c << (64u - nb);           // (nb >= 38 here: the shift is < 64)
+                    nb += len;
+                }
+                while (jc < j && nbc + (s_ent[jc] & 31u) <= (unsigned)kHtCodeBits) nbc += s_ent[jc++] & 31u;
+                s_key[i] = ((hi >> kHtCountBits) << kHtCountBits) | (uint64_t)(jc - i);
+                const unsigned len = s_ent[i] & 31u;         // symbol i leaves (it is in the buffer: j > i, and complete: jc > i)
+                hi = (hi << len) | (lo >> (64u - len));
+                lo <<= len;
+                nb -= len;
+                nbc -= len;
+            }
+        }
+        __syncthreads();
+        for (unsigned i = tid; i < (unsigned)kHtTile; i += kBlock) {
+            if (base + i < m) {
+                const uint64_t key = s_key[i];
+                K[base + i] = key;
+                if (partial)
+                    for (int p = 0; p < npass; p++) atomicAdd(&h[w][p][(unsigned)(key >> (8 * p)) & 255u], 1u);
+            }
+        }
+        __syncthreads();
+    }
+    if (partial)
+        for (int p = 0; p < npass; p++) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int k = 0; k < kWavesPerBlock; k++) c += h[k][p][tid];
+            partial[((uint64_t)p * kRadix + tid) * gridDim.x + blockIdx.x] = c;
+        }
+}
+
+// Sort of all m = text.n suffixes by their compressed 64-bit keys (eight passes); (k0, v0) / (k1, v1) as
+// radix_sort_kv64, the keys are made here.
+int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, uint32_t* scratch, hipStream_t st,
+                    int* result_in_1, sfx_build_stats* stats, const PackedText& text, const uint32_t* ht)
+{
+    *result_in_1 = 0;
+    if (m == 0) return SFX_OK;
+    if (m > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
+    const int npass = 8;
+    const bool sweep = use_sweep(m, npass);
+    RadixScratch scr(scratch, m);
+    {
+        Chunking ch = make_chunking(m, kHtTile, kHistAllGrid);
+        SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
+        SFX_LAUNCH("ht_keys", (double)m * (text.bits / 8.0 + 8.0), k_ht_keys, ch.blocks, kBlock, st, text, ht, m, ch.tiles_per_block, npass, k0,
+                   sweep ? scr.partial : (uint32_t*)nullptr);
+        if (sweep)
+            SFX_LAUNCH("radix_scan", (double)npass * kRadix * ch.blocks * 8, k_radix_scan, npass * kRadix, kBlock, st, scr.partial,
+                       ch.blocks, scr.totals);
+    }
+    uint64_t* kin = k0; uint32_t* vin = v0;
+    uint64_t* kout = k1; uint32_t* vout = v1;
+    int flips = 0;
+    for (int p = 0; p < npass; p++) {
+        const double algo = (double)m * ((p == 0 ? 8.0 : 12.0) + 12.0);
+        if (p == 0) SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKeyIota{kin}, DstKV{kout, vout}, m, 8 * p, 255u, scr, p, sweep, st));
+        else SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKV{kin, vin}, DstKV{kout, vout}, m, 8 * p, 255u, scr, p, sweep, st));
+        uint64_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+        flips ^= 1;
+        if (stats) { stats->radix_passes++; stats->elements_sorted += m; }
+    }
+    *result_in_1 = flips;
     return SFX_OK;
 }
 

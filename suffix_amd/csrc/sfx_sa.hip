@@ -39,6 +39,7 @@
 // sorts only the suffixes whose leading key bits fall in its bucket range and
 // refines with text rounds only (no ranks of foreign suffixes needed).
 #include <stdio.h>
+#include <vector>
 #include <string.h>
 
 #include "sfx_host.hpp"
@@ -585,6 +586,10 @@ __device__ __forceinline__ unsigned valid_mask(uint64_t i0, uint64_t m)
 // for two neighbours with DIFFERENT keys the common prefix is the number of equal leading symbols of the
 // keys -- no text access (97.7 % of the pairs of 100 MB of DNA).  Neighbours with equal keys get
 // kLcpPending and are compared on the text once the suffix array is final (k_lcp_pending).
+// the keys are compressed (k_ht_keys): a bucket's depth is the count in its key's low bits
+struct HtDepth {
+    int on;
+};
 struct LcpFuse {
     uint32_t* lcp;          // nullptr = off
     int pad_bits;           // unused high bits of a key
@@ -715,8 +720,22 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                uint32_t* __restrict__ V_next, uint32_t* __restrict__ G_next,
                uint32_t* __restrict__ R_next, int sa_in_place, uint64_t* __restrict__ rank_pairs,
                const uint16_t* __restrict__ flags_in, uint32_t* __restrict__ pair_hist, int pair_lo, int pair_nb,
-               const uint16_t* __restrict__ Hd, uint16_t* __restrict__ Hd_next, uint32_t hd_floor)
+               const uint16_t* __restrict__ Hd, uint16_t* __restrict__ Hd_next, uint32_t hd_floor, HtDepth ht,
+               uint32_t* __restrict__ min_depth)
 {
+    // ht.on (initial bucket pass over compressed keys): the depth of a bucket rides in its key;
+    // min_depth: smallest depth given to a kept element (the rank rounds' h, should the text rounds give way)
+    __shared__ uint32_t s_min;
+    if (ht.on) {
+        if (threadIdx.x == 0) s_min = 0xFFFFFFFFu;
+        __syncthreads();
+    }
+    uint32_t my_min = 0xFFFFFFFFu;
+    auto depth_of = [&](uint64_t i) -> uint32_t {
+        const uint32_t d = ht.on ? (uint32_t)((uint64_t)K[i] & (uint64_t)kHtMaxSym) : (Hd ? dmax<uint32_t>(Hd[i], hd_floor) : hd_floor);
+        my_min = dmin(my_min, d);
+        return d;
+    };
     // Hd_next (deep text rounds): the kept elements carry the depth of their bucket, at least hd_floor (what the
     // round's large-bucket path established for the buckets it split; the deep kernel wrote larger values itself)
     __shared__ uint32_t part_m[2][kWavesPerBlock], part_a[2][kWavesPerBlock];
@@ -737,7 +756,6 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     uint32_t c_keep = part_keep[blockIdx.x];
     (void)part_ghead;
     unsigned par = 0;
-    (void)K;
     // head / single bits of the thread's elements = SUB flag words of k_groups_reduce, one load
     // (25 MB per 10^8 elements instead of reading the keys a second time); the next tile's
     // words are in flight while this tile is scanned
@@ -804,7 +822,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                 S_next[pos] = slot;
                 V_next[pos] = suffix;
                 G_next[pos] = pos - ((uint32_t)i - my_head);
-                if (Hd_next) Hd_next[pos] = (uint16_t)(Hd ? dmax<uint32_t>(Hd[i], hd_floor) : hd_floor);
+                if (Hd_next) Hd_next[pos] = (uint16_t)depth_of(i);
             }
         } else
 #pragma unroll
@@ -853,7 +871,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                             S_next[run_keep] = slot[j];
                             V_next[run_keep] = suffix[j];
                             G_next[run_keep] = run_keep - back[j];   // bucket id = position of its head in the new list
-                            if (Hd_next) Hd_next[run_keep] = (uint16_t)(Hd ? dmax<uint32_t>(Hd[ib + j], hd_floor) : hd_floor);
+                            if (Hd_next) Hd_next[run_keep] = (uint16_t)depth_of(ib + j);
                             run_keep++;
                         }
                     }
@@ -864,6 +882,12 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         }
         c_head = dmax(c_head, tot_m);
         c_keep += tot_a;
+    }
+    if (ht.on && min_depth) {
+        for (int d = 32; d >= 1; d >>= 1) my_min = dmin(my_min, (uint32_t)__shfl_xor(my_min, d));
+        if (lane == 0) atomicMin(&s_min, my_min);
+        __syncthreads();
+        if (tid == 0 && s_min != 0xFFFFFFFFu) atomicMin(min_depth, s_min);
     }
     if (SUB == 1 && pair_hist) {
         __syncthreads();
@@ -1108,6 +1132,77 @@ static uint64_t packed_words(uint64_t n, const Alphabet* a)
 // rank array, so the n-element ISA scatter is skipped unless a further round is needed.
 constexpr uint64_t kTextFirstDivisor = 4;
 
+// ---- order-preserving code of the dense symbols (k_ht_keys, sfx_radix.hip) -------------------------
+// Optimal alphabetic binary tree over the symbol counts (dynamic programme over symbol ranges, O(sigma^3) <= 2.8 M steps
+// on the host); counts are floored so that no code is longer than kHtMaxLen bits.  Returns false when the code would
+// not pay: the alphabet fills its fixed width (random bytes), or fewer than two symbols.
+struct HtHost {
+    uint32_t ent[256];
+    int sigma;
+    double avg_len;
+};
+static bool ht_build(const unsigned long long* counts256, int fixed_bits, HtHost* out)
+{
+    unsigned long long w[256];
+    int ns = 0;
+    unsigned long long total = 0;
+    for (int c = 0; c < 256; c++)
+        if (counts256[c]) { w[ns++] = counts256[c]; total += counts256[c]; }
+    if (ns < 2 || total == 0) return false;
+    std::vector<double> cost_v((size_t)ns * ns);
+    std::vector<unsigned short> root_v((size_t)ns * ns);
+    double* const C = cost_v.data();
+    unsigned short* const R = root_v.data();
+    auto at = [ns](int i, int j) { return (size_t)i * ns + j; };
+    int len[256];
+    for (int shift = 16; shift >= 4; shift -= 2) {
+        double ww[256], pre[257];
+        const double floor_w = (double)total / (double)(1ull << shift);
+        pre[0] = 0;
+        for (int i = 0; i < ns; i++) { ww[i] = (double)w[i] > floor_w ? (double)w[i] : floor_w; pre[i + 1] = pre[i] + ww[i]; }
+        for (int i = 0; i < ns; i++) { C[at(i, i)] = 0; R[at(i, i)] = (unsigned short)i; }
+        for (int L = 2; L <= ns; L++) {
+            for (int i = 0; i + L <= ns; i++) {
+                const int j = i + L - 1;
+                double best = 1e300;
+                int bk = i;
+                for (int k = i; k < j; k++) {
+                    const double v = C[at(i, k)] + C[at(k + 1, j)];
+                    if (v < best) { best = v; bk = k; }
+                }
+                C[at(i, j)] = best + (pre[j + 1] - pre[i]);
+                R[at(i, j)] = (unsigned short)bk;
+            }
+        }
+        // codes by descent (explicit stack): left = 0, right = 1
+        struct Item { int i, j, d; uint32_t code; } stack[512];
+        int sp = 0;
+        stack[sp++] = Item{0, ns - 1, 0, 0u};
+        bool ok = true;
+        while (sp) {
+            const Item it = stack[--sp];
+            if (it.i == it.j) {
+                len[it.i] = it.d ? it.d : 1;
+                if (len[it.i] > kHtMaxLen) { ok = false; break; }
+                out->ent[it.i] = (it.d ? (it.code << (32 - it.d)) : 0u) | (uint32_t)len[it.i];
+                continue;
+            }
+            if (it.d >= kHtMaxLen) { ok = false; break; }
+            const int k = R[at(it.i, it.j)];
+            stack[sp++] = Item{k + 1, it.j, it.d + 1, (it.code << 1) | 1u};
+            stack[sp++] = Item{it.i, k, it.d + 1, it.code << 1};
+        }
+        if (!ok) continue;
+        double avg = 0;
+        for (int i = 0; i < ns; i++) avg += (double)w[i] / (double)total * len[i];
+        for (int i = ns; i < 256; i++) out->ent[i] = 0xFFFFFFFFu;
+        out->sigma = ns;
+        out->avg_len = avg;
+        return avg + 0.75 < (double)fixed_bits;
+    }
+    return false;
+}
+
 struct SaBuffers {
     uint64_t* K0; uint64_t* K1;                         // key ping-pong (8 B per element)
     uint32_t* VA; uint32_t* VB;                         // suffix ping-pong
@@ -1128,6 +1223,7 @@ struct SaBuffers {
     uint32_t* totals;
     unsigned long long* bins;                           // 256
     uint8_t* lut;                                       // 256
+    uint32_t* ht;                                       // order-preserving code of the dense symbols: [256] table, [256] minimum depth
 };
 
 static inline uint32_t* isa_scratch_h(SaBuffers& b) { return b.R; }       // n + 1024 u32, free between rounds
@@ -1167,7 +1263,9 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint32_t* totals = ar.template take<uint32_t>(64);
     unsigned long long* bins = ar.template take<unsigned long long>(256);
     uint8_t* lut = ar.template take<uint8_t>(256);
+    uint32_t* ht = ar.template take<uint32_t>(256 + 64);
     if (b) {
+        b->ht = ht;
         b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->G1 = G1; b->F = F; b->F8 = F8;
         b->Hd0 = Hd0; b->Hd1 = Hd1;
         b->counters = counters; b->deep_slots = deep_slots; b->block_counts = bc; b->R = R;
@@ -1212,7 +1310,8 @@ template <class KeyT>
 static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint64_t m, SaBuffers& b,
                        uint32_t* sa, uint32_t* isa, uint32_t* S_next, uint32_t* V_next,
                        uint32_t* R_next, hipStream_t st, int sa_mode, uint64_t n, sfx_build_stats& stats,
-                       uint64_t kept, const uint16_t* Hd = nullptr, uint16_t* Hd_next = nullptr, uint32_t hd_floor = 0)
+                       uint64_t kept, const uint16_t* Hd = nullptr, uint16_t* Hd_next = nullptr, uint32_t hd_floor = 0,
+                       HtDepth ht = HtDepth{0}, uint32_t* min_depth = nullptr)
 {
     const bool sa_in_place = sa_mode == 1;
     // the sorted keys K sit in one of K0/K1 (for 32-bit keys: in its first half); the other
@@ -1239,11 +1338,11 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
     if (sa_in_place && !isa && kept * kSparseApplyDivisor <= m)
         SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, kApplySub>), ch.blocks, kBlock, st, K, V, S, m,
                    ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
-                   b.G, R_next, 1, pairs, (const uint16_t*)b.F, (uint32_t*)nullptr, 0, 0, Hd, Hd_next, hd_floor);
+                   b.G, R_next, 1, pairs, (const uint16_t*)b.F, (uint32_t*)nullptr, 0, 0, Hd, Hd_next, hd_floor, ht, min_depth);
     else
         SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, 1>), ch.blocks, kBlock, st, K, V, S, m,
                    ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
-                   b.G, R_next, sa_mode, pairs, (const uint16_t*)b.F, pair_hist, pair_lo, pair_nb, Hd, Hd_next, hd_floor);
+                   b.G, R_next, sa_mode, pairs, (const uint16_t*)b.F, pair_hist, pair_lo, pair_nb, Hd, Hd_next, hd_floor, ht, min_depth);
     if (pairs) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, m, n, isa, b.hist, st, &stats, pair_blocks));
     return SFX_OK;
 }
@@ -1586,8 +1685,10 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
 template <class KeyT>
 static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool from_text, SaBuffers& b,
                            uint32_t* sa, uint32_t* isa, hipStream_t st, sfx_build_stats& stats,
-                           unsigned hist_blocks = 0, uint32_t* lcp_fuse = nullptr)
+                           unsigned hist_blocks = 0, uint32_t* lcp_fuse = nullptr, const HtHost* ht = nullptr)
 {
+    // ht (64-bit keys of a full build): the keys are the suffixes' symbols in an order-preserving prefix code (k_ht_keys);
+    // a bucket's depth is what its key holds (between kHtCodeBits / longest code and kHtMaxSym symbols)
     const KeyT* Kr;
     const uint32_t* Vr;
     uint32_t* V_next;
@@ -1604,8 +1705,11 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         V_next = b.VA;
         in_place = true;
     } else {
-        SFX_TRY(radix_sort_kv64(b.K0, b.VA, b.K1, b.VB, count, 0, pt.bits * cpk, b.hist, st, &in1, &stats,
-                                from_text ? &pt : nullptr));
+        if (ht && from_text && count == pt.n)
+            SFX_TRY(radix_sort_ht64(b.K0, b.VA, b.K1, b.VB, count, b.hist, st, &in1, &stats, pt, b.ht));
+        else
+            SFX_TRY(radix_sort_kv64(b.K0, b.VA, b.K1, b.VB, count, 0, pt.bits * cpk, b.hist, st, &in1, &stats,
+                                    from_text ? &pt : nullptr));
         Kr = (const KeyT*)(in1 ? b.K1 : b.K0);
         Vr = in1 ? b.VB : b.VA;
         V_next = in1 ? b.VA : b.VB;
@@ -1624,12 +1728,23 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     stats.active_after_initial = kept;
     // no rank array yet: its n-element scatter is only paid if the text rounds stall (refine)
     // (every bucket of the first active list shares the cpk symbols of the initial key: b.Hd0, the depths of the deep rounds)
-    SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place ? 1 : 0, pt.n, stats,
-                              kept, nullptr, b.Hd0, (uint32_t)cpk));
+    uint64_t h0 = (uint64_t)cpk;                        // symbols every bucket of the first active list shares
+    if (ht && kept > 0) {
+        SFX_HIP(hipMemsetAsync(b.ht + 256, 0xFF, sizeof(uint32_t), st));
+        SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place ? 1 : 0, pt.n, stats,
+                                  kept, nullptr, b.Hd0, 0u, HtDepth{1}, b.ht + 256));
+        uint32_t md = 0;
+        SFX_TRY(read_back(&md, b.ht + 256, sizeof(md), st));
+        if (md == 0xFFFFFFFFu || md == 0) return SFX_ERR_INTERNAL;
+        h0 = md;
+    } else {
+        SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place ? 1 : 0, pt.n, stats,
+                                  kept, nullptr, b.Hd0, (uint32_t)cpk));
+    }
     uint32_t* S_cur = b.S0;
     if (small_groups_pay(kept, groups))
-        SFX_TRY(small_groups_pass(pt, (uint64_t)cpk, b, sa, nullptr, &S_cur, &V_next, &kept, st, stats, lcp_fuse, true));
-    return refine(pt, cpk, b, sa, isa, S_cur, V_next, kept, st, stats, lcp_fuse);
+        SFX_TRY(small_groups_pass(pt, h0, b, sa, nullptr, &S_cur, &V_next, &kept, st, stats, lcp_fuse, true));
+    return refine(pt, (int)h0, b, sa, isa, S_cur, V_next, kept, st, stats, lcp_fuse);
 }
 
 // lcp_fuse != nullptr: also leave, in lcp_fuse[r], the LCP of every adjacent pair that the initial sort
@@ -1670,7 +1785,20 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
     stats.symbols_per_key = (uint32_t)cpk;
     if (cpk_out) *cpk_out = cpk;
     if (key_bits == 32) return sort_and_refine<uint32_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats, 0, lcp_fuse);
-    return sort_and_refine<uint64_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats, 0, lcp_fuse);
+    // 64-bit keys: compressed when the symbol counts say it pays (natural-language text: 13 symbols per key instead of 8).
+    // SFX_HT=0 (development): fixed-width keys.  (The fused LCP reads common prefixes off fixed-width keys: not with these.)
+    static const bool ht_on = [] { const char* e = dev_env("SFX_HT"); return !e || atoi(e) != 0; }();
+    static const uint64_t ht_min = [] { const char* e = dev_env("SFX_HT_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 16); }();
+    HtHost ht;
+    bool use_ht = false;
+    if (ht_on && !lcp_fuse && n >= ht_min) {
+        SFX_TRY(byte_histogram_dev(d_text, 0, n, reinterpret_cast<uint64_t*>(b.bins), st));
+        unsigned long long counts[256];
+        SFX_TRY(read_back(counts, b.bins, sizeof(counts), st));
+        use_ht = ht_build(counts, alpha.bits, &ht);
+        if (use_ht) SFX_HIP(hipMemcpyAsync(b.ht, ht.ent, sizeof(ht.ent), hipMemcpyHostToDevice, st));
+    }
+    return sort_and_refine<uint64_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats, 0, lcp_fuse, use_ht ? &ht : nullptr);
 }
 
 int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,
