@@ -251,17 +251,43 @@ template <> __device__ __forceinline__ uint64_t packed_key<uint64_t>(const Packe
 // A fixed-width key spends ceil(log2 sigma) bits on every symbol; natural-language text has 4-5 bits of
 // entropy per symbol.  An ALPHABETIC prefix code (codes ordered like the symbols, none a prefix of another:
 // Hu-Tucker / Garsia-Wachs trees) keeps the order of the strings -- two suffixes compare like the
-// concatenations of their symbols' codes -- so the key of the initial sort holds ~13 symbols of English instead
-// of 8 for one more radix pass.  The buckets then share a VARIABLE number of symbols: as many codes as fit the
-// key's kHtCodeBits code bits completely (at most kHtMaxSym).  That number is a function of those bits, so it
-// rides in the key's low kHtCountBits bits without changing the order of anything, and the bucket pass reads a
-// bucket's depth straight off its key (per-bucket depths: Hd, sfx_sa.hip).
+// concatenations of their symbols' codes -- so the 64 key bits of the initial sort hold ~14 symbols of English
+// instead of 8 for one more radix pass.  The buckets then share a VARIABLE number of symbols (as many codes as
+// fit the key completely, at most kHtMaxSym): that number is recovered from the key itself (ht_depth) by the
+// bucket pass and kept per bucket (Hd, sfx_sa.hip).
 // ent[s], s = dense symbol code: code left-aligned in bits 31..5, length (1..27) in bits 4..0; the smallest symbol's
 // code is all zeros, so the zero padding past the end of the text reads as that symbol.
 constexpr int kHtMaxLen = 27;
-constexpr int kHtCountBits = 4;
-constexpr int kHtCodeBits = 64 - kHtCountBits;
-constexpr unsigned kHtMaxSym = (1u << kHtCountBits) - 1u;
+constexpr unsigned kHtMaxSym = 16;                  // symbols a key is made from at most
+// t12[w], w = the next 12 key bits: symbols that lie completely inside them << 4 | bits they take (made on the
+// host, ht_build) -- two or three symbols per look-up; a code longer than 12 bits, and the last symbols before the
+// key's end, are found one at a time by bisection over the (ordered) codes.
+constexpr int kHtFastBits = 12;
+__device__ __forceinline__ uint32_t ht_depth(uint64_t key, const uint32_t* ent, const uint8_t* t12, int sigma)
+{
+    unsigned used = 0, cnt = 0;
+    while (cnt < kHtMaxSym && used < 64u) {
+        const uint64_t rest = key << used;
+        const unsigned f = t12[(unsigned)(rest >> (64 - kHtFastBits))];
+        const unsigned c = f >> 4, u = f & 15u;
+        if (c && used + u <= 64u && cnt + c <= kHtMaxSym) {
+            used += u;
+            cnt += c;
+            continue;
+        }
+        const uint32_t win = (uint32_t)(rest >> 32);
+        int lo = 0, hi = sigma - 1;                      // the largest symbol whose code is <= the window: the one it starts with
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((ent[mid] & ~31u) <= win) lo = mid; else hi = mid - 1;
+        }
+        const unsigned len = ent[lo] & 31u;
+        if (used + len > 64u) break;
+        used += len;
+        cnt++;
+    }
+    return cnt;
+}
 
 // number of bits needed to represent values in [0, v]
 __host__ __device__ inline int bits_for(uint64_t v)

@@ -1272,24 +1272,25 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
 }
 
 // ---- compressed keys of a whole text ---------------------------------------------------------------
-// key of position i = the codes of symbols i, i + 1, ... (at most kHtMaxSym of them) cut to kHtCodeBits bits, then the
-// number of those symbols whose code lies completely inside (sfx_device.hpp).  A thread takes kHtRun CONSECUTIVE
-// positions and keeps the codes of the symbols ahead of it in a 128-bit buffer: the key of the next position is the
-// buffer shifted by the length of the symbol that leaves, topped up with the codes of the symbols that now fit -- about
-// two table look-ups per position instead of one per symbol and position.  A workgroup takes tiles of kHtTile
-// positions: the code table entries of the tile's symbols (+ the kHtMaxSym - 1 beyond it) go to LDS first, the keys
-// leave through LDS in coalesced order, and the digit counts of all eight radix passes are taken on the way out (the
-// role of k_radix_hist_all).
+// key of position i = the codes of symbols i, i + 1, ... (at most kHtMaxSym of them) cut to 64 bits (sfx_device.hpp).
+// A thread takes kHtRun CONSECUTIVE positions and keeps the codes of the symbols ahead of it in a 128-bit buffer: the
+// key of the next position is the buffer shifted by the length of the symbol that leaves, topped up with the codes of
+// the symbols that now fit -- about two table look-ups per position instead of one per symbol and position.  A
+// workgroup takes tiles of kHtTile positions: the code table entries of the tile's symbols (+ the kHtMaxSym - 1 beyond
+// it) go to LDS first, the keys leave through LDS in coalesced order, and the digit counts of all eight radix passes
+// are taken on the way out (the role of k_radix_hist_all).  LDS rows are skewed by one word per run: a lane's run
+// starts 17 words after its neighbour's, not 16 (all lanes in one bank).
 constexpr int kHtRun = 16;
 constexpr int kHtTile = kBlock * kHtRun;                     // 4096 positions
 constexpr int kHtPad = 16;                                   // >= kHtMaxSym - 1
+__device__ __forceinline__ unsigned ht_skew(unsigned i) { return i + (i >> 4); }
 __global__ void __launch_bounds__(kBlock)
 k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t tiles_per_block, int npass,
           uint64_t* __restrict__ K, uint32_t* __restrict__ partial)
 {
     __shared__ uint32_t s_tab[256];
-    __shared__ uint32_t s_ent[kHtTile + kHtPad];
-    __shared__ uint64_t s_key[kHtTile];
+    __shared__ uint32_t s_ent[kHtTile + kHtPad + (kHtTile + kHtPad) / 16 + 1];
+    __shared__ uint64_t s_key[kHtTile + kHtTile / 16];
     __shared__ uint32_t h[kWavesPerBlock][kMaxPasses][kRadix];       // 32 KiB
     const unsigned tid = threadIdx.x, w = wave_id();
     s_tab[tid] = ent[tid];
@@ -1305,36 +1306,34 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
             const uint64_t p = base + i;                     // (positions past the text read as the padding's zero symbol)
             const uint64_t q = packed_word_index(t, p);
             const unsigned off = (unsigned)(p - q * (uint64_t)t.spw);
-            s_ent[i] = s_tab[p < t.n ? (t.words[q] >> (((unsigned)t.spw - 1u - off) * bits)) & smask : 0u];
+            s_ent[ht_skew(i)] = s_tab[p < t.n ? (t.words[q] >> (((unsigned)t.spw - 1u - off) * bits)) & smask : 0u];
         }
         __syncthreads();
         {
             const unsigned i0 = tid * (unsigned)kHtRun;
             uint64_t hi = 0, lo = 0;                         // the codes of symbols [i, j), nb bits, left-aligned in hi:lo
             unsigned nb = 0, j = i0;
-            unsigned jc = i0, nbc = 0;                       // symbols [i, jc) lie completely inside the first kHtCodeBits bits (nbc of them)
             for (unsigned i = i0; i < i0 + (unsigned)kHtRun; i++) {
-                while (nb < (unsigned)kHtCodeBits && j < i + kHtMaxSym) {
-                    const uint32_t e = s_ent[j++];
+                while (nb < 64u && j < i + kHtMaxSym) {
+                    const uint32_t e = s_ent[ht_skew(j)];
+                    j++;
                     const uint64_t c = (uint64_t)(e & ~31u) << 32;
                     const unsigned len = e & 31u;
                     hi |= c >> nb;
                     if (nb + len > 64u) lo |= c << (64u - nb);           // (nb >= 38 here: the shift is < 64)
                     nb += len;
                 }
-                while (jc < j && nbc + (s_ent[jc] & 31u) <= (unsigned)kHtCodeBits) nbc += s_ent[jc++] & 31u;
-                s_key[i] = ((hi >> kHtCountBits) << kHtCountBits) | (uint64_t)(jc - i);
-                const unsigned len = s_ent[i] & 31u;         // symbol i leaves (it is in the buffer: j > i, and complete: jc > i)
+                s_key[ht_skew(i)] = hi;
+                const unsigned len = s_ent[ht_skew(i)] & 31u;            // symbol i leaves (it is in the buffer: j > i)
                 hi = (hi << len) | (lo >> (64u - len));
                 lo <<= len;
                 nb -= len;
-                nbc -= len;
             }
         }
         __syncthreads();
         for (unsigned i = tid; i < (unsigned)kHtTile; i += kBlock) {
             if (base + i < m) {
-                const uint64_t key = s_key[i];
+                const uint64_t key = s_key[ht_skew(i)];
                 K[base + i] = key;
                 if (partial)
                     for (int p = 0; p < npass; p++) atomicAdd(&h[w][p][(unsigned)(key >> (8 * p)) & 255u], 1u);

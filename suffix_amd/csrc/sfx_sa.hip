@@ -586,9 +586,11 @@ __device__ __forceinline__ unsigned valid_mask(uint64_t i0, uint64_t m)
 // for two neighbours with DIFFERENT keys the common prefix is the number of equal leading symbols of the
 // keys -- no text access (97.7 % of the pairs of 100 MB of DNA).  Neighbours with equal keys get
 // kLcpPending and are compared on the text once the suffix array is final (k_lcp_pending).
-// the keys are compressed (k_ht_keys): a bucket's depth is the count in its key's low bits
+// depth of a bucket from its compressed key (ht_depth); ent == nullptr: fixed-width keys, uniform depth
+constexpr unsigned kHtTableWords = 256 + 64;                 // device layout: code table (256), minimum depth + spare (64), fast table
 struct HtDepth {
-    int on;
+    const uint32_t* ent;        // [256] code table ... [kHtTableWords ..] the 4096-entry fast table (bytes)
+    int sigma;
 };
 struct LcpFuse {
     uint32_t* lcp;          // nullptr = off
@@ -723,21 +725,38 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                const uint16_t* __restrict__ Hd, uint16_t* __restrict__ Hd_next, uint32_t hd_floor, HtDepth ht,
                uint32_t* __restrict__ min_depth)
 {
-    // ht.on (initial bucket pass over compressed keys): the depth of a bucket rides in its key;
+    // ht.ent (initial bucket pass over compressed keys): the depth of a bucket is what its key holds, ht_depth(K);
     // min_depth: smallest depth given to a kept element (the rank rounds' h, should the text rounds give way)
+    __shared__ uint32_t s_ht[256];
+    __shared__ uint32_t s_t12[(1 << kHtFastBits) / 4];
     __shared__ uint32_t s_min;
-    if (ht.on) {
+    if (ht.ent) {
+        s_ht[threadIdx.x] = threadIdx.x < (unsigned)ht.sigma ? ht.ent[threadIdx.x] : 0xFFFFFFFFu;
+        for (unsigned i = threadIdx.x; i < (1u << kHtFastBits) / 4u; i += kBlock) s_t12[i] = ht.ent[kHtTableWords + i];
         if (threadIdx.x == 0) s_min = 0xFFFFFFFFu;
         __syncthreads();
     }
     uint32_t my_min = 0xFFFFFFFFu;
+    KeyT last_key = 0;
+    uint32_t last_depth = 0;
+    bool have_last = false;
     auto depth_of = [&](uint64_t i) -> uint32_t {
-        const uint32_t d = ht.on ? (uint32_t)((uint64_t)K[i] & (uint64_t)kHtMaxSym) : (Hd ? dmax<uint32_t>(Hd[i], hd_floor) : hd_floor);
+        uint32_t d;
+        if (ht.ent) {
+            const KeyT k = K[i];
+            if (!(have_last && k == last_key)) {
+                last_depth = ht_depth((uint64_t)k, s_ht, reinterpret_cast<const uint8_t*>(s_t12), ht.sigma);
+                last_key = k;
+                have_last = true;
+            }
+            d = last_depth;
+        } else {
+            d = Hd ? dmax<uint32_t>(Hd[i], hd_floor) : hd_floor;
+        }
         my_min = dmin(my_min, d);
         return d;
     };
-    // Hd_next (deep text rounds): the kept elements carry the depth of their bucket, at least hd_floor (what the
-    // round's large-bucket path established for the buckets it split; the deep kernel wrote larger values itself)
+    // Hd_next (deep text rounds): the kept elements carry the depth of their bucket, at least hd_floor
     __shared__ uint32_t part_m[2][kWavesPerBlock], part_a[2][kWavesPerBlock];
     // pair_hist (with rank_pairs): digit counts of the passes that partition the pairs by suffix index (bits [pair_lo,
     // pair_nb), 8 per pass, at most 3) -- counted here, where the pairs are made, instead of by a pass over them
@@ -883,7 +902,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         c_head = dmax(c_head, tot_m);
         c_keep += tot_a;
     }
-    if (ht.on && min_depth) {
+    if (ht.ent && min_depth) {
         for (int d = 32; d >= 1; d >>= 1) my_min = dmin(my_min, (uint32_t)__shfl_xor(my_min, d));
         if (lane == 0) atomicMin(&s_min, my_min);
         __syncthreads();
@@ -1138,6 +1157,7 @@ constexpr uint64_t kTextFirstDivisor = 4;
 // not pay: the alphabet fills its fixed width (random bytes), or fewer than two symbols.
 struct HtHost {
     uint32_t ent[256];
+    uint8_t t12[1 << kHtFastBits];
     int sigma;
     double avg_len;
 };
@@ -1198,6 +1218,20 @@ static bool ht_build(const unsigned long long* counts256, int fixed_bits, HtHost
         for (int i = ns; i < 256; i++) out->ent[i] = 0xFFFFFFFFu;
         out->sigma = ns;
         out->avg_len = avg;
+        // fast table: the symbols that lie completely inside a 12-bit window, decoded greedily
+        for (unsigned wv = 0; wv < (1u << kHtFastBits); wv++) {
+            unsigned used = 0, c = 0;
+            for (;;) {
+                const uint32_t win = used < (unsigned)kHtFastBits ? (wv << (32 - kHtFastBits)) << used : 0u;
+                int sym = 0;
+                for (int i = 0; i < ns; i++) if ((out->ent[i] & ~31u) <= win) sym = i;
+                const unsigned l = out->ent[sym] & 31u;
+                if (used + l > (unsigned)kHtFastBits || c == 15) break;
+                used += l;
+                c++;
+            }
+            out->t12[wv] = (uint8_t)((c << 4) | used);
+        }
         return avg + 0.75 < (double)fixed_bits;
     }
     return false;
@@ -1263,7 +1297,7 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint32_t* totals = ar.template take<uint32_t>(64);
     unsigned long long* bins = ar.template take<unsigned long long>(256);
     uint8_t* lut = ar.template take<uint8_t>(256);
-    uint32_t* ht = ar.template take<uint32_t>(256 + 64);
+    uint32_t* ht = ar.template take<uint32_t>(kHtTableWords + (1u << kHtFastBits) / 4);
     if (b) {
         b->ht = ht;
         b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->G1 = G1; b->F = F; b->F8 = F8;
@@ -1311,7 +1345,7 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
                        uint32_t* sa, uint32_t* isa, uint32_t* S_next, uint32_t* V_next,
                        uint32_t* R_next, hipStream_t st, int sa_mode, uint64_t n, sfx_build_stats& stats,
                        uint64_t kept, const uint16_t* Hd = nullptr, uint16_t* Hd_next = nullptr, uint32_t hd_floor = 0,
-                       HtDepth ht = HtDepth{0}, uint32_t* min_depth = nullptr)
+                       HtDepth ht = HtDepth{nullptr, 0}, uint32_t* min_depth = nullptr)
 {
     const bool sa_in_place = sa_mode == 1;
     // the sorted keys K sit in one of K0/K1 (for 32-bit keys: in its first half); the other
@@ -1688,7 +1722,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
                            unsigned hist_blocks = 0, uint32_t* lcp_fuse = nullptr, const HtHost* ht = nullptr)
 {
     // ht (64-bit keys of a full build): the keys are the suffixes' symbols in an order-preserving prefix code (k_ht_keys);
-    // a bucket's depth is what its key holds (between kHtCodeBits / longest code and kHtMaxSym symbols)
+    // a bucket's depth is what its key holds (between 64 / longest code and kHtMaxSym symbols)
     const KeyT* Kr;
     const uint32_t* Vr;
     uint32_t* V_next;
@@ -1732,7 +1766,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     if (ht && kept > 0) {
         SFX_HIP(hipMemsetAsync(b.ht + 256, 0xFF, sizeof(uint32_t), st));
         SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place ? 1 : 0, pt.n, stats,
-                                  kept, nullptr, b.Hd0, 0u, HtDepth{1}, b.ht + 256));
+                                  kept, nullptr, b.Hd0, 0u, HtDepth{b.ht, ht->sigma}, b.ht + 256));
         uint32_t md = 0;
         SFX_TRY(read_back(&md, b.ht + 256, sizeof(md), st));
         if (md == 0xFFFFFFFFu || md == 0) return SFX_ERR_INTERNAL;
@@ -1796,7 +1830,10 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
         unsigned long long counts[256];
         SFX_TRY(read_back(counts, b.bins, sizeof(counts), st));
         use_ht = ht_build(counts, alpha.bits, &ht);
-        if (use_ht) SFX_HIP(hipMemcpyAsync(b.ht, ht.ent, sizeof(ht.ent), hipMemcpyHostToDevice, st));
+        if (use_ht) {
+            SFX_HIP(hipMemcpyAsync(b.ht, ht.ent, sizeof(ht.ent), hipMemcpyHostToDevice, st));
+            SFX_HIP(hipMemcpyAsync(b.ht + kHtTableWords, ht.t12, sizeof(ht.t12), hipMemcpyHostToDevice, st));
+        }
     }
     return sort_and_refine<uint64_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats, 0, lcp_fuse, use_ht ? &ht : nullptr);
 }
