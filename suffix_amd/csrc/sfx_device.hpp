@@ -257,36 +257,39 @@ template <> __device__ __forceinline__ uint64_t packed_key<uint64_t>(const Packe
 // bucket pass and kept per bucket (Hd, sfx_sa.hip).
 // ent[s], s = dense symbol code: code left-aligned in bits 31..5, length (1..27) in bits 4..0; the smallest symbol's
 // code is all zeros, so the zero padding past the end of the text reads as that symbol.
-constexpr int kHtMaxLen = 27;
+constexpr int kHtMaxLen = 12;                       // (= kHtFastBits: every code ends inside one fast-table window)
 constexpr unsigned kHtMaxSym = 16;                  // symbols a key is made from at most
-// t12[w], w = the next 12 key bits: symbols that lie completely inside them << 4 | bits they take (made on the
-// host, ht_build) -- two or three symbols per look-up; a code longer than 12 bits, and the last symbols before the
-// key's end, are found one at a time by bisection over the (ordered) codes.
+// t12[w], w = the next 12 key bits: bit k set = a symbol's code ENDS after k + 1 of them (greedy decode of w, made on
+// the host: ht_build) -- two or three symbols per look-up, and where fewer than 12 key bits are left the ends beyond
+// them are masked off.  No code is longer than 12 bits (ht_build floors the counts until that holds).
 constexpr int kHtFastBits = 12;
-__device__ __forceinline__ uint32_t ht_depth(uint64_t key, const uint32_t* ent, const uint8_t* t12, int sigma)
+// one step of the decode of `key` from bit `used` on; returns false when the key is exhausted
+__device__ __forceinline__ bool ht_depth_step(uint64_t key, unsigned& used, unsigned& cnt, const uint16_t* t12)
 {
-    unsigned used = 0, cnt = 0;
-    while (cnt < kHtMaxSym && used < 64u) {
-        const uint64_t rest = key << used;
-        const unsigned f = t12[(unsigned)(rest >> (64 - kHtFastBits))];
-        const unsigned c = f >> 4, u = f & 15u;
-        if (c && used + u <= 64u && cnt + c <= kHtMaxSym) {
-            used += u;
-            cnt += c;
-            continue;
-        }
-        const uint32_t win = (uint32_t)(rest >> 32);
-        int lo = 0, hi = sigma - 1;                      // the largest symbol whose code is <= the window: the one it starts with
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if ((ent[mid] & ~31u) <= win) lo = mid; else hi = mid - 1;
-        }
-        const unsigned len = ent[lo] & 31u;
-        if (used + len > 64u) break;
-        used += len;
-        cnt++;
+    if (used >= 64u || cnt >= kHtMaxSym) return false;
+    unsigned ends = t12[(unsigned)((key << used) >> (64 - kHtFastBits))];
+    const unsigned left = 64u - used;
+    if (left < (unsigned)kHtFastBits) ends &= (1u << left) - 1u;
+    if (!ends) return false;                             // (no code ends inside what is left; with 12 bits left one always does)
+    cnt += (unsigned)__popc(ends);
+    used += 32u - (unsigned)__clz((int)ends);
+    return true;
+}
+// depths of N keys at once (the look-ups of the N keys are independent: their LDS latencies overlap)
+template <int N>
+__device__ __forceinline__ void ht_depth_n(const uint64_t (&key)[N], unsigned want, const uint16_t* t12, uint32_t (&depth)[N])
+{
+    unsigned used[N], cnt[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { used[j] = 0; cnt[j] = 0; }
+    unsigned act = want;
+    while (act) {
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            if (((act >> j) & 1u) && !ht_depth_step(key[j], used[j], cnt[j], t12)) act &= ~(1u << j);
     }
-    return cnt;
+#pragma unroll
+    for (int j = 0; j < N; j++) depth[j] = cnt[j] < kHtMaxSym ? cnt[j] : kHtMaxSym;
 }
 
 // number of bits needed to represent values in [0, v]

@@ -1279,22 +1279,22 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
 // workgroup takes tiles of kHtTile positions: the code table entries of the tile's symbols (+ the kHtMaxSym - 1 beyond
 // it) go to LDS first, the keys leave through LDS in coalesced order, and the digit counts of all eight radix passes
 // are taken on the way out (the role of k_radix_hist_all).  LDS rows are skewed by one word per run: a lane's run
-// starts 17 words after its neighbour's, not 16 (all lanes in one bank).
-constexpr int kHtRun = 16;
-constexpr int kHtTile = kBlock * kHtRun;                     // 4096 positions
+// starts 9 words after its neighbour's, not 8 (a quarter of the banks).
+constexpr int kHtRun = 8;
+constexpr int kHtTile = kBlock * kHtRun;                     // 2048 positions
 constexpr int kHtPad = 16;                                   // >= kHtMaxSym - 1
-__device__ __forceinline__ unsigned ht_skew(unsigned i) { return i + (i >> 4); }
+__device__ __forceinline__ unsigned ht_skew(unsigned i) { return i + (i >> 3); }
 __global__ void __launch_bounds__(kBlock)
 k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t tiles_per_block, int npass,
           uint64_t* __restrict__ K, uint32_t* __restrict__ partial)
 {
     __shared__ uint32_t s_tab[256];
-    __shared__ uint32_t s_ent[kHtTile + kHtPad + (kHtTile + kHtPad) / 16 + 1];
-    __shared__ uint64_t s_key[kHtTile + kHtTile / 16];
-    __shared__ uint32_t h[kWavesPerBlock][kMaxPasses][kRadix];       // 32 KiB
-    const unsigned tid = threadIdx.x, w = wave_id();
+    __shared__ uint32_t s_ent[kHtTile + kHtPad + (kHtTile + kHtPad) / 8 + 1];
+    __shared__ uint64_t s_key[kHtTile + kHtTile / 8];
+    __shared__ uint32_t h[kMaxPasses][kRadix];                       // (one copy: the key bytes are spread evenly)
+    const unsigned tid = threadIdx.x;
     s_tab[tid] = ent[tid];
-    for (unsigned i = tid; i < kWavesPerBlock * kMaxPasses * kRadix; i += kBlock) (&h[0][0][0])[i] = 0;
+    for (unsigned i = tid; i < kMaxPasses * kRadix; i += kBlock) (&h[0][0])[i] = 0;
     __syncthreads();
     const unsigned bits = (unsigned)t.bits;
     const uint32_t smask = (1u << bits) - 1u;
@@ -1336,18 +1336,13 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
                 const uint64_t key = s_key[ht_skew(i)];
                 K[base + i] = key;
                 if (partial)
-                    for (int p = 0; p < npass; p++) atomicAdd(&h[w][p][(unsigned)(key >> (8 * p)) & 255u], 1u);
+                    for (int p = 0; p < npass; p++) atomicAdd(&h[p][(unsigned)(key >> (8 * p)) & 255u], 1u);
             }
         }
         __syncthreads();
     }
     if (partial)
-        for (int p = 0; p < npass; p++) {
-            uint32_t c = 0;
-#pragma unroll
-            for (int k = 0; k < kWavesPerBlock; k++) c += h[k][p][tid];
-            partial[((uint64_t)p * kRadix + tid) * gridDim.x + blockIdx.x] = c;
-        }
+        for (int p = 0; p < npass; p++) partial[((uint64_t)p * kRadix + tid) * gridDim.x + blockIdx.x] = h[p][tid];
 }
 
 // Sort of all m = text.n suffixes by their compressed 64-bit keys (eight passes); (k0, v0) / (k1, v1) as

@@ -727,35 +727,14 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
 {
     // ht.ent (initial bucket pass over compressed keys): the depth of a bucket is what its key holds, ht_depth(K);
     // min_depth: smallest depth given to a kept element (the rank rounds' h, should the text rounds give way)
-    __shared__ uint32_t s_ht[256];
-    __shared__ uint32_t s_t12[(1 << kHtFastBits) / 4];
+    __shared__ uint32_t s_t12[(1 << kHtFastBits) / 2];
     __shared__ uint32_t s_min;
     if (ht.ent) {
-        s_ht[threadIdx.x] = threadIdx.x < (unsigned)ht.sigma ? ht.ent[threadIdx.x] : 0xFFFFFFFFu;
-        for (unsigned i = threadIdx.x; i < (1u << kHtFastBits) / 4u; i += kBlock) s_t12[i] = ht.ent[kHtTableWords + i];
+        for (unsigned i = threadIdx.x; i < (1u << kHtFastBits) / 2u; i += kBlock) s_t12[i] = ht.ent[kHtTableWords + i];
         if (threadIdx.x == 0) s_min = 0xFFFFFFFFu;
         __syncthreads();
     }
     uint32_t my_min = 0xFFFFFFFFu;
-    KeyT last_key = 0;
-    uint32_t last_depth = 0;
-    bool have_last = false;
-    auto depth_of = [&](uint64_t i) -> uint32_t {
-        uint32_t d;
-        if (ht.ent) {
-            const KeyT k = K[i];
-            if (!(have_last && k == last_key)) {
-                last_depth = ht_depth((uint64_t)k, s_ht, reinterpret_cast<const uint8_t*>(s_t12), ht.sigma);
-                last_key = k;
-                have_last = true;
-            }
-            d = last_depth;
-        } else {
-            d = Hd ? dmax<uint32_t>(Hd[i], hd_floor) : hd_floor;
-        }
-        my_min = dmin(my_min, d);
-        return d;
-    };
     // Hd_next (deep text rounds): the kept elements carry the depth of their bucket, at least hd_floor
     __shared__ uint32_t part_m[2][kWavesPerBlock], part_a[2][kWavesPerBlock];
     // pair_hist (with rank_pairs): digit counts of the passes that partition the pairs by suffix index (bits [pair_lo,
@@ -764,6 +743,11 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     __shared__ uint32_t ph[SUB == 1 ? kWavesPerBlock : 1][kPairPasses][kRadixDev];
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int pair_passes = pair_hist ? (pair_nb - pair_lo + 7) / 8 : 0;
+    // dense form: what a tile keeps (and its (suffix, rank) pairs) leaves through LDS.  A thread's elements are 8
+    // consecutive ones, so direct stores put 4 bytes into each of 16 lines per instruction and touch every line eight
+    // times -- and a line write costs the CU the same whether it is partial or whole (radix pass).
+    __shared__ uint64_t stg_a[SUB == 1 ? kBlock * kGroupItems : 1];     // (slot, suffix) of the kept; then the pairs
+    __shared__ uint64_t stg_b[SUB == 1 ? kBlock * kGroupItems : 1];     // (bucket id, depth) of the kept
     if (SUB == 1 && pair_hist) {
         for (unsigned i = tid; i < (unsigned)(kWavesPerBlock * kPairPasses * kRadixDev); i += kBlock) (&ph[0][0][0])[i] = 0u;
         __syncthreads();
@@ -823,7 +807,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         par ^= 1u;
         const uint32_t ec = ba + ia - cnt;
         uint32_t run_head = dmax(c_head, dmax(bm, pm));          // index+1 of the last head before item 0
-        uint32_t run_keep = c_keep + ec;
+        const uint32_t run_keep = c_keep + ec;
         if (SUB > 1) {                                   // (the host picks SUB = 4 only with sa_in_place && !isa)
             // only the kept elements have anything to write (a few per cent of a first round):
             // walk the set bits of the keep mask; every quantity is a bit trick on the two masks
@@ -841,63 +825,137 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                 S_next[pos] = slot;
                 V_next[pos] = suffix;
                 G_next[pos] = pos - ((uint32_t)i - my_head);
-                if (Hd_next) Hd_next[pos] = (uint16_t)depth_of(i);
+                if (Hd_next) {
+                    uint32_t d = Hd ? dmax<uint32_t>(Hd[i], hd_floor) : hd_floor;
+                    if (ht.ent) {
+                        unsigned used = 0, cnt = 0;
+                        const uint64_t k64 = (uint64_t)K[i];
+                        while (ht_depth_step(k64, used, cnt, reinterpret_cast<const uint16_t*>(s_t12))) {}
+                        d = cnt < kHtMaxSym ? cnt : kHtMaxSym;
+                    }
+                    my_min = dmin(my_min, d);
+                    Hd_next[pos] = (uint16_t)d;
+                }
             }
-        } else
+        } else {
+            const uint64_t ib = i0;
+            const unsigned v8 = valid & 0xFFu, h8 = head & 0xFFu, k8 = keepm & 0xFFu;
+            uint32_t slot[kGroupItems], suffix[kGroupItems], head_slot[kGroupItems];
+            KeyT kk[kGroupItems];                                // (compressed keys: the depths are read off them -- fetched with the rest)
 #pragma unroll
-        for (int b = 0; b < SUB; b++) {
-            const uint64_t ib = i0 + (uint64_t)b * kGroupItems;
-            const unsigned v8 = (valid >> (8 * b)) & 0xFFu, h8 = (head >> (8 * b)) & 0xFFu, k8 = (keepm >> (8 * b)) & 0xFFu;
+            for (int j = 0; j < kGroupItems; j++) kk[j] = KeyT(0);
+            if (ht.ent && k8) {
+                if (v8 == 0xFFu) {
+                    struct alignas(16) KV { KeyT v[16 / sizeof(KeyT)]; };
+#pragma unroll
+                    for (int q = 0; q < (int)(kGroupItems * sizeof(KeyT) / 16); q++) {
+                        const KV x = *reinterpret_cast<const KV*>(K + ib + q * (16 / sizeof(KeyT)));
+#pragma unroll
+                        for (int u = 0; u < (int)(16 / sizeof(KeyT)); u++) kk[q * (16 / sizeof(KeyT)) + u] = x.v[u];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kGroupItems; j++) kk[j] = ((v8 >> j) & 1u) ? K[ib + j] : KeyT(0);
+                }
+            }
+            uint32_t dep[kGroupItems];
+            if (ht.ent && k8) {                                  // the depths of the kept elements' buckets, off their keys
+                uint64_t k64[kGroupItems];
+#pragma unroll
+                for (int j = 0; j < kGroupItems; j++) k64[j] = (uint64_t)kk[j];
+                // (a bucket's members share the key: one decode per run of equal keys)
+                unsigned want = 0;
+#pragma unroll
+                for (int j = 0; j < kGroupItems; j++)
+                    if (((k8 >> j) & 1u) && (j == 0 || !((k8 >> (j - 1)) & 1u) || k64[j] != k64[j - 1])) want |= 1u << j;
+                ht_depth_n<kGroupItems>(k64, want, reinterpret_cast<const uint16_t*>(s_t12), dep);
+#pragma unroll
+                for (int j = 1; j < kGroupItems; j++)
+                    if (((k8 >> j) & 1u) && !((want >> j) & 1u)) dep[j] = dep[j - 1];
+            } else {
+#pragma unroll
+                for (int j = 0; j < kGroupItems; j++)
+                    dep[j] = (Hd && ((k8 >> j) & 1u)) ? dmax<uint32_t>(Hd[ib + j], hd_floor) : hd_floor;
+            }
+            unsigned local_keep = ec;                            // the thread's first kept element, counted from the tile's
             if (k8 || ((isa || sa_in_place != 1) && v8)) {       // (all-singleton groups have nothing to write in place)
-                // gathers first (all in flight together), stores after: one memory round trip per group
-                uint32_t slot[kGroupItems], suffix[kGroupItems], head_slot[kGroupItems], back[kGroupItems];
+                // loads first (all in flight together, two 16-byte loads per array where the group is whole), stores after
+                const bool whole = v8 == 0xFFu && ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(S)) & 15u) == 0;
+                if (whole && S) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(S + ib), c = *reinterpret_cast<const uint4*>(S + ib + 4);
+                    slot[0] = a.x; slot[1] = a.y; slot[2] = a.z; slot[3] = a.w; slot[4] = c.x; slot[5] = c.y; slot[6] = c.z; slot[7] = c.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kGroupItems; j++) slot[j] = (((v8 >> j) & 1u) && S) ? S[ib + j] : (uint32_t)(ib + j);
+                }
+                if (whole && (sa_in_place != 1 || isa || k8 == 0xFFu)) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(V + ib), c = *reinterpret_cast<const uint4*>(V + ib + 4);
+                    suffix[0] = a.x; suffix[1] = a.y; suffix[2] = a.z; suffix[3] = a.w; suffix[4] = c.x; suffix[5] = c.y; suffix[6] = c.z; suffix[7] = c.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kGroupItems; j++)
+                        suffix[j] = (((v8 >> j) & 1u) && (sa_in_place != 1 || ((k8 >> j) & 1u) || isa)) ? V[ib + j] : 0u;
+                }
+                uint32_t rh = run_head;
 #pragma unroll
                 for (int j = 0; j < kGroupItems; j++) {
-                    const uint64_t i = ib + j;
                     const bool v = (v8 >> j) & 1u, keep = (k8 >> j) & 1u;
-                    if ((h8 >> j) & 1u) run_head = (uint32_t)i + 1u;
-                    const uint32_t my_head = run_head - 1u;
-                    back[j] = (uint32_t)i - my_head;             // distance to the bucket head (all kept in between)
-                    slot[j] = (v && S) ? S[i] : (uint32_t)i;
-                    suffix[j] = (v && (sa_in_place != 1 || keep || isa)) ? V[i] : 0u;
+                    if ((h8 >> j) & 1u) rh = (uint32_t)(ib + j) + 1u;
+                    const uint32_t my_head = rh - 1u;
                     head_slot[j] = (v && S && (isa || (keep && R_next))) ? S[my_head] : my_head;
                 }
+            }
+            if (rank_pairs) {                                    // the tile's pairs, in stream order
 #pragma unroll
                 for (int j = 0; j < kGroupItems; j++) {
+                    if ((v8 >> j) & 1u) {
+                        stg_a[tid * kGroupItems + j] = ((uint64_t)suffix[j] << 32) | (uint64_t)head_slot[j];
+                        if (pair_hist) {
+#pragma unroll
+                            for (int p = 0; p < kPairPasses; p++) {
+                                const int sh = pair_lo + 8 * p, nbits = pair_nb - sh < 8 ? pair_nb - sh : 8;
+                                if (p < pair_passes) atomicAdd(&ph[w][p][(suffix[j] >> sh) & ((1u << nbits) - 1u)], 1u);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                const unsigned nv = (unsigned)dmin<uint64_t>(kTile, end - tile);
+                for (unsigned k = tid; k < nv; k += kBlock) rank_pairs[tile + k] = stg_a[k];
+                __syncthreads();
+            }
+            {
+                uint32_t rh = run_head;
+#pragma unroll
+                for (int j = 0; j < kGroupItems; j++) {
+                    if ((h8 >> j) & 1u) rh = (uint32_t)(ib + j) + 1u;
                     if ((v8 >> j) & 1u) {
                         const bool keep = (k8 >> j) & 1u;
                         // sa_in_place: 0 = every element goes to its slot; 1 = V is the SA; 2 = only the elements that
                         // resolve now (the members of unresolved buckets would be rewritten every round)
                         if (sa_in_place == 0 || (sa_in_place == 2 && !keep)) sa[slot[j]] = suffix[j];
-                        if (isa) {
-                            // large texts: (suffix, rank) pairs out in stream order, scattered afterwards
-                            // through a partitioning pass (scatter_pairs_u32) instead of n random writes
-                            if (rank_pairs) {
-                                rank_pairs[ib + j] = ((uint64_t)suffix[j] << 32) | (uint64_t)head_slot[j];
-                                if (SUB == 1 && pair_hist) {
-#pragma unroll
-                                    for (int p = 0; p < kPairPasses; p++) {
-                                        const int sh = pair_lo + 8 * p, nbits = pair_nb - sh < 8 ? pair_nb - sh : 8;
-                                        if (p < pair_passes) atomicAdd(&ph[w][p][(suffix[j] >> sh) & ((1u << nbits) - 1u)], 1u);
-                                    }
-                                }
-                            } else {
-                                isa[suffix[j]] = head_slot[j];
-                            }
-                        }
+                        if (isa && !rank_pairs) isa[suffix[j]] = head_slot[j];
                         if (keep) {
-                            if (R_next) R_next[run_keep] = head_slot[j];
-                            S_next[run_keep] = slot[j];
-                            V_next[run_keep] = suffix[j];
-                            G_next[run_keep] = run_keep - back[j];   // bucket id = position of its head in the new list
-                            if (Hd_next) Hd_next[run_keep] = (uint16_t)depth_of(ib + j);
-                            run_keep++;
+                            const uint32_t back = (uint32_t)(ib + j) - (rh - 1u);   // distance to the bucket head (all kept in between)
+                            const uint32_t gpos = c_keep + local_keep;
+                            if (R_next) R_next[gpos] = head_slot[j];
+                            stg_a[local_keep] = ((uint64_t)slot[j] << 32) | (uint64_t)suffix[j];
+                            stg_b[local_keep] = ((uint64_t)(gpos - back) << 16) | (uint64_t)dep[j];
+                            my_min = dmin(my_min, dep[j]);
+                            local_keep++;
                         }
                     }
                 }
-            } else if (h8) {
-                run_head = (uint32_t)ib + (32u - (unsigned)__clz((int)h8));      // heads of skipped groups still count
             }
+            __syncthreads();
+            for (unsigned k = tid; k < tot_a; k += kBlock) {
+                const uint64_t e = stg_a[k], g = stg_b[k];
+                S_next[c_keep + k] = (uint32_t)(e >> 32);
+                V_next[c_keep + k] = (uint32_t)e;
+                G_next[c_keep + k] = (uint32_t)(g >> 16);        // bucket id = position of its head in the new list
+                if (Hd_next) Hd_next[c_keep + k] = (uint16_t)g;
+            }
+            __syncthreads();
         }
         c_head = dmax(c_head, tot_m);
         c_keep += tot_a;
@@ -1157,7 +1215,7 @@ constexpr uint64_t kTextFirstDivisor = 4;
 // not pay: the alphabet fills its fixed width (random bytes), or fewer than two symbols.
 struct HtHost {
     uint32_t ent[256];
-    uint8_t t12[1 << kHtFastBits];
+    uint16_t t12[1 << kHtFastBits];
     int sigma;
     double avg_len;
 };
@@ -1175,7 +1233,7 @@ static bool ht_build(const unsigned long long* counts256, int fixed_bits, HtHost
     unsigned short* const R = root_v.data();
     auto at = [ns](int i, int j) { return (size_t)i * ns + j; };
     int len[256];
-    for (int shift = 16; shift >= 4; shift -= 2) {
+    for (int shift = 16; shift >= 4; shift--) {
         double ww[256], pre[257];
         const double floor_w = (double)total / (double)(1ull << shift);
         pre[0] = 0;
@@ -1218,19 +1276,19 @@ static bool ht_build(const unsigned long long* counts256, int fixed_bits, HtHost
         for (int i = ns; i < 256; i++) out->ent[i] = 0xFFFFFFFFu;
         out->sigma = ns;
         out->avg_len = avg;
-        // fast table: the symbols that lie completely inside a 12-bit window, decoded greedily
+        // fast table: where the codes end inside a 12-bit window, decoded greedily
         for (unsigned wv = 0; wv < (1u << kHtFastBits); wv++) {
-            unsigned used = 0, c = 0;
+            unsigned used = 0, ends = 0;
             for (;;) {
                 const uint32_t win = used < (unsigned)kHtFastBits ? (wv << (32 - kHtFastBits)) << used : 0u;
                 int sym = 0;
                 for (int i = 0; i < ns; i++) if ((out->ent[i] & ~31u) <= win) sym = i;
                 const unsigned l = out->ent[sym] & 31u;
-                if (used + l > (unsigned)kHtFastBits || c == 15) break;
+                if (used + l > (unsigned)kHtFastBits) break;
                 used += l;
-                c++;
+                ends |= 1u << (used - 1u);
             }
-            out->t12[wv] = (uint8_t)((c << 4) | used);
+            out->t12[wv] = (uint16_t)ends;
         }
         return avg + 0.75 < (double)fixed_bits;
     }
@@ -1297,7 +1355,7 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint32_t* totals = ar.template take<uint32_t>(64);
     unsigned long long* bins = ar.template take<unsigned long long>(256);
     uint8_t* lut = ar.template take<uint8_t>(256);
-    uint32_t* ht = ar.template take<uint32_t>(kHtTableWords + (1u << kHtFastBits) / 4);
+    uint32_t* ht = ar.template take<uint32_t>(kHtTableWords + (1u << kHtFastBits) / 2);
     if (b) {
         b->ht = ht;
         b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->G1 = G1; b->F = F; b->F8 = F8;
@@ -1763,6 +1821,11 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     // no rank array yet: its n-element scatter is only paid if the text rounds stall (refine)
     // (every bucket of the first active list shares the cpk symbols of the initial key: b.Hd0, the depths of the deep rounds)
     uint64_t h0 = (uint64_t)cpk;                        // symbols every bucket of the first active list shares
+    if (!in_place) {
+        // every suffix goes to its slot: a plain copy (whole lines), not 4 bytes per lane and line from the bucket pass
+        SFX_HIP(hipMemcpyAsync(sa, Vr, count * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        in_place = true;
+    }
     if (ht && kept > 0) {
         SFX_HIP(hipMemsetAsync(b.ht + 256, 0xFF, sizeof(uint32_t), st));
         SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place ? 1 : 0, pt.n, stats,
