@@ -128,10 +128,12 @@ int sfx_query_batch_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa,
  *   lb[p], rb[p]   the rank range of the node the boundary belongs to (its string depth is lcp[p]);
  *   node[p]        that node's id = its leftmost boundary with that depth (0 = the root: [0, n-1], depth 0,
  *                  to which every boundary with lcp[p] == 0 belongs);
- *   parent[p]      the id of that node's parent (UINT32_MAX for the root's own entry p = 0);
+ *   parent[p]      the id of that node's parent (UINT32_MAX for every boundary of the root: p = 0 and every p with
+ *                  lcp[p] == 0 -- the root is nobody's child, its own included);
  * and for every RANK r:  leaf_parent[r] = id of the node the leaf of suffix sa[r] hangs under.
  * Node k's edge label is text[sa[lb[k]] + depth(parent) .. sa[lb[k]] + depth(k)); children are the nodes /
- * leaves whose parent is k -- the same tree as `to_suffix_tree`, as arrays.  All device pointers, n u32 each. */
+ * leaves whose parent is k -- the same tree as `to_suffix_tree`, as arrays.  All device pointers, n u32 each.
+ * Boundary 0 (in front of the first suffix) has depth 0 by definition: d_lcp[0] is not looked at. */
 uint64_t sfx_lcp_intervals_workspace_bytes(uint64_t n);
 int sfx_lcp_intervals_dev(const uint32_t* d_lcp, uint64_t n, uint32_t* d_lb, uint32_t* d_rb, uint32_t* d_node,
                           uint32_t* d_parent, uint32_t* d_leaf_parent, void* d_workspace, uint64_t workspace_bytes,

@@ -16,7 +16,9 @@
 //! What changes in the crate (nothing in `:140-312` or `lib.rs` changes):
 //!   * `sais_table`  (src/table.rs:378-386)  body after `vec![0u32; n]`
 //!   * `lcp_lens`    (src/table.rs:130-138)  body
-//!   * new additive  `SuffixTable::positions_batch` / `contains_batch`
+//!   * new additive  `SuffixTable::device_index()` (the resident index, kept by the caller across batches),
+//!     `positions_batch_on(&index, queries)` and the one-shot `positions_batch(queries)`
+//!   * texts below `MIN_DEVICE_LEN` bytes keep the crate's own CPU path (QuickCheck's strings never leave the host)
 //! `sais()`, `Bins`, `SuffixTypes` stay in the crate as the reference CPU path (feature `hip` off).
 
 use std::os::raw::{c_char, c_int, c_void};
@@ -49,6 +51,11 @@ extern "C" {
     fn sfx_build_sa_u32_dev(d_text: *const u8, n: u64, d_sa: *mut u32, ws: *mut c_void,
                             ws_bytes: u64, stream: *mut c_void) -> c_int;
 }
+
+/// Texts shorter than this stay on the crate's own CPU path (`sais`, `lcp_lens_quadratic`): a build on the device costs
+/// ~100 us of launches and two PCIe copies whatever the length, the reference needs ~1 us for QuickCheck's strings
+/// (README.md:116) and ~1 ms for 64 KiB.  The patched `sais_table` / `lcp_lens` compare against it.
+pub const MIN_DEVICE_LEN: usize = 1 << 16;
 
 fn check(status: c_int, what: &str) {
     if status != 0 {

@@ -147,18 +147,28 @@ struct DevBuf {
 // Stream of the host-pointer entry points: one non-blocking stream per calling thread, created on first
 // use, so that SuffixTable::new from several threads runs concurrently on the device instead of
 // serialising on the NULL stream ("per-call stream").  nullptr if creation fails.
+// A stream belongs to the device that was current when it was made: one per (thread, device), looked up by the
+// device current NOW (suffix_amd/device.py switches devices per call).
+constexpr int kMaxDevices = 16;
+static int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+    return (d >= 0 && d < kMaxDevices) ? d : 0;
+}
 static hipStream_t call_stream()
 {
-    thread_local hipStream_t st = nullptr;
-    thread_local bool tried = false;
-    if (!tried) {
-        tried = true;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
-            st = nullptr;
+    thread_local hipStream_t st[kMaxDevices] = {};
+    thread_local bool tried[kMaxDevices] = {};
+    const int d = current_device();
+    if (!tried[d]) {
+        tried[d] = true;
+        if (hipStreamCreateWithFlags(&st[d], hipStreamNonBlocking) != hipSuccess) {
+            st[d] = nullptr;
             (void)hipGetLastError();
         }
     }
-    return st;
+    return st[d];
 }
 // pooled device buffers must not go back to the pool while work that uses them may still be queued
 struct StreamDrain {
@@ -223,6 +233,8 @@ static int index_build_directory(sfx_index* ix, hipStream_t st)
     if (want_tree && hipMalloc((void**)&ix->d_tree, key_tree_words(ix->n) * sizeof(uint64_t)) == hipSuccess) {
         rc = key_tree_build_dev(ix->d_text, ix->n, ix->d_sa, ix->d_tree, ix->tree_off, &ix->tree_levels, st);
         if (rc != SFX_OK) return rc;
+        // the index is handed to callers who will query it on OTHER streams: the tree must be complete, not queued
+        SFX_HIP(hipStreamSynchronize(st));
     } else {
         ix->d_tree = nullptr;
         (void)hipGetLastError();
@@ -454,24 +466,33 @@ int sfx_index_query_dev(const sfx_index* ix, const uint8_t* d_qbytes, const uint
         // neighbouring lanes share tree nodes and probes.  Measured on config 5's 10^6 queries: the search kernel
         // 1.39 -> 1.23 ms, the 8-pass sort of the (key, query) pairs 0.24 ms -- not worth it, off by default
         static const bool want_order = [] { const char* e = dev_env("SFX_QUERY_ORDER"); return e && atoi(e) != 0; }();
-        // per-thread scratch (the list of queries that go on to phase 2; the ordering), kept across calls (no
-        // allocation, no synchronisation on the hot path); work queued on another stream may still be using it
-        // when the thread switches streams: drain that one first.  Without it the batch is answered in one phase.
-        struct QueryScratch { void* p = nullptr; uint64_t bytes = 0; hipStream_t last = nullptr; bool used = false; };
-        thread_local QueryScratch sc;
+        // scratch of phase 2 (the list of queries that go on; the ordering), kept across calls per (thread, device): no
+        // allocation and no host synchronisation on the hot path.  The previous batch may still be using it on another
+        // stream (whose handle may be gone by now): it left an EVENT behind, and this batch's stream waits on that -- on
+        // the device.  Without scratch the batch is answered in one phase.
+        struct QueryScratch { void* p = nullptr; uint64_t bytes = 0; hipEvent_t done = nullptr; bool used = false; };
+        thread_local QueryScratch scs[kMaxDevices];
+        QueryScratch& sc = scs[current_device()];
         void* os = nullptr;
         if (nq >= query_two_phase_min()) {
             const uint64_t need = query_scratch_bytes(nq, want_order);
-            if (sc.used && sc.last != (hipStream_t)stream) (void)hipStreamSynchronize(sc.last);
-            if (sc.bytes < need) {
-                if (sc.p) { (void)hipStreamSynchronize(sc.last); (void)hipFree(sc.p); sc.p = nullptr; sc.bytes = 0; }
-                if (hipMalloc(&sc.p, need) == hipSuccess) sc.bytes = need; else { sc.p = nullptr; (void)hipGetLastError(); }
+            if (!sc.done && hipEventCreateWithFlags(&sc.done, hipEventDisableTiming) != hipSuccess) { sc.done = nullptr; (void)hipGetLastError(); }
+            if (sc.done) {
+                if (sc.bytes < need) {
+                    if (sc.p) { if (sc.used) (void)hipEventSynchronize(sc.done); (void)hipFree(sc.p); sc.p = nullptr; sc.bytes = 0; sc.used = false; }
+                    if (hipMalloc(&sc.p, need) == hipSuccess) sc.bytes = need; else { sc.p = nullptr; (void)hipGetLastError(); }
+                }
+                if (sc.p) {
+                    if (sc.used) (void)hipStreamWaitEvent((hipStream_t)stream, sc.done, 0);
+                    os = sc.p;
+                }
             }
-            if (sc.p) { os = sc.p; sc.last = (hipStream_t)stream; sc.used = true; }
         }
-        return query_batch_tree_dev(ix->d_text, ix->n, ix->d_sa, ix->d_tree, ix->tree_off, ix->tree_levels, d_qbytes, d_qoff, nq,
-                                    d_start, d_end, d_found, d_any, (hipStream_t)stream, os, want_order, ix->d_dir, ix->d_lut, ix->bits,
-                                    ix->k, ix->dbits);
+        const int qrc = query_batch_tree_dev(ix->d_text, ix->n, ix->d_sa, ix->d_tree, ix->tree_off, ix->tree_levels, d_qbytes, d_qoff, nq,
+                                             d_start, d_end, d_found, d_any, (hipStream_t)stream, os, want_order, ix->d_dir, ix->d_lut,
+                                             ix->bits, ix->k, ix->dbits);
+        if (os) { (void)hipEventRecord(sc.done, (hipStream_t)stream); sc.used = true; }
+        return qrc;
     }
     return query_batch_dir_dev(ix->d_text, ix->n, ix->d_sa, ix->d_dir, ix->d_lut, ix->bits, ix->k, ix->dbits, d_qbytes, d_qoff, nq,
                                d_start, d_end, d_found, d_any, (hipStream_t)stream);

@@ -1743,7 +1743,9 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
             // (kept + launch overheads) against ~n for the rank array
             // SFX_SWITCH=text|rank is a development hook: never / always switch after the first round
             static const int force = [] { const char* e = dev_env("SFX_SWITCH"); return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'r' ? 2 : 0)); }();
-            if (kept * 4 > m * 3) stalled += kept + (4u << 20);
+            // (two thirds kept: measured on 1 GB of mixed-script UTF-8, whose first round keeps 75 % -- a second text
+            // round costs more than the rank array it postpones)
+            if (kept * 3 > m * 2) stalled += kept + (4u << 20);
             // (the depths of the deep rounds are 16-bit; a text that deep is a repeat anyway)
             const bool too_deep = deep && h + 2 * (uint64_t)wsym > 60000;
             if (isa && force != 1 && (stalled * 2 > n || force == 2 || too_deep)) {
@@ -1847,7 +1849,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
 // lcp_fuse != nullptr: also leave, in lcp_fuse[r], the LCP of every adjacent pair that the initial sort
 // already told apart (kLcpPending elsewhere); *cpk_out = symbols of the initial key
 static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,
-                         hipStream_t st, uint32_t* lcp_fuse, int* cpk_out)
+                         hipStream_t st, uint32_t* lcp_fuse, int* cpk_out, bool* fused_out = nullptr)
 {
     sfx_build_stats& stats = tls_build_stats();
     memset(&stats, 0, sizeof(stats));
@@ -1882,13 +1884,13 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
     stats.symbols_per_key = (uint32_t)cpk;
     if (cpk_out) *cpk_out = cpk;
     if (key_bits == 32) return sort_and_refine<uint32_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats, 0, lcp_fuse);
-    // 64-bit keys: compressed when the symbol counts say it pays (natural-language text: 13 symbols per key instead of 8).
-    // SFX_HT=0 (development): fixed-width keys.  (The fused LCP reads common prefixes off fixed-width keys: not with these.)
+    // 64-bit keys: compressed when the symbol counts say it pays (natural-language text: 14 symbols per key instead of 8).
+    // SFX_HT=0 (development): fixed-width keys.
     static const bool ht_on = [] { const char* e = dev_env("SFX_HT"); return !e || atoi(e) != 0; }();
     static const uint64_t ht_min = [] { const char* e = dev_env("SFX_HT_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 16); }();
     HtHost ht;
     bool use_ht = false;
-    if (ht_on && !lcp_fuse && n >= ht_min) {
+    if (ht_on && n >= ht_min) {
         SFX_TRY(byte_histogram_dev(d_text, 0, n, reinterpret_cast<uint64_t*>(b.bins), st));
         unsigned long long counts[256];
         SFX_TRY(read_back(counts, b.bins, sizeof(counts), st));
@@ -1897,6 +1899,12 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
             SFX_HIP(hipMemcpyAsync(b.ht, ht.ent, sizeof(ht.ent), hipMemcpyHostToDevice, st));
             SFX_HIP(hipMemcpyAsync(b.ht + kHtTableWords, ht.t12, sizeof(ht.t12), hipMemcpyHostToDevice, st));
         }
+    }
+    // (compressed keys: common prefixes cannot be read off them symbol by symbol -- the caller computes the LCP array
+    // separately, which at 28 ms per GB costs less than sorting on fixed-width keys would)
+    if (use_ht) {
+        if (fused_out) *fused_out = false;
+        lcp_fuse = nullptr;
     }
     return sort_and_refine<uint64_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats, 0, lcp_fuse, use_ht ? &ht : nullptr);
 }
@@ -1929,12 +1937,13 @@ int build_sa_lcp_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, uint
     int cpk = 0;
     // the lower-bound encoding needs the top bit of an LCP value
     const bool fuse = n < 0x80000000ull;
-    SFX_TRY(build_sa_impl(d_text, n, d_sa, ws, ws_bytes, st, fuse ? d_lcp : nullptr, &cpk));
+    bool fused = fuse;
+    SFX_TRY(build_sa_impl(d_text, n, d_sa, ws, ws_bytes, st, fuse ? d_lcp : nullptr, &cpk, &fused));
     const sfx_build_stats stats = tls_build_stats();
     bool done = false;
     // pairs split by rank rounds only carry a lower bound: when the text needed ranks for most of its
     // suffixes, finishing those pairs one by one is the separate routine's job (sampling, Phi / PLCP)
-    if (fuse && (stats.rank_rounds == 0 || stats.active_after_initial * 4 <= n))
+    if (fused && (stats.rank_rounds == 0 || stats.active_after_initial * 4 <= n))
         SFX_TRY(lcp_finish_pending_dev(d_text, n, d_sa, d_lcp, (uint64_t)cpk, ws, ws_bytes, st, &done));
     if (!done) SFX_TRY(build_lcp_u32_dev(d_text, n, d_sa, d_lcp, ws, ws_bytes, st));
     tls_build_stats() = stats;

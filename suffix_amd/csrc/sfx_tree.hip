@@ -31,14 +31,14 @@ struct Pyramid {
 };
 
 __global__ void __launch_bounds__(kBlock)
-k_pyr_reduce(const uint32_t* __restrict__ in, uint64_t n_in, uint32_t* __restrict__ out, uint64_t n_out)
+k_pyr_reduce(const uint32_t* __restrict__ in, uint64_t n_in, uint32_t* __restrict__ out, uint64_t n_out, int first_is_zero)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n_out; j += stride) {
         uint32_t m = 0xFFFFFFFFu;
         const uint64_t b = j * kPyrFan, e = dmin<uint64_t>(b + kPyrFan, n_in);
         for (uint64_t i = b; i < e; i++) m = dmin(m, in[i]);
-        out[j] = m;
+        out[j] = (j == 0 && first_is_zero) ? 0u : m;             // (boundary 0 has depth 0 whatever lcp[0] holds)
     }
 }
 
@@ -50,7 +50,7 @@ __device__ __forceinline__ uint64_t prev_smaller(const Pyramid& py, uint64_t p, 
     for (;;) {                                               // climb: scan to the left inside the current block
         bool found = false;
         for (;;) {
-            if (py.lvl[l][idx] < v) { found = true; break; }
+            if ((l == 0 && idx == 0) || py.lvl[l][idx] < v) { found = true; break; }     // (boundary 0: depth 0 by definition)
             if (idx % kPyrFan == 0) break;
             idx--;
         }
@@ -61,7 +61,7 @@ __device__ __forceinline__ uint64_t prev_smaller(const Pyramid& py, uint64_t p, 
     while (l > 0) {                                          // descend: the rightmost child below v
         l--;
         int64_t c = dmin<int64_t>(idx * kPyrFan + kPyrFan - 1, (int64_t)py.len[l] - 1);
-        while (py.lvl[l][c] >= v) c--;
+        while (!(l == 0 && c == 0) && py.lvl[l][c] >= v) c--;
         idx = c;
     }
     return (uint64_t)idx;
@@ -125,7 +125,7 @@ k_tree_parents(const uint32_t* __restrict__ lcp, uint64_t n, const uint32_t* __r
         // leaf of rank p: under the deeper of boundaries p and p + 1
         const uint32_t dl = lcp[p], dr = p + 1 < n ? lcp[p + 1] : 0u;
         leaf_parent[p] = dl >= dr ? node[p] : node[p + 1];
-        if (node[p] == 0) { parent[p] = p == 0 ? kNoNode : 0u; continue; }      // (the root has no parent)
+        if (node[p] == 0) { parent[p] = kNoNode; continue; }                     // (the root has no parent: every boundary of depth 0)
         const uint64_t l = lb[p], r = (uint64_t)rb[p] + 1;                        // the two delimiting boundaries
         const uint32_t vl = lcp[l], vr = r < n ? lcp[r] : 0u;
         parent[p] = vl >= vr ? node[l] : node[r];
@@ -179,7 +179,7 @@ int lcp_intervals_dev(const uint32_t* d_lcp, uint64_t n, uint32_t* d_lb, uint32_
     while (py.levels < kPyrMaxLevels && len > 1) {
         const uint64_t out_len = (len + kPyrFan - 1) / kPyrFan;
         const unsigned grid = (unsigned)dmin<uint64_t>((out_len + kBlock - 1) / kBlock, kMaxGrid);
-        SFX_LAUNCH("tree_pyramid", (double)len * 4, k_pyr_reduce, grid, kBlock, st, py.lvl[py.levels - 1], len, w, out_len);
+        SFX_LAUNCH("tree_pyramid", (double)len * 4, k_pyr_reduce, grid, kBlock, st, py.lvl[py.levels - 1], len, w, out_len, 1);
         py.lvl[py.levels] = w;
         py.len[py.levels] = out_len;
         py.levels++;

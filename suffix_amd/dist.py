@@ -63,6 +63,11 @@ def _gather_flat(dst, src, group=None, async_op=False):
             return fn(dst, src, group=group, async_op=async_op)
         except (NotImplementedError, AttributeError):
             pass
+        except RuntimeError as e:
+            # older stacks raise RuntimeError for a backend without the flat form; anything else is the collective's own
+            msg = str(e).lower()
+            if not any(w in msg for w in ("not supported", "unsupported", "not implemented", "does not support")):
+                raise
     return dist.all_gather(list(dst.split(src.numel())), src, group=group, async_op=async_op)
 
 
@@ -211,9 +216,19 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
     # a slice whose repeats are too long for text-symbol refinement needs ranks of suffixes that other
     # ranks own: every rank then builds the whole suffix array (replicas) and keeps its slice -- correct
     # for any text, not scalable, and announced in `timings`
-    need = torch.tensor([1 if rc == SFX_ERR_NEEDS_RANKS else 0], dtype=torch.int64, device=dev)
+    # (a rank whose build failed for another reason must not be dragged into the fallback: its error is the answer)
+    failed = rc not in (0, SFX_ERR_NEEDS_RANKS)
+    need = torch.tensor([1 if rc == SFX_ERR_NEEDS_RANKS else 0, 1 if failed else 0], dtype=torch.int64, device=dev)
     dist.all_reduce(need, op=dist.ReduceOp.MAX, group=group)
-    if int(need.item()):
+    if failed:
+        eng.check(rc, "sfx_build_sa_range_u32_dev")
+    if int(need[1].item()):
+        raise RuntimeError(f"rank {rank}: the range build failed on another rank")
+    if int(need[0].item()):
+        import warnings
+        warnings.warn("suffix_amd.dist: a slice needs rank refinement (a repeat of thousands of symbols): every rank builds "
+                      "the whole suffix array and keeps its slice -- correct, but ~50 n bytes of workspace per GPU and no "
+                      "multi-GPU speed-up for this text", RuntimeWarning, stacklevel=2)
         del ws
         if text is None:
             text = gather_shards(shard, lens, group)

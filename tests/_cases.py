@@ -401,6 +401,7 @@ def suffix_tree_topology(eng, orc, device="cpu", scale=1):
             v = L[p]
             if p == 0 or v == 0:
                 assert (got["lb"][p], got["rb"][p], got["node"][p]) == (0, n - 1, 0)
+                assert got["parent"][p] == 0xFFFFFFFF           # the root is nobody's child (not its own either)
                 continue
             l = p - 1
             while L[l] >= v:

@@ -61,6 +61,9 @@ constexpr unsigned hipStreamNonBlocking = 1;
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned) { return hipStreamCreate(st); }
 hipError_t hipStreamDestroy(hipStream_t st);
 hipError_t hipEventCreate(hipEvent_t* e);
+constexpr unsigned hipEventDisableTiming = 2;
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t st);
 hipError_t hipEventSynchronize(hipEvent_t e);

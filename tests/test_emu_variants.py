@@ -81,6 +81,15 @@ if os.environ.get("SFX_HYBRID_MIN"):
     if cap < 400:
         names = kernels_of(skewed)
         assert "radix_hist16_text" in names and "bucket_sort_lds" not in names, names
+if os.environ.get("SFX_HT_MIN"):
+    # compressed keys: skewed symbol counts (long and short codes side by side), a symbol that occurs once, runs of the
+    # smallest symbol (its code is all zeros, like the padding past the end) at the end of the text and before it
+    rngh2 = np.random.default_rng(99)
+    zipf = np.minimum(rngh2.zipf(1.3, 40000), 200).astype(np.uint8)
+    texts.append(zipf.tobytes() + bytes([250]) + zipf[:3000].tobytes())
+    low = bytes([int(zipf.min())])
+    texts.append(zipf[:20000].tobytes() + low * 40 + zipf[5000:9000].tobytes() + low * 25)
+    texts.append(_gen.utf8_mixed(30000).tobytes())
 if os.environ.get("SFX_DEEP_ITERS") or os.environ.get("SFX_DEEP_KPT"):
     # deep text rounds: buckets finished inside one wave, members that stay tied leaving with their own depth (capped
     # iterations: every round leaves such buckets), buckets above the wave's window on the large path, fused LCP values
@@ -164,8 +173,12 @@ VARIANTS = {
     "deep-one-iteration": {"SFX_DEEP_ITERS": "1"},
     "deep-two-iterations-small-windows": {"SFX_DEEP_ITERS": "2", "SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
     "deep-small-windows-key64": {"SFX_DEEP_ITERS": "24", "SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "3"},
-    "deep-256-position-windows": {"SFX_DEEP_KPT": "4"},
-    "deep-1024-position-windows": {"SFX_DEEP_KPT": "16", "SFX_DEEP_ITERS": "3"},
+    "deep-512-position-windows": {"SFX_DEEP_KPT": "8", "SFX_DEEP_ITERS": "3"},
+    # 64-bit initial keys in an order-preserving prefix code (k_ht_keys): buckets of different depths from the first list on
+    "compressed-keys": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24"},
+    "compressed-keys-small-windows-one-iteration": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "1", "SFX_TILE_SMALL": "1",
+                                                    "SFX_SEG_SMALL": "1", "SFX_MAX_GRID": "3"},
+    "compressed-keys-off": {"SFX_FORCE_KEY64": "1", "SFX_HT": "0", "SFX_DEEP_ITERS": "24"},
 }
 
 

@@ -2,10 +2,10 @@
 size-gated code paths the small parity cases cannot reach (run with -m gpu):
 
   * config 3 / config 5: SA, LCP (and the 10^6 positions() queries) through the C ABI, sha256 of the
-    complete arrays compared with tests/golden/fullsize_pins.json -- the pins were recorded by the run in
-    which the complete SA and LCP arrays were compared element by element with the oracle
-    (profiles/r2_fullsize_full_oracle.jsonl); config 5's query answers are compared with the oracle here,
-    all 10^6 of them;
+    complete arrays compared with tests/golden/fullsize_pins.json; config 5's query answers are compared with
+    the oracle here, all 10^6 of them;
+  * (tests/test_gpu_zfull_oracle.py, last in the session: the COMPLETE 10^9-entry SA and LCP arrays of configs 3, 5
+    and the high-LCP text against the oracle's, element by element)
   * n >= 2^27: rank rounds whose rank-array updates go through the partitioned scatter
     (scatter_pairs_u32), complete SA and LCP compared with the oracle;
   * n >= 2^30: the chunked radix schedule (one-sweep status words no longer fit), property gate.

@@ -86,9 +86,17 @@ def test_crate_is_cargo_ready():
     added = [l[1:] for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++")]
     removed = [l for l in patch.splitlines() if l.startswith("-") and not l.startswith("---")]
     assert not removed, "the patch must not delete reference code (the CPU path stays)"
-    assert sum('cfg(feature = "hip")' in l for l in added) == 4
+    assert sum('cfg(feature = "hip")' in l for l in added) == 6
     assert any("::suffix_hip::sais_table(text)" in l for l in added)
     assert any("::suffix_hip::lcp_lens(self.text(), self.table())" in l for l in added)
+    # short texts stay on the reference's own CPU path (both seams compare against the crate's threshold) ...
+    assert sum("::suffix_hip::MIN_DEVICE_LEN" in l for l in added) == 2
+    assert "pub const MIN_DEVICE_LEN: usize" in lib
+    # ... and the resident index outlives a batch: the caller holds the handle, positions_batch builds none per call
+    assert any("pub fn device_index(&self) -> ::suffix_hip::DeviceIndex" in l for l in added)
+    assert any("pub fn positions_batch_on<'a>(" in l for l in added)
+    body = patch[patch.index("pub fn positions_batch_on"):patch.index("pub fn positions_batch<'a>")]
+    assert "DeviceIndex::new" not in body
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src") or shutil.which("patch") is None,
