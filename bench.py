@@ -110,6 +110,51 @@ def _sha_u32(t):
     return hashlib.sha256(memoryview(t.cpu().numpy())).hexdigest()
 
 
+def running_commit():
+    """The commit this code was built from: git where there is a checkout, else the stamp __graft_entry__.build() leaves
+    next to the library (the GPU boxes get a snapshot without .git)."""
+    try:
+        import subprocess
+        out = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5)
+        if out.returncode == 0 and out.stdout.strip():
+            return out.stdout.strip()
+    except (OSError, ValueError, Exception):
+        pass
+    try:
+        return open(os.path.join(ROOT, "suffix_amd", "_build_commit.txt")).read().strip() or "unknown"
+    except OSError:
+        return os.environ.get("SFX_COMMIT", "unknown")
+
+
+def kernel_rooflines(rep, pmc_kernels=None, min_share=0.15):
+    """Every kernel that takes at least min_share of the profiled build: algorithmic bytes per launch / mean launch time
+    against the HBM peak, and the measured HBM traffic per launch where the committed PMC summary has the kernel."""
+    total = sum(r["total_ms"] for r in rep) or 1.0
+    out = []
+    for r in sorted(rep, key=lambda r: -r["total_ms"]):
+        share = r["total_ms"] / total
+        if share < min_share or r["launches"] == 0 or r["total_ms"] <= 0:
+            continue
+        per_b = r["algo_bytes"] / r["launches"]
+        per_ms = r["total_ms"] / r["launches"]
+        ach = per_b / (per_ms * 1e-3) / 1e9
+        ent = {"kernel": r["name"], "share_of_build": round(share, 3), "launches": r["launches"], "avg_launch_ms": round(per_ms, 4),
+               "algo_bytes_per_launch": per_b, "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+               "traffic": None}
+        pk = (pmc_kernels or {}).get(r["name"])
+        if pk:
+            ent["traffic"] = round(pk["hbm_bytes_per_launch"])
+        out.append(ent)
+    return out
+
+
+def load_pmc(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except (OSError, ValueError):
+        return {}
+
+
 def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
     """One BASELINE config at full size on one GPU: device-resident SA (+ LCP, + the
     10^6 positions() queries of config 5), timed with the inputs already in HBM; sha256 of the text, SA,
@@ -151,6 +196,8 @@ def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
     prof = sorted(eng.profile_report(), key=lambda r: -r["total_ms"])
     eng.profile(False)
     rec["top_kernels_ms"] = {r["name"]: round(r["total_ms"], 2) for r in prof[:8]}
+    engine_algo = sum(r["algo_bytes"] for r in prof)
+    pmc_cfg = load_pmc("r3_pmc_fullsize.json").get(key, {})
     del ws
     lws = sdev.lcp_workspace(n, dev)
     lcp = torch.empty(n, dtype=torch.int32, device=dev)
@@ -177,6 +224,13 @@ def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
     # W_SA(u32) ~ 69 B per input byte for deep-recursion text, W_LCP = 22
     rec["roofline"] = {"whole_path": {"algo_bytes_per_input_byte": 69.0, "achieved_GB/s": round(69.0 * n / best / 1e9, 1),
                                       "frac_of_hbm_peak": round(69.0 * n / best / 1e9 / HBM_PEAK_GBS, 4)},
+                       # what the engine itself moves (sum of its kernels' algorithmic bytes) next to SA-IS's 69
+                       "engine": {"algo_bytes_per_input_byte": round(engine_algo / n, 1),
+                                  "times_sais": round(engine_algo / n / 69.0, 2),
+                                  "achieved_GB/s": round(engine_algo / best / 1e9, 1),
+                                  "frac_of_hbm_peak": round(engine_algo / best / 1e9 / HBM_PEAK_GBS, 4)},
+                       "kernels": kernel_rooflines(prof, pmc_cfg.get("kernels"), 0.10),
+                       "traffic_commit": pmc_cfg.get("commit"),
                        "lcp": {"algo_bytes_per_input_byte": 22.0, "achieved_GB/s": round(22.0 * n / t_lcp / 1e9, 1)}}
     rec["sha256_sa"] = _sha_u32(sa)
     rec["sha256_lcp"] = _sha_u32(lcp)
@@ -433,6 +487,9 @@ def main():
         "algo_bytes_per_launch": per_launch_bytes,
         "share_of_step": round(dom["total_ms"] / total_ms, 3),
         "kernel_ms": {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items())},
+        # every kernel with at least 15 % of the step, each against the HBM peak (traffic: filled in below)
+        "kernels": kernel_rooflines(rep, None, 0.15),
+        "engine_algo_bytes_per_input_byte": round(sum(r["algo_bytes"] for r in rep) / max(n_local, 1), 1),
         # whole path at SURVEY.md 8d's figure (65 algorithmic B per input byte, u32 DNA)
         "whole_path": {"algo_bytes_per_input_byte": 65.0,
                        "achieved": round(65.0 * value / 1e3, 1), "unit": "GB/s",
@@ -446,6 +503,10 @@ def main():
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
+            for kr in roofline["kernels"]:
+                pk = pmc.get("kernels", {}).get(kr["kernel"])
+                if pk:
+                    kr["traffic"] = round(pk["hbm_bytes_per_launch"])
             ent = pmc.get("kernels", {}).get(dom["name"])
             if ent:
                 roofline["traffic"] = round(ent["hbm_bytes_per_launch"])
@@ -454,12 +515,7 @@ def main():
                 # the counters come from their own rocprofv3 passes (they cannot be collected inside this run):
                 # the commit they were collected at, next to the commit that is running, if it can be told
                 roofline["traffic_commit"] = pmc.get("commit", "unknown")
-                try:
-                    import subprocess
-                    roofline["this_commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
-                                                             text=True, timeout=5).stdout.strip() or os.environ.get("SFX_COMMIT", "unknown")
-                except (OSError, subprocess.SubprocessError):
-                    roofline["this_commit"] = os.environ.get("SFX_COMMIT", "unknown")
+                roofline["this_commit"] = running_commit()
         except (ValueError, KeyError, OSError):
             pass
 
@@ -475,8 +531,6 @@ def main():
             "runs_128B_unaligned_copy": round(E.microbench(E.MB_RUNSCATTER, 8 * n_local, 128, 0), 1),
             "runs_128B_aligned_copy": round(E.microbench(E.MB_RUNSCATTER, 8 * n_local, 128, 1), 1),
         }
-        # the radix pass is a read + run-scatter; its practical ceiling is the unaligned-run rate
-        roofline["frac_of_run_scatter"] = round(achieved / max(roofline["scatter_bw"]["runs_128B_unaligned_copy"], 1e-9), 4)
     if args.calibrate and world == 1:
         eng.microbench(eng.MB_COPY, 1 << 30, 0, 0, 1)
         eng.microbench(eng.MB_RUNSCATTER, 8 * n_local, 128, 0, 1)

@@ -47,6 +47,11 @@ if os.environ.get("TIME_FUSED") == "1":
     rec["fused_lcp_equals_separate"] = bool(torch.equal(l2, lcp))
     rec["sha256_lcp"] = hashlib.sha256(lcp.cpu().numpy().tobytes()).hexdigest()[:16]
     del l2, lcp, ws2
+if os.environ.get("PMC_CALIBRATE") == "1":
+    # known byte counts for the counter calibrations of scripts/gpu_pmc_fullsize.sh: a 1 GiB copy, 2^28 random 4-byte reads
+    ws = None
+    eng.microbench(eng.MB_COPY, 1 << 30, 0, 0, 1)
+    eng.microbench(eng.MB_GATHER4, 1 << 30, 0, 0, 1)
 if os.environ.get("TIME_SHA", "1") == "1":
     rec["sha256_sa"] = hashlib.sha256(sa.cpu().numpy().tobytes()).hexdigest()[:16]
 print(json.dumps(rec), flush=True)
