@@ -26,9 +26,9 @@ elif args and args[0] == "--fullsize":
     full_out, full_key, full_builds, args = args[1], args[2], int(args[3]), args[4:]
 
 # profile name of the engine (sfx_kernel_stat.name) for each kernel symbol
-NAMES = [("k_radix_pass<sfx::SrcE64", "radix_scatter_u32"), ("k_radix_pass<sfx::SrcText32", "radix_scatter_text_u32"),
+NAMES = [("k_radix_pass<sfx::SrcE64, sfx::DstE64, 11, true, true, 16, false", "radix_scatter_u32"), ("k_radix_pass<sfx::SrcE64, sfx::DstSplit32", "radix_scatter_u32"), ("k_radix_pass<sfx::SrcText32", "radix_scatter_text_u32"),
          ("k_radix_pass<sfx::SrcKV", "radix_scatter_u64"), ("k_radix_pass<sfx::SrcText64", "radix_scatter_text_u64"),
-         ("k_groups_apply<unsigned int>", "groups_apply_u32"), ("k_groups_apply<unsigned long>", "groups_apply_u64"),
+         ("k_groups_apply<unsigned int", "groups_apply_u32"), ("k_groups_apply<unsigned long", "groups_apply_u64"),
          ("k_groups_reduce", "groups_reduce"), ("k_radix_hist_all<sfx::SrcText32", "radix_hist_all_text_u32"),
          ("k_pack_text", "pack_text"), ("k_small_groups", "small_groups"), ("k_byte_presence", "byte_presence"),
          ("k_tile_sort", "tile_sort"), ("k_seg_gather", "seg_gather"), ("k_lcp_windows_packed", "lcp_windows_packed"),

@@ -188,8 +188,6 @@ struct SegTileHost { uint32_t begin, count, seg_start, info, mseg, pad[3]; };
 int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg, uint64_t nlarge, uint32_t* V,
                        uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit, uint16_t* Hd = nullptr,
                        uint32_t wsym = 0);
-int segmented_sort_kv64(uint64_t* K0, uint32_t* V0, uint64_t* K1, uint32_t* V1, int npass, const SegSort& q, uint32_t nseg,
-                        uint64_t nlarge, uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit);
 // target[idx] = val for m (idx << 32 | val) pairs, idx < n: one partitioning pass on the top
 // bits of idx, then a scatter whose writes stay inside a cache-sized window of `target`.
 // `tmp` is m u64 of scratch, `radix_scratch` as for the sorts.  Pays for 4n >> Infinity Cache.
@@ -255,16 +253,6 @@ __device__ __forceinline__ uint32_t lcp_from_key2(const LcpEmit& L, uint32_t ka,
 {
     return lcp_from_key2_at(L, L.h, ka, kb, sa, sb);
 }
-__device__ __forceinline__ uint32_t lcp_from_key2_64(const LcpEmit& L, uint64_t ka, uint64_t kb, uint32_t sa, uint32_t sb)
-{
-    const uint32_t la = L.n - sa, lb = L.n - sb;
-    if (!((ka & kb) >> 63)) return la < lb ? la : lb;
-    const uint64_t x = ka ^ kb;
-    const uint32_t lz = (uint32_t)__clzll((long long)x) - (64u - (uint32_t)L.field_bits64);
-    const uint32_t v = L.h + ((lz * L.inv_bits) >> 16);
-    if (v > la) return kLcpBoundFlag | L.h;
-    return v < lb ? v : lb;
-}
 constexpr unsigned kDeepSlotWords = 1024 * 8;
 struct TileRound {
     LcpEmit emit;
@@ -284,18 +272,13 @@ struct TileRound {
     uint32_t* V_other;
     SegSort seg;                  // scratch of the segmented sort
 };
-int tile_round_text(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
-                    sfx_build_stats* stats);
 LcpEmit make_lcp_emit(uint32_t* lcp, const uint32_t* S, const PackedText& pt, uint64_t h, bool rank_mode);
 // deep text round (sfx_tile.hip): buckets of a few hundred members are finished inside one wave, each from its own
 // depth r.Hd (deep_text_symbols(pt) symbols per gather); larger ones are split by their next text_round_symbols(pt) symbols
 int deep_text_symbols(const PackedText& pt);
+int text_key64_symbols(const PackedText& pt);       // symbols of a 64-bit text key (flag in bit 63)
 inline int text_round_symbols(const PackedText& pt) { return pt.kbits == 32 ? pt.spw - 1 : pt.spw; }
 int deep_round_text(const PackedText& pt, const TileRound& r, uint64_t m, hipStream_t st, sfx_build_stats* stats);
-// text round on 64-bit keys: text_key64_symbols(pt) symbols per round
-int text_key64_symbols(const PackedText& pt);
-int tile_round_text64(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
-                      sfx_build_stats* stats);
 // (needs n - 1 + h < 2^32: key2 = rank + h)
 int tile_round_rank(const uint32_t* isa, uint64_t n, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
                     sfx_build_stats* stats);

@@ -1528,26 +1528,6 @@ k_seg_finish(const uint64_t* __restrict__ E, const SegTile* __restrict__ tiles, 
     }
 }
 
-// 64-bit text keys (K = key2, V = suffix, sorted in place as key / value arrays): flags and fused LCP
-__global__ void __launch_bounds__(kBlock)
-k_seg_finish64(const uint64_t* __restrict__ K, const uint32_t* __restrict__ V, const SegTile* __restrict__ tiles,
-               const uint32_t* __restrict__ ntiles, uint8_t* __restrict__ F8, LcpEmit emit)
-{
-    const uint32_t nt = *ntiles;
-    for (uint32_t t = blockIdx.x; t < nt; t += gridDim.x) {
-        const SegTile d = tiles[t];
-        const uint64_t seg_end = (uint64_t)d.seg_start + d.pad[1];
-        for (uint32_t i = threadIdx.x; i < d.count; i += kBlock) {
-            const uint64_t p = (uint64_t)d.begin + i;
-            const uint64_t key = K[p];
-            const bool head = p == d.seg_start || K[p - 1] != key;
-            const bool last = p + 1 == seg_end || K[p + 1] != key;
-            F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
-            if (emit.lcp && head && p != d.seg_start) emit.lcp[emit.S[p]] = lcp_from_key2_64(emit, K[p - 1], key, V[p - 1], V[p]);
-        }
-    }
-}
-
 // tile of the segmented sort: E64 elements (rank rounds) or 64-bit keys + values (text rounds)
 uint32_t seg_tile_elems(bool kv)
 {
@@ -1570,21 +1550,6 @@ static int seg_passes(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t* stat
     }
     return SFX_OK;
 }
-template <int KPT, int NW>
-static int seg_passes_kv(uint64_t* K0, uint32_t* V0, uint64_t* K1, uint32_t* V1, const SegSort& q, uint32_t* status,
-                         uint64_t status_words, hipStream_t st, double algo, int npass)
-{
-    for (int p = 0; p < npass; p++) {
-        SFX_HIP(hipMemsetAsync(status, 0, status_words * sizeof(uint32_t), st));
-        SegArgs sa = {reinterpret_cast<const SegTile*>(q.tiles), q.counters, q.segexcl, p, npass};
-        const bool odd = p & 1;
-        SFX_LAUNCH("seg_radix_pass_kv", algo, (k_radix_pass<SrcKV, DstKV, KPT, true, true, NW, true>), kMaxGrid / 4, NW * kWave, st,
-                   SrcKV{odd ? K1 : K0, odd ? V1 : V0}, DstKV{odd ? K0 : K1, odd ? V0 : V1}, (uint64_t)0, 8 * p, 255u, (uint64_t)0,
-                   (const uint32_t*)nullptr, (const uint32_t*)nullptr, status, q.counters + 4 + p, sa);
-    }
-    return SFX_OK;
-}
-
 // tile table of the segments q.segs[0, nseg) (device side; the tile count stays on the device)
 int segmented_layout(const SegSort& q, uint32_t nseg, bool kv, hipStream_t st, uint32_t skip_upto)
 {
@@ -1616,29 +1581,6 @@ int segmented_sort_e64(uint64_t* A, uint64_t* B, const SegSort& q, uint32_t nseg
     SFX_LAUNCH("seg_finish", (double)nlarge * 13, k_seg_finish, grid, kBlock, st, A, reinterpret_cast<const SegTile*>(q.tiles),
                q.counters, V, F8, emit, Hd, wsym);
     if (stats) { stats->radix_passes += 4; stats->elements_sorted += 4 * nlarge; }
-    return SFX_OK;
-}
-
-// The same for 64-bit keys: K0[p] = key2, V0[p] = suffix at the positions of the segments, (K1, V1) the
-// ping-pong buffers; key bits [0, 8 * npass) are sorted (npass even: the result is back in K0 / V0).
-int segmented_sort_kv64(uint64_t* K0, uint32_t* V0, uint64_t* K1, uint32_t* V1, int npass, const SegSort& q, uint32_t nseg,
-                        uint64_t nlarge, uint8_t* F8, hipStream_t st, sfx_build_stats* stats, const LcpEmit& emit)
-{
-    if (nseg == 0) return SFX_OK;
-    if (npass < 2 || npass > kSegMaxPasses || (npass & 1)) return SFX_ERR_INTERNAL;
-    const uint32_t te = seg_tile_elems(true);
-    const unsigned grid = (unsigned)dmin<uint64_t>(nlarge / te + nseg, kMaxGrid);
-    SFX_LAUNCH("seg_hist", (double)nlarge * 8, k_seg_hist, grid, kBlock, st, K0, reinterpret_cast<const SegTile*>(q.tiles),
-               q.counters, q.tilehist, npass, 0);
-    SFX_LAUNCH("seg_scan", 0.0, k_seg_scan, grid, kBlock, st, reinterpret_cast<const SegTile*>(q.tiles), q.counters,
-               q.tilehist, q.segexcl, npass);
-    const uint64_t status_words = (2 * (nlarge / te) + 2) * kRadix;
-    if (status_words > q.status_words) return SFX_ERR_WORKSPACE;
-    if (seg_small()) SFX_TRY((seg_passes_kv<9, 8>(K0, V0, K1, V1, q, q.status, status_words, st, (double)nlarge * 24, npass)));
-    else SFX_TRY((seg_passes_kv<9, 16>(K0, V0, K1, V1, q, q.status, status_words, st, (double)nlarge * 24, npass)));
-    SFX_LAUNCH("seg_finish", (double)nlarge * 9, k_seg_finish64, grid, kBlock, st, (const uint64_t*)K0, (const uint32_t*)V0,
-               reinterpret_cast<const SegTile*>(q.tiles), q.counters, F8, emit);
-    if (stats) { stats->radix_passes += npass; stats->elements_sorted += (uint64_t)npass * nlarge; }
     return SFX_OK;
 }
 

@@ -1673,15 +1673,9 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
 {
     const uint64_t n = pt.n;
     uint64_t h = (uint64_t)cpk;
-    // symbols of a text round: 32-bit key2 (flag + up to 31 bits of symbols).  SFX_TEXT_KEY=64 selects 64-bit
-    // keys (twice the symbols per round, half the rounds): measured on 1 GB inputs (profiles/
-    // r2_text_key64_vs_32.jsonl) 178 vs 186 ms English-like, 149 vs 144 ms on round 1's English-like input, 316 vs
-    // 282 ms UTF-8 -- a round is bound by sorting work (bits x members: 8 LDS passes / 8 segmented 24-byte
-    // passes instead of 4 + 4 over two rounds), not by its key gather, so the wider key does not pay
-    static const bool key64 = [] { const char* e = dev_env("SFX_TEXT_KEY"); return e && atoi(e) == 64; }();
-    // SFX_DEEP=0 (development): the text rounds of round 2, one list pass per text_round_symbols symbols
-    static const bool deep = [] { const char* e = dev_env("SFX_DEEP"); return !e || atoi(e) != 0; }();
-    const int wsym = (key64 && !deep) ? text_key64_symbols(pt) : text_round_symbols(pt);
+    // symbols a split by the large-bucket path adds to a bucket's depth (32-bit key2: flag + up to 31 bits of symbols).
+    // (64-bit keys for that path were measured in round 2 and did not pay: a level is bound by sorting work, bits x members.)
+    const int wsym = text_round_symbols(pt);
     bool rank_mode = false;
     uint64_t stalled = 0;
     int rounds = 0;
@@ -1698,7 +1692,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         TileRound tr;
         tr.emit = make_lcp_emit(lcp, S_cur, pt, h, rank_mode);
         tr.G = b.G; tr.V = V_cur; tr.F8 = b.F8; tr.F = b.F;
-        const bool deep_round = deep && !rank_mode;
+        const bool deep_round = !rank_mode;
         tr.Hd = deep_round ? hd_of(b, S_cur) : nullptr;
         tr.wsym = (uint32_t)wsym;
         tr.part_head = b.part_head; tr.part_keep = b.part_keep; tr.part_ghead = b.part_ghead;
@@ -1715,9 +1709,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         tr.seg.status_words = radix_scratch_words(m) - 64;
         tr.seg.counters = b.hist;
         if (rank_mode) SFX_TRY(tile_round_rank(isa, n, h, tr, m, st, &stats));
-        else if (deep) { SFX_TRY(deep_round_text(pt, tr, m, st, &stats)); any_deep = true; }
-        else if (key64) SFX_TRY(tile_round_text64(pt, h, tr, m, st, &stats));
-        else SFX_TRY(tile_round_text(pt, h, tr, m, st, &stats));
+        else { SFX_TRY(deep_round_text(pt, tr, m, st, &stats)); any_deep = true; }
         Chunking ch = make_chunking(m, kApplyTile);
         SFX_LAUNCH("groups_scan", 0.0, k_groups_scan, 1, kBlock, st, b.part_head, b.part_keep, b.part_ghead, ch.blocks,
                    b.totals);
@@ -1747,7 +1739,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
             // round costs more than the rank array it postpones)
             if (kept * 3 > m * 2) stalled += kept + (4u << 20);
             // (the depths of the deep rounds are 16-bit; a text that deep is a repeat anyway)
-            const bool too_deep = deep && h + 2 * (uint64_t)wsym > 60000;
+            const bool too_deep = h + 2 * (uint64_t)wsym > 60000;
             if (isa && force != 1 && (stalled * 2 > n || force == 2 || too_deep)) {
                 // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
                 SFX_TRY(build_ranks(b, sa, n, V_next, S_next, kept, isa, st, stats));
@@ -1763,7 +1755,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         m = kept;
         if (small_groups_pay(m, kept_groups))
             SFX_TRY(small_groups_pass(pt, h, b, sa, rank_mode ? isa : nullptr, &S_cur, &V_cur, &m, st, stats, lcp,
-                                      deep && !rank_mode));
+                                      !rank_mode));
     }
     if (any_deep) {
         unsigned long long g = 0;

@@ -43,18 +43,6 @@ struct TextKey {
     __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return at(i, h); }
     __device__ __forceinline__ uint32_t depth_default() const { return (uint32_t)h; }
 };
-// text round on a 64-bit key: 1 << 63 | the next wsym64 symbols, or n-1-i
-struct TextKey64 {
-    PackedText t;
-    uint64_t h;
-    int shift;                  // 2 * kbits - wsym64 * bits: symbols of the 2-word window that do not fit beside the flag
-    __device__ __forceinline__ uint64_t operator()(uint32_t i) const
-    {
-        const uint64_t p = (uint64_t)i + h;
-        if (p >= t.n) return t.n - 1 - (uint64_t)i;
-        return (1ull << 63) | (packed_key64(t, p) >> shift);
-    }
-};
 // rank round: key2 = rank of suffix i+h (+h), or n-1-i; the caller guarantees n-1+h < 2^32
 struct RankKey {
     const uint32_t* isa;
@@ -328,280 +316,6 @@ k_tile_sort(KeyFn keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* _
     if (tid == 0) atomicAdd(owned_total, (unsigned long long)tot);
 }
 
-// ---- the same for 64-bit text keys ------------------------------------------------------------
-// Twice the symbols per round = half the rounds = half the key gathers (one random 128-byte line per
-// member and round is what a round costs most, and the wider window comes out of the same line).  Keys
-// (u64) and (bucket | window offset) words (u32) sit in two LDS arrays; the radix part runs one pass per
-// key byte that actually differs among the tile's big-bucket members, then the label pass.
-template <int NW, int KPT>
-struct TileSmem64 {
-    static constexpr int kWin = NW * kWave * KPT;
-    static constexpr bool kAliasMasks = KPT >= 4;
-    uint64_t stage[kWin];
-    uint64_t masks[kAliasMasks ? 1 : NW * kRadixDev];
-    uint32_t aux[kWin];                                     // (bucket id or label) << kIdxBits | window offset
-    uint32_t sufwin[kWin];
-    uint16_t posmap[kWin];
-    uint16_t hslot[kWin / 2];
-    uint8_t blabel[kWin / 2];
-    uint32_t cnt[NW][kRadixDev];
-    uint32_t part[2][NW];
-    uint64_t part64[NW];
-    unsigned long long diff;                                // OR of (key ^ first key) over the big region
-};
-
-template <int NW, int KPT, int kPairMax>
-__global__ void __launch_bounds__(NW * kWave)
-k_tile_sort64(TextKey64 keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* __restrict__ V,
-              uint8_t* __restrict__ F8, unsigned long long* __restrict__ owned_total, uint2* __restrict__ segs, LcpEmit emit)
-{
-    constexpr int kThreads = NW * kWave;
-    constexpr int kWin = kThreads * KPT;
-    constexpr int kT = kWin / 2;
-    constexpr int kTmax = kWin - kT;
-    constexpr int kIdxBits = ilog2_c(kWin);
-    static_assert((1 << kIdxBits) == kWin, "window must be a power of two");
-    static_assert(kThreads >= kRadixDev, "thread d owns digit d");
-    static_assert(kPairMax < kTmax && kWin / (kPairMax + 1) < 256, "size test / dense labels");
-    __shared__ TileSmem64<NW, KPT> s;
-    const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    const unsigned long long mybit = 1ull << lane;
-    const uint64_t base = (uint64_t)blockIdx.x * kT;
-    uint32_t* gwin = reinterpret_cast<uint32_t*>(s.stage);
-    for (unsigned i = tid; i < (unsigned)kWin; i += kThreads) gwin[i] = (base + i < m) ? G[base + i] : 0xFFFFFFFFu;
-    if (tid == 0) s.diff = 0ull;
-    __syncthreads();
-    for (unsigned i = tid; i < (unsigned)kT; i += kThreads) {                  // large buckets: reported by their last member
-        const uint64_t p = base + i;
-        if (p >= m) break;
-        const uint32_t g = gwin[i];
-        if ((p + 1 == m || gwin[i + 1] != g) && p - g + 1 > (uint64_t)kTmax) {
-            const unsigned long long k = atomicAdd(&owned_total[1], 1ull);
-            segs[k] = uint2{g, (uint32_t)(p - g + 1)};
-        }
-    }
-    uint32_t suf[KPT], lg[KPT];
-    uint64_t key2[KPT];
-    unsigned own = 0, big = 0, bighead = 0;
-    const unsigned i0 = tid * KPT;
-#pragma unroll
-    for (int j = 0; j < KPT; j++) {
-        const uint64_t p = base + i0 + j;
-        suf[j] = p < m ? V[p] : 0u;
-        const uint32_t g = gwin[i0 + j];
-        bool o = p < m && (uint64_t)g >= base && (uint64_t)g < base + kT;
-        bool bg = false;
-        lg[j] = 0u;
-        if (o) {
-            const unsigned lh = (unsigned)((uint64_t)g - base);
-            const uint64_t far = (uint64_t)g + kTmax;
-            if (far < m && gwin[lh + kTmax] == g) o = false;
-            else bg = (uint64_t)g + kPairMax < m && gwin[lh + kPairMax] == g;
-            lg[j] = lh;
-        }
-        own |= (o ? 1u : 0u) << j;
-        big |= ((o && bg) ? 1u : 0u) << j;
-        bighead |= ((o && bg && lg[j] == i0 + j) ? 1u : 0u) << j;
-    }
-#pragma unroll
-    for (int j = 0; j < KPT; j++) key2[j] = ((own >> j) & 1u) ? keyfn(suf[j]) : 0ull;
-    const uint64_t cnt = (uint64_t)__popc(own & ~big) | ((uint64_t)__popc(big) << 16) | ((uint64_t)__popc(bighead) << 32);
-    uint64_t incl = wave_scan_add(cnt);
-    if (lane == 63) s.part64[w] = incl;
-    __syncthreads();
-    uint64_t before = 0, total = 0;
-#pragma unroll
-    for (unsigned k = 0; k < (unsigned)NW; k++) {
-        const uint64_t q = s.part64[k];
-        if (k < w) before += q;
-        total += q;
-    }
-    const unsigned ns = (unsigned)total & 0xFFFFu, nb = (unsigned)(total >> 16) & 0xFFFFu;
-    if (ns + nb == 0) return;
-    {
-        const uint64_t ex = before + incl - cnt;
-        unsigned at_s = (unsigned)ex & 0xFFFFu, at_b = ns + ((unsigned)(ex >> 16) & 0xFFFFu), lab = (unsigned)(ex >> 32);
-#pragma unroll
-        for (int j = 0; j < KPT; j++) {
-            s.sufwin[i0 + j] = suf[j];
-            if ((bighead >> j) & 1u) s.blabel[lg[j]] = (uint8_t)lab++;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < KPT; j++) {
-            if ((own >> j) & 1u) {
-                const bool bg = (big >> j) & 1u;
-                const unsigned at = bg ? at_b++ : at_s++;
-                const unsigned mid = bg ? (unsigned)s.blabel[lg[j]] : lg[j];
-                s.stage[at] = key2[j];
-                s.aux[at] = (mid << kIdxBits) | (i0 + j);
-                s.posmap[at] = (uint16_t)(i0 + j);
-                if (!bg && lg[j] == i0 + j) s.hslot[lg[j]] = (uint16_t)at;
-            }
-        }
-    }
-    __syncthreads();
-
-    {   // small buckets: all-pairs ranking on (key2, window offset)
-        constexpr int kPer = (kWin + kThreads - 1) / kThreads;
-        uint64_t mk[kPer];
-        uint32_t ma[kPer];
-        unsigned dest[kPer];
-#pragma unroll
-        for (int k = 0; k < kPer; k++) {
-            const unsigned j = tid + (unsigned)k * kThreads;
-            dest[k] = 0xFFFFFFFFu;
-            if (j < ns) {
-                const uint64_t key = s.stage[j];
-                const uint32_t a = s.aux[j];
-                const unsigned b0 = s.hslot[a >> kIdxBits];
-                unsigned r = 0;
-                for (unsigned t = b0; t < ns && t < b0 + (unsigned)kPairMax; t++) {
-                    const uint32_t at = s.aux[t];
-                    if ((at >> kIdxBits) != (a >> kIdxBits)) break;
-                    const uint64_t kt = s.stage[t];
-                    r += (kt < key || (kt == key && at < a)) ? 1u : 0u;
-                }
-                mk[k] = key;
-                ma[k] = a;
-                dest[k] = b0 + r;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kPer; k++)
-            if (dest[k] != 0xFFFFFFFFu) { s.stage[dest[k]] = mk[k]; s.aux[dest[k]] = ma[k]; }
-    }
-    __syncthreads();
-
-    if (nb > 0) {
-        unsigned long long* const my_flags =
-            TileSmem64<NW, KPT>::kAliasMasks ? reinterpret_cast<unsigned long long*>(s.stage) + w * kRadixDev
-                                             : reinterpret_cast<unsigned long long*>(s.masks) + w * kRadixDev;
-        {   // which key bytes differ at all among the big-bucket members of this tile?
-            const uint64_t first = s.stage[ns];
-            uint64_t d = 0;
-            for (unsigned q = tid; q < nb; q += kThreads) d |= s.stage[ns + q] ^ first;
-            for (int o = 32; o >= 1; o >>= 1) d |= __shfl_xor(d, o);
-            if (lane == 0 && d) atomicOr(&s.diff, (unsigned long long)d);
-        }
-        __syncthreads();
-        const uint64_t diff = s.diff;
-        unsigned par = 1;
-        auto pass = [&](int byte) {                         // byte 0..7: key bytes; 8: the label
-            uint64_t key[KPT];
-            uint32_t ax[KPT], pos[KPT];
-#pragma unroll
-            for (int r = 0; r < KPT; r++) {
-                const unsigned q = w * (kWave * KPT) + r * kWave + lane;
-                key[r] = q < nb ? s.stage[ns + q] : ~0ull;
-                ax[r] = q < nb ? s.aux[ns + q] : 0xFFFFFFFFu;
-            }
-            constexpr int kSave = TileSmem64<NW, KPT>::kAliasMasks ? (NW * kRadixDev + kThreads - 1) / kThreads : 0;
-            uint64_t saved[kSave > 0 ? kSave : 1];
-#pragma unroll
-            for (int k = 0; k < kSave; k++) {
-                const unsigned q = tid + (unsigned)k * kThreads;
-                saved[k] = (q < (unsigned)(NW * kRadixDev) && q < ns) ? s.stage[q] : 0ull;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kRadixDev / kWave; k++) {
-                my_flags[k * kWave + lane] = 0ull;
-                s.cnt[w][k * kWave + lane] = 0u;
-            }
-            wave_sync();
-            auto digit = [&](int r) -> unsigned {
-                return byte < 8 ? (unsigned)(key[r] >> (8 * byte)) & 255u : (ax[r] >> kIdxBits) & 255u;
-            };
-#pragma unroll
-            for (int r = 0; r < KPT; r++) {
-                pos[r] = 0;
-                if (w * (kWave * KPT) + r * kWave < nb) pos[r] = rank_round<true>(digit(r), my_flags, s.cnt[w], mybit);
-            }
-            __syncthreads();
-            {
-                const bool owner = tid < (unsigned)kRadixDev;
-                uint32_t c[NW], tile_count = 0;
-#pragma unroll
-                for (int k = 0; k < NW; k++) {
-                    c[k] = owner ? s.cnt[k][tid] : 0u;
-                    tile_count += c[k];
-                }
-                const uint32_t ex = block_scan_excl_1b<NW>(tile_count, s.part, par);
-                if (owner) {
-                    uint32_t run = ex;
-#pragma unroll
-                    for (int k = 0; k < NW; k++) {
-                        s.cnt[k][tid] = run;
-                        run += c[k];
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kSave; k++) {
-                const unsigned q = tid + (unsigned)k * kThreads;
-                if (q < (unsigned)(NW * kRadixDev) && q < ns) s.stage[q] = saved[k];
-            }
-#pragma unroll
-            for (int r = 0; r < KPT; r++) {
-                const unsigned q = w * (kWave * KPT) + r * kWave + lane;
-                if (q < nb) {
-                    const unsigned d = ns + pos[r] + s.cnt[w][digit(r)];
-                    s.stage[d] = key[r];
-                    s.aux[d] = ax[r];
-                }
-            }
-            __syncthreads();
-        };
-        for (int b = 0; b < 8; b++)
-            if ((diff >> (8 * b)) & 255ull) pass(b);
-        pass(8);
-    }
-
-    const unsigned tot = ns + nb;
-    for (unsigned i = tid; i < tot; i += kThreads) {
-        const uint64_t key = s.stage[i];
-        const uint32_t a = s.aux[i];
-        const unsigned mid = a >> kIdxBits;
-        const bool same_prev = i != 0 && i != ns && (s.aux[i - 1] >> kIdxBits) == mid;
-        const bool same_next = i + 1 != tot && i + 1 != ns && (s.aux[i + 1] >> kIdxBits) == mid;
-        const bool head = !same_prev || s.stage[i - 1] != key;
-        const bool last = !same_next || s.stage[i + 1] != key;
-        const uint64_t p = base + s.posmap[i];
-        const uint32_t sfx = s.sufwin[a & (unsigned)(kWin - 1)];
-        V[p] = sfx;
-        F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
-        if (emit.lcp && head && same_prev)
-            emit.lcp[emit.S[p]] = lcp_from_key2_64(emit, s.stage[i - 1], key, s.sufwin[s.aux[i - 1] & (unsigned)(kWin - 1)], sfx);
-    }
-    if (tid == 0) atomicAdd(owned_total, (unsigned long long)tot);
-}
-
-// key2 (64-bit) at the list positions of the large buckets: K[p] = key2 (the suffixes stay where they are: V)
-__global__ void __launch_bounds__(kBlock)
-k_seg_gather64(TextKey64 keyfn, const uint32_t* __restrict__ V, const SegTileHost* __restrict__ tiles,
-               const uint32_t* __restrict__ ntiles, uint64_t* __restrict__ K)
-{
-    const uint32_t nt = *ntiles;
-    for (uint32_t t = blockIdx.x; t < nt; t += gridDim.x) {
-        const uint32_t begin = tiles[t].begin, count = tiles[t].count;
-        constexpr int U = 4;
-        for (uint32_t i0 = threadIdx.x; i0 < count; i0 += U * kBlock) {
-            uint32_t sfx[U];
-            uint64_t k2[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) sfx[u] = (i0 + u * kBlock < count) ? V[(uint64_t)begin + i0 + u * kBlock] : 0u;
-#pragma unroll
-            for (int u = 0; u < U; u++) k2[u] = (i0 + u * kBlock < count) ? keyfn(sfx[u]) : 0ull;
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (i0 + u * kBlock < count) K[(uint64_t)begin + i0 + u * kBlock] = k2[u];
-        }
-    }
-}
-
 // ---- large buckets ----------------------------------------------------------------------
 // key2 << 32 | suffix at the list positions of the large buckets (the tile table of the segmented sort
 // says where they are): the one gather per member that the LDS path does inside k_tile_sort
@@ -766,7 +480,7 @@ k_seg_single(KeyFn keyfn, const uint2* __restrict__ segs, uint32_t nseg, uint32_
 // Buckets above W - H members are announced to the large-bucket path exactly as k_tile_sort does.
 struct DeepTextKey {
     PackedText t;
-    int shift;                  // 2 * kbits - wsym * bits (see TextKey64)
+    int shift;                  // 2 * kbits - wsym * bits: symbols of the 2-word window that do not fit beside the flag
     int wsym;                   // symbols per key
     __device__ __forceinline__ uint64_t operator()(uint32_t i, uint32_t depth) const
     {
@@ -778,7 +492,7 @@ struct DeepTextKey {
 constexpr uint32_t kDeepMaxDepth = 65000;                   // Hd is 16 bits
 
 // LCP of a class head (suffix sb, key kb) with a member of the class in front of it (suffix sa, key ka) when the
-// members of their bucket share `depth` symbols: lcp_from_key2_64 with the depth of the bucket instead of the round's
+// members of their bucket share `depth` symbols (the 64-bit form of lcp_from_key2_at)
 __device__ __forceinline__ uint32_t lcp_deep(const LcpEmit& L, uint32_t depth, uint64_t ka, uint64_t kb, uint32_t sa, uint32_t sb)
 {
     const uint32_t la = L.n - sa, lb = L.n - sb;
@@ -1314,62 +1028,10 @@ LcpEmit make_lcp_emit(uint32_t* lcp, const uint32_t* S, const PackedText& pt, ui
     return e;
 }
 
-int tile_round_text(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
-                    sfx_build_stats* stats)
-{
-    return tile_round_impl(TextKey{pt, h, pt.kbits == 32 ? pt.bits : 0}, r, m, st, stats);
-}
 int text_key64_symbols(const PackedText& pt)
 {
     const int two = 2 * pt.spw, fit = 63 / pt.bits;
     return two < fit ? two : fit;
-}
-
-int tile_round_text64(const PackedText& pt, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,
-                      sfx_build_stats* stats)
-{
-    if (m == 0) return SFX_OK;
-    if (m > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
-    const int wsym = text_key64_symbols(pt);
-    const TextKey64 keyfn = {pt, h, 2 * pt.kbits - wsym * pt.bits};
-    const int npass_bits = wsym * pt.bits + 1;                      // symbols + the flag in bit 63 ...
-    (void)npass_bits;
-    SFX_HIP(hipMemsetAsync(r.counters, 0, 2 * sizeof(unsigned long long), st));
-    uint64_t tmax;
-    if (tile_small()) {
-        constexpr int kWin = 4 * kWave * 1;
-        tmax = kWin - kWin / 2;
-        const uint64_t tiles = (m + kWin / 2 - 1) / (kWin / 2);
-        SFX_LAUNCH("tile_sort64", (double)m * 17, (k_tile_sort64<4, 1, 32>), (unsigned)tiles, 4 * kWave, st, keyfn, r.G, m, r.V,
-                   r.F8, r.counters, reinterpret_cast<uint2*>(r.seg.segs), r.emit);
-    } else {
-        constexpr int kWin = 8 * kWave * 4;
-        tmax = kWin - kWin / 2;
-        const uint64_t tiles = (m + kWin / 2 - 1) / (kWin / 2);
-        if (tiles > 0x7FFFFFFFull) return SFX_ERR_TOO_LARGE;
-        SFX_LAUNCH("tile_sort64", (double)m * 17, (k_tile_sort64<8, 4, 32>), (unsigned)tiles, 8 * kWave, st, keyfn, r.G, m, r.V,
-                   r.F8, r.counters, reinterpret_cast<uint2*>(r.seg.segs), r.emit);
-    }
-    unsigned long long host[2] = {0, 0};
-    SFX_TRY(read_back(host, r.counters, sizeof(host), st));
-    if (host[0] > m || host[1] > m / (tmax + 1)) return SFX_ERR_INTERNAL;
-    const uint64_t nlarge = m - host[0];
-    const uint32_t nseg = (uint32_t)host[1];
-    if ((nlarge == 0) != (nseg == 0)) return SFX_ERR_INTERNAL;
-    if (stats) stats->tile_sorted += host[0];
-    if (nseg > 0) {
-        SFX_TRY(segmented_layout(r.seg, nseg, true, st));
-        const unsigned grid = (unsigned)dmin<uint64_t>(nlarge / seg_tile_elems(true) + nseg, kMaxGrid);
-        SFX_LAUNCH("seg_gather", (double)nlarge * 16, k_seg_gather64, grid, kBlock, st, keyfn, (const uint32_t*)r.V,
-                   reinterpret_cast<const SegTileHost*>(r.seg.tiles), (const uint32_t*)r.seg.counters, r.EA);
-        // the flag byte (bit 63 and what lies between it and the symbols) is sorted too: consumed suffixes first
-        SFX_TRY(segmented_sort_kv64(r.EA, r.V, r.EB, r.V_other, 8, r.seg, nseg, nlarge, r.F8, st, stats, r.emit));
-        if (stats) stats->large_sorted += nlarge;
-    }
-    Chunking ch = make_chunking(m, kFlagChunkTile);
-    SFX_LAUNCH("flags_reduce", (double)m * 1.25, k_flags_reduce, ch.blocks, kBlock, st, r.F8, m,
-               ch.tiles_per_block * kFlagChunkTile, r.part_head, r.part_keep, r.part_ghead, r.F);
-    return SFX_OK;
 }
 
 int tile_round_rank(const uint32_t* isa, uint64_t n, uint64_t h, const TileRound& r, uint64_t m, hipStream_t st,

@@ -25,10 +25,10 @@ import _gen, oracle
 from suffix_amd import Engine, SuffixTable
 oracle.build()
 eng = Engine(os.path.join({here!r}, "emu", "libsuffix_emu.so"))
-texts = [_gen.dna(40000, seed=9).tobytes(),                      # E64 path, several tiles
-         _gen.english_like(15000, seed=3).tobytes(),             # 64-bit keys, rank rounds
-         b"AAAAAAAAAAAAAAAAAAAAAAAC" * 600,                      # long repeats: many rounds
-         _gen.dna(9000, seed=3).tobytes() + b"A" * 3000]
+texts = [_gen.dna(24000, seed=9).tobytes(),                      # E64 path, several tiles
+         _gen.english_like(10000, seed=3).tobytes(),             # 64-bit keys, rank rounds
+         b"AAAAAAAAAAAAAAAAAAAAAAAC" * 400,                      # long repeats: many rounds
+         _gen.dna(6000, seed=3).tobytes() + b"A" * 2000]
 if os.environ.get("SFX_LCP_DIRECT_MIN"):
     # the sample says "low LCP", one run reaches the cap of the direct path -> Phi/PLCP redoes the array;
     # then short texts whose last windows run off the end
@@ -85,25 +85,25 @@ if os.environ.get("SFX_HT_MIN"):
     # compressed keys: skewed symbol counts (long and short codes side by side), a symbol that occurs once, runs of the
     # smallest symbol (its code is all zeros, like the padding past the end) at the end of the text and before it
     rngh2 = np.random.default_rng(99)
-    zipf = np.minimum(rngh2.zipf(1.3, 40000), 200).astype(np.uint8)
+    zipf = np.minimum(rngh2.zipf(1.3, 15000), 200).astype(np.uint8)
     texts.append(zipf.tobytes() + bytes([250]) + zipf[:3000].tobytes())
     low = bytes([int(zipf.min())])
-    texts.append(zipf[:20000].tobytes() + low * 40 + zipf[5000:9000].tobytes() + low * 25)
-    texts.append(_gen.utf8_mixed(30000).tobytes())
+    texts.append(zipf[:8000].tobytes() + low * 40 + zipf[5000:9000].tobytes() + low * 25)
+    texts.append(_gen.utf8_mixed(12000).tobytes())
 if os.environ.get("SFX_DEEP_ITERS") or os.environ.get("SFX_DEEP_KPT"):
     # deep text rounds: buckets finished inside one wave, members that stay tied leaving with their own depth (capped
     # iterations: every round leaves such buckets), buckets above the wave's window on the large path, fused LCP values
     # from the keys of the iteration that splits a pair.  Repeats of 20 .. 300 symbols in 2 .. 40 copies over three alphabets.
     rngd = np.random.default_rng(2024)
-    for sigma, n0 in ((4, 30000), (60, 20000), (200, 20000)):
+    for sigma, n0 in ((4, 12000), (60, 8000), (200, 8000)):
         body = rngd.integers(0, sigma, n0, dtype=np.uint8)
         parts = [body.tobytes()]
-        for _ in range(25):
+        for _ in range(12):
             a = int(rngd.integers(0, n0 - 400)); ln = int(rngd.integers(20, 300)); cp = int(rngd.integers(2, 40))
             for _ in range(cp):
                 parts.append(body[a:a + ln].tobytes() + bytes(rngd.integers(0, sigma, 3, dtype=np.uint8).tolist()))
         texts.append(b"".join(parts))
-    texts.append(_gen.english_like(30000, seed=8).tobytes() * 2 + b"!")
+    texts.append(_gen.english_like(12000, seed=8).tobytes() * 2 + b"!")
     for t in texts:
         exp = oracle.sais(t)
         st2, lcp2 = SuffixTable.new_with_lcp(t, engine=eng)
@@ -150,9 +150,6 @@ VARIANTS = {
     "small-tiles-small-segments": {"SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
     "small-tiles-key64-multi-tile": {"SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "3", "SFX_SEG_SMALL": "1"},
     "key64": {"SFX_FORCE_KEY64": "1"},
-    # text rounds on 64-bit keys (opt-in): the 64-bit LDS sort and the key/value form of the segmented sort
-    "text-key64": {"SFX_TEXT_KEY": "64"},
-    "text-key64-small-tiles": {"SFX_TEXT_KEY": "64", "SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
     # hybrid initial sort forced on small inputs
     "hybrid-initial-sort": {"SFX_HYBRID_MIN": "1"},
     # a few oversized sub-buckets (gathered, sorted device-wide, copied back), the 256 x 16 geometry, several sub-buckets
@@ -166,19 +163,17 @@ VARIANTS = {
     # rank rounds through round 1's composite-key sort (the fallback for key2 = rank + h beyond 32 bits)
     "composite-rank-rounds": {"SFX_FORCE_COMPOSITE": "1"},
     "tile-1024x4-pair32": {"SFX_TILE_GEOM": "1", "SFX_TILE_PAIR": "32"},
-    "tile-512x8": {"SFX_TILE_GEOM": "2"},
     "tile-512x4-key64": {"SFX_TILE_GEOM": "3", "SFX_FORCE_KEY64": "1"},
     # deep text rounds (k_deep_wave): one / two iterations per round (every round leaves tied members with their own
     # depth), 128-position windows (more buckets on the large path, more waves per text), the other window sizes
     "deep-one-iteration": {"SFX_DEEP_ITERS": "1"},
     "deep-two-iterations-small-windows": {"SFX_DEEP_ITERS": "2", "SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
-    "deep-small-windows-key64": {"SFX_DEEP_ITERS": "24", "SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "3"},
+    "deep-small-windows-key64": {"SFX_DEEP_ITERS": "24", "SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1"},
     "deep-512-position-windows": {"SFX_DEEP_KPT": "8", "SFX_DEEP_ITERS": "3"},
     # 64-bit initial keys in an order-preserving prefix code (k_ht_keys): buckets of different depths from the first list on
     "compressed-keys": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24"},
     "compressed-keys-small-windows-one-iteration": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "1", "SFX_TILE_SMALL": "1",
                                                     "SFX_SEG_SMALL": "1", "SFX_MAX_GRID": "3"},
-    "compressed-keys-off": {"SFX_FORCE_KEY64": "1", "SFX_HT": "0", "SFX_DEEP_ITERS": "24"},
 }
 
 
