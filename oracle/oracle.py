@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "libsfx_oracle.so")
 _lib = None
 
 __all__ = ["build", "sais", "naive_sa", "lcp_quadratic", "lcp_kasai", "positions",
-           "positions_batch", "any_position", "definitional_sa"]
+           "positions_batch", "any_position", "definitional_sa", "suffix_tree_sweep"]
 
 
 def build(force=False):
@@ -49,6 +49,8 @@ def _load():
         L.orc_any_position.argtypes = [u8p, u64, u32p, u8p, u64,
                                        ctypes.POINTER(ctypes.c_uint32)]
         L.orc_any_position.restype = ctypes.c_int
+        L.orc_suffix_tree_sweep.argtypes = [u32p, u64, u32p, u32p, u32p, u32p, u32p]
+        L.orc_suffix_tree_sweep.restype = None
         _lib = L
     return _lib
 
@@ -139,3 +141,14 @@ def any_position(text, sa, query):
     pos = ctypes.c_uint32(0)
     ok = _load().orc_any_position(_p(t), t.size, _p(sa), _p(q), q.size, ctypes.byref(pos))
     return int(pos.value) if ok else None
+
+
+def suffix_tree_sweep(lcp):
+    """to_suffix_tree (suffix_tree/src/lib.rs:392-505) over an LCP array, as flat arrays: dict(lb, rb, node, parent,
+    leaf_parent), n u32 each (see orc_suffix_tree_sweep)."""
+    lcp = np.ascontiguousarray(lcp, dtype=np.uint32)
+    n = lcp.size
+    out = {k: np.zeros(n, dtype=np.uint32) for k in ("lb", "rb", "node", "parent", "leaf_parent")}
+    if n:
+        _load().orc_suffix_tree_sweep(lcp.ctypes.data, n, *(out[k].ctypes.data for k in ("lb", "rb", "node", "parent", "leaf_parent")))
+    return out

@@ -22,6 +22,7 @@
  *   orc_lcp_kasai       src/table.rs:314-346  (commented-out linear variant)
  *   orc_positions       src/table.rs:223-259  positions + :900-914 binary_search
  *   orc_any_position    src/table.rs:279-293  any_position (contains = found)
+ *   orc_suffix_tree_sweep  suffix_tree/src/lib.rs:392-505  to_suffix_tree (the SA + LCP sweep, as flat arrays)
  */
 #define _GNU_SOURCE
 #include <stdint.h>
@@ -251,4 +252,66 @@ int orc_any_position(const uint8_t *text, uint64_t n, const uint32_t *sa,
         if (r < 0) lo = mid + 1; else hi = mid;
     }
     return 0;
+}
+
+/* to_suffix_tree, /root/reference/suffix_tree/src/lib.rs:392-505, as flat arrays.  The reference walks the suffix
+ * array with the LCP array and keeps the path from the root to the last leaf (`ancestor_lcp_len` :393-411 climbs it):
+ * an lcp equal to the depth of the node it stops at adds a leaf there (:423-442), a larger one splits the edge to that
+ * node's right-most child with a new internal node of depth lcp (:443-499).  Every internal node is an lcp-interval;
+ * here the open path is an explicit stack and the tree comes out as, per boundary p (between ranks p - 1 and p):
+ *   lb[p], rb[p]   rank range of the node that boundary p belongs to (depth lcp[p]; the root for lcp[p] == 0, p == 0)
+ *   node[p]        id of that node = the boundary that CREATED it (:455 `Node::internal`), its leftmost one of that depth; 0 = root
+ *   parent[p]      id of its parent (UINT32_MAX for the root)
+ * and per rank r: leaf_parent[r] = id of the node the leaf of suffix sa[r] ends up under (a leaf that is the right-most
+ * child when the next boundary is deeper moves under the new node, :470-473).  lcp[0] is taken as 0. */
+void orc_suffix_tree_sweep(const uint32_t *lcp, uint64_t n, uint32_t *lb, uint32_t *rb, uint32_t *node,
+                           uint32_t *parent, uint32_t *leaf_parent)
+{
+    if (n == 0) return;
+    typedef struct { uint32_t depth, lb, id, parent; } open_node;
+    open_node *stack = (open_node *)malloc((size_t)(n + 1) * sizeof(open_node));
+    uint32_t *rb_of = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));      /* rb of the node with id = boundary */
+    uint32_t *par_of = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    uint32_t *lb_of = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    size_t sp = 0;
+    stack[sp++] = (open_node){0u, 0u, 0u, UINT32_MAX};                       /* the root (SuffixTree::init :418) */
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t l = i ? lcp[i] : 0u;
+        uint32_t child_lb = (uint32_t)(i ? i - 1 : 0);                       /* leftmost rank under the right-most child of vins */
+        int64_t child_id = -1;                                               /* ... that child, if it is an internal node */
+        while (stack[sp - 1].depth > l) {                                    /* ancestor_lcp_len :397-409 */
+            const open_node c = stack[--sp];
+            rb_of[c.id] = (uint32_t)(i - 1);                                 /* closed: nothing after rank i - 1 is below it */
+            lb_of[c.id] = c.lb;
+            par_of[c.id] = c.parent;
+            child_lb = c.lb;
+            child_id = (int64_t)c.id;
+        }
+        open_node *vins = &stack[sp - 1];
+        if (vins->depth == l) {                                              /* Ordering::Equal :423: a new leaf under vins */
+            node[i] = vins->id;
+            leaf_parent[i] = vins->id;
+        } else {                                                             /* Ordering::Less :443: split, new internal node */
+            const open_node in = {l, child_lb, (uint32_t)i, vins->id};
+            stack[sp++] = in;
+            node[i] = (uint32_t)i;
+            leaf_parent[i] = (uint32_t)i;
+            /* the old right-most child hangs under the new node now (:470-473): leaf i - 1, or the node closed last */
+            if (child_id >= 0) par_of[child_id] = (uint32_t)i;
+            else leaf_parent[i - 1] = (uint32_t)i;
+        }
+    }
+    while (sp) {
+        const open_node c = stack[--sp];
+        rb_of[c.id] = (uint32_t)(n - 1);
+        lb_of[c.id] = c.lb;
+        par_of[c.id] = c.parent;
+    }
+    for (uint64_t p = 0; p < n; p++) {
+        const uint32_t id = node[p];
+        lb[p] = lb_of[id];
+        rb[p] = rb_of[id];
+        parent[p] = par_of[id];
+    }
+    free(stack); free(rb_of); free(par_of); free(lb_of);
 }

@@ -94,26 +94,138 @@ __device__ __forceinline__ uint64_t next_smaller(const Pyramid& py, uint64_t p, 
     return idx;
 }
 
-// per boundary p in [0, n): lb, rb, node id (kNoNode for p = 0 and for boundaries of the root other than its id 0)
-__global__ void __launch_bounds__(kBlock)
-k_lcp_intervals(Pyramid py, uint64_t n, uint32_t* __restrict__ lb, uint32_t* __restrict__ rb, uint32_t* __restrict__ node)
+// per boundary p in [0, n): lb, rb, node id (0 for the root: p = 0 and every boundary of depth 0).
+// The three nearest-smaller searches of a boundary nearly always end inside its neighbourhood: a workgroup stages
+// kIvTile values in LDS under a binary min-tree (tr[1] = the tile's minimum, tr[kIvTile + i] = value i) and answers
+// them there -- up the tree until a sibling holds a smaller value, down to the nearest one: <= 2 log2(kIvTile) LDS reads,
+// the same for every lane (a linear scan was measured first: one lane with a distant answer holds up its wave, 170 ms
+// per 10^9 boundaries against round 2's 126-133 through the global pyramid alone).  A search that leaves the tile
+// continues in the global min-pyramid from the tile's edge.
+constexpr int kIvTile = 2048;
+// nearest position < i (tile coordinates) with a value < v, or -1
+__device__ __forceinline__ int iv_prev_smaller(const uint32_t* tr, int i, uint32_t v)
 {
-    const uint32_t* lcp = py.lvl[0];
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += stride) {
-        const uint32_t v = lcp[p];
-        if (p == 0 || v == 0) {                              // the root: every boundary of depth 0
-            lb[p] = 0;
-            rb[p] = (uint32_t)(n - 1);
-            node[p] = 0;
-            continue;
-        }
-        const uint64_t l = prev_smaller(py, p, v);
-        const uint64_t r = next_smaller(py, p, v, false, n);
-        lb[p] = (uint32_t)l;
-        rb[p] = (uint32_t)(r - 1);
-        node[p] = (uint32_t)next_smaller(py, l, v, true, n);  // leftmost boundary of the interval with its depth (<= p)
+    unsigned k = (unsigned)(kIvTile + i);
+    for (;;) {
+        if (k <= 1u) return -1;
+        if ((k & 1u) && tr[k - 1u] < v) { k--; break; }
+        k >>= 1;
     }
+    while (k < (unsigned)kIvTile) {
+        k = 2u * k + 1u;
+        if (tr[k] >= v) k--;
+    }
+    return (int)k - kIvTile;
+}
+// nearest position > i with a value < v (or <= v with or_equal), or kIvTile
+__device__ __forceinline__ int iv_next_smaller(const uint32_t* tr, int i, uint32_t v, bool or_equal)
+{
+    auto hit = [&](uint32_t x) { return or_equal ? x <= v : x < v; };
+    unsigned k = (unsigned)(kIvTile + i);
+    for (;;) {
+        if (k <= 1u) return kIvTile;
+        if (!(k & 1u) && hit(tr[k + 1u])) { k++; break; }
+        k >>= 1;
+    }
+    while (k < (unsigned)kIvTile) {
+        k = 2u * k;
+        if (!hit(tr[k])) k++;
+    }
+    return (int)k - kIvTile;
+}
+// A search that leaves the tile goes on in the global pyramid -- dozens of dependent loads, for which the other 63
+// lanes of the wave would wait.  Such boundaries (a fraction of a per cent: the shallow ones, whose intervals are huge)
+// are therefore LISTED (per tile in LDS, one device-wide reservation per tile) and finished by a second, dense launch,
+// one listed boundary per lane.  bit 32 / 33 of a list entry: the left / right search is open.
+constexpr uint64_t kIvLeftOpen = 1ull << 32, kIvRightOpen = 1ull << 33;
+__device__ __forceinline__ void iv_finish(const Pyramid& py, uint64_t n, uint64_t e, uint32_t* __restrict__ lb, uint32_t* __restrict__ rb,
+                                          uint32_t* __restrict__ node)
+{
+    const uint64_t p = e & 0xFFFFFFFFull;
+    const uint64_t base = p / kIvTile * kIvTile;
+    const uint32_t v = py.lvl[0][p];
+    if (e & kIvLeftOpen) {
+        const uint64_t l = prev_smaller(py, base, v);                    // (everything in [base, p) is >= v)
+        lb[p] = (uint32_t)l;
+        node[p] = (uint32_t)next_smaller(py, l, v, true, n);             // leftmost boundary of the interval with its depth (<= p)
+    }
+    if (e & kIvRightOpen) rb[p] = (uint32_t)(next_smaller(py, base + kIvTile - 1, v, false, n) - 1);
+}
+__global__ void __launch_bounds__(kBlock)
+k_lcp_intervals(Pyramid py, uint64_t n, uint64_t tiles_per_block, uint32_t* __restrict__ lb, uint32_t* __restrict__ rb,
+                uint32_t* __restrict__ node, uint64_t* __restrict__ open_list, uint64_t open_cap,
+                unsigned long long* __restrict__ open_count)
+{
+    __shared__ uint32_t tr[2 * kIvTile];
+    __shared__ uint64_t esc[kIvTile];
+    __shared__ uint32_t n_esc;
+    __shared__ unsigned long long esc_base;
+    const uint32_t* lcp = py.lvl[0];
+    const uint64_t tile0 = (uint64_t)blockIdx.x * tiles_per_block;
+    for (uint64_t tile = tile0; tile < tile0 + tiles_per_block; tile++) {
+        const uint64_t base = tile * kIvTile;
+        if (base >= n) break;
+        if (threadIdx.x == 0) n_esc = 0;
+        for (unsigned i = threadIdx.x; i < (unsigned)kIvTile; i += kBlock) {
+            const uint64_t g = base + i;
+            tr[kIvTile + i] = (g == 0 || g >= n) ? 0u : lcp[g];          // (boundary 0 and the end of the array: depth 0)
+        }
+        __syncthreads();
+        for (unsigned w = kIvTile / 2; w >= 1; w >>= 1) {                // level by level: w nodes, ids [w, 2w)
+            for (unsigned k = w + threadIdx.x; k < 2 * w; k += kBlock) tr[k] = dmin(tr[2 * k], tr[2 * k + 1]);
+            __syncthreads();
+        }
+        for (unsigned i = threadIdx.x; i < (unsigned)kIvTile; i += kBlock) {
+            const uint64_t p = base + i;
+            if (p >= n) break;
+            const uint32_t v = tr[kIvTile + i];
+            if (p == 0 || v == 0) {                           // the root: every boundary of depth 0
+                lb[p] = 0;
+                rb[p] = (uint32_t)(n - 1);
+                node[p] = 0;
+                continue;
+            }
+            uint64_t open = 0;
+            const int jl = iv_prev_smaller(tr, (int)i, v);
+            if (jl >= 0) {
+                lb[p] = (uint32_t)(base + (uint64_t)jl);
+                // leftmost boundary of the interval with its depth: the first value <= v after l (everything between is >= v)
+                node[p] = (uint32_t)(base + (uint64_t)iv_next_smaller(tr, jl, v, true));     // (<= i: position i qualifies)
+            } else {
+                open |= kIvLeftOpen;
+            }
+            const int jr = iv_next_smaller(tr, (int)i, v, false);
+            if (jr < kIvTile) rb[p] = (uint32_t)(dmin<uint64_t>(base + (uint64_t)jr, n) - 1);
+            else if (base + kIvTile >= n) rb[p] = (uint32_t)(n - 1);
+            else open |= kIvRightOpen;
+            if (open) esc[atomicAdd(&n_esc, 1u)] = open | p;
+        }
+        __syncthreads();
+        const uint32_t cnt = n_esc;
+        if (cnt) {
+            if (threadIdx.x == 0) esc_base = atomicAdd(open_count, (unsigned long long)cnt);
+            __syncthreads();
+            const unsigned long long at = esc_base;
+            if (at + cnt <= open_cap) {
+                for (unsigned k = threadIdx.x; k < cnt; k += kBlock) open_list[at + k] = esc[k];
+            } else {                                          // (the list is full -- a monotone LCP array: finished here, slowly)
+                for (unsigned k = threadIdx.x; k < cnt; k += kBlock) iv_finish(py, n, esc[k], lb, rb, node);
+            }
+        }
+        __syncthreads();
+    }
+}
+// the listed boundaries, one per lane
+__global__ void __launch_bounds__(kBlock)
+k_lcp_intervals_open(Pyramid py, uint64_t n, const uint64_t* __restrict__ open_list, uint64_t open_cap,
+                     const unsigned long long* __restrict__ open_count, uint32_t* __restrict__ lb, uint32_t* __restrict__ rb,
+                     uint32_t* __restrict__ node)
+{
+    // (entries reserved beyond the capacity were finished by their tiles; reservations never leave gaps below it)
+    unsigned long long cnt = *open_count;
+    if (cnt > open_cap) cnt = open_cap;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < cnt; k += stride) iv_finish(py, n, open_list[k], lb, rb, node);
 }
 // parent of the node a boundary belongs to, and the parent of every leaf
 __global__ void __launch_bounds__(kBlock)
@@ -161,7 +273,12 @@ static uint64_t pyramid_words(uint64_t n)
     }
     return words;
 }
-uint64_t lcp_intervals_workspace_bytes(uint64_t n) { return pyramid_words(n) * sizeof(uint32_t) + 256; }
+// (+ the list of boundaries whose searches leave their tile: n / 16 entries, and its counter)
+static uint64_t open_list_cap(uint64_t n) { return n / 16 + 4096; }
+uint64_t lcp_intervals_workspace_bytes(uint64_t n)
+{
+    return ((pyramid_words(n) * sizeof(uint32_t) + 255) & ~uint64_t(255)) + 256 + open_list_cap(n) * sizeof(uint64_t) + 256;
+}
 
 int lcp_intervals_dev(const uint32_t* d_lcp, uint64_t n, uint32_t* d_lb, uint32_t* d_rb, uint32_t* d_node, uint32_t* d_parent,
                       uint32_t* d_leaf_parent, void* ws, uint64_t ws_bytes, hipStream_t st)
@@ -188,7 +305,18 @@ int lcp_intervals_dev(const uint32_t* d_lcp, uint64_t n, uint32_t* d_lb, uint32_
     }
     for (int l = py.levels; l < kPyrMaxLevels; l++) { py.lvl[l] = nullptr; py.len[l] = 0; }
     const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
-    SFX_LAUNCH("tree_intervals", (double)n * 16, k_lcp_intervals, grid, kBlock, st, py, n, d_lb, d_rb, d_node);
+    {
+        char* tail = reinterpret_cast<char*>(ws) + ((pyramid_words(n) * sizeof(uint32_t) + 255) & ~uint64_t(255));
+        unsigned long long* open_count = reinterpret_cast<unsigned long long*>(tail);
+        uint64_t* open_list = reinterpret_cast<uint64_t*>(tail + 256);
+        const uint64_t cap = open_list_cap(n);
+        SFX_HIP(hipMemsetAsync(open_count, 0, sizeof(unsigned long long), st));
+        Chunking ch = make_chunking(n, kIvTile, 4 * kMaxGrid);
+        SFX_LAUNCH("tree_intervals", (double)n * 16, k_lcp_intervals, ch.blocks, kBlock, st, py, n, ch.tiles_per_block, d_lb, d_rb, d_node,
+                   open_list, cap, open_count);
+        SFX_LAUNCH("tree_intervals_open", 0.0, k_lcp_intervals_open, grid, kBlock, st, py, n, (const uint64_t*)open_list, cap,
+                   (const unsigned long long*)open_count, d_lb, d_rb, d_node);
+    }
     SFX_LAUNCH("tree_parents", (double)n * 28, k_tree_parents, grid, kBlock, st, d_lcp, n, (const uint32_t*)d_lb,
                (const uint32_t*)d_rb, (const uint32_t*)d_node, d_parent, d_leaf_parent);
     return SFX_OK;

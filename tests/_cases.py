@@ -427,6 +427,10 @@ def suffix_tree_topology(eng, orc, device="cpu", scale=1):
         nodes, rb_of = _stack_sweep_tree(lcp)
         sweep = {(d, l, rb_of[(d, l)]) for (d, l) in nodes}
         assert sweep == exp_nodes, (len(sweep), len(exp_nodes), text[:20])
+        # ... and every array equal to the oracle's restatement of that sweep (oracle/sfx_oracle.c: orc_suffix_tree_sweep)
+        ref = orc.suffix_tree_sweep(lcp)
+        for k in ("lb", "rb", "node", "parent", "leaf_parent"):
+            assert np.array_equal(got[k], ref[k].astype(np.int64)), (k, text[:20])
     # generalized suffix array: positions -> (document, offset)
     docs = [b"alpha beta", b"", b"gamma", b"delta epsilon zeta"]
     starts, blob = [], b""
@@ -442,6 +446,24 @@ def suffix_tree_topology(eng, orc, device="cpu", scale=1):
     dh, _ = sdev.doc_lookup(torch.from_numpy(hits.view(np.int32).copy()).to(device),
                             torch.tensor(starts, dtype=torch.int64).to(device), engine=eng)
     assert sorted(dh.cpu().numpy().tolist()) == [0, 3]
+
+
+def suffix_tree_at_scale(eng, orc, text, device="cuda"):
+    """sfx_lcp_intervals_dev on a text of megabytes: all five arrays against the oracle's restatement of the
+    reference's sweep (suffix_tree/src/lib.rs:392-505), which is linear."""
+    import torch
+
+    from suffix_amd import device as sdev
+    t = torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy()).to(device)
+    sa, lcp = sdev.build_sa_lcp(t, engine=eng)
+    lcp_h = lcp.cpu().numpy().view(np.uint32)
+    assert np.array_equal(lcp_h, orc.lcp_kasai(text, sa.cpu().numpy().view(np.uint32)))
+    got = sdev.lcp_intervals(lcp, engine=eng)
+    ref = orc.suffix_tree_sweep(lcp_h)
+    for k in ("lb", "rb", "node", "parent", "leaf_parent"):
+        g = got[k].cpu().numpy().view(np.uint32)
+        assert np.array_equal(g, ref[k]), (k, len(text), int(np.flatnonzero(g != ref[k])[0]))
+    return int((ref["node"] == np.arange(len(text), dtype=np.uint32)).sum())          # internal nodes (ids = their own boundary)
 
 
 def range_slices(eng, orc, text, nranges, device="cpu", packed=False, top_bits=14):

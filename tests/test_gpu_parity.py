@@ -66,6 +66,15 @@ def test_suffix_tree_topology_and_doc_lookup(eng, oracle):
     _cases.suffix_tree_topology(eng, oracle, device="cuda", scale=3)
 
 
+def test_suffix_tree_topology_at_scale(eng, oracle):
+    """12 MB of DNA and of English-like text: lb / rb / node / parent / leaf_parent of every boundary against the
+    oracle's linear restatement of to_suffix_tree (suffix_tree/src/lib.rs:392-505)."""
+    import _gen
+    nd = _cases.suffix_tree_at_scale(eng, oracle, _gen.dna(12_000_000, seed=77).tobytes())
+    ne = _cases.suffix_tree_at_scale(eng, oracle, _gen.english_like(12_000_000).tobytes())
+    assert nd > 4_000_000 and ne > 4_000_000, (nd, ne)
+
+
 def test_fused_sa_lcp(eng, oracle):
     _cases.fused_lcp_tails(eng, oracle, iters=40, scale=50)
 

@@ -127,3 +127,43 @@ def test_generators_are_deterministic():
     assert e.size == 5000 and e.max() < 127
     u = _gen.utf8_mixed(5000)
     u.tobytes().decode("utf-8")
+
+
+def test_suffix_tree_sweep_restatement(oracle):
+    """orc_suffix_tree_sweep (suffix_tree/src/lib.rs:392-505 as flat arrays) against the definition: the node of a
+    boundary is the lcp-interval around it (nearest smaller values by brute force), ids are leftmost boundaries, a
+    leaf hangs under the deeper of its two boundaries; and against the Python restatement of the sweep in _cases."""
+    import numpy as np
+    import _cases
+    import _gen
+    rng = np.random.default_rng(5)
+    texts = [b"banana", b"mississippi", b"a" * 50, b"ab" * 30 + b"a", _gen.fibonacci_string(11), b"x", b"xy",
+             _gen.dna(3000, seed=2).tobytes(), _gen.english_like(3000).tobytes(), bytes(rng.integers(0, 4, 2000, dtype=np.uint8))]
+    for text in texts:
+        n = len(text)
+        sa = oracle.sais(text)
+        L = oracle.lcp_kasai(text, sa).astype(np.int64)
+        r = {k: v.astype(np.int64) for k, v in oracle.suffix_tree_sweep(L.astype(np.uint32)).items()}
+        for p in range(n):
+            v = L[p] if p else 0
+            if v == 0:
+                assert (r["lb"][p], r["rb"][p], r["node"][p], r["parent"][p]) == (0, n - 1, 0, 0xFFFFFFFF)
+                continue
+            l = p - 1
+            while l > 0 and L[l] >= v:
+                l -= 1
+            q = p + 1
+            while q < n and L[q] >= v:
+                q += 1
+            node = l + 1
+            while L[node] > v:
+                node += 1
+            assert (r["lb"][p], r["rb"][p], r["node"][p]) == (l, q - 1, node), (p, text[:16])
+            vl, vr = (L[l] if l else 0), (L[q] if q < n else 0)
+            assert r["parent"][p] == (r["node"][l] if vl >= vr else r["node"][q]), (p, text[:16])
+        for k in range(n):
+            dl, dr = (L[k] if k else 0), (L[k + 1] if k + 1 < n else 0)
+            assert r["leaf_parent"][k] == (r["node"][k] if dl >= dr else r["node"][k + 1])
+        nodes, rb_of = _cases._stack_sweep_tree(L.astype(np.uint32))
+        mine = {(int(L[p]), int(r["lb"][p])) for p in range(1, n) if L[p] > 0}
+        assert mine == set(nodes), text[:16]
