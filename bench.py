@@ -126,9 +126,17 @@ def running_commit():
         return os.environ.get("SFX_COMMIT", "unknown")
 
 
-def kernel_rooflines(rep, pmc_kernels=None, min_share=0.15):
+# kernels whose cost is one random 128-byte line per key they fetch, not the bytes they stream: (statistics field that counts
+# their fetches).  The chip's ceiling for that access shape is the random 4-byte gather probe (sfx_microbench MB_GATHER4,
+# 210 GB/s of payload = 52.5 G fetches/s, profiles/r1c_microbench.jsonl; PMC: 128 bytes fetched per read, r3_pmc_fullsize.json)
+GATHER_BOUND = {"deep_wave": "deep_gathers", "tile_sort": None}      # (tile_sort: one fetch per member = algorithmic bytes / 17)
+GATHER_PROBE_GPS = 52.5
+
+
+def kernel_rooflines(rep, pmc_kernels=None, min_share=0.15, stats=None):
     """Every kernel that takes at least min_share of the profiled build: algorithmic bytes per launch / mean launch time
-    against the HBM peak, and the measured HBM traffic per launch where the committed PMC summary has the kernel."""
+    against the HBM peak, and the measured HBM traffic per launch where the committed PMC summary has the kernel.
+    Gather-bound kernels also carry their key fetches per second against the random-gather probe."""
     total = sum(r["total_ms"] for r in rep) or 1.0
     out = []
     for r in sorted(rep, key=lambda r: -r["total_ms"]):
@@ -144,6 +152,12 @@ def kernel_rooflines(rep, pmc_kernels=None, min_share=0.15):
         pk = (pmc_kernels or {}).get(r["name"])
         if pk:
             ent["traffic"] = round(pk["hbm_bytes_per_launch"])
+        if r["name"] in GATHER_BOUND:
+            fld = GATHER_BOUND[r["name"]]
+            fetches = (stats or {}).get(fld, 0) if fld else r["algo_bytes"] / 17.0
+            gps = fetches / (r["total_ms"] * 1e-3) / 1e9
+            ent["gather"] = {"key_fetches": int(fetches), "G_fetches/s": round(gps, 1), "probe_G/s": GATHER_PROBE_GPS,
+                             "frac_of_probe": round(gps / GATHER_PROBE_GPS, 3)}
         out.append(ent)
     return out
 
@@ -229,7 +243,7 @@ def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
                                   "times_sais": round(engine_algo / n / 69.0, 2),
                                   "achieved_GB/s": round(engine_algo / best / 1e9, 1),
                                   "frac_of_hbm_peak": round(engine_algo / best / 1e9 / HBM_PEAK_GBS, 4)},
-                       "kernels": kernel_rooflines(prof, pmc_cfg.get("kernels"), 0.10),
+                       "kernels": kernel_rooflines(prof, pmc_cfg.get("kernels"), 0.10, rec.get("build")),
                        "traffic_commit": pmc_cfg.get("commit"),
                        "lcp": {"algo_bytes_per_input_byte": 22.0, "achieved_GB/s": round(22.0 * n / t_lcp / 1e9, 1)}}
     rec["sha256_sa"] = _sha_u32(sa)

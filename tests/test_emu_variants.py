@@ -85,30 +85,31 @@ if os.environ.get("SFX_HT_MIN"):
     # compressed keys: skewed symbol counts (long and short codes side by side), a symbol that occurs once, runs of the
     # smallest symbol (its code is all zeros, like the padding past the end) at the end of the text and before it
     rngh2 = np.random.default_rng(99)
-    zipf = np.minimum(rngh2.zipf(1.3, 15000), 200).astype(np.uint8)
+    zipf = np.minimum(rngh2.zipf(1.3, 10000), 200).astype(np.uint8)
     texts.append(zipf.tobytes() + bytes([250]) + zipf[:3000].tobytes())
     low = bytes([int(zipf.min())])
-    texts.append(zipf[:8000].tobytes() + low * 40 + zipf[5000:9000].tobytes() + low * 25)
-    texts.append(_gen.utf8_mixed(12000).tobytes())
+    texts.append(zipf[:6000].tobytes() + low * 40 + zipf[5000:8000].tobytes() + low * 25)
+    texts.append(_gen.utf8_mixed(8000).tobytes())
 if os.environ.get("SFX_DEEP_ITERS") or os.environ.get("SFX_DEEP_KPT"):
     # deep text rounds: buckets finished inside one wave, members that stay tied leaving with their own depth (capped
     # iterations: every round leaves such buckets), buckets above the wave's window on the large path, fused LCP values
     # from the keys of the iteration that splits a pair.  Repeats of 20 .. 300 symbols in 2 .. 40 copies over three alphabets.
     rngd = np.random.default_rng(2024)
-    for sigma, n0 in ((4, 12000), (60, 8000), (200, 8000)):
+    for sigma, n0 in ((4, 7000), (60, 5000), (200, 5000)):
         body = rngd.integers(0, sigma, n0, dtype=np.uint8)
         parts = [body.tobytes()]
-        for _ in range(12):
-            a = int(rngd.integers(0, n0 - 400)); ln = int(rngd.integers(20, 300)); cp = int(rngd.integers(2, 40))
+        for _ in range(8):
+            a = int(rngd.integers(0, n0 - 400)); ln = int(rngd.integers(20, 300)); cp = int(rngd.integers(2, 24))
             for _ in range(cp):
                 parts.append(body[a:a + ln].tobytes() + bytes(rngd.integers(0, sigma, 3, dtype=np.uint8).tolist()))
         texts.append(b"".join(parts))
-    texts.append(_gen.english_like(12000, seed=8).tobytes() * 2 + b"!")
+    texts.append(_gen.english_like(7000, seed=8).tobytes() * 2 + b"!")
     for t in texts:
         exp = oracle.sais(t)
         st2, lcp2 = SuffixTable.new_with_lcp(t, engine=eng)
         assert np.array_equal(st2.table(), exp), ("fused SA", len(t))
         assert np.array_equal(lcp2, oracle.lcp_kasai(t, exp)), ("fused LCP", len(t))
+    texts = texts[:2] + texts[-2:]                     # (the separate calls below: the same kernels without the LCP emission)
 # (TEST_TEXTS: how many of the texts a variant needs -- the radix schedules see every pass on the first two, the index
 # variants have their own cases below)
 texts = texts[:int(os.environ.get("TEST_TEXTS", len(texts)))]
