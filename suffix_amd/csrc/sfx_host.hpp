@@ -161,10 +161,10 @@ unsigned radix_e64_presort_hist(uint64_t m, int bit_lo, int bit_hi);
 inline uint32_t* radix_partial(uint32_t* scratch) { return scratch; }
 int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, int bit_lo,
                     int bit_hi, uint32_t* scratch, hipStream_t st, int* result_in_1,
-                    sfx_build_stats* stats, const PackedText* text);
+                    sfx_build_stats* stats, const PackedText* text, uint32_t* last_v = nullptr);
 // the same over the compressed keys (k_ht_keys) of all m = text.n suffixes; ht = the code table on the device
 int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, uint32_t* scratch, hipStream_t st,
-                    int* result_in_1, sfx_build_stats* stats, const PackedText& text, const uint32_t* ht);
+                    int* result_in_1, sfx_build_stats* stats, const PackedText& text, const uint32_t* ht, uint32_t* last_v = nullptr);
 // Segmented sort of the large buckets of a refinement round (sfx_radix.hip).  Scratch:
 //   segs      8 B per segment, filled by the caller          tiles    32 B per tile (<= nlarge / tile + nseg)
 //   tilehist  4 KiB per tile of a multi-tile segment (<= 2 * nlarge / tile)

@@ -1347,8 +1347,10 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
 
 // Sort of all m = text.n suffixes by their compressed 64-bit keys (eight passes); (k0, v0) / (k1, v1) as
 // radix_sort_kv64, the keys are made here.
+// last_v (both sorts): the suffixes of the LAST pass go there instead of into v0 / v1 (the caller's SA: every suffix
+// lands in its slot without a copy); the keys still end in k0 / k1 as *result_in_1 says.
 int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, uint32_t* scratch, hipStream_t st,
-                    int* result_in_1, sfx_build_stats* stats, const PackedText& text, const uint32_t* ht)
+                    int* result_in_1, sfx_build_stats* stats, const PackedText& text, const uint32_t* ht, uint32_t* last_v)
 {
     *result_in_1 = 0;
     if (m == 0) return SFX_OK;
@@ -1370,8 +1372,9 @@ int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
     int flips = 0;
     for (int p = 0; p < npass; p++) {
         const double algo = (double)m * ((p == 0 ? 8.0 : 12.0) + 12.0);
-        if (p == 0) SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKeyIota{kin}, DstKV{kout, vout}, m, 8 * p, 255u, scr, p, sweep, st));
-        else SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKV{kin, vin}, DstKV{kout, vout}, m, 8 * p, 255u, scr, p, sweep, st));
+        uint32_t* vdst = (last_v && p == npass - 1) ? last_v : vout;
+        if (p == 0) SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKeyIota{kin}, DstKV{kout, vdst}, m, 8 * p, 255u, scr, p, sweep, st));
+        else SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKV{kin, vin}, DstKV{kout, vdst}, m, 8 * p, 255u, scr, p, sweep, st));
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
         flips ^= 1;
@@ -1383,10 +1386,10 @@ int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
 
 int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, int bit_lo, int bit_hi,
                     uint32_t* scratch, hipStream_t st, int* result_in_1, sfx_build_stats* stats,
-                    const PackedText* text)
+                    const PackedText* text, uint32_t* last_v)
 {
     *result_in_1 = 0;
-    if (m == 0 || bit_hi <= bit_lo) return SFX_OK;
+    if (m == 0 || bit_hi <= bit_lo) return last_v ? SFX_ERR_INTERNAL : SFX_OK;
     if (m > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
     const int npass = radix_pass_count(bit_lo, bit_hi);
     const bool sweep = use_sweep(m, npass);
@@ -1406,10 +1409,11 @@ int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
         const bool first_text = text && p == 0;
         const double in_bytes = first_text ? text->bits / 8.0 : 12.0;
         const double algo = (double)m * (in_bytes + 12.0);
+        uint32_t* vdst = (last_v && p == npass - 1) ? last_v : vout;
         if (first_text) {
-            SFX_TRY(run_pass("radix_scatter_text_u64", algo, tsrc, DstKV{kout, vout}, m, shift, mask, scr, p, sweep, st));
+            SFX_TRY(run_pass("radix_scatter_text_u64", algo, tsrc, DstKV{kout, vdst}, m, shift, mask, scr, p, sweep, st));
         } else {
-            SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKV{kin, vin}, DstKV{kout, vout}, m, shift, mask, scr, p, sweep, st));
+            SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKV{kin, vin}, DstKV{kout, vdst}, m, shift, mask, scr, p, sweep, st));
         }
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;

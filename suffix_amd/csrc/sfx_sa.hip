@@ -729,8 +729,9 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     // min_depth: smallest depth given to a kept element (the rank rounds' h, should the text rounds give way)
     __shared__ uint32_t s_t12[(1 << kHtFastBits) / 2];
     __shared__ uint32_t s_min;
-    if (ht.ent) {
+    if (ht.ent)
         for (unsigned i = threadIdx.x; i < (1u << kHtFastBits) / 2u; i += kBlock) s_t12[i] = ht.ent[kHtTableWords + i];
+    if (ht.ent || min_depth) {
         if (threadIdx.x == 0) s_min = 0xFFFFFFFFu;
         __syncthreads();
     }
@@ -960,7 +961,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         c_head = dmax(c_head, tot_m);
         c_keep += tot_a;
     }
-    if (ht.ent && min_depth) {
+    if (min_depth) {
         for (int d = 32; d >= 1; d >>= 1) my_min = dmin(my_min, (uint32_t)__shfl_xor(my_min, d));
         if (lane == 0) atomicMin(&s_min, my_min);
         __syncthreads();
@@ -1718,8 +1719,13 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         const uint64_t kept = host_totals[0], kept_groups = host_totals[1];
         // (SA slots are written when a suffix resolves; the members of still-unresolved buckets only if ranks
         // have to be built from the array: build_ranks below)
+        // (deep rounds: the smallest depth a kept bucket leaves with -- what the rank rounds may assume of every bucket,
+        // should the build switch now; usually a few symbols more than h + wsym, which only the large buckets are held to)
+        uint32_t* min_depth = deep_round ? b.ht + 256 : nullptr;
+        if (min_depth) SFX_HIP(hipMemsetAsync(min_depth, 0xFF, sizeof(uint32_t), st));
         SFX_TRY(round_apply<uint64_t>(b.K0, V_cur, S_cur, m, b, sa, rank_mode ? isa : nullptr, S_next, V_next, nullptr,
-                                      st, 2, n, stats, kept, tr.Hd, deep_round ? hd_of(b, S_next) : nullptr, 0u));
+                                      st, 2, n, stats, kept, tr.Hd, deep_round ? hd_of(b, S_next) : nullptr, 0u,
+                                      HtDepth{nullptr, 0}, min_depth));
         // SFX_TRACE=1 (development): one line per round
         static const bool trace = [] { const char* e = dev_env("SFX_TRACE"); return e && atoi(e) != 0; }();
         if (trace)
@@ -1742,6 +1748,12 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
             const bool too_deep = h + 2 * (uint64_t)wsym > 60000;
             if (isa && force != 1 && (stalled * 2 > n || force == 2 || too_deep)) {
                 // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
+                uint32_t md = 0;
+                SFX_TRY(read_back(&md, b.ht + 256, sizeof(md), st));
+                if (md != 0xFFFFFFFFu) {
+                    if ((uint64_t)md < h) return SFX_ERR_INTERNAL;           // (every kept bucket went at least one level down)
+                    h = md;
+                }
                 SFX_TRY(build_ranks(b, sa, n, V_next, S_next, kept, isa, st, stats));
                 rank_mode = true;
             } else if (!isa && (stalled * 2 > n || stats.text_rounds > (uint32_t)kMaxTextOnlyRounds || too_deep)) {
@@ -1791,14 +1803,16 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         V_next = b.VA;
         in_place = true;
     } else {
+        // (the last pass drops every suffix straight into its SA slot, as the E64 sort does)
         if (ht && from_text && count == pt.n)
-            SFX_TRY(radix_sort_ht64(b.K0, b.VA, b.K1, b.VB, count, b.hist, st, &in1, &stats, pt, b.ht));
+            SFX_TRY(radix_sort_ht64(b.K0, b.VA, b.K1, b.VB, count, b.hist, st, &in1, &stats, pt, b.ht, sa));
         else
             SFX_TRY(radix_sort_kv64(b.K0, b.VA, b.K1, b.VB, count, 0, pt.bits * cpk, b.hist, st, &in1, &stats,
-                                    from_text ? &pt : nullptr));
+                                    from_text ? &pt : nullptr, sa));
         Kr = (const KeyT*)(in1 ? b.K1 : b.K0);
-        Vr = in1 ? b.VB : b.VA;
-        V_next = in1 ? b.VA : b.VB;
+        Vr = sa;
+        V_next = b.VA;
+        in_place = true;
     }
     uint64_t kept = 0, groups = 0;
     LcpFuse fuse = {nullptr, 0, 0, 0};
@@ -1815,11 +1829,6 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     // no rank array yet: its n-element scatter is only paid if the text rounds stall (refine)
     // (every bucket of the first active list shares the cpk symbols of the initial key: b.Hd0, the depths of the deep rounds)
     uint64_t h0 = (uint64_t)cpk;                        // symbols every bucket of the first active list shares
-    if (!in_place) {
-        // every suffix goes to its slot: a plain copy (whole lines), not 4 bytes per lane and line from the bucket pass
-        SFX_HIP(hipMemcpyAsync(sa, Vr, count * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-        in_place = true;
-    }
     if (ht && kept > 0) {
         SFX_HIP(hipMemsetAsync(b.ht + 256, 0xFF, sizeof(uint32_t), st));
         SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place ? 1 : 0, pt.n, stats,
