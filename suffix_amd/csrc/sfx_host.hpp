@@ -254,6 +254,9 @@ __device__ __forceinline__ uint32_t lcp_from_key2(const LcpEmit& L, uint32_t ka,
     return lcp_from_key2_at(L, L.h, ka, kb, sa, sb);
 }
 constexpr unsigned kDeepSlotWords = 1024 * 8;
+// flag bytes of a round (F8): 1 = first of its (bucket, key2) class, 2 = class of one, 4 = placed by the deep kernel,
+// kRankKept = member of the class that starts where its old bucket started (its head slot, hence its rank, is unchanged)
+constexpr unsigned kRankKept = 8u;
 struct TileRound {
     LcpEmit emit;
     const uint32_t* G;
@@ -264,6 +267,7 @@ struct TileRound {
     uint16_t* F;
     uint32_t* part_head; uint32_t* part_keep; uint32_t* part_ghead;
     uint32_t* block_counts;       // kMaxGrid
+    uint32_t* part_pairs;         // rank rounds: per-chunk count of the members whose rank changes (kMaxGrid; nullptr: not wanted)
     uint32_t* totals;
     unsigned long long* counters; // 4
     unsigned long long* deep_slots; // kDeepSlotWords: per-wave-class counter lines of the deep text rounds

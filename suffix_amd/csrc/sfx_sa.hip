@@ -676,10 +676,12 @@ k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t chunk,
 // single workgroup: turn the partials into carries (exclusive max / sums); totals[0..1]
 __global__ void __launch_bounds__(kBlock)
 k_groups_scan(uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep,
-              uint32_t* __restrict__ part_ghead, unsigned nb, uint32_t* __restrict__ totals)
+              uint32_t* __restrict__ part_ghead, unsigned nb, uint32_t* __restrict__ totals,
+              uint32_t* __restrict__ part_pairs = nullptr)
 {
+    // part_pairs (rank rounds): per-chunk counts of the members whose rank changes -> where each chunk's pairs start; totals[2]
     __shared__ uint32_t part[kWavesPerBlock];
-    uint32_t c_head = 0, c_keep = 0, c_ghead = 0;
+    uint32_t c_head = 0, c_keep = 0, c_ghead = 0, c_pairs = 0;
     for (unsigned base = 0; base < nb; base += kBlock) {
         unsigned i = base + threadIdx.x;
         bool valid = i < nb;
@@ -693,11 +695,17 @@ k_groups_scan(uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep
             part_keep[i] = c_keep + ek;
             part_ghead[i] = c_ghead + eg;
         }
+        if (part_pairs) {
+            uint32_t tp;
+            const uint32_t ep = block_scan_add_excl(valid ? part_pairs[i] : 0u, part, tp);
+            if (valid) part_pairs[i] = c_pairs + ep;
+            c_pairs += tp;
+        }
         c_head = dmax(c_head, th);
         c_keep += tk;
         c_ghead += tg;
     }
-    if (threadIdx.x == 0) { totals[0] = c_keep; totals[1] = c_ghead; }
+    if (threadIdx.x == 0) { totals[0] = c_keep; totals[1] = c_ghead; totals[2] = c_pairs; }
 }
 
 // K,V: sorted keys / suffixes of the m active elements; S: their SA slots in
@@ -723,8 +731,11 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                uint32_t* __restrict__ R_next, int sa_in_place, uint64_t* __restrict__ rank_pairs,
                const uint16_t* __restrict__ flags_in, uint32_t* __restrict__ pair_hist, int pair_lo, int pair_nb,
                const uint16_t* __restrict__ Hd, uint16_t* __restrict__ Hd_next, uint32_t hd_floor, HtDepth ht,
-               uint32_t* __restrict__ min_depth)
+               uint32_t* __restrict__ min_depth, const uint8_t* __restrict__ F8 = nullptr,
+               const uint32_t* __restrict__ part_pairs = nullptr)
 {
+    // F8 + part_pairs (rank rounds): a member flagged kRankKept sits in the class that starts where its old bucket
+    // started -- same head slot, same rank: no pair, no write.  The pairs of a chunk then start at part_pairs[chunk].
     // ht.ent (initial bucket pass over compressed keys): the depth of a bucket is what its key holds, ht_depth(K);
     // min_depth: smallest depth given to a kept element (the rank rounds' h, should the text rounds give way)
     __shared__ uint32_t s_t12[(1 << kHtFastBits) / 2];
@@ -737,7 +748,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     }
     uint32_t my_min = 0xFFFFFFFFu;
     // Hd_next (deep text rounds): the kept elements carry the depth of their bucket, at least hd_floor
-    __shared__ uint32_t part_m[2][kWavesPerBlock], part_a[2][kWavesPerBlock];
+    __shared__ uint32_t part_m[2][kWavesPerBlock], part_a[2][kWavesPerBlock], part_p[2][kWavesPerBlock];
     // pair_hist (with rank_pairs): digit counts of the passes that partition the pairs by suffix index (bits [pair_lo,
     // pair_nb), 8 per pass, at most 3) -- counted here, where the pairs are made, instead of by a pass over them
     constexpr int kPairPasses = 3;
@@ -758,6 +769,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     if (end > m) end = m;
     uint32_t c_head = part_head[blockIdx.x];     // index+1 of the last head before the chunk
     uint32_t c_keep = part_keep[blockIdx.x];
+    uint64_t c_pairs = part_pairs ? (uint64_t)part_pairs[blockIdx.x] : begin;    // (every element a pair: chunk i's start at i * chunk)
     (void)part_ghead;
     unsigned par = 0;
     // head / single bits of the thread's elements = SUB flag words of k_groups_reduce, one load
@@ -791,19 +803,28 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         const uint32_t keepm = valid & ~single;
         const uint32_t hmax = head ? (uint32_t)i0 + (32u - (unsigned)__clz((int)head)) : 0u;
         const uint32_t cnt = (uint32_t)__popc(keepm);
-        // one barrier for both scans: exclusive max of hmax, exclusive sum of cnt
-        uint32_t im = wave_scan_max(hmax), ia = wave_scan_add(cnt);
+        // (dense form, rank rounds) the elements whose rank changes: the valid ones without kRankKept
+        uint32_t pairm = SUB == 1 ? (valid & 0xFFu) : 0u;
+        if (SUB == 1 && F8 && pairm) {
+            const uint64_t f8 = *reinterpret_cast<const uint64_t*>(F8 + i0);       // (i0 is a multiple of 8, F8 padded)
+            pairm &= ~(uint32_t)((((f8 >> 3) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+        }
+        const uint32_t pcnt = (SUB == 1 && rank_pairs) ? (uint32_t)__popc(pairm) : 0u;
+        // one barrier for the scans: exclusive max of hmax, exclusive sums of cnt and pcnt
+        uint32_t im = wave_scan_max(hmax), ia = wave_scan_add(cnt), ip = 0;
+        if (SUB == 1 && rank_pairs) ip = wave_scan_add(pcnt);
         uint32_t pm = __shfl_up(im, 1u);
         if (lane == 0) pm = 0;
-        if (lane == 63) { part_m[par][w] = im; part_a[par][w] = ia; }
+        if (lane == 63) { part_m[par][w] = im; part_a[par][w] = ia; part_p[par][w] = ip; }
         __syncthreads();
-        uint32_t bm = 0, ba = 0, tot_m = 0, tot_a = 0;
+        uint32_t bm = 0, ba = 0, bp = 0, tot_m = 0, tot_a = 0, tot_p = 0;
 #pragma unroll
         for (unsigned k = 0; k < (unsigned)kWavesPerBlock; k++) {
-            const uint32_t qm = part_m[par][k], qa = part_a[par][k];
-            if (k < w) { bm = dmax(bm, qm); ba += qa; }
+            const uint32_t qm = part_m[par][k], qa = part_a[par][k], qp = part_p[par][k];
+            if (k < w) { bm = dmax(bm, qm); ba += qa; bp += qp; }
             tot_m = dmax(tot_m, qm);
             tot_a += qa;
+            tot_p += qp;
         }
         par ^= 1u;
         const uint32_t ec = ba + ia - cnt;
@@ -907,10 +928,11 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                 }
             }
             if (rank_pairs) {                                    // the tile's pairs, in stream order
+                unsigned at = bp + ip - pcnt;
 #pragma unroll
                 for (int j = 0; j < kGroupItems; j++) {
-                    if ((v8 >> j) & 1u) {
-                        stg_a[tid * kGroupItems + j] = ((uint64_t)suffix[j] << 32) | (uint64_t)head_slot[j];
+                    if ((pairm >> j) & 1u) {
+                        stg_a[at++] = ((uint64_t)suffix[j] << 32) | (uint64_t)head_slot[j];
                         if (pair_hist) {
 #pragma unroll
                             for (int p = 0; p < kPairPasses; p++) {
@@ -921,8 +943,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                     }
                 }
                 __syncthreads();
-                const unsigned nv = (unsigned)dmin<uint64_t>(kTile, end - tile);
-                for (unsigned k = tid; k < nv; k += kBlock) rank_pairs[tile + k] = stg_a[k];
+                for (unsigned k = tid; k < tot_p; k += kBlock) rank_pairs[c_pairs + k] = stg_a[k];
                 __syncthreads();
             }
             {
@@ -935,7 +956,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                         // sa_in_place: 0 = every element goes to its slot; 1 = V is the SA; 2 = only the elements that
                         // resolve now (the members of unresolved buckets would be rewritten every round)
                         if (sa_in_place == 0 || (sa_in_place == 2 && !keep)) sa[slot[j]] = suffix[j];
-                        if (isa && !rank_pairs) isa[suffix[j]] = head_slot[j];
+                        if (isa && !rank_pairs && ((pairm >> j) & 1u)) isa[suffix[j]] = head_slot[j];
                         if (keep) {
                             const uint32_t back = (uint32_t)(ib + j) - (rh - 1u);   // distance to the bucket head (all kept in between)
                             const uint32_t gpos = c_keep + local_keep;
@@ -960,6 +981,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         }
         c_head = dmax(c_head, tot_m);
         c_keep += tot_a;
+        c_pairs += tot_p;
     }
     if (min_depth) {
         for (int d = 32; d >= 1; d >>= 1) my_min = dmin(my_min, (uint32_t)__shfl_xor(my_min, d));
@@ -1404,8 +1426,12 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
                        uint32_t* sa, uint32_t* isa, uint32_t* S_next, uint32_t* V_next,
                        uint32_t* R_next, hipStream_t st, int sa_mode, uint64_t n, sfx_build_stats& stats,
                        uint64_t kept, const uint16_t* Hd = nullptr, uint16_t* Hd_next = nullptr, uint32_t hd_floor = 0,
-                       HtDepth ht = HtDepth{nullptr, 0}, uint32_t* min_depth = nullptr)
+                       HtDepth ht = HtDepth{nullptr, 0}, uint32_t* min_depth = nullptr, const uint8_t* rank_flags = nullptr,
+                       const uint32_t* part_pairs = nullptr, uint64_t npairs = 0)
 {
+    // rank_flags / part_pairs / npairs (rank rounds after an LDS or segmented sort): only the members whose rank changes
+    // are written -- npairs of the m (k_flags_reduce counted them)
+    const uint64_t pair_count = rank_flags ? npairs : m;
     const bool sa_in_place = sa_mode == 1;
     // the sorted keys K sit in one of K0/K1 (for 32-bit keys: in its first half); the other
     // one is free for the (suffix, rank) pairs, and K's own buffer is free once this kernel is done
@@ -1422,7 +1448,7 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
     int pair_lo = 0, pair_nb = 0;
     unsigned pair_blocks = 0;
     if (pairs) {
-        const unsigned most = scatter_pairs_presort_hist(m, n, &pair_lo, &pair_nb);
+        const unsigned most = scatter_pairs_presort_hist(pair_count, n, &pair_lo, &pair_nb);
         if (most && ch.blocks <= most && (pair_nb - pair_lo + 7) / 8 <= 3) { pair_hist = b.hist; pair_blocks = ch.blocks; }
     }
     const char* name = sizeof(KeyT) == 4 ? "groups_apply_u32" : "groups_apply_u64";
@@ -1435,8 +1461,9 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
     else
         SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, 1>), ch.blocks, kBlock, st, K, V, S, m,
                    ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
-                   b.G, R_next, sa_mode, pairs, (const uint16_t*)b.F, pair_hist, pair_lo, pair_nb, Hd, Hd_next, hd_floor, ht, min_depth);
-    if (pairs) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, m, n, isa, b.hist, st, &stats, pair_blocks));
+                   b.G, R_next, sa_mode, pairs, (const uint16_t*)b.F, pair_hist, pair_lo, pair_nb, Hd, Hd_next, hd_floor, ht, min_depth,
+                   rank_flags, part_pairs);
+    if (pairs && pair_count) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, pair_count, n, isa, b.hist, st, &stats, pair_blocks));
     return SFX_OK;
 }
 
@@ -1698,6 +1725,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         tr.wsym = (uint32_t)wsym;
         tr.part_head = b.part_head; tr.part_keep = b.part_keep; tr.part_ghead = b.part_ghead;
         tr.block_counts = b.block_counts; tr.totals = b.totals; tr.counters = b.counters; tr.deep_slots = b.deep_slots;
+        tr.part_pairs = rank_mode ? b.block_counts : nullptr;   // (idle during a round)
         // scratch of the segmented sort: element ping-pong in K0 / K1; tile table and segment list in the
         // slot list of the next round (free until round_apply), per-tile digit counts in G1, per-segment
         // digit offsets in R, status words in the radix scratch
@@ -1713,10 +1741,10 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         else { SFX_TRY(deep_round_text(pt, tr, m, st, &stats)); any_deep = true; }
         Chunking ch = make_chunking(m, kApplyTile);
         SFX_LAUNCH("groups_scan", 0.0, k_groups_scan, 1, kBlock, st, b.part_head, b.part_keep, b.part_ghead, ch.blocks,
-                   b.totals);
-        uint32_t host_totals[2] = {0, 0};
+                   b.totals, tr.part_pairs);
+        uint32_t host_totals[3] = {0, 0, 0};
         SFX_TRY(read_back(host_totals, b.totals, sizeof(host_totals), st));
-        const uint64_t kept = host_totals[0], kept_groups = host_totals[1];
+        const uint64_t kept = host_totals[0], kept_groups = host_totals[1], rank_changes = host_totals[2];
         // (SA slots are written when a suffix resolves; the members of still-unresolved buckets only if ranks
         // have to be built from the array: build_ranks below)
         // (deep rounds: the smallest depth a kept bucket leaves with -- what the rank rounds may assume of every bucket,
@@ -1725,14 +1753,14 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         if (min_depth) SFX_HIP(hipMemsetAsync(min_depth, 0xFF, sizeof(uint32_t), st));
         SFX_TRY(round_apply<uint64_t>(b.K0, V_cur, S_cur, m, b, sa, rank_mode ? isa : nullptr, S_next, V_next, nullptr,
                                       st, 2, n, stats, kept, tr.Hd, deep_round ? hd_of(b, S_next) : nullptr, 0u,
-                                      HtDepth{nullptr, 0}, min_depth));
+                                      HtDepth{nullptr, 0}, min_depth, rank_mode ? b.F8 : nullptr, tr.part_pairs, rank_changes));
         // SFX_TRACE=1 (development): one line per round
         static const bool trace = [] { const char* e = dev_env("SFX_TRACE"); return e && atoi(e) != 0; }();
         if (trace)
-            fprintf(stderr, "round %d %s h=%llu m=%llu lds=%llu large=%llu kept=%llu kept_groups=%llu gathers=%llu\n", rounds,
+            fprintf(stderr, "round %d %s h=%llu m=%llu lds=%llu large=%llu kept=%llu kept_groups=%llu gathers=%llu rank_changes=%llu\n", rounds,
                     rank_mode ? "rank" : "text", (unsigned long long)h, (unsigned long long)m,
                     (unsigned long long)stats.tile_sorted, (unsigned long long)stats.large_sorted, (unsigned long long)kept,
-                    (unsigned long long)kept_groups, (unsigned long long)stats.deep_gathers);
+                    (unsigned long long)kept_groups, (unsigned long long)stats.deep_gathers, (unsigned long long)rank_changes);
         h = rank_mode ? h * 2 : h + (uint64_t)wsym;
         stats.rounds++;
         if (rank_mode) stats.rank_rounds++; else stats.text_rounds++;

@@ -71,6 +71,7 @@ struct TileSmem {
     uint16_t posmap[kWin];                                  // window offset that slot j of `stage` writes to
     uint16_t hslot[kWin / 2];                               // slot of the head of the bucket with local id g
     uint8_t blabel[kWin / 2];                               // big buckets: dense label (rank among the tile's big buckets)
+    uint16_t bslot[256];                                    // ... and the first slot of the big bucket with that label
     uint32_t cnt[NW][kRadixDev];
     uint32_t part[2][NW];
     uint64_t part64[NW];
@@ -182,6 +183,7 @@ k_tile_sort(KeyFn keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* _
                 s.stage[at] = ((uint64_t)key2[j] << 32) | ((uint64_t)mid << kIdxBits) | (uint64_t)(i0 + j);
                 s.posmap[at] = (uint16_t)(i0 + j);
                 if (!bg && lg[j] == i0 + j) s.hslot[lg[j]] = (uint16_t)at;
+                if (bg && lg[j] == i0 + j) s.bslot[mid] = (uint16_t)at;
             }
         }
     }
@@ -303,7 +305,11 @@ k_tile_sort(KeyFn keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* _
         const uint64_t p = base + s.posmap[i];
         const uint32_t sfx = s.sufwin[(unsigned)key & (unsigned)(kWin - 1)];
         V[p] = sfx;
-        F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
+        // 8: in the class that starts where the bucket starts -- its head, hence its members' rank, stays (kRankKept)
+        const unsigned mid = (unsigned)(key >> kIdxBits) & ((1u << (32 - kIdxBits)) - 1u);
+        const unsigned first = i < ns ? (unsigned)s.hslot[mid & (unsigned)(kT - 1)] : (unsigned)s.bslot[mid & 255u];
+        const bool kept_rank = (s.stage[first] >> kIdxBits) == cls;
+        F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u) | (kept_rank ? kRankKept : 0u));
         if (emit.lcp && head && i != 0 && i != ns) {
             // a class head that is not the first member of its bucket: split from its predecessor by this round
             const uint64_t kp = s.stage[i - 1];
@@ -449,7 +455,8 @@ k_seg_single(KeyFn keyfn, const uint2* __restrict__ segs, uint32_t nseg, uint32_
                 const bool last = idx + 1 == size || (uint32_t)(stage[idx + 1] >> 32) != k2;
                 const uint64_t p = (uint64_t)begin + idx;
                 V[p] = (uint32_t)e;
-                F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u));
+                const bool kept_rank = (uint32_t)(stage[0] >> 32) == k2;           // (the bucket's first class: same head, same rank)
+                F8[p] = (uint8_t)((head ? 1u : 0u) | ((head && last) ? 2u : 0u) | (kept_rank ? kRankKept : 0u));
                 if (Hd) Hd[p] = (uint16_t)(depth + wsym);
                 if (emit.lcp && head && idx != 0) {                   // split from its predecessor in this round
                     const uint64_t ep = stage[idx - 1];
@@ -803,14 +810,16 @@ k_deep_wave(DeepTextKey keyfn, const uint32_t* __restrict__ G, uint64_t m, uint3
 // ---- flag bytes -> flag words + partials (the role of k_groups_reduce after a key sort) ----
 __global__ void __launch_bounds__(kBlock)
 k_flags_reduce(const uint8_t* __restrict__ F8, uint64_t m, uint64_t chunk, uint32_t* __restrict__ part_head,
-               uint32_t* __restrict__ part_keep, uint32_t* __restrict__ part_ghead, uint16_t* __restrict__ flags_out)
+               uint32_t* __restrict__ part_keep, uint32_t* __restrict__ part_ghead, uint16_t* __restrict__ flags_out,
+               uint32_t* __restrict__ part_pairs)
 {
-    __shared__ uint32_t red[3][kWavesPerBlock];
+    // part_pairs (rank rounds): elements of the chunk whose rank changes (flag kRankKept clear)
+    __shared__ uint32_t red[4][kWavesPerBlock];
     const unsigned tid = threadIdx.x;
     uint64_t begin = (uint64_t)blockIdx.x * chunk;               // chunk: a multiple of 8 elements
     uint64_t end = begin + chunk;
     if (end > m) end = m;
-    uint32_t last_head = 0, keep = 0, ghead = 0;
+    uint32_t last_head = 0, keep = 0, ghead = 0, pairs = 0;
     for (uint64_t i0 = begin + (uint64_t)tid * 8; i0 < end; i0 += (uint64_t)kBlock * 8) {
         const uint64_t f = *reinterpret_cast<const uint64_t*>(F8 + i0);      // (F8 is padded to a multiple of 8)
         const unsigned valid = (i0 + 8 <= m) ? 0xFFu : ((1u << (unsigned)(m - i0)) - 1u);
@@ -821,24 +830,29 @@ k_flags_reduce(const uint8_t* __restrict__ F8, uint64_t m, uint64_t chunk, uint3
         if (head) last_head = (uint32_t)i0 + (32u - (unsigned)__clz((int)head));
         keep += (uint32_t)__popc(valid & ~single);
         ghead += (uint32_t)__popc(head & ~single);
+        const unsigned same = (unsigned)((((f >> 3) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+        pairs += (uint32_t)__popc(valid & ~same);
     }
     for (int d = 32; d >= 1; d >>= 1) {
         last_head = dmax(last_head, __shfl_xor(last_head, d));
         keep += __shfl_xor(keep, d);
         ghead += __shfl_xor(ghead, d);
+        pairs += __shfl_xor(pairs, d);
     }
     if (lane_id() == 0) {
         red[0][wave_id()] = last_head;
         red[1][wave_id()] = keep;
         red[2][wave_id()] = ghead;
+        red[3][wave_id()] = pairs;
     }
     __syncthreads();
     if (tid == 0) {
-        uint32_t a = 0, b = 0, c = 0;
-        for (int k = 0; k < kWavesPerBlock; k++) { a = dmax(a, red[0][k]); b += red[1][k]; c += red[2][k]; }
+        uint32_t a = 0, b = 0, c = 0, e = 0;
+        for (int k = 0; k < kWavesPerBlock; k++) { a = dmax(a, red[0][k]); b += red[1][k]; c += red[2][k]; e += red[3][k]; }
         part_head[blockIdx.x] = a;
         part_keep[blockIdx.x] = b;
         part_ghead[blockIdx.x] = c;
+        if (part_pairs) part_pairs[blockIdx.x] = e;
     }
 }
 
@@ -917,7 +931,7 @@ static int flags_phase(const TileRound& r, uint64_t m, hipStream_t st)
 {
     Chunking ch = make_chunking(m, kFlagChunkTile);
     SFX_LAUNCH("flags_reduce", (double)m * 1.25, k_flags_reduce, ch.blocks, kBlock, st, r.F8, m,
-               ch.tiles_per_block * kFlagChunkTile, r.part_head, r.part_keep, r.part_ghead, r.F);
+               ch.tiles_per_block * kFlagChunkTile, r.part_head, r.part_keep, r.part_ghead, r.F, r.part_pairs);
     return SFX_OK;
 }
 
