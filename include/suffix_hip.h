@@ -237,7 +237,7 @@ typedef struct {
     uint32_t sigma;           /* distinct byte values                          */
     uint32_t bits_per_symbol;
     uint32_t key_bits;        /* width of the initial k-mer key (32 or 64)     */
-    uint32_t symbols_per_key; /* k                                             */
+    uint32_t symbols_per_key; /* k (compressed 64-bit keys: the average, 64 / mean code length) */
     uint32_t rounds;          /* refinement rounds after the initial sort      */
     uint32_t reserved;
     uint64_t active_after_initial;

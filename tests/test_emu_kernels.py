@@ -37,11 +37,11 @@ def test_fasta_10k(emu, oracle, golden, fasta):
 
 
 def test_random_small(emu, oracle):
-    _cases.random_small(emu, oracle, iters=100, max_len=90, seed=101)
+    _cases.random_small(emu, oracle, iters=60, max_len=90, seed=101)
 
 
 def test_unicode(emu, oracle):
-    _cases.unicode_strings(emu, oracle, iters=60, seed=5)
+    _cases.unicode_strings(emu, oracle, iters=40, seed=5)
 
 
 def test_structured(emu, oracle):
@@ -78,7 +78,7 @@ def test_suffix_tree_topology_and_doc_lookup(emu, oracle):
 
 
 def test_random_medium_sweep(emu, oracle):
-    _cases.random_medium_sweep(emu, oracle, iters=10, max_len=4000, seed=5)
+    _cases.random_medium_sweep(emu, oracle, iters=7, max_len=4000, seed=5)
 
 
 def test_fused_sa_lcp(emu, oracle):

@@ -49,8 +49,8 @@ if os.environ.get("SFX_HYBRID_MIN"):
     rngh = np.random.default_rng(5)
     blocks = [bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for _ in range(4)]
     texts.append(b"".join(blocks[int(k)] + bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for k in rngh.integers(0, 4, 3600)))
-    texts += [_gen.uniform_bytes(20000, 5, 2, base=65).tobytes(), _gen.uniform_bytes(20000, 16, 3, base=65).tobytes(),
-              _gen.uniform_bytes(25000, 2, 4, base=65).tobytes()]
+    texts += [_gen.uniform_bytes(12000, 5, 2, base=65).tobytes(), _gen.uniform_bytes(12000, 16, 3, base=65).tobytes(),
+              _gen.uniform_bytes(14000, 2, 4, base=65).tobytes()]
     from suffix_amd import device as sdev
     for t in texts[:1]:                                 # the fused SA + LCP entry over the same initial sort
         import torch
@@ -60,7 +60,7 @@ if os.environ.get("SFX_HYBRID_MIN"):
         assert np.array_equal(sa.numpy().view(np.uint32), exp) and np.array_equal(lcp.numpy().view(np.uint32), oracle.lcp_kasai(t, exp))
     # which route the first text takes (random DNA: no sub-bucket above a handful) and a text with three planted
     # sub-buckets of ~130 suffixes (oversized under SFX_HYBRID_CAP=100: gathered, sorted device-wide, copied back)
-    planted = _gen.dna(70000, seed=3).tobytes() + b"".join(
+    planted = _gen.dna(44000, seed=3).tobytes() + b"".join(
         blocks[int(k)] + bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for k in rngh.integers(0, 3, 400))
     texts.append(planted)
     def kernels_of(t):
@@ -73,10 +73,10 @@ if os.environ.get("SFX_HYBRID_MIN"):
     names = kernels_of(texts[0])
     # (cap 3: 6 % of that text sits in sub-buckets of more than 3 suffixes -- above the 1/64 the route tolerates)
     assert ("bucket_sort_lds" in names) == (cap > 10) and "oversize_gather" not in names, names
-    names = kernels_of(planted)                                       # 0.5 % of it in the three planted sub-buckets
+    names = kernels_of(planted)                                       # 0.8 % of it in the three planted sub-buckets
     assert ("bucket_sort_lds" in names) == (cap > 10) and ("oversize_gather" in names) == (10 < cap < 400), names
     # most of the suffixes in oversized sub-buckets: the four-pass sort
-    skewed = np.frombuffer(b"ACGT", dtype=np.uint8)[rngh.choice(4, size=30000, p=[0.85, 0.05, 0.05, 0.05])].tobytes()
+    skewed = np.frombuffer(b"ACGT", dtype=np.uint8)[rngh.choice(4, size=20000, p=[0.85, 0.05, 0.05, 0.05])].tobytes()
     texts.append(skewed)
     if cap < 400:
         names = kernels_of(skewed)

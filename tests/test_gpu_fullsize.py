@@ -147,6 +147,29 @@ def test_chunked_radix_schedule_2p30(eng):
     torch.cuda.empty_cache()
 
 
+def test_chunked_radix_schedule_compressed_keys_2p30(eng):
+    """1.1 * 10^9 B of English-like text: compressed 64-bit keys (k_ht_keys) through the chunked schedule of the
+    key/value passes (m >= 2^30: no one-sweep status words), deep rounds on 6 * 10^8 tied suffixes; the size-independent
+    property gate (permutation, every adjacent pair in order, sampled LCP bytes)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from suffix_amd import device as sdev
+    n = 1_100_000_000
+    host = _gen.english_like(n)
+    dev = torch.device("cuda", 0)
+    text = torch.from_numpy(host).to(dev)
+    eng.profile(True); eng.profile_reset()
+    sa = sdev.build_sa(text)
+    torch.cuda.synchronize()
+    names = {r["name"] for r in eng.profile_report()}
+    eng.profile(False)
+    assert "radix_hist" in names and "ht_keys" in names and "deep_wave" in names, names
+    ok, how = bench.verify_sa_chunked(torch, sdev, text, sa)
+    assert ok, how
+    del text, sa
+    torch.cuda.empty_cache()
+
+
 def test_two_gpu_bench_over_rccl():
     """bench.py --gpus 2 under torch.distributed.run with the nccl (= RCCL) backend, one rank per GPU: the
     partitioned build's first contact with RCCL.  Skipped on 1-GPU boxes (the driver's multi-GPU node runs it)."""

@@ -141,6 +141,44 @@ def test_hybrid_initial_sort_56mb(eng, oracle):
         del text, sa, sa2, lcp2
 
 
+def test_compressed_keys_symbol_distributions(eng, oracle):
+    """64-bit initial keys in the order-preserving prefix code (k_ht_keys) over byte distributions that stress the code
+    construction: Zipf over 200 values (code words of 1 .. 12 bits side by side), two dominant symbols next to 150 rare
+    ones (the length limit of 12 bits binds: the counts are floored), a symbol that occurs once, geometric counts, and
+    uniform bytes over 256 / 97 values (no code saves 0.75 bits per symbol: fixed-width keys).  6 MB each, complete SA and
+    LCP against the oracle, through the separate entries and the one-call entry."""
+    import torch
+    from suffix_amd import device as sdev
+    n = 6_000_000
+    rng = np.random.default_rng(2718)
+    def draw(p):
+        p = np.asarray(p, dtype=np.float64)
+        return rng.choice(len(p), size=n, p=p / p.sum()).astype(np.uint8)
+    zipf = draw(1.0 / np.arange(1, 201) ** 1.2)
+    two = draw([0.46, 0.46] + [0.08 / 150] * 150) + 40
+    once = zipf.copy(); once[n // 3] = 255
+    geom = draw(0.7 ** np.arange(0, 64)) + 1
+    words = _gen.english_like(n)
+    cases = ((zipf, True), (two, True), (once, True), (geom, True), (words, True),
+             (rng.integers(0, 256, n, dtype=np.uint8), False), (_gen.uniform_bytes(n, 97, 5, base=20), False))
+    for host, compressed in cases:
+        host = np.ascontiguousarray(host)
+        text = torch.from_numpy(host).cuda()
+        eng.profile(True); eng.profile_reset()
+        sa = sdev.build_sa(text)
+        torch.cuda.synchronize()
+        names = {r["name"] for r in eng.profile_report()}
+        eng.profile(False)
+        assert ("ht_keys" in names) == compressed, (names, eng.build_stats())
+        exp = oracle.sais(host.tobytes())
+        assert np.array_equal(sa.cpu().numpy().view(np.uint32), exp)
+        want = oracle.lcp_kasai(host.tobytes(), exp)
+        assert np.array_equal(sdev.build_lcp(text, sa).cpu().numpy().view(np.uint32), want)
+        sa2, lcp2 = sdev.build_sa_lcp(text)
+        assert np.array_equal(sa2.cpu().numpy().view(np.uint32), exp) and np.array_equal(lcp2.cpu().numpy().view(np.uint32), want)
+        del text, sa, sa2, lcp2
+
+
 @pytest.mark.parametrize("sigma", [2, 5, 16])
 def test_hybrid_initial_sort_other_alphabets(eng, sigma):
     """The hybrid route on keys of 32 one-bit symbols and 8 four-bit symbols, 56 * 10^6 suffixes each, through the
