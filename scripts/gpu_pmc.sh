@@ -14,7 +14,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-for
 # kernel-trace statistics of the bench command itself (no counters)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-verify --no-microbench --configs '' > $OUT/stats.log 2>&1; echo "stats rc=$?"
 cd $ROOT
-python scripts/pmc_summary.py --json $OUT/pmc_latest.json $OUT/fetch $OUT/write $OUT/sq $OUT/tcc > $OUT/pmc_summary.csv
+SFX_COMMIT=$(cat suffix_amd/_build_commit.txt 2>/dev/null || echo unknown) python scripts/pmc_summary.py --json $OUT/pmc_latest.json $OUT/fetch $OUT/write $OUT/sq $OUT/tcc > $OUT/pmc_summary.csv
 f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv && head -20 $OUT/kernel_stats.csv
 find $OUT -name "*.csv" -size +5M -delete
 cat $OUT/pmc_latest.json
