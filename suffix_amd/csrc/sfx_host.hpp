@@ -154,7 +154,7 @@ uint64_t radix_scratch_words(uint64_t m);
 //    digit) * hist_blocks + workgroup]; only honoured when radix_e64_presort_hist() said so.
 int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, uint32_t* scratch,
                    hipStream_t st, int* result_in_1, sfx_build_stats* stats, const PackedText* text,
-                   uint32_t* split_v, uint32_t** split_k_out, unsigned hist_blocks = 0);
+                   uint32_t* split_v, uint32_t** split_k_out, unsigned hist_blocks = 0, int elem_bits = 0);
 // > 0: an E64 sort of m elements on bits [bit_lo, bit_hi) takes digit counts from its producer,
 // from at most this many workgroups
 unsigned radix_e64_presort_hist(uint64_t m, int bit_lo, int bit_hi);

@@ -599,6 +599,38 @@ k_hist16_text(PackedText t, int drop, uint64_t words_per_block, uint32_t* __rest
     uint32_t* out = partial + (uint64_t)blockIdx.x * kH16Words;
     for (unsigned i = tid; i < (unsigned)kH16Words; i += kH16Threads) out[i] = h[i];
 }
+// The same counts from (key << 32 | suffix) elements that already exist (a slice of the partitioned build): bits
+// [shift, shift + 16) of the element.
+__global__ void __launch_bounds__(kH16Threads)
+k_hist16_e64(const uint64_t* __restrict__ E, uint64_t m, int shift, uint64_t per_block, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[kH16Words];                                 // 128 KiB
+    const unsigned tid = threadIdx.x;
+    const uint64_t qb = (uint64_t)blockIdx.x * per_block;
+    const uint64_t qe = dmin<uint64_t>(m, qb + per_block);
+    for (unsigned i = tid; i < (unsigned)kH16Words; i += kH16Threads) h[i] = 0;
+    __syncthreads();
+    // (one workgroup per CU: eight elements per thread in flight, or the sweep waits on its own loads)
+    constexpr int kFly = 8;
+    for (uint64_t q0 = qb; q0 < qe; q0 += (uint64_t)kH16Threads * kFly) {
+        uint64_t e[kFly];
+#pragma unroll
+        for (int k = 0; k < kFly; k++) {
+            const uint64_t q = q0 + (uint64_t)k * kH16Threads + tid;
+            e[k] = q < qe ? E[q] : ~0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < kFly; k++) {
+            if (q0 + (uint64_t)k * kH16Threads + tid < qe) {
+                const uint32_t top = (uint32_t)(e[k] >> shift) & 0xFFFFu;
+                atomicAdd(&h[top >> 1], (top & 1u) ? 65536u : 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* out = partial + (uint64_t)blockIdx.x * kH16Words;
+    for (unsigned i = tid; i < (unsigned)kH16Words; i += kH16Threads) out[i] = h[i];
+}
 // bins[b] += the counts of a slice of the workgroups' partial histograms: workgroup x + 64 y takes the 1024 bins
 // from 1024 x (2 KB of every partial, one 8-byte load per thread) and the partials y, y + split, ...
 constexpr int kH16ReduceBins = 1024;
@@ -1070,12 +1102,17 @@ static bool use_sweep(uint64_t m, int npass)
 //   SFX_HYBRID=0 switches it off; SFX_HYBRID_MIN=<suffixes> (tests) moves the lower bound; SFX_HYBRID_CAP=<elements>
 //   (tests) lowers the size from which a sub-bucket counts as oversized.
 constexpr int kBucketNW = 16, kBucketKPT = 16;                // the largest geometry: sub-buckets of up to 16384 suffixes
+// elem_bits > 0 (a slice of the partitioned build): the elements exist already, in e0, with keys below 2^elem_bits
+// (k_range_filter stores key - first key of the range): the sub-bucket of an element is its key >> (elem_bits - 16), the
+// histogram is counted from the elements (k_hist16_e64), both device-wide passes read elements (e0 -> e1 -> e0) and the
+// LDS sort reads e0; when the route gives way nothing has been touched but e1 and the scratch.
 static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, const RadixScratch& scr,
                                 hipStream_t st, sfx_build_stats* stats, const PackedText& text, uint32_t* split_v,
-                                uint32_t** split_k_out, bool* done, bool* windows_ready)
+                                uint32_t** split_k_out, bool* done, bool* windows_ready, int elem_bits = 0)
 {
     *done = false;
     *windows_ready = false;
+    const bool from_elems = elem_bits > 0;
     static const int enabled = [] { const char* e = dev_env("SFX_HYBRID"); return e ? atoi(e) : 1; }();
     static const uint64_t min_m = [] { const char* e = dev_env("SFX_HYBRID_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 25); }();
     static const uint32_t cap = [] {
@@ -1084,10 +1121,11 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
         const uint32_t v = e ? (uint32_t)atoi(e) : full;
         return v >= 1 && v < full ? v : full;
     }();
-    const int key_bits = bit_hi - bit_lo;
-    if (!enabled || bit_lo != 32 || key_bits != text.kbits || key_bits < 24 || m != text.n || m < min_m || m > (1ull << 28))
-        return SFX_OK;
+    const int key_bits = from_elems ? elem_bits : bit_hi - bit_lo;
+    if (!enabled || bit_lo != 32 || key_bits < 24 || key_bits > bit_hi - bit_lo || m < min_m || m > (1ull << 28)) return SFX_OK;
+    if (!from_elems && (key_bits != text.kbits || m != text.n)) return SFX_OK;
     const int low_bits = key_bits - 16;
+    const int top_hi = bit_lo + key_bits;                      // the sub-bucket = element bits [top_hi - 16, top_hi)
     // counts / sub-bucket starts, statistics and the oversize list sit at the END of the histogram scratch: the
     // device-wide sort of the oversized sub-buckets (<= 4 passes) uses its first half
     constexpr uint64_t kReserve = 1u << 18;
@@ -1096,14 +1134,18 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     OversizeEntry* over = reinterpret_cast<OversizeEntry*>(bins + kH16Bins + 128);
     static_assert(kH16Bins + 128 + 4 * kOversizeMax <= kReserve, "the reserve holds bins, statistics and the oversize list");
     uint32_t* partial = reinterpret_cast<uint32_t*>(e1);       // [workgroups][65536]: e1 is idle until the second pass
-    const uint64_t nwords = (m + (uint64_t)text.spw - 1) / (uint64_t)text.spw;
+    const uint64_t nwords = from_elems ? m : (m + (uint64_t)text.spw - 1) / (uint64_t)text.spw;    // (units of the histogram sweep)
     const uint64_t room = m * sizeof(uint64_t) / (kH16Words * sizeof(uint32_t));     // partial histograms that fit e1
     if (room == 0) return SFX_OK;
     Chunking ch = make_chunking(nwords, kH16Threads, (unsigned)dmin<uint64_t>(room, 256));
     SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
     SFX_HIP(hipMemsetAsync(bins, 0, (kH16Bins + 128) * sizeof(uint32_t), st));             // (the counts and the statistics)
-    SFX_LAUNCH("radix_hist16_text", (double)m * text.bits / 8.0, k_hist16_text, ch.blocks, kH16Threads, st, text, low_bits,
-               ch.tiles_per_block * kH16Threads, partial);
+    if (from_elems)
+        SFX_LAUNCH("radix_hist16_elems", (double)m * 8.0, k_hist16_e64, ch.blocks, kH16Threads, st, (const uint64_t*)e0, m, top_hi - 16,
+                   ch.tiles_per_block * kH16Threads, partial);
+    else
+        SFX_LAUNCH("radix_hist16_text", (double)m * text.bits / 8.0, k_hist16_text, ch.blocks, kH16Threads, st, text, low_bits,
+                   ch.tiles_per_block * kH16Threads, partial);
     SFX_LAUNCH("radix_hist16_reduce", (double)ch.blocks * kH16Words * 4, k_hist16_reduce, (kH16Bins / kH16ReduceBins) * kH16ReduceSplit, kBlock, st,
                (const uint32_t*)partial, ch.blocks, bins);
     SFX_LAUNCH("radix_hist16_scan", (double)kH16Bins * 8, k_hist16_scan, 1, kH16Threads, st, bins, scr.totals, scr.totals + kRadix,
@@ -1123,7 +1165,7 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     if (give_way) {
         // the four-pass sort takes its digit totals from this histogram when its digits are whole symbols
         // (prepare_sweep_windows would count the 8-bit windows again)
-        if (text.kbits == 32 && (8 % text.bits) == 0 && bit_hi == 64) {
+        if (!from_elems && text.kbits == 32 && (8 % text.bits) == 0 && bit_hi == 64) {
             SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
             SFX_LAUNCH("radix_window_from_hist16", 0.0, k_window_from_hist16, 1, kBlock, st, scr.totals, (uint32_t)(3 * (8 / text.bits)));
             SFX_LAUNCH("radix_window_fix", 0.0, k_window_fix, 1, kBlock, st, text, scr.totals);
@@ -1132,10 +1174,16 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
         return SFX_OK;
     }
     const bool sweep = true;
-    SrcText32 tsrc = {text};
-    SFX_TRY(run_pass("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), tsrc, DstE64{e0}, m, bit_hi - 16, 255u, scr, 0,
-                     sweep, st));
-    SFX_TRY(run_pass("radix_scatter_u32", (double)m * 16.0, SrcE64{e0}, DstE64{e1}, m, bit_hi - 8, 255u, scr, 1, sweep, st));
+    if (from_elems) {
+        SFX_TRY(run_pass("radix_scatter_u32", (double)m * 16.0, SrcE64{e0}, DstE64{e1}, m, top_hi - 16, 255u, scr, 0, sweep, st));
+        SFX_TRY(run_pass("radix_scatter_u32", (double)m * 16.0, SrcE64{e1}, DstE64{e0}, m, top_hi - 8, 255u, scr, 1, sweep, st));
+        uint64_t* t = e0; e0 = e1; e1 = t;                     // (from here on: e1 = the array sorted by its top 16 bits, e0 = free)
+    } else {
+        SrcText32 tsrc = {text};
+        SFX_TRY(run_pass("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), tsrc, DstE64{e0}, m, top_hi - 16, 255u, scr, 0,
+                         sweep, st));
+        SFX_TRY(run_pass("radix_scatter_u32", (double)m * 16.0, SrcE64{e0}, DstE64{e1}, m, top_hi - 8, 255u, scr, 1, sweep, st));
+    }
     uint32_t* split_k = reinterpret_cast<uint32_t*>(e0);       // (the first half of e0; the oversized sub-buckets are sorted in the second)
     const uint64_t* over_sorted = nullptr;
     if (nover) {
@@ -1207,8 +1255,10 @@ unsigned scatter_pairs_presort_hist(uint64_t m, uint64_t n, int* lo_out, int* nb
 
 int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, uint32_t* scratch, hipStream_t st,
                    int* result_in_1, sfx_build_stats* stats, const PackedText* text, uint32_t* split_v,
-                   uint32_t** split_k_out, unsigned hist_blocks)
+                   uint32_t** split_k_out, unsigned hist_blocks, int elem_bits)
 {
+    // elem_bits (with split_v, without text): the keys of the elements in e0 are all below 2^elem_bits -- a slice of the
+    // partitioned build; lets the hybrid route take it
     *result_in_1 = 0;
     if (split_k_out) *split_k_out = (uint32_t*)e1;
     if (m == 0) return SFX_OK;
@@ -1221,6 +1271,12 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
     if (sweep && text && split_v && npass >= 3) {
         bool done = false;
         SFX_TRY(hybrid_sort_e64_text(e0, e1, m, bit_lo, bit_hi, scr, st, stats, *text, split_v, split_k_out, &done, &windows_ready));
+        if (done) return SFX_OK;
+    }
+    if (sweep && !text && split_v && npass >= 3 && elem_bits > 0) {
+        bool done = false, unused = false;
+        SFX_TRY(hybrid_sort_e64_text(e0, e1, m, bit_lo, bit_hi, scr, st, stats, PackedText{nullptr, 0, 0, 1, 0, 1.0}, split_v, split_k_out,
+                                     &done, &unused, elem_bits));
         if (done) return SFX_OK;
     }
     SrcText32 tsrc = {text ? *text : PackedText{nullptr, 0, 0, 1, 0, 1.0}};

@@ -267,8 +267,9 @@ k_key_hist_raw(const uint8_t* __restrict__ text, uint64_t n, uint64_t begin, uin
         if (h[i]) atomicAdd(&bins[i], (unsigned long long)h[i]);
 }
 
-// Emit (key, suffix) for the suffixes whose top key bits fall in [bin_lo, bin_hi)
-// (32-bit keys: as E64 elements in kout, vout unused).
+// Emit (key - first key of the range, suffix) for the suffixes whose top key bits fall in [bin_lo, bin_hi)
+// (32-bit keys: as E64 elements in kout, vout unused).  Order and equality are those of the keys, and a slice's keys
+// fit bits_for(range width - 1) bits: what the hybrid initial sort of a slice goes by (radix_sort_e64, elem_bits).
 // phase 0 counts per workgroup, phase 1 writes at the scanned offsets (stream
 // compaction; order = text order).
 // (A one-pass variant that reserves output per tile with an atomic cursor was measured
@@ -377,7 +378,7 @@ k_range_filter(PackedText src, int key_bits_used, int top_bits, uint32_t bin_lo,
             while (k) {
                 const unsigned j = (unsigned)__ffs((int)k) - 1u;
                 k &= k - 1u;
-                const KeyT key = key_at(j);
+                const KeyT key = (KeyT)(key_at(j) - key_lo);
                 if (count_digits) count_key((uint32_t)key);
                 if (sizeof(KeyT) == 4) {                // E64 element: (key << 32) | suffix
                     stage_k[at] = ((uint64_t)key << 32) | (uint64_t)(uint32_t)(p0 + j);
@@ -407,7 +408,7 @@ k_range_filter(PackedText src, int key_bits_used, int top_bits, uint32_t bin_lo,
                 const unsigned j = (unsigned)__ffs((int)k) - 1u;
                 k &= k - 1u;
                 if (dst < capacity) {
-                    const KeyT key = key_at(j);
+                    const KeyT key = (KeyT)(key_at(j) - key_lo);
                     if (count_digits) count_key((uint32_t)key);
                     if (sizeof(KeyT) == 4) {
                         reinterpret_cast<uint64_t*>(kout)[dst] = ((uint64_t)key << 32) | (uint64_t)(uint32_t)(p0 + j);
@@ -1811,7 +1812,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
 template <class KeyT>
 static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool from_text, SaBuffers& b,
                            uint32_t* sa, uint32_t* isa, hipStream_t st, sfx_build_stats& stats,
-                           unsigned hist_blocks = 0, uint32_t* lcp_fuse = nullptr, const HtHost* ht = nullptr)
+                           unsigned hist_blocks = 0, uint32_t* lcp_fuse = nullptr, const HtHost* ht = nullptr, int elem_bits = 0)
 {
     // ht (64-bit keys of a full build): the keys are the suffixes' symbols in an order-preserving prefix code (k_ht_keys);
     // a bucket's depth is what its key holds (between 64 / longest code and kHtMaxSym symbols)
@@ -1825,7 +1826,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         // leaves the sorted 32-bit keys in the element buffer it did not read
         uint32_t* k32 = nullptr;
         SFX_TRY(radix_sort_e64(b.K0, b.K1, count, 32, 32 + pt.bits * cpk, b.hist, st, &in1, &stats,
-                               from_text ? &pt : nullptr, sa, &k32, hist_blocks));
+                               from_text ? &pt : nullptr, sa, &k32, hist_blocks, from_text ? 0 : elem_bits));
         Kr = (const KeyT*)k32;
         Vr = sa;
         V_next = b.VA;
@@ -2012,6 +2013,12 @@ static int range_build(const PackedText& pt, int cpk, int top_bits, uint32_t bin
                        uint32_t* block_counts, hipStream_t st, sfx_build_stats& stats)
 {
     const uint64_t n = pt.n;
+    if (bin_lo == 0 && bin_hi == (1u << top_bits)) {
+        // the whole key space (a world of one): nothing to filter -- the text-fed initial sort of the full build, text rounds only
+        *count_out = n;
+        if (n > capacity) return SFX_ERR_WORKSPACE;
+        return sort_and_refine<KeyT>(pt, cpk, n, true, b, d_sa_part, nullptr, st, stats);
+    }
     // (at most as many workgroups as the sort accepts digit counts from)
     Chunking ch = make_chunking((n + (uint64_t)pt.spw - 1) / (uint64_t)pt.spw, kBlock, 1024);  // in packed words
     const uint64_t chunk = ch.tiles_per_block * kBlock;
@@ -2044,7 +2051,11 @@ static int range_build(const PackedText& pt, int cpk, int top_bits, uint32_t bin
         SFX_LAUNCH("range_emit", (double)n * pt.bits / 8.0 + (double)host_total * (sizeof(KeyT) + 4),
                    (k_range_filter<KeyT, 0>), ch.blocks, kBlock, st, pt, pt.bits * cpk, top_bits, bin_lo, bin_hi,
                    chunk, 1, block_counts, capacity, k0, b.VA, digit_partial);
-    return sort_and_refine<KeyT>(pt, cpk, host_total, false, b, d_sa_part, nullptr, st, stats, hist_blocks);
+    // (the keys of the slice, less its first key, fit elem_bits bits)
+    const uint64_t width = (uint64_t)(bin_hi - bin_lo) << (pt.bits * cpk - top_bits);
+    const int elem_bits = bits_for(width > 1 ? width - 1 : 1);
+    return sort_and_refine<KeyT>(pt, cpk, host_total, false, b, d_sa_part, nullptr, st, stats, hist_blocks, nullptr, nullptr,
+                                 sizeof(KeyT) == 4 ? elem_bits : 0);
 }
 
 // packed-text plumbing of the partitioned build: a rank packs its own shard (global symbol

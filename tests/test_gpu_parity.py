@@ -305,6 +305,42 @@ def test_partitioned_build_single_rank_slices(eng, oracle):
             assert (int(total[k]) == ee - es) and (total[k] == 0 or int(gstart[k]) == es), (q, gstart[k], total[k], es, ee)
 
 
+def test_range_build_hybrid_slices(eng, oracle):
+    """Slices of >= 2^25 suffixes take the hybrid initial sort too (keys relative to the first key of the range, the
+    histogram of their top 16 bits counted from the emitted elements): 110 MB of DNA for 3 virtual ranks, and 40 MB for
+    one (the whole key space: the text-fed route of the full build); the slices concatenate to the oracle's suffix array."""
+    import ctypes
+    import torch
+    from suffix_amd import dist as sdist
+    from suffix_amd.device import _p
+    for n, nranges in ((110_000_000, 3), (40_000_000, 1)):
+        text = _gen.dna(n, seed=77 + nranges)
+        t = torch.from_numpy(text).cuda()
+        bb = torch.zeros(256, dtype=torch.int64, device="cuda")
+        eng.check(eng.lib.sfx_byte_histogram_dev(_p(t), 0, n, _p(bb), None), "bh")
+        kb = torch.zeros(1 << 14, dtype=torch.int64, device="cuda")
+        eng.check(eng.lib.sfx_key_histogram_dev(_p(t), n, 0, n, _p(bb), 14, _p(kb), None), "kh")
+        pieces = []
+        eng.profile(True); eng.profile_reset()
+        for lo, hi, off, cnt in sdist.plan_ranges(kb.cpu(), nranges):
+            part = torch.empty(max(cnt, 1), dtype=torch.int32, device="cuda")
+            ws = torch.empty(int(eng.lib.sfx_sa_range_workspace_bytes(n, max(cnt, 1))), dtype=torch.uint8, device="cuda")
+            got = ctypes.c_uint64(0)
+            eng.check(eng.lib.sfx_build_sa_range_u32_dev(_p(t), n, _p(bb), 14, lo, hi, max(cnt, 1), _p(part),
+                                                         ctypes.byref(got), _p(ws), ws.numel(), None), "range")
+            assert int(got.value) == cnt
+            pieces.append(part[:cnt].cpu().numpy().view(np.uint32))
+            del ws, part
+        names = {r["name"] for r in eng.profile_report()}
+        eng.profile(False)
+        # (one rank = the whole key space: no filter, the text-fed route of the full build)
+        assert ("radix_hist16_elems" if nranges > 1 else "radix_hist16_text") in names and "bucket_sort_lds" in names, names
+        assert ("range_emit" in names) == (nranges > 1), names
+        assert np.array_equal(np.concatenate(pieces), oracle.sais(text.tobytes()))
+        del t
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("nranges", [2, 9])
 def test_range_build_many_ranges(eng, oracle, nranges):
     """Dense (LDS-compacted) and sparse (direct-store) tiles of the range filter, raw and packed input."""
