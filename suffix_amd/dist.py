@@ -23,6 +23,7 @@ no collective after step 1.
 """
 import ctypes
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -156,18 +157,20 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
     tb = min(top_bits, sym_bits * max(1, spw))
     ph.mark("byte_hist")
 
-    # 1. the text on every GPU -- packed when the shards pack into whole words (bits/8 of the
-    #    raw volume over xGMI, and no rank packs the whole text), raw otherwise or on request.
-    #    Equal shard lengths that are multiples of the symbols-per-word: the common case of a
-    #    byte stream cut by the launcher; anything else takes the raw text.
-    packed_path = len(set(lens)) == 1 and (m % spw == 0) and m >= 64
+    # 1. the text on every GPU -- as packed symbol codes (bits/8 of the raw volume over xGMI, and no rank packs the
+    #    whole text) whenever every shard has at least 64 bytes; raw otherwise or on request.  A rank packs the words of
+    #    the GLOBAL word grid that lie wholly inside its shard; a word that straddles two shards (ragged shards, or shard
+    #    lengths that are no multiple of the symbols per word) and the last, partial word of the text are assembled on
+    #    every rank from the first / last 64 bytes of each shard, which are exchanged anyway (halo of the key histogram).
+    packed_path = min(lens) >= 64
     text = None
     if packed_path:
         # key bits near the end of a shard reach into the next shard: a 64-byte halo is enough
-        heads = torch.empty(64 * world, dtype=torch.uint8, device=dev)
-        _gather_flat(heads, shard[:64].contiguous(), group)
+        edge = torch.cat([shard[:64], shard[-64:]]).contiguous()
+        edges = torch.empty(128 * world, dtype=torch.uint8, device=dev)
+        _gather_flat(edges, edge, group)
         if rank + 1 < world:
-            local = torch.cat([shard, heads[64 * (rank + 1):64 * (rank + 2)]])
+            local = torch.cat([shard, edges[128 * (rank + 1):128 * (rank + 1) + 64]])
         else:
             local = shard
         hist_text, hist_n, hist_lo, hist_hi = local, local.numel(), 0, m
@@ -177,15 +180,29 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
         hist_text, hist_n, hist_lo, hist_hi = text, n, begin, begin + m
 
     # the big exchange (the packed shards) starts now and runs under the key histogram
-    packed = mine = packed_work = None
+    packed = mine = packed_work = allw = None
+    aligned = False
     if packed_path:
-        wps = m // spw                                             # words per shard
-        packed = torch.zeros(wps * world + 4, dtype=torch.int32, device=dev)   # + the zero tail keys read into
-        mine = torch.empty(wps, dtype=torch.int32, device=dev)
+        begins = [sum(lens[:r]) for r in range(world)]
+        q0 = [(b + spw - 1) // spw for b in begins]                # first word wholly inside shard r
+        q1 = [(b + ln) // spw for b, ln in zip(begins, lens)]      # one past its last whole word
+        nfull = [max(0, e - a) for a, e in zip(q0, q1)]
+        aligned = all(b % spw == 0 for b in begins) and len(set(nfull)) == 1 and n % spw == 0
+        packed = torch.zeros((n + spw - 1) // spw + 4, dtype=torch.int32, device=dev)   # + the zero tail keys read into
         scratch = torch.empty(256, dtype=torch.uint8, device=dev)
-        eng.check(eng.lib.sfx_pack_text_dev(_p(shard), m, _p(byte_bins), _p(scratch), _p(mine), wps, stream),
-                  "sfx_pack_text_dev")
-        packed_work = _gather_flat(packed[:wps * world], mine, group, async_op=True)
+        mxw = max(nfull)
+        mine = torch.zeros(max(mxw, 1), dtype=torch.int32, device=dev)
+        skip = q0[rank] * spw - begin
+        if nfull[rank]:
+            eng.check(eng.lib.sfx_pack_text_dev(_p(shard[skip:]), nfull[rank] * spw, _p(byte_bins), _p(scratch), _p(mine),
+                                                nfull[rank], stream), "sfx_pack_text_dev")
+        if aligned:
+            packed_work = _gather_flat(packed[:mxw * world], mine, group, async_op=True)
+        else:
+            allw = torch.empty(max(mxw, 1) * world, dtype=torch.int32, device=dev)
+            packed_work = _gather_flat(allw, mine, group, async_op=True)
+    if timings is not None:
+        timings["text_exchange"] = ("packed words" + ("" if aligned else " (ragged word grid)")) if packed_path else "raw bytes"
     ph.mark("all_gather_issue")
 
     # 3. bucket-boundary histogram
@@ -195,6 +212,34 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
     ph.mark("key_hist")
     if packed_work is not None:
         packed_work.wait()
+    if allw is not None:
+        # ragged: every rank's whole words to their place in the global word grid, then the words that straddle shards
+        mxw = max(max(nfull), 1)
+        for r in range(world):
+            if nfull[r]:
+                packed[q0[r]:q0[r] + nfull[r]] = allw[r * mxw:r * mxw + nfull[r]]
+        eb = edges.cpu().numpy()
+        present = (byte_bins > 0).cpu().numpy()
+        code = np.cumsum(present) - 1                              # dense symbol codes, as k_make_lut assigns them
+        def symbol(p):                                             # code of text position p near a shard boundary
+            r = max(k for k in range(world) if begins[k] <= p)
+            o = p - begins[r]
+            if o < 64:
+                return int(code[eb[128 * r + o]])
+            back = begins[r] + lens[r] - p                         # 1 .. 64 from the end of shard r
+            assert 1 <= back <= 64, (p, r)
+            return int(code[eb[128 * r + 128 - back]])
+        idx, val = [], []
+        for q in sorted(set([b // spw for b in begins[1:] if b % spw] + ([n // spw] if n % spw else []))):
+            w = 0
+            for j in range(spw):
+                p = q * spw + j
+                if p < n:
+                    w |= symbol(p) << ((spw - 1 - j) * sym_bits)
+            idx.append(q)
+            val.append(w - (1 << 32) if w >= (1 << 31) else w)
+        if idx:
+            packed[torch.tensor(idx, dtype=torch.int64, device=dev)] = torch.tensor(val, dtype=torch.int32, device=dev)
     ph.mark("all_gather_wait")
     dist.all_reduce(key_bins, op=dist.ReduceOp.SUM, group=group)
 

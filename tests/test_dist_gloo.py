@@ -43,6 +43,8 @@ else:
 timings = {{}}
 part, offset, n, text = sdist.build_sa_partitioned(shard, engine=eng, top_bits=10, return_text=True, timings=timings)
 assert "range_build" in timings and "key_hist" in timings, timings
+# every shard has >= 64 bytes: the text travels as packed symbol codes, ragged shards included
+assert timings["text_exchange"].startswith("packed words") and (kind != "ragged" or "ragged" in timings["text_exchange"]), timings
 if kind in ("periodic", "unary"):                          # repeats longer than text refinement can settle inside a slice
     assert "fallback" in timings, timings
 else:
