@@ -1234,8 +1234,8 @@ static uint64_t packed_words(uint64_t n, const Alphabet* a)
 constexpr uint64_t kTextFirstDivisor = 4;
 
 // ---- order-preserving code of the dense symbols (k_ht_keys, sfx_radix.hip) -------------------------
-// Optimal alphabetic binary tree over the symbol counts (dynamic programme over symbol ranges, O(sigma^3) <= 2.8 M steps
-// on the host); counts are floored so that no code is longer than kHtMaxLen bits.  Returns false when the code would
+// Optimal alphabetic binary tree over the symbol counts (dynamic programme over symbol ranges with Knuth's bounds on the
+// roots, O(sigma^2) on the host); counts are floored so that no code is longer than kHtMaxLen bits.  Returns false when the code would
 // not pay: the alphabet fills its fixed width (random bytes), or fewer than two symbols.
 struct HtHost {
     uint32_t ent[256];
@@ -1268,7 +1268,13 @@ static bool ht_build(const unsigned long long* counts256, int fixed_bits, HtHost
                 const int j = i + L - 1;
                 double best = 1e300;
                 int bk = i;
-                for (int k = i; k < j; k++) {
+                // (Knuth / Yao: the range weight is monotone and satisfies the quadrangle inequality, so an optimal root of
+                // (i, j) lies between those of (i, j - 1) and (i + 1, j) -- O(sigma^2) in all)
+                int klo = R[at(i, j - 1)], khi = R[at(i + 1, j)];
+                if (klo < i) klo = i;
+                if (khi > j - 1) khi = j - 1;
+                if (khi < klo) khi = klo;
+                for (int k = klo; k <= khi; k++) {
                     const double v = C[at(i, k)] + C[at(k + 1, j)];
                     if (v < best) { best = v; bk = k; }
                 }
@@ -1305,8 +1311,11 @@ static bool ht_build(const unsigned long long* counts256, int fixed_bits, HtHost
             unsigned used = 0, ends = 0;
             for (;;) {
                 const uint32_t win = used < (unsigned)kHtFastBits ? (wv << (32 - kHtFastBits)) << used : 0u;
-                int sym = 0;
-                for (int i = 0; i < ns; i++) if ((out->ent[i] & ~31u) <= win) sym = i;
+                int sym = 0;                                   // the last symbol whose code word is <= the window (code words ascend)
+                for (int lo_s = 0, hi_s = ns - 1; lo_s <= hi_s;) {
+                    const int mid = (lo_s + hi_s) / 2;
+                    if ((out->ent[mid] & ~31u) <= win) { sym = mid; lo_s = mid + 1; } else { hi_s = mid - 1; }
+                }
                 const unsigned l = out->ent[sym] & 31u;
                 if (used + l > (unsigned)kHtFastBits) break;
                 used += l;
@@ -1779,10 +1788,9 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
                 // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
                 uint32_t md = 0;
                 SFX_TRY(read_back(&md, b.ht + 256, sizeof(md), st));
-                if (md != 0xFFFFFFFFu) {
-                    if ((uint64_t)md < h) return SFX_ERR_INTERNAL;           // (every kept bucket went at least one level down)
-                    h = md;
-                }
+                // (every kept bucket went at least one level down: h is a bound of its own; a 16-bit depth that wrapped
+                // is a smaller, still valid, bound of its bucket and must not pull h down)
+                if (md != 0xFFFFFFFFu && (uint64_t)md > h) h = md;
                 SFX_TRY(build_ranks(b, sa, n, V_next, S_next, kept, isa, st, stats));
                 rank_mode = true;
             } else if (!isa && (stalled * 2 > n || stats.text_rounds > (uint32_t)kMaxTextOnlyRounds || too_deep)) {

@@ -206,10 +206,11 @@ k_lcp_intervals(Pyramid py, uint64_t n, uint64_t tiles_per_block, uint32_t* __re
             if (threadIdx.x == 0) esc_base = atomicAdd(open_count, (unsigned long long)cnt);
             __syncthreads();
             const unsigned long long at = esc_base;
-            if (at + cnt <= open_cap) {
-                for (unsigned k = threadIdx.x; k < cnt; k += kBlock) open_list[at + k] = esc[k];
-            } else {                                          // (the list is full -- a monotone LCP array: finished here, slowly)
-                for (unsigned k = threadIdx.x; k < cnt; k += kBlock) iv_finish(py, n, esc[k], lb, rb, node);
+            // (what does not fit the list -- a monotone LCP array -- is finished here, slowly; every slot below the
+            // capacity that was reserved is written, so the second launch reads no gap)
+            for (unsigned k = threadIdx.x; k < cnt; k += kBlock) {
+                if (at + k < open_cap) open_list[at + k] = esc[k];
+                else iv_finish(py, n, esc[k], lb, rb, node);
             }
         }
         __syncthreads();

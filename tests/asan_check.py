@@ -7,6 +7,7 @@ same C ABI.  Not part of the pytest suite (several minutes); run by hand after k
     LD_PRELOAD=$(gcc -print-file-name=libasan.so) \\
     ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 \\
     SFX_LCP_DIRECT_MIN=8 python tests/asan_check.py            # variants: add SFX_PARTITION_MIN=1 SFX_MAX_GRID=3 SFX_QUERY_PHASE_MIN=1 SFX_HYBRID_MIN=1 [SFX_HYBRID_CAP=100]
+                                                                # SFX_FORCE_KEY64=1 SFX_HT_MIN=1 [SFX_DEEP_ITERS=1 SFX_TILE_SMALL=1 SFX_SEG_SMALL=1]
 """
 import os
 import sys
@@ -64,3 +65,26 @@ for t in (planted(5000, b"ACGT", 16, 20) + planted(2000, b"ACGT", 16, 24), plant
     st = SuffixTable(t, engine=eng)
     assert np.array_equal(st.table(), oracle.sais(t))
 print("large buckets + rank rounds ok")
+# round 3: deep text rounds (per-bucket depths, residues, fused LCP emission), compressed 64-bit keys (SFX_FORCE_KEY64=1
+# SFX_HT_MIN=1), the suffix-tree topology's open list on a monotone LCP array, slices through the hybrid route
+# (SFX_HYBRID_MIN=1: keys relative to the range's first key)
+rng2 = np.random.default_rng(2024)
+for sigma, n0 in ((4, 9000), (60, 6000), (200, 6000)):
+    body = rng2.integers(0, sigma, n0, dtype=np.uint8)
+    parts = [body.tobytes()]
+    for _ in range(8):
+        a = int(rng2.integers(0, n0 - 400)); ln = int(rng2.integers(20, 300)); cp = int(rng2.integers(2, 30))
+        for _ in range(cp):
+            parts.append(body[a:a + ln].tobytes() + bytes(rng2.integers(0, sigma, 3, dtype=np.uint8).tolist()))
+    t = b"".join(parts)
+    exp = oracle.sais(t)
+    st2, lcp2 = SuffixTable.new_with_lcp(t, engine=eng)
+    assert np.array_equal(st2.table(), exp) and np.array_equal(lcp2, oracle.lcp_kasai(t, exp))
+zipf = np.minimum(np.random.default_rng(99).zipf(1.3, 12000), 200).astype(np.uint8).tobytes()
+for t in (zipf + bytes([250]) + zipf[:2000], _gen.utf8_mixed(9000).tobytes(), _gen.english_like(20000, seed=5).tobytes()):
+    assert np.array_equal(SuffixTable(t, engine=eng).table(), oracle.sais(t))
+print("deep rounds + compressed keys ok")
+_cases.suffix_tree_at_scale(eng, oracle, b"a" * 9000 + b"b" + _gen.dna(7000, seed=2).tobytes(), device="cpu")
+for nr in (1, 3):
+    _cases.range_slices(eng, oracle, _gen.dna(56001, seed=8).tobytes(), nr, packed=True)
+print("tree at scale + slice hybrid ok")

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import _cases
+import _gen
 from suffix_amd import Engine
 
 EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
@@ -75,6 +76,13 @@ def test_index_directory_queries(emu, oracle):
 
 def test_suffix_tree_topology_and_doc_lookup(emu, oracle):
     _cases.suffix_tree_topology(emu, oracle)
+
+
+def test_suffix_tree_open_list_overflow(emu, oracle):
+    """A monotone LCP array (a^9000 b ...): every boundary's search to the right leaves its tile, more of them than the
+    list of open searches holds (n / 16 + 4096) -- the tiles finish the overflow themselves and the second launch must
+    not read a slot that was reserved but never written (found by the AddressSanitizer run)."""
+    _cases.suffix_tree_at_scale(emu, oracle, b"a" * 9000 + b"b" + _gen.dna(3000, seed=2).tobytes(), device="cpu")
 
 
 def test_random_medium_sweep(emu, oracle):
