@@ -38,6 +38,7 @@
 // The same kernels serve the range-partitioned (multi-GPU) build, where a rank
 // sorts only the suffixes whose leading key bits fall in its bucket range and
 // refines with text rounds only (no ranks of foreign suffixes needed).
+#include <math.h>
 #include <stdio.h>
 #include <vector>
 #include <string.h>
@@ -1192,12 +1193,22 @@ struct Alphabet {
     int bits;           // bits per symbol
     int spw;            // symbols per packed word = floor(32/bits)
     int kbits;          // bits * spw (<= 32)
+    double h0;          // order-0 entropy in bits per symbol when the bins are the byte COUNTS of the text, else < 0
 };
 
-static Alphabet make_alphabet(const unsigned long long* bins)
+// n: length of the text the bins describe (bins that sum to it are counts, not presence flags)
+static Alphabet make_alphabet(const unsigned long long* bins, uint64_t n = 0)
 {
     Alphabet a;
     a.sigma = 0;
+    a.h0 = -1.0;
+    unsigned long long total = 0;
+    for (int c = 0; c < 256; c++) total += bins[c];
+    if (n > 256 && total == n) {
+        a.h0 = 0.0;
+        for (int c = 0; c < 256; c++)
+            if (bins[c]) { const double q = (double)bins[c] / (double)n; a.h0 -= q * log2(q); }
+    }
     for (int c = 0; c < 256; c++) if (bins[c]) a.sigma++;
     a.bits = bits_for(a.sigma > 1 ? a.sigma - 1 : 1);
     a.spw = 32 / a.bits;
@@ -1215,9 +1226,15 @@ static void choose_key(const Alphabet& a, uint64_t n, int* key_bits, int* cpk)
     int spw = a.spw;
     int l2 = bits_for(a.sigma) - 1;                 // floor(log2 sigma), sigma >= 1
     if (l2 < 1) l2 = 1;
+    // what a symbol tells apart: log2 sigma on evenly used symbols; the order-0 entropy when the counts are known and the
+    // alphabet is large enough to be used unevenly (natural-language text: 4.2 bits of 7 -- four symbols of a 32-bit
+    // key leave nearly every suffix of a megabyte tied: 8 MB of English-like text 3.1 ms with 32-bit keys, 1.9 ms with
+    // 64-bit compressed keys; 4 MB 2.25 / 1.49; 1 MB 1.18 / 0.99).  Small alphabets (DNA) keep the first rule.
+    double per = (double)l2;
+    if (a.h0 > 0.0 && a.sigma > 16 && a.h0 < per) per = a.h0;
     // SFX_FORCE_KEY64=1 is a test hook (the 64-bit-key path on inputs small enough for the emulator)
     static const bool force64 = [] { const char* e = dev_env("SFX_FORCE_KEY64"); return e && atoi(e) != 0; }();
-    if (!force64 && spw * l2 >= bits_for(n) + 1) { *key_bits = 32; *cpk = spw; }
+    if (!force64 && (double)spw * per >= (double)(bits_for(n) + 1)) { *key_bits = 32; *cpk = spw; }
     else { *key_bits = 64; *cpk = 2 * spw; }
 }
 
@@ -1501,7 +1518,7 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
     unsigned long long host_bins[256];
     if (!packed_in) SFX_LAUNCH("make_lut", 0.0, k_make_lut, 1, kBlock, st, d_bins, d_lut);
     SFX_TRY(read_back(host_bins, d_bins, sizeof(host_bins), st));
-    *alpha = make_alphabet(host_bins);
+    *alpha = make_alphabet(host_bins, n);
     if (packed_in) {
         pt->words = packed_in;
         pt->n = n;
@@ -1921,6 +1938,19 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
     stats.key_bits = (uint32_t)key_bits;
     stats.symbols_per_key = (uint32_t)cpk;
     if (cpk_out) *cpk_out = cpk;
+    // a large alphabet may be used unevenly: the counts decide (one more pass over the text, only where it can matter)
+    unsigned long long counts[256];
+    bool have_counts = false;
+    if (key_bits == 32 && alpha.sigma > 16 && n >= (1ull << 16)) {
+        SFX_TRY(byte_histogram_dev(d_text, 0, n, reinterpret_cast<uint64_t*>(b.bins), st));
+        SFX_TRY(read_back(counts, b.bins, sizeof(counts), st));
+        have_counts = true;
+        Alphabet counted = make_alphabet(counts, n);
+        choose_key(counted, n, &key_bits, &cpk);
+        stats.key_bits = (uint32_t)key_bits;
+        stats.symbols_per_key = (uint32_t)cpk;
+        if (cpk_out) *cpk_out = cpk;
+    }
     if (key_bits == 32) return sort_and_refine<uint32_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats, 0, lcp_fuse);
     // 64-bit keys: compressed when the symbol counts say it pays (natural-language text: 14 symbols per key instead of 8).
     // SFX_HT=0 (development): fixed-width keys.
@@ -1929,9 +1959,10 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
     HtHost ht;
     bool use_ht = false;
     if (ht_on && n >= ht_min) {
-        SFX_TRY(byte_histogram_dev(d_text, 0, n, reinterpret_cast<uint64_t*>(b.bins), st));
-        unsigned long long counts[256];
-        SFX_TRY(read_back(counts, b.bins, sizeof(counts), st));
+        if (!have_counts) {
+            SFX_TRY(byte_histogram_dev(d_text, 0, n, reinterpret_cast<uint64_t*>(b.bins), st));
+            SFX_TRY(read_back(counts, b.bins, sizeof(counts), st));
+        }
         use_ht = ht_build(counts, alpha.bits, &ht);
         if (use_ht) {
             stats.symbols_per_key = (uint32_t)(64.0 / ht.avg_len);           // (on average: the code words differ in length)
@@ -2001,9 +2032,9 @@ int key_histogram_dev(const uint8_t* d_text, uint64_t n, uint64_t begin, uint64_
     if (begin == end) return SFX_OK;
     unsigned long long host_bins[256];
     SFX_TRY(read_back(host_bins, d_byte_bins, sizeof(host_bins), st));
-    const Alphabet alpha = make_alphabet(host_bins);
+    const Alphabet alpha = make_alphabet(host_bins, n);
     int key_bits, cpk;
-    choose_key(alpha, n, &key_bits, &cpk);                  // (key width from the WHOLE text's length)
+    choose_key(alpha, n, &key_bits, &cpk);                  // (key width from the WHOLE text's length and counts)
     if (alpha.bits * cpk < top_bits) return SFX_ERR_ARG;
     const int nsym = (top_bits + alpha.bits - 1) / alpha.bits;
     const uint64_t cnt = end - begin;

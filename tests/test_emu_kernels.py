@@ -85,6 +85,23 @@ def test_suffix_tree_open_list_overflow(emu, oracle):
     _cases.suffix_tree_at_scale(emu, oracle, b"a" * 9000 + b"b" + _gen.dna(3000, seed=2).tobytes(), device="cpu")
 
 
+def test_key_width_from_symbol_counts(emu, oracle):
+    """A large alphabet used unevenly (natural-language text: 4.2 bits of entropy in 7-bit symbols; here Zipf bytes) takes 64-bit keys --
+    compressed ones -- from 2^16 bytes on, although 4 symbols x log2(sigma) would cover log2(n) + 1 bits; the same
+    alphabet used evenly keeps 32-bit keys (choose_key, sfx_sa.hip)."""
+    from suffix_amd import SuffixTable
+    zipf = np.minimum(np.random.default_rng(21).zipf(1.3, 66000), 150).astype(np.uint8).tobytes()     # ~3 bits of entropy in 8-bit symbols
+    for text, bits in ((zipf, 64), (_gen.uniform_bytes(66000, 150, 4, base=40).tobytes(), 32)):
+        emu.profile(True); emu.profile_reset()
+        st = SuffixTable(text, engine=emu)
+        sa = st.table()
+        names = {r["name"] for r in emu.profile_report()}
+        emu.profile(False)
+        stats = emu.build_stats()
+        assert stats["key_bits"] == bits and ("ht_keys" in names) == (bits == 64), (stats, sorted(names))
+        assert np.array_equal(sa, oracle.sais(text))
+
+
 def test_random_medium_sweep(emu, oracle):
     _cases.random_medium_sweep(emu, oracle, iters=7, max_len=4000, seed=5)
 
