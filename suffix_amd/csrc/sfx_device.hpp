@@ -153,6 +153,12 @@ __device__ __forceinline__ uint32_t rank_round(unsigned d, unsigned long long* f
 // positions [j*spw, (j+1)*spw) in its low kbits = bits*spw bits; positions past the
 // end of the text read as 0 and the array carries 3 extra zero words, so a key can be
 // fetched at any position < n with 2-3 aligned loads and a funnel shift.
+// Occupancy request of a kernel (waves per SIMD: the compiler fits the registers to it).  The CPU emulator of the tests
+// (tests/emu/hip/hip_runtime.h) defines it away.
+#ifndef SFX_WAVES_PER_EU
+#define SFX_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
+
 struct PackedText {
     const uint32_t* words;
     uint64_t n;

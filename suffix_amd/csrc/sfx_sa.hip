@@ -722,8 +722,10 @@ k_groups_scan(uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep
 // no rank array, few kept elements -- only the set bits of the keep mask are visited.  SUB = 1
 // is the dense form (every element writes its SA slot and / or rank): 8 elements per thread
 // keep 4x as many gathers in flight.
-template <class KeyT, int SUB>
-__global__ void __launch_bounds__(kBlock)
+// HT / PAIRS: the instantiation carries the end-mask table of compressed keys / the digit counts of the rank pairs in LDS
+// (a launch without them keeps 32 KB of staging and nothing else: five workgroups per CU instead of three)
+template <class KeyT, int SUB, bool HT = true, bool PAIRS = true>
+__global__ void __launch_bounds__(kBlock) SFX_WAVES_PER_EU(SUB == 1 ? 4 : 1, 8)
 k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                const uint32_t* __restrict__ S, uint64_t m, uint64_t chunk,
                const uint32_t* __restrict__ part_head, const uint32_t* __restrict__ part_keep,
@@ -740,9 +742,9 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     // started -- same head slot, same rank: no pair, no write.  The pairs of a chunk then start at part_pairs[chunk].
     // ht.ent (initial bucket pass over compressed keys): the depth of a bucket is what its key holds, ht_depth(K);
     // min_depth: smallest depth given to a kept element (the rank rounds' h, should the text rounds give way)
-    __shared__ uint32_t s_t12[(1 << kHtFastBits) / 2];
+    __shared__ uint32_t s_t12[HT ? (1 << kHtFastBits) / 2 : 1];
     __shared__ uint32_t s_min;
-    if (ht.ent)
+    if (HT && ht.ent)
         for (unsigned i = threadIdx.x; i < (1u << kHtFastBits) / 2u; i += kBlock) s_t12[i] = ht.ent[kHtTableWords + i];
     if (ht.ent || min_depth) {
         if (threadIdx.x == 0) s_min = 0xFFFFFFFFu;
@@ -754,7 +756,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     // pair_hist (with rank_pairs): digit counts of the passes that partition the pairs by suffix index (bits [pair_lo,
     // pair_nb), 8 per pass, at most 3) -- counted here, where the pairs are made, instead of by a pass over them
     constexpr int kPairPasses = 3;
-    __shared__ uint32_t ph[SUB == 1 ? kWavesPerBlock : 1][kPairPasses][kRadixDev];
+    __shared__ uint32_t ph[(SUB == 1 && PAIRS) ? kWavesPerBlock : 1][kPairPasses][kRadixDev];
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int pair_passes = pair_hist ? (pair_nb - pair_lo + 7) / 8 : 0;
     // dense form: what a tile keeps (and its (suffix, rank) pairs) leaves through LDS.  A thread's elements are 8
@@ -762,7 +764,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     // times -- and a line write costs the CU the same whether it is partial or whole (radix pass).
     __shared__ uint64_t stg_a[SUB == 1 ? kBlock * kGroupItems : 1];     // (slot, suffix) of the kept; then the pairs
     __shared__ uint64_t stg_b[SUB == 1 ? kBlock * kGroupItems : 1];     // (bucket id, depth) of the kept
-    if (SUB == 1 && pair_hist) {
+    if (SUB == 1 && PAIRS && pair_hist) {
         for (unsigned i = tid; i < (unsigned)(kWavesPerBlock * kPairPasses * kRadixDev); i += kBlock) (&ph[0][0][0])[i] = 0u;
         __syncthreads();
     }
@@ -851,7 +853,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                 G_next[pos] = pos - ((uint32_t)i - my_head);
                 if (Hd_next) {
                     uint32_t d = Hd ? dmax<uint32_t>(Hd[i], hd_floor) : hd_floor;
-                    if (ht.ent) {
+                    if (HT && ht.ent) {
                         unsigned used = 0, cnt = 0;
                         const uint64_t k64 = (uint64_t)K[i];
                         while (ht_depth_step(k64, used, cnt, reinterpret_cast<const uint16_t*>(s_t12))) {}
@@ -868,7 +870,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
             KeyT kk[kGroupItems];                                // (compressed keys: the depths are read off them -- fetched with the rest)
 #pragma unroll
             for (int j = 0; j < kGroupItems; j++) kk[j] = KeyT(0);
-            if (ht.ent && k8) {
+            if (HT && ht.ent && k8) {
                 if (v8 == 0xFFu) {
                     struct alignas(16) KV { KeyT v[16 / sizeof(KeyT)]; };
 #pragma unroll
@@ -883,7 +885,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                 }
             }
             uint32_t dep[kGroupItems];
-            if (ht.ent && k8) {                                  // the depths of the kept elements' buckets, off their keys
+            if (HT && ht.ent && k8) {                            // the depths of the kept elements' buckets, off their keys
                 uint64_t k64[kGroupItems];
 #pragma unroll
                 for (int j = 0; j < kGroupItems; j++) k64[j] = (uint64_t)kk[j];
@@ -935,7 +937,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                 for (int j = 0; j < kGroupItems; j++) {
                     if ((pairm >> j) & 1u) {
                         stg_a[at++] = ((uint64_t)suffix[j] << 32) | (uint64_t)head_slot[j];
-                        if (pair_hist) {
+                        if (PAIRS && pair_hist) {
 #pragma unroll
                             for (int p = 0; p < kPairPasses; p++) {
                                 const int sh = pair_lo + 8 * p, nbits = pair_nb - sh < 8 ? pair_nb - sh : 8;
@@ -991,7 +993,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         __syncthreads();
         if (tid == 0 && s_min != 0xFFFFFFFFu) atomicMin(min_depth, s_min);
     }
-    if (SUB == 1 && pair_hist) {
+    if (SUB == 1 && PAIRS && pair_hist) {
         __syncthreads();
         for (int p = 0; p < pair_passes; p++) {
             uint32_t c = 0;
@@ -1485,11 +1487,19 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
         SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, kApplySub>), ch.blocks, kBlock, st, K, V, S, m,
                    ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
                    b.G, R_next, 1, pairs, (const uint16_t*)b.F, (uint32_t*)nullptr, 0, 0, Hd, Hd_next, hd_floor, ht, min_depth);
-    else
-        SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, 1>), ch.blocks, kBlock, st, K, V, S, m,
-                   ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
-                   b.G, R_next, sa_mode, pairs, (const uint16_t*)b.F, pair_hist, pair_lo, pair_nb, Hd, Hd_next, hd_floor, ht, min_depth,
-                   rank_flags, part_pairs);
+    else {
+#define SFX_APPLY(HTV, PV)                                                                                                          \
+        SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, 1, HTV, PV>), ch.blocks, kBlock, st, K, V, S, m,                               \
+                   ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,            \
+                   b.G, R_next, sa_mode, pairs, (const uint16_t*)b.F, pair_hist, pair_lo, pair_nb, Hd, Hd_next, hd_floor, ht, min_depth, \
+                   rank_flags, part_pairs)
+        if (ht.ent && pair_hist) return SFX_ERR_INTERNAL;      // (compressed keys belong to the initial pass, pairs to rank rounds)
+        if (sizeof(KeyT) == 8 && ht.ent) SFX_APPLY((sizeof(KeyT) == 8), false);
+        else if (sizeof(KeyT) == 8 && pair_hist) SFX_APPLY(false, (sizeof(KeyT) == 8));
+        else if (ht.ent || pair_hist) return SFX_ERR_INTERNAL;
+        else SFX_APPLY(false, false);
+#undef SFX_APPLY
+    }
     if (pairs && pair_count) SFX_TRY(scatter_pairs_u32(pairs, pairs_tmp, pair_count, n, isa, b.hist, st, &stats, pair_blocks));
     return SFX_OK;
 }

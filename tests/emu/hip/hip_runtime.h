@@ -26,6 +26,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static
+#define SFX_WAVES_PER_EU(lo, hi)                 /* occupancy requests mean nothing to the emulator */
 
 struct dim3 {
     unsigned x, y, z;
