@@ -756,16 +756,18 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
     // pair_hist (with rank_pairs): digit counts of the passes that partition the pairs by suffix index (bits [pair_lo,
     // pair_nb), 8 per pass, at most 3) -- counted here, where the pairs are made, instead of by a pass over them
     constexpr int kPairPasses = 3;
-    __shared__ uint32_t ph[(SUB == 1 && PAIRS) ? kWavesPerBlock : 1][kPairPasses][kRadixDev];
+    constexpr int kPhCopies = 2;                                          // (two waves share a copy: 6 KB, so that four workgroups fit a CU)
+    __shared__ uint32_t ph[(SUB == 1 && PAIRS) ? kPhCopies : 1][kPairPasses][kRadixDev];
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int pair_passes = pair_hist ? (pair_nb - pair_lo + 7) / 8 : 0;
     // dense form: what a tile keeps (and its (suffix, rank) pairs) leaves through LDS.  A thread's elements are 8
     // consecutive ones, so direct stores put 4 bytes into each of 16 lines per instruction and touch every line eight
     // times -- and a line write costs the CU the same whether it is partial or whole (radix pass).
     __shared__ uint64_t stg_a[SUB == 1 ? kBlock * kGroupItems : 1];     // (slot, suffix) of the kept; then the pairs
-    __shared__ uint64_t stg_b[SUB == 1 ? kBlock * kGroupItems : 1];     // (bucket id, depth) of the kept
+    __shared__ uint32_t stg_g[SUB == 1 ? kBlock * kGroupItems : 1];     // bucket id of the kept
+    __shared__ uint16_t stg_d[SUB == 1 ? kBlock * kGroupItems : 1];     // ... and the depth of their bucket
     if (SUB == 1 && PAIRS && pair_hist) {
-        for (unsigned i = tid; i < (unsigned)(kWavesPerBlock * kPairPasses * kRadixDev); i += kBlock) (&ph[0][0][0])[i] = 0u;
+        for (unsigned i = tid; i < (unsigned)(kPhCopies * kPairPasses * kRadixDev); i += kBlock) (&ph[0][0][0])[i] = 0u;
         __syncthreads();
     }
     uint64_t begin = (uint64_t)blockIdx.x * chunk;
@@ -941,7 +943,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
 #pragma unroll
                             for (int p = 0; p < kPairPasses; p++) {
                                 const int sh = pair_lo + 8 * p, nbits = pair_nb - sh < 8 ? pair_nb - sh : 8;
-                                if (p < pair_passes) atomicAdd(&ph[w][p][(suffix[j] >> sh) & ((1u << nbits) - 1u)], 1u);
+                                if (p < pair_passes) atomicAdd(&ph[w % kPhCopies][p][(suffix[j] >> sh) & ((1u << nbits) - 1u)], 1u);
                             }
                         }
                     }
@@ -966,7 +968,8 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                             const uint32_t gpos = c_keep + local_keep;
                             if (R_next) R_next[gpos] = head_slot[j];
                             stg_a[local_keep] = ((uint64_t)slot[j] << 32) | (uint64_t)suffix[j];
-                            stg_b[local_keep] = ((uint64_t)(gpos - back) << 16) | (uint64_t)dep[j];
+                            stg_g[local_keep] = gpos - back;
+                            stg_d[local_keep] = (uint16_t)dep[j];
                             my_min = dmin(my_min, dep[j]);
                             local_keep++;
                         }
@@ -975,11 +978,11 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
             }
             __syncthreads();
             for (unsigned k = tid; k < tot_a; k += kBlock) {
-                const uint64_t e = stg_a[k], g = stg_b[k];
+                const uint64_t e = stg_a[k];
                 S_next[c_keep + k] = (uint32_t)(e >> 32);
                 V_next[c_keep + k] = (uint32_t)e;
-                G_next[c_keep + k] = (uint32_t)(g >> 16);        // bucket id = position of its head in the new list
-                if (Hd_next) Hd_next[c_keep + k] = (uint16_t)g;
+                G_next[c_keep + k] = stg_g[k];                   // bucket id = position of its head in the new list
+                if (Hd_next) Hd_next[c_keep + k] = stg_d[k];
             }
             __syncthreads();
         }
@@ -998,7 +1001,7 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
         for (int p = 0; p < pair_passes; p++) {
             uint32_t c = 0;
 #pragma unroll
-            for (int k = 0; k < kWavesPerBlock; k++) c += ph[k][p][tid];
+            for (int k = 0; k < kPhCopies; k++) c += ph[k][p][tid];
             pair_hist[((uint64_t)p * kRadixDev + tid) * gridDim.x + blockIdx.x] = c;
         }
     }
