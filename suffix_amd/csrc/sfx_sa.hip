@@ -1486,10 +1486,16 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
     const char* name = sizeof(KeyT) == 4 ? "groups_apply_u32" : "groups_apply_u64";
     const double algo = (double)m * (0.25 + (sa_in_place ? 0 : 8) + (isa ? 4 : 0) + (S ? 4 : 0));
     uint32_t* sa_arg = sa_in_place ? (uint32_t*)nullptr /* V is the SA */ : sa;
-    if (sa_in_place && !isa && kept * kSparseApplyDivisor <= m)
-        SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, kApplySub>), ch.blocks, kBlock, st, K, V, S, m,
-                   ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,
-                   b.G, R_next, 1, pairs, (const uint16_t*)b.F, (uint32_t*)nullptr, 0, 0, Hd, Hd_next, hd_floor, ht, min_depth);
+    if (sa_in_place && !isa && kept * kSparseApplyDivisor <= m) {
+#define SFX_APPLY_SPARSE(HTV)                                                                                                       \
+        SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, kApplySub, HTV, false>), ch.blocks, kBlock, st, K, V, S, m,                    \
+                   ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, sa_arg, isa, S_next, V_next,            \
+                   b.G, R_next, 1, pairs, (const uint16_t*)b.F, (uint32_t*)nullptr, 0, 0, Hd, Hd_next, hd_floor, ht, min_depth)
+        if (sizeof(KeyT) == 8 && ht.ent) SFX_APPLY_SPARSE((sizeof(KeyT) == 8));
+        else if (ht.ent) return SFX_ERR_INTERNAL;
+        else SFX_APPLY_SPARSE(false);
+#undef SFX_APPLY_SPARSE
+    }
     else {
 #define SFX_APPLY(HTV, PV)                                                                                                          \
         SFX_LAUNCH(name, algo, (k_groups_apply<KeyT, 1, HTV, PV>), ch.blocks, kBlock, st, K, V, S, m,                               \
@@ -1636,6 +1642,12 @@ static int small_groups_pass(const PackedText& pt, uint64_t h, SaBuffers& b, uin
     stats.small_bucket_resolved += cnt - left;
     *m = left;
     return SFX_OK;
+}
+__global__ void __launch_bounds__(kBlock)
+k_fill_u16(uint16_t* __restrict__ p, uint64_t n, uint16_t v)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 // worth it when the average unresolved bucket is small
 static bool small_groups_pay(uint64_t m, uint64_t groups) { return m > 0 && groups * 4 >= m; }
@@ -1905,12 +1917,18 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         if (md == 0xFFFFFFFFu || md == 0) return SFX_ERR_INTERNAL;
         h0 = md;
     } else {
+        // (fixed-width keys: every bucket of the first list shares cpk symbols -- the depths are filled in below, for what
+        // the direct pass leaves: on uniform DNA that is nothing, and the bucket pass saves a fourth scattered store)
         SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place ? 1 : 0, pt.n, stats,
-                                  kept, nullptr, b.Hd0, (uint32_t)cpk));
+                                  kept, nullptr, nullptr, (uint32_t)cpk));
     }
     uint32_t* S_cur = b.S0;
     if (small_groups_pay(kept, groups))
-        SFX_TRY(small_groups_pass(pt, h0, b, sa, nullptr, &S_cur, &V_next, &kept, st, stats, lcp_fuse, true));
+        SFX_TRY(small_groups_pass(pt, h0, b, sa, nullptr, &S_cur, &V_next, &kept, st, stats, lcp_fuse, ht != nullptr));
+    if (!ht && kept > 0) {
+        const unsigned grid = (unsigned)dmin<uint64_t>((kept + kBlock * 4 - 1) / (kBlock * 4), kMaxGrid);
+        SFX_LAUNCH("depth_fill", (double)kept * 2, k_fill_u16, grid, kBlock, st, hd_of(b, S_cur), kept, (uint16_t)cpk);
+    }
     return refine(pt, (int)h0, b, sa, isa, S_cur, V_next, kept, st, stats, lcp_fuse);
 }
 
