@@ -915,7 +915,12 @@ static int large_phase(const KeyFn& keyfn, const TileRound& r, uint32_t nseg, ui
     if (singles) {
         const uint2* segs = reinterpret_cast<const uint2*>(r.seg.segs);
         const unsigned grid = (unsigned)dmin<uint64_t>(nseg, (uint64_t)grid_cap() * 2);
-        SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<4, 16, KeyFn>), grid, 4 * kWave, st, keyfn, segs, nseg, 0u, 4096u,
+        // (most large buckets are small ones: up to 1024 members a workgroup needs 12 KB of LDS instead of 37 -- thirteen
+        // of them share a CU instead of four, and the kernel waits on its gathers: config 3 13.0 -> 11.5 ms.  512 threads x 8
+        // for 1025 .. 4096 members: 11.9)
+        SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<4, 4, KeyFn>), grid, 4 * kWave, st, keyfn, segs, nseg, 0u, 1024u,
+                   r.V, r.F8, r.emit, r.Hd, r.wsym);
+        SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<4, 16, KeyFn>), grid, 4 * kWave, st, keyfn, segs, nseg, 1024u, 4096u,
                    r.V, r.F8, r.emit, r.Hd, r.wsym);
         if (top > 4096u) {
             SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<16, 11, KeyFn>), dmin(grid, grid_cap()), 16 * kWave, st,
