@@ -1345,6 +1345,7 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
           uint64_t* __restrict__ K, uint32_t* __restrict__ partial)
 {
     __shared__ uint32_t s_tab[256];
+    __shared__ uint32_t s_words[(kHtTile + kHtPad) / 4 + 4];            // the tile's packed words (at least 4 symbols per word)
     __shared__ uint32_t s_ent[kHtTile + kHtPad + (kHtTile + kHtPad) / 8 + 1];
     __shared__ uint64_t s_key[kHtTile + kHtTile / 8];
     __shared__ uint32_t h[kMaxPasses][kRadix];                       // (one copy: the key bytes are spread evenly)
@@ -1358,11 +1359,22 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
     for (uint64_t tile = tile0; tile < tile0 + tiles_per_block; tile++) {
         const uint64_t base = tile * kHtTile;
         if (base >= m) break;
+        // the tile's packed words first, two or three independent loads per thread (a load per symbol made the tile wait
+        // for eight global round trips in a row: 5.9 ms per 10^9 positions, most of it latency)
+        const uint64_t q0 = packed_word_index(t, base);
+        const uint64_t qlast = (t.n + (uint64_t)t.spw - 1) / (uint64_t)t.spw + 2;         // (three zero words behind the text)
+        const unsigned nw = (unsigned)(packed_word_index(t, base + kHtTile + kHtPad - 1) - q0) + 1u;
+#pragma unroll
+        for (int k = 0; k < (int)(((kHtTile + kHtPad) / 4 + 4 + kBlock - 1) / kBlock); k++) {
+            const unsigned w = tid + (unsigned)k * kBlock;
+            if (w < nw) s_words[w] = q0 + w <= qlast ? t.words[q0 + w] : 0u;
+        }
+        __syncthreads();
         for (unsigned i = tid; i < (unsigned)(kHtTile + kHtPad); i += kBlock) {
             const uint64_t p = base + i;                     // (positions past the text read as the padding's zero symbol)
             const uint64_t q = packed_word_index(t, p);
             const unsigned off = (unsigned)(p - q * (uint64_t)t.spw);
-            s_ent[ht_skew(i)] = s_tab[p < t.n ? (t.words[q] >> (((unsigned)t.spw - 1u - off) * bits)) & smask : 0u];
+            s_ent[ht_skew(i)] = s_tab[p < t.n ? (s_words[(unsigned)(q - q0)] >> (((unsigned)t.spw - 1u - off) * bits)) & smask : 0u];
         }
         __syncthreads();
         {
