@@ -269,12 +269,18 @@ constexpr unsigned kHtMaxSym = 16;                  // symbols a key is made fro
 // the host: ht_build) -- two or three symbols per look-up, and where fewer than 12 key bits are left the ends beyond
 // them are masked off.  No code is longer than 12 bits (ht_build floors the counts until that holds).
 constexpr int kHtFastBits = 12;
+// Bits of a compressed key that are sorted (and mean anything): the top kHtKeyBits of the 64-bit word, the rest is zero.
+// (56 = seven radix passes instead of eight was measured on 1 GB texts: one 7 ms pass less, but 12.1 symbols of
+// English-like text per key instead of 13.8 leave 649 M suffixes to the rounds instead of 540 M -- 116.9 against 111.4 ms;
+// mixed-script UTF-8 229 against 223, near-duplicate documents 399 against 390.  All 64 bits it is.)
+constexpr int kHtKeyBits = 64;
+static_assert(kHtKeyBits % 8 == 0 && kHtKeyBits >= 32 && kHtKeyBits <= 64, "whole radix digits");
 // one step of the decode of `key` from bit `used` on; returns false when the key is exhausted
 __device__ __forceinline__ bool ht_depth_step(uint64_t key, unsigned& used, unsigned& cnt, const uint16_t* t12)
 {
-    if (used >= 64u || cnt >= kHtMaxSym) return false;
+    if (used >= (unsigned)kHtKeyBits || cnt >= kHtMaxSym) return false;
     unsigned ends = t12[(unsigned)((key << used) >> (64 - kHtFastBits))];
-    const unsigned left = 64u - used;
+    const unsigned left = (unsigned)kHtKeyBits - used;
     if (left < (unsigned)kHtFastBits) ends &= (1u << left) - 1u;
     if (!ends) return false;                             // (no code ends inside what is left; with 12 bits left one always does)
     cnt += (unsigned)__popc(ends);

@@ -1391,7 +1391,7 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
                     if (nb + len > 64u) lo |= c << (64u - nb);           // (nb >= 38 here: the shift is < 64)
                     nb += len;
                 }
-                s_key[ht_skew(i)] = hi;
+                s_key[ht_skew(i)] = kHtKeyBits == 64 ? hi : (hi & ~((1ull << (64 - kHtKeyBits)) - 1ull));   // (the bits that are sorted)
                 const unsigned len = s_ent[ht_skew(i)] & 31u;            // symbol i leaves (it is in the buffer: j > i)
                 hi = (hi << len) | (lo >> (64u - len));
                 lo <<= len;
@@ -1404,7 +1404,7 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
                 const uint64_t key = s_key[ht_skew(i)];
                 K[base + i] = key;
                 if (partial)
-                    for (int p = 0; p < npass; p++) atomicAdd(&h[p][(unsigned)(key >> (8 * p)) & 255u], 1u);
+                    for (int p = 0; p < npass; p++) atomicAdd(&h[p][(unsigned)(key >> (64 - kHtKeyBits + 8 * p)) & 255u], 1u);
             }
         }
         __syncthreads();
@@ -1423,7 +1423,8 @@ int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
     *result_in_1 = 0;
     if (m == 0) return SFX_OK;
     if (m > 0xFFFFFFFFull) return SFX_ERR_TOO_LARGE;
-    const int npass = 8;
+    const int npass = kHtKeyBits / 8;                          // (the low 64 - kHtKeyBits bits of the keys are zero)
+    const int bit0 = 64 - kHtKeyBits;
     const bool sweep = use_sweep(m, npass);
     RadixScratch scr(scratch, m);
     {
@@ -1441,8 +1442,8 @@ int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
     for (int p = 0; p < npass; p++) {
         const double algo = (double)m * ((p == 0 ? 8.0 : 12.0) + 12.0);
         uint32_t* vdst = (last_v && p == npass - 1) ? last_v : vout;
-        if (p == 0) SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKeyIota{kin}, DstKV{kout, vdst}, m, 8 * p, 255u, scr, p, sweep, st));
-        else SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKV{kin, vin}, DstKV{kout, vdst}, m, 8 * p, 255u, scr, p, sweep, st));
+        if (p == 0) SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKeyIota{kin}, DstKV{kout, vdst}, m, bit0 + 8 * p, 255u, scr, p, sweep, st));
+        else SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKV{kin, vin}, DstKV{kout, vdst}, m, bit0 + 8 * p, 255u, scr, p, sweep, st));
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
         flips ^= 1;

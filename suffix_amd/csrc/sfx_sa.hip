@@ -1996,7 +1996,7 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
         }
         use_ht = ht_build(counts, alpha.bits, &ht);
         if (use_ht) {
-            stats.symbols_per_key = (uint32_t)(64.0 / ht.avg_len);           // (on average: the code words differ in length)
+            stats.symbols_per_key = (uint32_t)((double)kHtKeyBits / ht.avg_len);   // (on average: the code words differ in length)
             SFX_HIP(hipMemcpyAsync(b.ht, ht.ent, sizeof(ht.ent), hipMemcpyHostToDevice, st));
             SFX_HIP(hipMemcpyAsync(b.ht + kHtTableWords, ht.t12, sizeof(ht.t12), hipMemcpyHostToDevice, st));
         }
