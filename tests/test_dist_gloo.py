@@ -25,6 +25,8 @@ kind = os.environ["SFX_CASE"]
 m = {{"periodic": 1200, "unary": 600}}.get(kind, 6000)
 if kind == "ragged":                                       # shards of different lengths (and not multiples of a word)
     m = [5000, 6001, 4377][rank]
+if kind == "tiny":                                         # a shard below 64 bytes: the text travels as raw bytes
+    m = [700, 33, 912][rank]
 if kind == "dna":
     full = _gen.dna(m * world, seed=99)
 elif kind == "text":
@@ -33,10 +35,12 @@ elif kind == "unary":
     full = np.frombuffer(b"a" * (m * world), dtype=np.uint8)      # one key bin: every rank but one gets an empty slice
 elif kind == "ragged":
     full = _gen.dna(5000 + 6001 + 4377, seed=98)
+elif kind == "tiny":
+    full = _gen.dna(700 + 33 + 912, seed=97)
 else:
     full = np.frombuffer((b"ab" * (m * world // 2)), dtype=np.uint8)
-if kind == "ragged":
-    lo = sum([5000, 6001, 4377][:rank])
+if kind in ("ragged", "tiny"):
+    lo = sum(([5000, 6001, 4377] if kind == "ragged" else [700, 33, 912])[:rank])
     shard = torch.from_numpy(np.ascontiguousarray(full[lo:lo + m]).copy())
 else:
     shard = torch.from_numpy(np.ascontiguousarray(full[rank * m:(rank + 1) * m]).copy())
@@ -44,7 +48,10 @@ timings = {{}}
 part, offset, n, text = sdist.build_sa_partitioned(shard, engine=eng, top_bits=10, return_text=True, timings=timings)
 assert "range_build" in timings and "key_hist" in timings, timings
 # every shard has >= 64 bytes: the text travels as packed symbol codes, ragged shards included
-assert timings["text_exchange"].startswith("packed words") and (kind != "ragged" or "ragged" in timings["text_exchange"]), timings
+if kind == "tiny":
+    assert timings["text_exchange"] == "raw bytes", timings
+else:
+    assert timings["text_exchange"].startswith("packed words") and (kind != "ragged" or "ragged" in timings["text_exchange"]), timings
 if kind in ("periodic", "unary"):                          # repeats longer than text refinement can settle inside a slice
     assert "fallback" in timings, timings
 else:
@@ -56,7 +63,7 @@ np.save(os.path.join(os.environ["SFX_OUT"], f"off{{rank}}.npy"), np.array([offse
 lcp = sdist.build_lcp_partitioned(text, part, engine=eng)
 np.save(os.path.join(os.environ["SFX_OUT"], f"lcp{{rank}}.npy"), lcp.numpy().view(np.uint32))
 fb = full.tobytes()
-qm = 4000 if kind == "ragged" else m
+qm = 4000 if kind == "ragged" else (600 if kind == "tiny" else m)
 qs = [fb[100:106], fb[-7:], b"zzzz", fb[qm // 2:qm // 2 + 2], fb[qm - 2:qm + 3], fb[5:6]]
 qb = torch.from_numpy(np.frombuffer(b"".join(qs), dtype=np.uint8).copy())
 qoff = torch.tensor(np.concatenate([[0], np.cumsum([len(q) for q in qs])]), dtype=torch.int64)
@@ -84,7 +91,7 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-@pytest.mark.parametrize("case,world", [("dna", 2), ("text", 2), ("periodic", 2), ("unary", 2), ("dna", 3), ("ragged", 3)])
+@pytest.mark.parametrize("case,world", [("dna", 2), ("text", 2), ("periodic", 2), ("unary", 2), ("dna", 3), ("ragged", 3), ("tiny", 3)])
 def test_partitioned_build_ranks(tmp_path, oracle, case, world):
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(HERE, "emu")])
     script = tmp_path / "worker.py"
@@ -104,6 +111,8 @@ def test_partitioned_build_ranks(tmp_path, oracle, case, world):
         full = np.frombuffer(b"a" * (m * world), dtype=np.uint8)
     elif case == "ragged":
         full = _gen.dna(5000 + 6001 + 4377, seed=98)
+    elif case == "tiny":
+        full = _gen.dna(700 + 33 + 912, seed=97)
     else:
         full = np.frombuffer((b"ab" * (m * world // 2)), dtype=np.uint8)
     exp = oracle.sais(full.tobytes())
@@ -117,7 +126,7 @@ def test_partitioned_build_ranks(tmp_path, oracle, case, world):
     text = full.tobytes()
     lcps = [np.load(tmp_path / f"lcp{r}.npy") for r in range(world)]
     assert np.array_equal(np.concatenate(lcps), oracle.lcp_quadratic(text, exp))
-    qm = 4000 if case == "ragged" else m
+    qm = 4000 if case == "ragged" else (600 if case == "tiny" else m)
     qs = [text[100:106], text[-7:], b"zzzz", text[qm // 2:qm // 2 + 2], text[qm - 2:qm + 3], text[5:6]]
     for r in range(world):                                   # every rank holds the same global answer
         q = np.load(tmp_path / f"q{r}.npy")
