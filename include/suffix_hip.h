@@ -151,7 +151,10 @@ int sfx_doc_lookup_dev(const uint32_t* d_positions, uint64_t count, const uint64
  *         (cf. Bins::find_sizes :686-704).  Ranks all-reduce(sum) them; the
  *         result defines the dense symbol codes, identically on every rank.
  * Step 2  sfx_key_histogram_dev: every suffix has a key = its first k symbols
- *         packed big-endian (k fixed by the global alphabet and n); this counts,
+ *         packed big-endian (k fixed by the global byte COUNTS and n -- an alphabet of
+ *         more than 16 symbols that is used unevenly gets the wider key: the rule looks
+ *         at the order-0 entropy -- so steps 2 and 4 must be given the same all-reduced
+ *         counts, not presence flags); this counts,
  *         for the suffixes starting in the rank's shard, the top `top_bits`
  *         (<= 14) bits of that key into 2^top_bits u64 bins.  Ranks all-reduce
  *         them = the bucket-boundary histogram exchange.
