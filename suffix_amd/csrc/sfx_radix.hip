@@ -557,6 +557,144 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
     }
 }
 
+// ---- the one-sweep pass of the dense sorts, round 4 ------------------------------------------------------------------------
+// Same tile engine and look-back protocol as k_radix_pass<..., ONESWEEP = true>, without what the chunked and the segmented
+// schedules need (no second key array, no per-tile descriptors) and with 16-bit counts: a tile is < 65536 elements, per-wave
+// counts and tile-local bucket starts fit 16 bits, and the 8 KB that saves -- together with the registers the leaner loop
+// frees -- let an E64 tile grow from 11 to 16 elements per thread (16384 elements: 512-byte runs per bucket, a third fewer
+// look-backs) and a KV tile from 9 to 10.  lab/radix_lab2.hip, 100 M elements, ms per pass: E64 11 / 12 / 14 / 16 / 17 per
+// thread = 0.471 / 0.449 / 0.441 / 0.423 / 0.451 (17 spills); KV 9 / 10 / 11 / 12 = 0.616 / 0.595 / 0.602 / 0.70 (round 3's
+// kernel at 9: 0.70).  What the lab's phase timers say bounds a pass (profiles/r4_radix_lab.txt): ranking 25 %, waiting for
+// the look-back 26 % (it grows with the number of workgroups in flight), waiting for the tile's loads 16 %, scan 12 %; the
+// stores are asynchronous and cost what the memory side charges for the two partial 64-byte blocks at the ends of every run
+// (~50 ps each, whoever completes the block later; the lane -> address mapping does not matter: lab/store_probe.hip).
+template <int KPT, bool HAS_VAL, int NW>
+struct SweepSmem {
+    uint64_t stage[NW * kWave * KPT];                   // (the match masks of the ranking alias its first NW x 2 KiB)
+    uint32_t stage_v[HAS_VAL ? NW * kWave * KPT : 1];
+    uint16_t cnt[NW][kRadix];                           // per-wave digit counts, then per-wave tile-local bases
+    uint32_t off[kRadix];                               // global bucket head minus tile-local bucket start
+    uint32_t part[2][NW];
+    uint32_t ticket;
+};
+// rank_round<true> with 16-bit counts
+__device__ __forceinline__ uint32_t rank_round16(unsigned d, unsigned long long* flags_w, uint16_t* cnt_w, unsigned long long mybit)
+{
+    atomicOr(&flags_w[d], mybit);
+    wave_sync();
+    const unsigned long long peers = flags_w[d];
+    const uint32_t pre = cnt_w[d];
+    wave_sync();
+    const unsigned below = lanes_below(peers);
+    if (below == 0) {
+        flags_w[d] = 0ull;
+        cnt_w[d] = (uint16_t)(pre + (uint32_t)__popcll(peers));
+    }
+    wave_sync();
+    return pre + below;
+}
+template <class Src, class Dst, int KPT, int NW>
+__global__ void __launch_bounds__(NW * kWave, 1)
+k_radix_sweep(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const uint32_t* __restrict__ digit_total,
+              uint32_t* __restrict__ status, uint32_t* __restrict__ ticket)
+{
+    constexpr bool HAS_VAL = Src::kHasVal;
+    constexpr int kThreads = NW * kWave;
+    constexpr int kTile = kThreads * KPT;
+    static_assert(kWave * KPT >= kRadix, "the match masks must fit the staging buffer");
+    static_assert(kTile < 65536, "16-bit tile positions");
+    __shared__ SweepSmem<KPT, HAS_VAL, NW> s;
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const unsigned long long mybit = 1ull << lane;
+    const bool owner = tid < (unsigned)kRadix;                   // thread d owns bucket d
+    unsigned par = 0;
+    unsigned long long* const my_flags = reinterpret_cast<unsigned long long*>(s.stage) + w * kRadix;
+    if (owner) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0;
+    }
+    const uint32_t my_head = block_scan_excl_1b<NW>(owner ? digit_total[tid] : 0u, s.part, par);   // global start of bucket `tid`
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) s.ticket = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const uint32_t tile_no = s.ticket;
+        const uint64_t tile = (uint64_t)tile_no * kTile;
+        if (tile >= m) break;
+        const unsigned nvalid = (unsigned)dmin<uint64_t>(kTile, m - tile);
+        // load: wave-striped, 64 consecutive elements per round; padding sorts last in the tile
+        uint64_t key[KPT];
+        uint32_t val[HAS_VAL ? KPT : 1];
+        uint32_t pos[KPT];
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            const unsigned idx = w * (kWave * KPT) + r * kWave + lane;
+            key[r] = (idx < nvalid) ? src.key(tile + idx) : ~0ull;
+            if (HAS_VAL) val[r] = (idx < nvalid) ? src.val(tile + idx) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kRadix / kWave; k++) my_flags[k * kWave + lane] = 0ull;
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < KPT; r++) pos[r] = rank_round16(digit_of(key[r], shift, mask), my_flags, s.cnt[w], mybit);
+        __syncthreads();
+        // thread d: bucket d's size in this tile -> tile-local start, per-wave bases, look-back
+        LookBack lb;
+        uint32_t real_count = 0, tile_ex = 0;
+        {
+            uint32_t c[NW], tile_count = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                c[k] = owner ? s.cnt[k][tid] : 0u;
+                tile_count += c[k];
+            }
+            const uint32_t ex = block_scan_excl_1b<NW>(tile_count, s.part, par);
+            if (owner) {
+                uint32_t run = ex;
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    s.cnt[k][tid] = (uint16_t)run;
+                    run += c[k];
+                }
+                // padding elements all carry the largest digit (== mask)
+                real_count = tile_count - ((tid == mask) ? (uint32_t)(kTile - nvalid) : 0u);
+                tile_ex = ex;
+                lookback_begin(status, tile_no, tid, real_count, lb, tile_no == 0);       // loads in flight during the staging
+            }
+        }
+        __syncthreads();
+        // reorder through LDS: every bucket's elements become one contiguous run
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            const unsigned p = pos[r] + s.cnt[w][digit_of(key[r], shift, mask)];
+            s.stage[p] = key[r];
+            if (HAS_VAL) s.stage_v[p] = val[r];
+        }
+        if (owner) s.off[tid] = my_head + lookback_finish(status, tile_no, tid, real_count, lb, tile_no == 0) - tile_ex;
+        __syncthreads();
+        // small batches: all LDS reads of a batch are in flight together; batches of 1 .. KPT tie as long as nothing spills
+        constexpr int kOut = (KPT % 4 == 0) ? 4 : ((KPT % 3 == 0) ? 3 : ((KPT % 2 == 0) ? 2 : 1));
+#pragma unroll
+        for (int r0 = 0; r0 < KPT; r0 += kOut) {
+#pragma unroll
+            for (int r = r0; r < r0 + kOut; r++) {
+                key[r] = s.stage[r * kThreads + tid];
+                if (HAS_VAL) val[r] = s.stage_v[r * kThreads + tid];
+            }
+#pragma unroll
+            for (int r = r0; r < r0 + kOut; r++) pos[r] = s.off[digit_of(key[r], shift, mask)] + (r * kThreads + tid);
+#pragma unroll
+            for (int r = r0; r < r0 + kOut; r++)
+                if ((unsigned)(r * kThreads) + tid < nvalid) dst.store(pos[r], key[r], HAS_VAL ? val[r] : 0u);
+        }
+        if (owner) {
+#pragma unroll
+            for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- hybrid initial sort: two device-wide passes on the top 16 key bits, the rest in LDS ----------
 // An LSD sort moves every element once per 8 key bits through the CU write path (0.41 of HBM peak, §9 of
 // DESIGN.md).  When the text is large enough that the 65536 sub-buckets of the top 16 key bits hold a few
@@ -957,13 +1095,13 @@ struct RadixTuning { int sweep, kpt, rank, nw, kpt_text, kpt_kv; };
 static RadixTuning radix_tuning()
 {
     static const RadixTuning t = [] {
-        RadixTuning r = {1, 11, 1, 16, 16, 9};          // measured best on MI355X (profiles/r1c_radix_variants.txt):
-                                                // 1024-thread workgroups, 8192-element tiles = 256-byte runs
+        RadixTuning r = {1, 16, 1, 16, 16, 10};         // measured best on MI355X (round 4, lab/radix_lab2.hip): 1024-thread
+                                                // workgroups, 16384-element E64 tiles (512-byte runs), 10240-element KV tiles
         if (const char* e = dev_env("SFX_RADIX_SWEEP")) r.sweep = atoi(e) ? 1 : 0;
         if (const char* e = dev_env("SFX_RADIX_KPT")) r.kpt = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 8;
         if (const char* e = dev_env("SFX_RADIX_RANK")) r.rank = atoi(e) ? 1 : 0;
         if (const char* e = dev_env("SFX_RADIX_KPT_TEXT")) r.kpt_text = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 16;
-        if (const char* e = dev_env("SFX_RADIX_KPT_KV")) r.kpt_kv = atoi(e) == 9 ? 9 : 8;
+        if (const char* e = dev_env("SFX_RADIX_KPT_KV")) r.kpt_kv = (atoi(e) >= 8 && atoi(e) <= 10) ? atoi(e) : 8;
         if (const char* e = dev_env("SFX_RADIX_NW")) r.nw = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 4);
         return r;
     }();
@@ -1001,9 +1139,14 @@ static int launch_pass(const char* name, double algo_bytes, const Src& src, cons
         const uint64_t tiles = (m + kTile - 1) / kTile;
         const unsigned grid = (unsigned)dmin<uint64_t>(tiles, kMaxGrid);
         SFX_HIP(hipMemsetAsync(scr.status, 0, tiles * kRadix * sizeof(uint32_t), st));
-        SFX_LAUNCH(name, algo_bytes, (k_radix_pass<Src, Dst, KPT, true, RANK_ATOMIC, NW>), grid, kThreads, st, src, dst, m,
-                   shift, mask, (uint64_t)0, (const uint32_t*)nullptr, (const uint32_t*)(scr.totals + pass * kRadix),
-                   scr.status, scr.tickets + pass);
+        if constexpr (RANK_ATOMIC && NW == 16 && kTile < 65536) {
+            SFX_LAUNCH(name, algo_bytes, (k_radix_sweep<Src, Dst, KPT, NW>), grid, kThreads, st, src, dst, m, shift, mask,
+                       (const uint32_t*)(scr.totals + pass * kRadix), scr.status, scr.tickets + pass);
+        } else {
+            SFX_LAUNCH(name, algo_bytes, (k_radix_pass<Src, Dst, KPT, true, RANK_ATOMIC, NW>), grid, kThreads, st, src, dst, m,
+                       shift, mask, (uint64_t)0, (const uint32_t*)nullptr, (const uint32_t*)(scr.totals + pass * kRadix),
+                       scr.status, scr.tickets + pass);
+        }
     } else {
         Chunking ch = make_chunking(m, kTile);
         const uint64_t chunk = ch.tiles_per_block * kTile;
@@ -1038,8 +1181,9 @@ static int run_pass(const char* name, double algo_bytes, const Src& src, const D
             if (kk == 11) SFX_PASS_NW(11, 16);
         }
         if constexpr (Src::kHasVal && !Src::kFromText) {
-            // KV passes (12-byte elements): 9 per thread is the largest tile without spills;
-            // 8 / 9 / 10 measured 106.2 / 102.0 / 105.1 ms over the 23 KV passes of config 3
+            // KV passes (12-byte elements): 10 per thread is the largest tile without spills in k_radix_sweep
+            // (round 3's kernel: 9; 8 / 9 / 10 measured 106.2 / 102.0 / 105.1 ms over the 23 KV passes of config 3 then)
+            if (t.kpt_kv == 10) SFX_PASS_NW(10, 16);
             if (t.kpt_kv == 9) SFX_PASS_NW(9, 16);
         }
         SFX_PASS_NW(8, 16);
