@@ -13,7 +13,9 @@ build of suffix_amd/dist.py: every rank contributes a 100 MB shard, the job
 builds the SA of the N*100 MB text, each rank producing its contiguous slice
 ("weak" scaling: suffixes sorted per GPU stay fixed).
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+Rank 0 prints the full records on lines that start with "DETAIL " (headline, then one per full-size config) and, last,
+ONE compact JSON line (< 4 KB; see DESIGN.md "Measurement" for every field) that carries, per config, {sa_ms, lcp_ms,
+fused_ms, bit_exact, engine_BpB, engine_frac, whole_path_frac, dominant kernel} inside `roofline.configs`.
 """
 import argparse
 import json
@@ -167,6 +169,27 @@ def load_pmc(name):
         return json.load(open(os.path.join(ROOT, "profiles", name)))
     except (OSError, ValueError):
         return {}
+
+
+def compact_config(key, rec):
+    """What the final JSON line keeps of a full-size config record (the record itself is printed on a DETAIL line of its
+    own, before the final line: the driver keeps a few KB of stdout tail and the scalar keys of the last line)."""
+    if "sa_ms" not in rec:
+        return {"key": key, "error": rec.get("error") or rec.get("skipped")}
+    rf = rec.get("roofline", {})
+    out = {"key": key, "n": rec.get("n"), "sa_ms": rec.get("sa_ms"), "lcp_ms": rec.get("lcp_ms"),
+           "fused_ms": rec.get("fused_sa_lcp", {}).get("ms"), "bit_exact": rec.get("bit_exact_vs_pins"),
+           "engine_BpB": rf.get("engine", {}).get("algo_bytes_per_input_byte"),
+           "engine_frac": rf.get("engine", {}).get("frac_of_hbm_peak"),
+           "whole_path_frac": rf.get("whole_path", {}).get("frac_of_hbm_peak")}
+    ks = rf.get("kernels") or []
+    if ks:
+        k = ks[0]
+        tr = round(k["traffic"] / k["algo_bytes_per_launch"], 2) if k.get("traffic") and k.get("algo_bytes_per_launch") else None
+        out["dominant"] = {"kernel": k["kernel"], "frac": k["frac"], "share": k["share_of_build"], "traffic_ratio": tr}
+    if "queries" in rec:
+        out["Mqueries/s"] = rec["queries"].get("Mqueries/s")
+    return out
 
 
 def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
@@ -638,20 +661,52 @@ def main():
                 configs.append({"config": key, "error": f"{type(exc).__name__}: {exc}"})
 
     if rank == 0:
+        # DETAIL lines first (one JSON object each, never the last line): everything round 3 packed into one 25 KB line
+        workload = (f"{n_local} B synthetic DNA (sigma=4, uniform, splitmix64) per GPU, u32 indices, device-resident text -> device SA"
+                    + ("" if world == 1 else f"; range-partitioned over {world} GPUs, text {n_total} B"))
+        print("DETAIL " + json.dumps({"detail": "headline", "config": {"workload": workload, "text_bytes_total": n_total, "build": stats,
+                                                                        "partitioned_phases_ms": phases},
+                                      "roofline": roofline, "cpu_baseline": cpu, "lcp": lcp_info, "verification": how}))
+        cfg_keys = [k for k in args.configs.split(",") if k] if configs is not None else []
+        for key, rec in zip(cfg_keys, configs or []):
+            print("DETAIL " + json.dumps({"detail": key, **rec}))
+        engine_bpb = roofline["engine_algo_bytes_per_input_byte"]
+        short_roof = {"bound": "hbm", "kernel": roofline["kernel"], "achieved": roofline["achieved"], "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": roofline["frac"], "traffic": roofline.get("traffic"),
+                      "avg_launch_ms": roofline["avg_launch_ms"], "algo_bytes_per_launch": roofline["algo_bytes_per_launch"],
+                      "share_of_step": roofline["share_of_step"],
+                      "traffic_commit": roofline.get("traffic_commit"), "this_commit": roofline.get("this_commit"),
+                      # the engine's own algorithmic bytes (what its kernels declare) per input byte, and that against the HBM peak
+                      "engine_BpB": engine_bpb, "engine_frac": round(engine_bpb * value / 1e3 / HBM_PEAK_GBS, 4),
+                      # SURVEY 8d's SA-IS figure (65 B per input byte) against the same time
+                      "whole_path_frac": roofline["whole_path"]["frac"],
+                      "kernels": [{"kernel": k["kernel"], "frac": k["frac"], "share": k["share_of_build"],
+                                   "traffic_ratio": (round(k["traffic"] / k["algo_bytes_per_launch"], 2) if k.get("traffic") else None)}
+                                  for k in roofline["kernels"]],
+                      "configs": [compact_config(k, r) for k, r in zip(cfg_keys, configs or [])]}
+        short_cpu = None
+        if cpu:
+            short_cpu = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+                         "sample": cpu["sample"][:160], "cpu_model": cpu.get("cpu_model")}
+        short_lcp = None
+        if lcp_info:
+            short_lcp = {"ms": lcp_info["ms_per_step"], "fused_sa_lcp_ms": lcp_info.get("fused_sa_lcp", {}).get("ms_per_step"),
+                         "bit_exact_vs_oracle": lcp_info.get("bit_exact_vs_oracle")}
         out = {
             "metric": METRIC, "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"{n_local} B synthetic DNA (sigma=4, uniform, splitmix64) per GPU, "
-                                   f"u32 indices, device-resident text -> device SA"
-                                   + ("" if world == 1 else f"; range-partitioned over {world} GPUs, "
-                                      f"text {n_total} B"),
-                       "text_bytes_total": n_total, "build": stats, "partitioned_phases_ms": phases},
-            "roofline": roofline, "cpu_baseline": cpu, "lcp": lcp_info,
-            "verified": verified, "verification": how, "configs": configs,
+            "config": {"workload": workload, "text_bytes_total": n_total, "partitioned_phases_ms": phases},
+            "roofline": short_roof, "cpu_baseline": short_cpu, "lcp": short_lcp,
+            "verified": verified, "verification": how[:200],
         }
-        print(json.dumps(out))
+        line = json.dumps(out)
+        if len(line) > 4000:                            # the driver keeps ~7 KB of tail: never let the last line outgrow it
+            out["roofline"]["kernels"] = out["roofline"]["kernels"][:2]
+            out["verification"] = how[:80]
+            line = json.dumps(out)
+        print(line)
     if world > 1:
         dist.destroy_process_group()
 

@@ -18,7 +18,11 @@
 //!   * `lcp_lens`    (src/table.rs:130-138)  body
 //!   * new additive  `SuffixTable::device_index()` (the resident index, kept by the caller across batches),
 //!     `positions_batch_on(&index, queries)` and the one-shot `positions_batch(queries)`
-//!   * texts below `MIN_DEVICE_LEN` bytes keep the crate's own CPU path (QuickCheck's strings never leave the host)
+//!   * texts below `min_device_len()` bytes keep the crate's own CPU path.  The default is `MIN_DEVICE_LEN` = 64 KiB (a trip
+//!     to the device costs ~100 us whatever the length): right for production, but every string of the upstream tests --
+//!     QuickCheck's (< 100 bytes) and the literals of `tests/tests.rs` -- is far below it.  A TEST RUN THEREFORE SETS
+//!     `SUFFIX_HIP_MIN_LEN=0` (read once per process) or builds with `--features hip-always`: then all 31 upstream tests
+//!     cross the FFI, the empty text and the one-byte text included (tests/tests.rs:42-65).
 //! `sais()`, `Bins`, `SuffixTypes` stay in the crate as the reference CPU path (feature `hip` off).
 
 use std::os::raw::{c_char, c_int, c_void};
@@ -56,6 +60,27 @@ extern "C" {
 /// ~100 us of launches and two PCIe copies whatever the length, the reference needs ~1 us for QuickCheck's strings
 /// (README.md:116) and ~1 ms for 64 KiB.  The patched `sais_table` / `lcp_lens` compare against it.
 pub const MIN_DEVICE_LEN: usize = 1 << 16;
+
+/// The threshold the patched `sais_table` / `lcp_lens` compare against: `MIN_DEVICE_LEN`, unless the crate was built with the
+/// `always` feature (the parent crate's `hip-always`: 0) or the environment names another one (`SUFFIX_HIP_MIN_LEN=<bytes>`,
+/// read once per process).  `SUFFIX_HIP_MIN_LEN=0 cargo test --features hip` is how the upstream test-suite -- whose
+/// strings are all far below 64 KiB -- is made to run on the device (tests/tests.rs:73-96).
+pub fn min_device_len() -> usize {
+    use std::sync::atomic::{AtomicUsize, Ordering};
+    static CACHED: AtomicUsize = AtomicUsize::new(usize::MAX);
+    let v = CACHED.load(Ordering::Relaxed);
+    if v != usize::MAX {
+        return v;
+    }
+    let default = if cfg!(feature = "always") { 0 } else { MIN_DEVICE_LEN };
+    let parsed = std::env::var("SUFFIX_HIP_MIN_LEN")
+        .ok()
+        .and_then(|s| s.trim().parse::<usize>().ok())
+        .map(|x| if x == usize::MAX { usize::MAX - 1 } else { x })
+        .unwrap_or(default);
+    CACHED.store(parsed, Ordering::Relaxed);
+    parsed
+}
 
 fn check(status: c_int, what: &str) {
     if status != 0 {

@@ -166,20 +166,30 @@ struct PackedText {
     int spw;            // symbols per word
     int kbits;          // bits * spw  (<= 32)
     double inv_spw;     // 1.0 / spw
+    int spw_log2 = -1;  // log2(spw) when spw is a power of two (bits in {1, 2, 4, 8}: DNA, bytes), else -1
 };
+__host__ __device__ inline int packed_spw_log2(int spw) { return (spw & (spw - 1)) == 0 ? 31 - __builtin_clz((unsigned)spw) : -1; }
 
 // p / spw for any spw in 1..32, exact for p < 2^52: (p + 0.5) / spw is at least
 // 0.5/32 away from every integer, far more than the rounding error of the product.
+// (power-of-two spw: a shift -- the double-precision form is ~10 VALU instructions, several of them quarter-rate, per key,
+// and the text-fed radix pass extracts 16 keys per thread and tile)
 __device__ __forceinline__ uint64_t packed_word_index(const PackedText& t, uint64_t p)
 {
+    if (t.spw_log2 >= 0) return p >> t.spw_log2;
     return (uint64_t)(((double)p + 0.5) * t.inv_spw);
 }
 
+__device__ __forceinline__ unsigned packed_word_offset(const PackedText& t, uint64_t p, uint64_t q)
+{
+    if (t.spw_log2 >= 0) return (unsigned)p & ((unsigned)t.spw - 1u);
+    return (unsigned)(p - q * (uint64_t)t.spw);
+}
 // the spw symbols starting at position p, as a kbits-bit big-endian number
 __device__ __forceinline__ uint32_t packed_key32(const PackedText& t, uint64_t p)
 {
     const uint64_t q = packed_word_index(t, p);
-    const unsigned off = (unsigned)(p - q * (uint64_t)t.spw);
+    const unsigned off = packed_word_offset(t, p, q);
     // (the two words as ONE 8-byte load: a gather is 64 different lines to the wave, and every load instruction
     // looks each of them up in the L1 again)
     uint64_t pair;
@@ -192,7 +202,7 @@ __device__ __forceinline__ uint32_t packed_key32(const PackedText& t, uint64_t p
 __device__ __forceinline__ uint64_t packed_key64(const PackedText& t, uint64_t p)
 {
     const uint64_t q = packed_word_index(t, p);
-    const unsigned off = (unsigned)(p - q * (uint64_t)t.spw);
+    const unsigned off = packed_word_offset(t, p, q);
     struct { uint32_t w[3]; } three;                                  // (one 12-byte load)
     __builtin_memcpy(&three, t.words + q, 12);
     const uint64_t w0 = three.w[0], w1 = three.w[1], w2 = three.w[2];
@@ -212,7 +222,7 @@ struct PackedWalk {
     __device__ __forceinline__ void init(const PackedText& t, uint64_t p)
     {
         q = packed_word_index(t, p);
-        off = (unsigned)(p - q * (uint64_t)t.spw);
+        off = packed_word_offset(t, p, q);
         w0 = t.words[q];
         w1 = t.words[q + 1];
         w2 = sizeof(KeyT) == 8 ? t.words[q + 2] : 0u;

@@ -1517,7 +1517,7 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
         for (unsigned i = tid; i < (unsigned)(kHtTile + kHtPad); i += kBlock) {
             const uint64_t p = base + i;                     // (positions past the text read as the padding's zero symbol)
             const uint64_t q = packed_word_index(t, p);
-            const unsigned off = (unsigned)(p - q * (uint64_t)t.spw);
+            const unsigned off = packed_word_offset(t, p, q);
             s_ent[ht_skew(i)] = s_tab[p < t.n ? (s_words[(unsigned)(q - q0)] >> (((unsigned)t.spw - 1u - off) * bits)) & smask : 0u];
         }
         __syncthreads();

@@ -1484,7 +1484,11 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
         if (most && ch.blocks <= most && (pair_nb - pair_lo + 7) / 8 <= 3) { pair_hist = b.hist; pair_blocks = ch.blocks; }
     }
     const char* name = sizeof(KeyT) == 4 ? "groups_apply_u32" : "groups_apply_u64";
-    const double algo = (double)m * (0.25 + (sa_in_place ? 0 : 8) + (isa ? 4 : 0) + (S ? 4 : 0));
+    // algorithmic bytes: every element's flags (2 bits), key and suffix are read (+ its slot from the second round on);
+    // a resolved suffix is written to the SA (unless the array in V is the SA); a kept one leaves as suffix + slot + bucket
+    // id + 16-bit depth = 14 bytes; a rank round adds one 8-byte (suffix, rank) pair per member whose rank changes
+    const double algo = (double)m * (0.25 + sizeof(KeyT) + 4 + (S ? 4 : 0)) + (sa_in_place ? 0.0 : 4.0 * (double)(m - dmin<uint64_t>(kept, m))) +
+                        14.0 * (double)kept + (isa ? 8.0 * (double)pair_count : 0.0);
     uint32_t* sa_arg = sa_in_place ? (uint32_t*)nullptr /* V is the SA */ : sa;
     if (sa_in_place && !isa && kept * kSparseApplyDivisor <= m) {
 #define SFX_APPLY_SPARSE(HTV)                                                                                                       \
@@ -1545,6 +1549,7 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
         pt->spw = alpha->spw;
         pt->kbits = alpha->kbits;
         pt->inv_spw = 1.0 / alpha->spw;
+        pt->spw_log2 = packed_spw_log2(alpha->spw);
         return SFX_OK;
     }
     uint64_t nw = n_words_out ? n_words_out : packed_words(n, alpha);
@@ -1573,6 +1578,7 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
     pt->spw = alpha->spw;
     pt->kbits = alpha->kbits;
     pt->inv_spw = 1.0 / alpha->spw;
+    pt->spw_log2 = packed_spw_log2(alpha->spw);
     return SFX_OK;
 }
 

@@ -918,14 +918,17 @@ static int large_phase(const KeyFn& keyfn, const TileRound& r, uint32_t nseg, ui
         // (most large buckets are small ones: up to 1024 members a workgroup needs 12 KB of LDS instead of 37 -- thirteen
         // of them share a CU instead of four, and the kernel waits on its gathers: config 3 13.0 -> 11.5 ms.  512 threads x 8
         // for 1025 .. 4096 members: 11.9)
+        // (algorithmic bytes: the host knows the members of all size classes together, not of each -- the first launch
+        // declares all of them, 13 bytes per member (suffix in, suffix + flag byte out, 4-byte key gathered), the others none,
+        // so the sum over the launches is right; round 3 declared the total on every launch, four times too much)
         SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<4, 4, KeyFn>), grid, 4 * kWave, st, keyfn, segs, nseg, 0u, 1024u,
                    r.V, r.F8, r.emit, r.Hd, r.wsym);
-        SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<4, 16, KeyFn>), grid, 4 * kWave, st, keyfn, segs, nseg, 1024u, 4096u,
+        SFX_LAUNCH("seg_single_lds", 0.0, (k_seg_single<4, 16, KeyFn>), grid, 4 * kWave, st, keyfn, segs, nseg, 1024u, 4096u,
                    r.V, r.F8, r.emit, r.Hd, r.wsym);
         if (top > 4096u) {
-            SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<16, 11, KeyFn>), dmin(grid, grid_cap()), 16 * kWave, st,
+            SFX_LAUNCH("seg_single_lds", 0.0, (k_seg_single<16, 11, KeyFn>), dmin(grid, grid_cap()), 16 * kWave, st,
                        keyfn, segs, nseg, 4096u, 11264u, r.V, r.F8, r.emit, r.Hd, r.wsym);
-            SFX_LAUNCH("seg_single_lds", (double)nlarge * 13, (k_seg_single<16, 16, KeyFn>), dmin(grid, grid_cap()), 16 * kWave, st,
+            SFX_LAUNCH("seg_single_lds", 0.0, (k_seg_single<16, 16, KeyFn>), dmin(grid, grid_cap()), 16 * kWave, st,
                        keyfn, segs, nseg, 11264u, top, r.V, r.F8, r.emit, r.Hd, r.wsym);
         }
     }

@@ -90,8 +90,17 @@ def test_crate_is_cargo_ready():
     assert any("::suffix_hip::sais_table(text)" in l for l in added)
     assert any("::suffix_hip::lcp_lens(self.text(), self.table())" in l for l in added)
     # short texts stay on the reference's own CPU path (both seams compare against the crate's threshold) ...
-    assert sum("::suffix_hip::MIN_DEVICE_LEN" in l for l in added) == 2
-    assert "pub const MIN_DEVICE_LEN: usize" in lib
+    assert sum("::suffix_hip::min_device_len()" in l for l in added) == 2
+    assert "pub const MIN_DEVICE_LEN: usize" in lib and "pub fn min_device_len() -> usize" in lib
+    # ... except in a test run: the upstream tests (tests/tests.rs: QuickCheck strings < 100 B, literals) are all far below
+    # the production threshold, so the run must be able to set it to 0 -- environment (read once) or cargo feature
+    assert 'std::env::var("SUFFIX_HIP_MIN_LEN")' in lib and 'cfg!(feature = "always")' in lib
+    assert "MIN_DEVICE_LEN" not in patch, "the seams must compare against min_device_len(), not the constant"
+    assert "always = []" in manifest
+    cargo_patch = open(os.path.join(CRATE, "Cargo.toml.patch")).read()
+    assert 'hip-always = ["hip", "suffix-hip/always"]' in cargo_patch
+    readme = open(os.path.join(CRATE, "README.md")).read()
+    assert "SUFFIX_HIP_MIN_LEN=0" in readme and "--features hip-always" in readme
     # ... and the resident index outlives a batch: the caller holds the handle, positions_batch builds none per call
     assert any("pub fn device_index(&self) -> ::suffix_hip::DeviceIndex" in l for l in added)
     assert any("pub fn positions_batch_on<'a>(" in l for l in added)
