@@ -467,8 +467,8 @@ def main():
         tv = torch.tensor([ph.get(k, 0.0) for k in names], dtype=torch.float64, device=dev)
         dist.all_reduce(tv, op=dist.ReduceOp.MAX)
         phases = {k: round(float(v), 3) for k, v in zip(names, tv.tolist())}
-        if "fallback" in ph:
-            phases["fallback"] = ph["fallback"]
+        if "fallback" in ph.get("info", {}):
+            phases["fallback"] = ph["info"]["fallback"]
 
     # ---- lcp_lens on the same text (reported next to the headline, never part of `value`:
     # SuffixTable::new builds the suffix array only, src/table.rs:79-91; the LCP array is a

@@ -242,7 +242,7 @@ typedef struct {
     uint32_t key_bits;        /* width of the initial k-mer key (32 or 64)     */
     uint32_t symbols_per_key; /* k (compressed 64-bit keys: the average, 64 / mean code length) */
     uint32_t rounds;          /* refinement rounds after the initial sort      */
-    uint32_t reserved;
+    uint32_t reserved;        /* bit 0: sfx_build_sa_lcp_u32 stopped reading LCP values off the sort (most suffixes tied on the initial key) */
     uint64_t active_after_initial;
     uint64_t radix_passes;
     uint64_t elements_sorted; /* sum over passes of elements moved             */
@@ -253,7 +253,13 @@ typedef struct {
     uint32_t rank_rounds;     /* refinement rounds keyed by ranks (prefix doubling)               */
     uint64_t deep_gathers;    /* 64-bit key gathers of the deep text rounds (one random line each) */
 } sfx_build_stats;
+/* Writes sizeof(sfx_build_stats) bytes AS OF THE LIBRARY'S header.  The struct has grown (round 3 appended deep_gathers:
+ * 104 -> 112 bytes) and may grow again, always at its end: a consumer compiled against an older header must use
+ * sfx_build_stats_read instead, or it is written past its struct. */
 void sfx_last_build_stats(sfx_build_stats* out);
+/* The size-aware form: copies the first min(out_bytes, sizeof(sfx_build_stats)) bytes and returns the library's
+ * sizeof(sfx_build_stats) (so a caller can tell which trailing fields it got).  out == NULL: only the size. */
+uint64_t sfx_build_stats_read(void* out, uint64_t out_bytes);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,7 @@ ABI = [
     ("sfx_profile_reset", None, []),
     ("sfx_profile_report", _int, [ctypes.POINTER(KernelStat), _int]),
     ("sfx_last_build_stats", None, [ctypes.POINTER(BuildStats)]),
+    ("sfx_build_stats_read", _u64, [_vp, _u64]),
 ]
 
 
@@ -133,8 +134,9 @@ class Engine:
             raise SuffixHipError("no HIP device visible; suffix_amd has no CPU fallback")
 
     def build_stats(self):
+        # the size-aware form: a library whose struct is longer than this binding's copies only what fits
         s = BuildStats()
-        self.lib.sfx_last_build_stats(ctypes.byref(s))
+        self.lib.sfx_build_stats_read(ctypes.byref(s), ctypes.sizeof(s))
         return s.as_dict()
 
     MB_COPY, MB_SCATTER4, MB_GATHER1, MB_GATHER4, MB_RUNSCATTER = range(5)

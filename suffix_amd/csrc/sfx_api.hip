@@ -150,17 +150,20 @@ struct DevBuf {
 // A stream belongs to the device that was current when it was made: one per (thread, device), looked up by the
 // device current NOW (suffix_amd/device.py switches devices per call).
 constexpr int kMaxDevices = 16;
+// -1: the ordinal does not fit the per-device tables (or cannot be told): such a call runs on the NULL stream and without
+// cached scratch -- never on a stream, event or buffer that was made on another device
 static int current_device()
 {
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
-    return (d >= 0 && d < kMaxDevices) ? d : 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (d >= 0 && d < kMaxDevices) ? d : -1;
 }
 static hipStream_t call_stream()
 {
     thread_local hipStream_t st[kMaxDevices] = {};
     thread_local bool tried[kMaxDevices] = {};
     const int d = current_device();
+    if (d < 0) return nullptr;
     if (!tried[d]) {
         tried[d] = true;
         if (hipStreamCreateWithFlags(&st[d], hipStreamNonBlocking) != hipSuccess) {
@@ -472,9 +475,11 @@ int sfx_index_query_dev(const sfx_index* ix, const uint8_t* d_qbytes, const uint
         // the device.  Without scratch the batch is answered in one phase.
         struct QueryScratch { void* p = nullptr; uint64_t bytes = 0; hipEvent_t done = nullptr; bool used = false; };
         thread_local QueryScratch scs[kMaxDevices];
-        QueryScratch& sc = scs[current_device()];
+        const int dev = current_device();
+        QueryScratch none;
+        QueryScratch& sc = dev >= 0 ? scs[dev] : none;
         void* os = nullptr;
-        if (nq >= query_two_phase_min()) {
+        if (dev >= 0 && nq >= query_two_phase_min()) {
             const uint64_t need = query_scratch_bytes(nq, want_order);
             if (!sc.done && hipEventCreateWithFlags(&sc.done, hipEventDisableTiming) != hipSuccess) { sc.done = nullptr; (void)hipGetLastError(); }
             if (sc.done) {
@@ -679,6 +684,14 @@ int sfx_profile_report(sfx_kernel_stat* out, int cap)
 void sfx_last_build_stats(sfx_build_stats* out)
 {
     if (out) *out = tls_build_stats();
+}
+uint64_t sfx_build_stats_read(void* out, uint64_t out_bytes)
+{
+    if (out && out_bytes) {
+        const sfx_build_stats& s = tls_build_stats();
+        memcpy(out, &s, (size_t)(out_bytes < sizeof(s) ? out_bytes : sizeof(s)));
+    }
+    return (uint64_t)sizeof(sfx_build_stats);
 }
 
 }  // extern "C"

@@ -285,11 +285,22 @@ constexpr int kHtFastBits = 12;
 // mixed-script UTF-8 229 against 223, near-duplicate documents 399 against 390.  All 64 bits it is.)
 constexpr int kHtKeyBits = 64;
 static_assert(kHtKeyBits % 8 == 0 && kHtKeyBits >= 32 && kHtKeyBits <= 64, "whole radix digits");
+// the kHtFastBits key bits from bit `used` on (zeros past the key's end), used < 64.  32-bit funnel shifts: the 64-bit
+// shift pair (key << used) >> 52 is two quarter-rate instructions, and the decode loops run this once per two or three
+// symbols of every key they look at (round 4: k_groups_reduce with compressed keys 11.2 -> see DESIGN.md)
+__device__ __forceinline__ unsigned ht_window(uint64_t key, unsigned used)
+{
+    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+    const uint32_t a = used < 32u ? hi : lo, b = used < 32u ? lo : 0u;
+    const unsigned sh = used & 31u;
+    // (a:b) << sh, top 32 bits: __funnelshift_l(b, a, sh) = (a << sh) | (b >> (32 - sh)), sh in 0 .. 31
+    return __funnelshift_l(b, a, sh) >> (32 - kHtFastBits);
+}
 // one step of the decode of `key` from bit `used` on; returns false when the key is exhausted
 __device__ __forceinline__ bool ht_depth_step(uint64_t key, unsigned& used, unsigned& cnt, const uint16_t* t12)
 {
     if (used >= (unsigned)kHtKeyBits || cnt >= kHtMaxSym) return false;
-    unsigned ends = t12[(unsigned)((key << used) >> (64 - kHtFastBits))];
+    unsigned ends = t12[ht_window(key, used)];
     const unsigned left = (unsigned)kHtKeyBits - used;
     if (left < (unsigned)kHtFastBits) ends &= (1u << left) - 1u;
     if (!ends) return false;                             // (no code ends inside what is left; with 12 bits left one always does)
@@ -297,21 +308,44 @@ __device__ __forceinline__ bool ht_depth_step(uint64_t key, unsigned& used, unsi
     used += 32u - (unsigned)__clz((int)ends);
     return true;
 }
-// depths of N keys at once (the look-ups of the N keys are independent: their LDS latencies overlap)
+// Symbols two DIFFERENT compressed keys share: the code words that end inside their common leading bits (the decodes of the
+// two keys agree up to there, so either key will do); with common == kHtKeyBits: the symbols the key holds (ht_depth).
+// N keys per lane at once.  The body of the loop is predicated, not branched: a per-key `if (still going)` inside the
+// per-lane `while` cost ~360 instructions per key (8 divergent branches per step, exec mask saved and restored around
+// each) -- 9.3 ms per 10^9 keys in k_groups_reduce, 2900 wave instructions per 512 keys; one back edge per step: 4.4 ms.
 template <int N>
-__device__ __forceinline__ void ht_depth_n(const uint64_t (&key)[N], unsigned want, const uint16_t* t12, uint32_t (&depth)[N])
+__device__ __forceinline__ void ht_common_n(const uint64_t (&key)[N], const unsigned (&common)[N], const uint16_t* t12, uint32_t (&sym)[N])
 {
     unsigned used[N], cnt[N];
 #pragma unroll
     for (int j = 0; j < N; j++) { used[j] = 0; cnt[j] = 0; }
-    unsigned act = want;
-    while (act) {
+    bool more = true;
+    while (more) {
+        more = false;
 #pragma unroll
-        for (int j = 0; j < N; j++)
-            if (((act >> j) & 1u) && !ht_depth_step(key[j], used[j], cnt[j], t12)) act &= ~(1u << j);
+        for (int j = 0; j < N; j++) {
+            const unsigned lim = common[j] < (unsigned)kHtKeyBits ? common[j] : (unsigned)kHtKeyBits;
+            const bool live = used[j] < lim && cnt[j] < kHtMaxSym;
+            unsigned ends = t12[ht_window(key[j], used[j] & 63u)];
+            const unsigned left = live ? lim - used[j] : 0u;
+            if (left < (unsigned)kHtFastBits) ends &= (1u << left) - 1u;
+            const bool ok = live && ends != 0u;
+            cnt[j] += ok ? (unsigned)__popc(ends) : 0u;
+            used[j] += ok ? 32u - (unsigned)__clz((int)ends) : 0u;
+            more |= ok;
+        }
     }
 #pragma unroll
-    for (int j = 0; j < N; j++) depth[j] = cnt[j] < kHtMaxSym ? cnt[j] : kHtMaxSym;
+    for (int j = 0; j < N; j++) sym[j] = cnt[j] < kHtMaxSym ? cnt[j] : kHtMaxSym;
+}
+// depths of N keys at once (bit j of `want`: key j is wanted): the symbols each key holds
+template <int N>
+__device__ __forceinline__ void ht_depth_n(const uint64_t (&key)[N], unsigned want, const uint16_t* t12, uint32_t (&depth)[N])
+{
+    unsigned common[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) common[j] = ((want >> j) & 1u) ? (unsigned)kHtKeyBits : 0u;
+    ht_common_n<N>(key, common, t12, depth);
 }
 
 // number of bits needed to represent values in [0, v]

@@ -599,16 +599,25 @@ struct LcpFuse {
     int pad_bits;           // unused high bits of a key
     uint32_t inv_bits;      // ceil(65536 / bits): x / bits for x < 64 (checked on the host)
     uint32_t pending;       // kLcpBoundFlag | symbols of the key: what neighbours with equal keys are known to share
+    const uint32_t* ht;     // compressed keys (round 4): the device tables (HtDepth::ent); the symbols two keys share are the
+                            // code words that end inside their common leading bits (ht_common_n), equal keys share all the
+                            // symbols the key holds
 };
 
-template <class KeyT>
+// HT: the keys are compressed (order-preserving prefix code, k_ht_keys) and the LCP is wanted
+template <class KeyT, bool HT = false>
 __global__ void __launch_bounds__(kBlock)
 k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t chunk,
                 uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep,
                 uint32_t* __restrict__ part_ghead, uint16_t* __restrict__ flags_out, LcpFuse fuse)
 {
     __shared__ uint32_t red[3][kWavesPerBlock];
+    __shared__ uint32_t s_t12[HT ? (1 << kHtFastBits) / 2 : 1];
     const unsigned tid = threadIdx.x;
+    if (HT) {
+        for (unsigned i = threadIdx.x; i < (1u << kHtFastBits) / 2u; i += kBlock) s_t12[i] = fuse.ht[kHtTableWords + i];
+        __syncthreads();
+    }
     uint64_t begin = (uint64_t)blockIdx.x * chunk;               // chunk: a multiple of kApplyTile elements
     uint64_t end = begin + chunk;
     if (end > m) end = m;
@@ -634,11 +643,31 @@ k_groups_reduce(const KeyT* __restrict__ K, uint64_t m, uint64_t chunk,
             flags_out[iu / kGroupItems] = (uint16_t)(head | (single << 8));
             if (fuse.lcp) {
                 uint32_t l[kGroupItems];
+                if (HT) {
+                    uint64_t k64[kGroupItems];
+                    unsigned common[kGroupItems];
+                    // (equal keys are not decoded here: the pair stays pending with the bound every key guarantees --
+                    // kHtKeyBits / kHtMaxLen whole code words -- and either a deep round overwrites it with the exact value or
+                    // the pending pass starts its comparison one 8-byte step earlier; decoding them too cost 10 ms per 10^9)
+                    bool same[kGroupItems];
+#pragma unroll
+                    for (int j = 0; j < kGroupItems; j++) {
+                        const uint64_t x = (uint64_t)(cur.k[j] ^ cur.k[j + 1]);
+                        k64[j] = (uint64_t)cur.k[j + 1];
+                        same[j] = x == 0;
+                        common[j] = x ? (unsigned)__clzll((long long)x) : 0u;
+                    }
+                    ht_common_n<kGroupItems>(k64, common, reinterpret_cast<const uint16_t*>(s_t12), l);
+#pragma unroll
+                    for (int j = 0; j < kGroupItems; j++)
+                        l[j] = (iu + j == 0) ? 0u : (same[j] ? (kLcpBoundFlag | (uint32_t)(kHtKeyBits / kHtMaxLen)) : l[j]);
+                } else {
 #pragma unroll
                 for (int j = 0; j < kGroupItems; j++) {
                     const uint64_t x = (uint64_t)(cur.k[j] ^ cur.k[j + 1]);
                     const unsigned lz = (unsigned)__clzll((long long)x) - (unsigned)(64 - 8 * (int)sizeof(KeyT)) - (unsigned)fuse.pad_bits;
                     l[j] = (iu + j == 0) ? 0u : (x ? (lz * fuse.inv_bits) >> 16 : fuse.pending);
+                }
                 }
                 if (iu + kGroupItems <= m) {
                     *reinterpret_cast<uint4*>(fuse.lcp + iu) = uint4{l[0], l[1], l[2], l[3]};
@@ -1439,9 +1468,13 @@ uint64_t sa_range_workspace_bytes(uint64_t n, uint64_t max_count)
 // bucket statistics of the sorted active list: reduce -> scan -> {kept, kept buckets} on the host
 template <class KeyT>
 static int round_totals(const KeyT* K, uint64_t m, SaBuffers& b, hipStream_t st, uint64_t* kept,
-                        uint64_t* kept_groups, LcpFuse fuse = LcpFuse{nullptr, 0, 0, 0})
+                        uint64_t* kept_groups, LcpFuse fuse = LcpFuse{nullptr, 0, 0, 0, nullptr})
 {
     Chunking ch = make_chunking(m, kApplyTile);
+    if (sizeof(KeyT) == 8 && fuse.lcp && fuse.ht)
+        SFX_LAUNCH("groups_reduce", (double)m * (sizeof(KeyT) + 4), (k_groups_reduce<KeyT, sizeof(KeyT) == 8>), ch.blocks, kBlock,
+                   st, K, m, ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, b.F, fuse);
+    else
     SFX_LAUNCH("groups_reduce", (double)m * (sizeof(KeyT) + (fuse.lcp ? 4 : 0)), (k_groups_reduce<KeyT>), ch.blocks, kBlock,
                st, K, m, ch.tiles_per_block * kApplyTile, b.part_head, b.part_keep, b.part_ghead, b.F, fuse);
     SFX_LAUNCH("groups_scan", 0.0, k_groups_scan, 1, kBlock, st, b.part_head, b.part_keep,
@@ -1900,9 +1933,10 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         in_place = true;
     }
     uint64_t kept = 0, groups = 0;
-    LcpFuse fuse = {nullptr, 0, 0, 0};
+    LcpFuse fuse = {nullptr, 0, 0, 0, nullptr};
     if (lcp_fuse) {                                     // (full builds only: slot r of the sorted keys is SA slot r)
         fuse.lcp = lcp_fuse;
+        fuse.ht = ht ? b.ht : nullptr;
         fuse.pending = kLcpBoundFlag | (uint32_t)cpk;
         fuse.pad_bits = 8 * (int)sizeof(KeyT) - pt.bits * cpk;
         fuse.inv_bits = (65536u + (unsigned)pt.bits - 1u) / (unsigned)pt.bits;
@@ -1911,6 +1945,13 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     }
     SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups, fuse));
     stats.active_after_initial = kept;
+    // A text most of whose suffixes stay tied on 64 key bits (mixed-script UTF-8: 86 %, frequent words in buckets of 10^5 ..
+    // 10^7) will need rank rounds, whose splits only give lower bounds -- the one-call entry point then runs the separate
+    // LCP routine whatever was emitted (build_sa_lcp_u32_dev), so the rounds stop emitting: stats.reserved bit 0
+    if (lcp_fuse && ht && kept * 4 > count * 3) {
+        lcp_fuse = nullptr;
+        stats.reserved |= 1u;
+    }
     // no rank array yet: its n-element scatter is only paid if the text rounds stall (refine)
     // (every bucket of the first active list shares the cpk symbols of the initial key: b.Hd0, the depths of the deep rounds)
     uint64_t h0 = (uint64_t)cpk;                        // symbols every bucket of the first active list shares
@@ -2007,12 +2048,10 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
             SFX_HIP(hipMemcpyAsync(b.ht + kHtTableWords, ht.t12, sizeof(ht.t12), hipMemcpyHostToDevice, st));
         }
     }
-    // (compressed keys: common prefixes cannot be read off them symbol by symbol -- the caller computes the LCP array
-    // separately, which at 28 ms per GB costs less than sorting on fixed-width keys would)
-    if (use_ht) {
-        if (fused_out) *fused_out = false;
-        lcp_fuse = nullptr;
-    }
+    // (compressed keys, round 4: the symbols two different keys share are the code words that end inside their common
+    // leading bits -- ht_common_n in k_groups_reduce; equal keys share the symbols the key holds, at most kHtMaxSym, which
+    // is also how many suffixes at the end of the text have zero-padded keys: the tail fix of the pending pass redoes them)
+    if (use_ht && cpk_out) *cpk_out = (int)kHtMaxSym;
     return sort_and_refine<uint64_t>(pt, cpk, n, true, b, d_sa, b.isa, st, stats, 0, lcp_fuse, use_ht ? &ht : nullptr);
 }
 
@@ -2050,7 +2089,7 @@ int build_sa_lcp_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, uint
     bool done = false;
     // pairs split by rank rounds only carry a lower bound: when the text needed ranks for most of its
     // suffixes, finishing those pairs one by one is the separate routine's job (sampling, Phi / PLCP)
-    if (fused && (stats.rank_rounds == 0 || stats.active_after_initial * 4 <= n))
+    if (fused && !(stats.reserved & 1u) && (stats.rank_rounds == 0 || stats.active_after_initial * 4 <= n))
         SFX_TRY(lcp_finish_pending_dev(d_text, n, d_sa, d_lcp, (uint64_t)cpk, ws, ws_bytes, st, &done));
     if (!done) SFX_TRY(build_lcp_u32_dev(d_text, n, d_sa, d_lcp, ws, ws_bytes, st));
     tls_build_stats() = stats;

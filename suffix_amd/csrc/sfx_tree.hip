@@ -235,12 +235,13 @@ k_tree_parents(const uint32_t* __restrict__ lcp, uint64_t n, const uint32_t* __r
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += stride) {
-        // leaf of rank p: under the deeper of boundaries p and p + 1
-        const uint32_t dl = lcp[p], dr = p + 1 < n ? lcp[p + 1] : 0u;
+        // leaf of rank p: under the deeper of boundaries p and p + 1.  Boundary 0 has depth 0 whatever d_lcp[0] holds
+        // ("not looked at", include/suffix_hip.h: k_pyr_reduce, prev_smaller and k_lcp_intervals ignore it too)
+        const uint32_t dl = p ? lcp[p] : 0u, dr = p + 1 < n ? lcp[p + 1] : 0u;
         leaf_parent[p] = dl >= dr ? node[p] : node[p + 1];
         if (node[p] == 0) { parent[p] = kNoNode; continue; }                     // (the root has no parent: every boundary of depth 0)
         const uint64_t l = lb[p], r = (uint64_t)rb[p] + 1;                        // the two delimiting boundaries
-        const uint32_t vl = lcp[l], vr = r < n ? lcp[r] : 0u;
+        const uint32_t vl = l ? lcp[l] : 0u, vr = r < n ? lcp[r] : 0u;
         parent[p] = vl >= vr ? node[l] : node[r];
     }
 }

@@ -127,7 +127,9 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
     SA[offset : offset + sa_part.numel()] of the global suffix array.
     index_dtype=torch.int64 widens the slice to u64 indices (BASELINE config 4);
     return_text=True appends the all-gathered text (needed for LCP / queries);
-    timings = {} collects per-phase milliseconds (byte_hist, all_gather, key_hist, plan, range_build)."""
+    timings = {} collects per-phase milliseconds (byte_hist, all_gather_issue, key_hist, all_gather_wait, plan, range_build:
+    every value a number) and, under the one non-numeric key timings["info"], notes as strings ("text_exchange": how the
+    text travelled; "fallback": present when every rank built the whole array)."""
     eng = engine or default_engine()
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -202,7 +204,7 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
             allw = torch.empty(max(mxw, 1) * world, dtype=torch.int32, device=dev)
             packed_work = _gather_flat(allw, mine, group, async_op=True)
     if timings is not None:
-        timings["text_exchange"] = ("packed words" + ("" if aligned else " (ragged word grid)")) if packed_path else "raw bytes"
+        timings.setdefault("info", {})["text_exchange"] = ("packed words" + ("" if aligned else " (ragged word grid)")) if packed_path else "raw bytes"
     ph.mark("all_gather_issue")
 
     # 3. bucket-boundary histogram
@@ -282,7 +284,7 @@ def build_sa_partitioned(shard, group=None, engine=None, top_bits=TOP_BITS, retu
         part = full[offset:offset + count].clone()
         del full
         if timings is not None:
-            timings["fallback"] = "replicated build (a slice needed rank refinement)"
+            timings.setdefault("info", {})["fallback"] = "replicated build (a slice needed rank refinement)"
     else:
         eng.check(rc, "sfx_build_sa_range_u32_dev")
         if int(got.value) != count:

@@ -431,6 +431,14 @@ def suffix_tree_topology(eng, orc, device="cpu", scale=1):
         ref = orc.suffix_tree_sweep(lcp)
         for k in ("lb", "rb", "node", "parent", "leaf_parent"):
             assert np.array_equal(got[k], ref[k].astype(np.int64)), (k, text[:20])
+        # include/suffix_hip.h: "d_lcp[0] is not looked at" -- a caller whose LCP routine leaves anything there (0xFFFFFFFF, the
+        # text length ...) gets the same tree: leaf 0's parent and the parents of the nodes delimited by boundary 0 included
+        for junk in (0xFFFFFFFF, n, 1):
+            poisoned = lcp.copy()
+            poisoned[0] = junk
+            t2 = sdev.lcp_intervals(torch.from_numpy(poisoned.view(np.int32).copy()).to(device), engine=eng)
+            for k in ("lb", "rb", "node", "parent", "leaf_parent"):
+                assert np.array_equal(t2[k].cpu().numpy().view(np.uint32), ref[k]), (k, junk, text[:20])
     # generalized suffix array: positions -> (document, offset)
     docs = [b"alpha beta", b"", b"gamma", b"delta epsilon zeta"]
     starts, blob = [], b""

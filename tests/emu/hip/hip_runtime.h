@@ -144,6 +144,7 @@ template <class T> static inline T __shfl_xor(T v, int mask, int width = 64)
 
 // ---- bit ops / atomics -------------------------------------------------------
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline unsigned __funnelshift_l(unsigned lo, unsigned hi, unsigned shift) { shift &= 31u; return shift ? (hi << shift) | (lo >> (32u - shift)) : hi; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }

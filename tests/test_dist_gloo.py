@@ -49,13 +49,14 @@ part, offset, n, text = sdist.build_sa_partitioned(shard, engine=eng, top_bits=1
 assert "range_build" in timings and "key_hist" in timings, timings
 # every shard has >= 64 bytes: the text travels as packed symbol codes, ragged shards included
 if kind == "tiny":
-    assert timings["text_exchange"] == "raw bytes", timings
+    assert timings["info"]["text_exchange"] == "raw bytes", timings
 else:
-    assert timings["text_exchange"].startswith("packed words") and (kind != "ragged" or "ragged" in timings["text_exchange"]), timings
+    assert timings["info"]["text_exchange"].startswith("packed words") and (kind != "ragged" or "ragged" in timings["info"]["text_exchange"]), timings
 if kind in ("periodic", "unary"):                          # repeats longer than text refinement can settle inside a slice
-    assert "fallback" in timings, timings
+    assert "fallback" in timings["info"], timings
 else:
-    assert "fallback" not in timings, timings
+    assert "fallback" not in timings["info"], timings
+    assert all(isinstance(v, (int, float)) for k, v in timings.items() if k != "info"), timings      # phases are numbers
 np.save(os.path.join(os.environ["SFX_OUT"], f"part{{rank}}.npy"), part.numpy().view(np.uint32))
 np.save(os.path.join(os.environ["SFX_OUT"], f"off{{rank}}.npy"), np.array([offset, n]))
 # the partitioned index in use: per-slice LCP (one suffix index exchanged per rank) and

@@ -170,6 +170,29 @@ def test_chunked_radix_schedule_compressed_keys_2p30(eng):
     torch.cuda.empty_cache()
 
 
+def test_config4_virtual_ranks(eng):
+    """BASELINE config 4 at its stated size on one GPU: 4 * 10^9 B of DNA, the four ranges of plan_ranges built one after
+    another by sfx_build_sa_range_packed_u32_dev (what each of the 4 ranks would run), every slice equal to its stretch of
+    one single-GPU build of the same text (itself gated: permutation + every adjacent pair in order), sizes summing to n,
+    sha256 of the concatenation equal, u64 widening checked; per-rank milliseconds go to gpurun_out/ (copied to
+    profiles/r4_config4_virtual.jsonl).  tests/_config4.py."""
+    import _config4
+    n = 4_000_000_000
+    free, _total = torch.cuda.mem_get_info()
+    if free < 240e9:
+        pytest.skip("needs ~230 GB of free HBM for the single-GPU comparison build")
+    recs = _config4.rehearse(n, world=4)
+    assert len(recs) == 5 and all(r["equals_single_gpu_slice"] for r in recs[:4])
+    assert max(r["largest_position"] for r in recs[:4]) >= (1 << 31)          # positions beyond 2^31 were placed
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "r4_config4_virtual.jsonl"), "w") as f:
+            for r in recs:
+                f.write(json.dumps(r) + "\n")
+    except OSError:
+        pass
+
+
 def test_two_gpu_bench_over_rccl():
     """bench.py --gpus 2 under torch.distributed.run with the nccl (= RCCL) backend, one rank per GPU: the
     partitioned build's first contact with RCCL.  Skipped on 1-GPU boxes (the driver's multi-GPU node runs it)."""
