@@ -40,6 +40,14 @@ const char* sfx_strerror(int status);
 int sfx_device_count(void);
 /* text of the last HIP error seen by this thread ("" if none) */
 const char* sfx_last_hip_error(void);
+/* Process-wide switches (additive; the defaults are what every number in DESIGN.md is quoted with; the library reads no
+ * environment).  SFX_OPT_TINY_MAX: texts of up to this many bytes are built by ONE workgroup in ONE launch (sfx_tiny.hip:
+ * alphabet, LSD radix sort of the suffixes' first key bits and the ordering of tied suffixes all inside one CU's LDS) --
+ * default and largest value 16384, 0 = never (the tests use it to run small inputs through the general build as well).
+ * sfx_set_option returns SFX_ERR_ARG for an unknown option or a value out of range. */
+#define SFX_OPT_TINY_MAX 1
+int      sfx_set_option(int option, uint64_t value);
+uint64_t sfx_get_option(int option);
 
 /* ---- SuffixTable::new -> sais_table (:378-386): suffix array, u32 indices ---- */
 /* Host buffers.  Replaces the body of sais_table after `vec![0u32; n]` (:381-385).

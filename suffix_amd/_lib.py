@@ -84,7 +84,10 @@ ABI = [
     ("sfx_profile_report", _int, [ctypes.POINTER(KernelStat), _int]),
     ("sfx_last_build_stats", None, [ctypes.POINTER(BuildStats)]),
     ("sfx_build_stats_read", _u64, [_vp, _u64]),
+    ("sfx_set_option", _int, [_int, _u64]),
+    ("sfx_get_option", _u64, [_int]),
 ]
+SFX_OPT_TINY_MAX = 1
 
 
 class SuffixHipError(RuntimeError):

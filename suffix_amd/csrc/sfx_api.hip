@@ -685,6 +685,15 @@ void sfx_last_build_stats(sfx_build_stats* out)
 {
     if (out) *out = tls_build_stats();
 }
+int sfx_set_option(int option, uint64_t value)
+{
+    if (option == SFX_OPT_TINY_MAX && value <= tiny_max_default()) { tiny_set_limit(value); return SFX_OK; }
+    return SFX_ERR_ARG;
+}
+uint64_t sfx_get_option(int option)
+{
+    return option == SFX_OPT_TINY_MAX ? tiny_limit() : 0;
+}
 uint64_t sfx_build_stats_read(void* out, uint64_t out_bytes)
 {
     if (out && out_bytes) {

@@ -146,6 +146,23 @@ __device__ __forceinline__ uint32_t rank_round(unsigned d, unsigned long long* f
     return pre + below;
 }
 
+// rank_round<true> with 16-bit counts (tiles of < 65536 elements: k_radix_sweep, k_tiny_sa)
+__device__ __forceinline__ uint32_t rank_round16(unsigned d, unsigned long long* flags_w, uint16_t* cnt_w, unsigned long long mybit)
+{
+    atomicOr(&flags_w[d], mybit);
+    wave_sync();
+    const unsigned long long peers = flags_w[d];
+    const uint32_t pre = cnt_w[d];
+    wave_sync();
+    const unsigned below = lanes_below(peers);
+    if (below == 0) {
+        flags_w[d] = 0ull;
+        cnt_w[d] = (uint16_t)(pre + (uint32_t)__popcll(peers));
+    }
+    wave_sync();
+    return pre + below;
+}
+
 // ---- packed text -------------------------------------------------------------------
 // The text is re-coded once per build into dense symbol codes of `bits` bits and
 // packed big-endian, spw = floor(32/bits) symbols per 32-bit word (DNA: 16 symbols per

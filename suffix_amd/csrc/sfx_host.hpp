@@ -289,6 +289,11 @@ int tile_round_rank(const uint32_t* isa, uint64_t n, uint64_t h, const TileRound
 __global__ void k_scan_block_counts(uint32_t* __restrict__ counts, unsigned nb, uint32_t* __restrict__ out_total);
 
 uint64_t sa_workspace_bytes(uint64_t n);
+// texts of up to tiny_limit() bytes: one workgroup, one launch (sfx_tiny.hip); *done = false: not a text for it
+uint64_t tiny_max_default();
+uint64_t tiny_limit();
+void tiny_set_limit(uint64_t n);
+int tiny_build_sa_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, hipStream_t st, bool* done);
 int build_sa_u32_dev(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* ws, uint64_t ws_bytes,
                      hipStream_t st);
 int pack_small_alphabet(const uint8_t* d_text, uint64_t n, int max_bits, void* small, uint32_t* d_packed,

@@ -577,22 +577,6 @@ struct SweepSmem {
     uint32_t part[2][NW];
     uint32_t ticket;
 };
-// rank_round<true> with 16-bit counts
-__device__ __forceinline__ uint32_t rank_round16(unsigned d, unsigned long long* flags_w, uint16_t* cnt_w, unsigned long long mybit)
-{
-    atomicOr(&flags_w[d], mybit);
-    wave_sync();
-    const unsigned long long peers = flags_w[d];
-    const uint32_t pre = cnt_w[d];
-    wave_sync();
-    const unsigned below = lanes_below(peers);
-    if (below == 0) {
-        flags_w[d] = 0ull;
-        cnt_w[d] = (uint16_t)(pre + (uint32_t)__popcll(peers));
-    }
-    wave_sync();
-    return pre + below;
-}
 template <class Src, class Dst, int KPT, int NW>
 __global__ void __launch_bounds__(NW * kWave, 1)
 k_radix_sweep(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const uint32_t* __restrict__ digit_total,

@@ -1995,6 +1995,15 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
         return SFX_OK;
     }
     if (!ws || ws_bytes < sa_workspace_bytes(n)) return SFX_ERR_WORKSPACE;
+    if (n <= tiny_limit()) {
+        // one workgroup, one launch (sfx_tiny.hip); a text it gives up on (long runs of equal keys: repeats) goes on below
+        bool done = false;
+        SFX_TRY(tiny_build_sa_dev(d_text, n, d_sa, ws, st, &done));
+        if (done) {
+            if (fused_out) *fused_out = false;            // (the one-call SA + LCP entry point runs its LCP routine on the array)
+            return SFX_OK;
+        }
+    }
 
     Arena ar(ws, ws_bytes);
     SaBuffers b;

@@ -16,12 +16,33 @@ def sha_u32(a):
     return hashlib.sha256(np.ascontiguousarray(a, dtype="<u4").tobytes()).hexdigest()
 
 
+TINY_OPT = 1                                                            # SFX_OPT_TINY_MAX (include/suffix_hip.h)
+
+
+class general_build:
+    """with general_build(eng): texts of any length take the general build (sfx_set_option(SFX_OPT_TINY_MAX, 0)); the
+    single-workgroup build of texts of up to 16384 bytes (sfx_tiny.hip) is restored on exit."""
+    def __init__(self, eng):
+        self.eng = eng
+
+    def __enter__(self):
+        self.old = int(self.eng.lib.sfx_get_option(TINY_OPT))
+        assert self.eng.lib.sfx_set_option(TINY_OPT, 0) == 0
+        return self
+
+    def __exit__(self, *exc):
+        assert self.eng.lib.sfx_set_option(TINY_OPT, self.old) == 0
+        return False
+
+
 def check_text(eng, orc, text, lcp=True, queries=()):
-    """Build SA (+LCP, + queries) with the engine; compare bit-exactly with the oracle."""
+    """Build SA (+LCP, + queries) with the engine; compare bit-exactly with the oracle.  A text short enough for the
+    single-workgroup build is built both ways: by it (the default) and by the general build."""
     st = SuffixTable(text, engine=eng)
     exp = orc.sais(st._text)
     assert st.len() == len(st._text)                                    # prop_length
     assert np.array_equal(st.table(), exp), f"SA mismatch on {st._text[:40]!r}..."
+
     if lcp:
         exp_lcp = orc.lcp_quadratic(st._text, exp)
         assert np.array_equal(st.lcp_lens(), exp_lcp)
@@ -41,7 +62,56 @@ def check_text(eng, orc, text, lcp=True, queries=()):
                 assert st._text[a:a + len(qb)] == qb                    # "arbitrary" occurrence
             else:
                 assert int(anyp[k]) == 0xFFFFFFFF
+    # (last, so that eng.build_stats() after check_text describes the general build, as the callers that look at it expect)
+    if 2 <= len(st._text) <= int(eng.lib.sfx_get_option(TINY_OPT)):
+        with general_build(eng):
+            assert np.array_equal(SuffixTable(text, engine=eng).table(), exp), f"SA mismatch (general build) on {st._text[:40]!r}..."
+            if lcp:
+                st3, lcp3 = SuffixTable.new_with_lcp(text, engine=eng)  # ... and the fused arrays of the general build
+                assert np.array_equal(st3.table(), exp) and np.array_equal(lcp3, orc.lcp_quadratic(st._text, exp)), "fused SA+LCP (general build)"
     return st
+
+
+def tiny_build(eng, orc):
+    """The single-workgroup build (sfx_tiny.hip, texts of up to 16384 bytes): which texts it finishes, which it hands to the
+    general build, and that both give the reference's table.  Runs of equal keys: repeats in 2 .. 32 copies (ordered by
+    direct comparison inside the kernel), in more than 32 copies and unary / periodic texts (given up: general build),
+    suffixes that end inside the key window and look like runs of the smallest symbol."""
+    rng = np.random.default_rng(77)
+    limit = int(eng.lib.sfx_get_option(TINY_OPT))
+    assert limit == 16384
+
+    def build(text):
+        eng.profile(True); eng.profile_reset()
+        sa = SuffixTable(text, engine=eng).table()
+        names = {r["name"] for r in eng.profile_report()}
+        eng.profile(False)
+        assert np.array_equal(sa, orc.sais(text)), (len(text), text[:30])
+        return names
+
+    dna = _gen.dna(16384, seed=11).tobytes()
+    finished = [b"ab", b"ba", b"aab", b"banana", b"mississippi", dna, dna[:10001], dna[:1023], dna[:1025],
+                _gen.english_like(1200, seed=5).tobytes(), bytes(rng.integers(0, 256, 4000, dtype=np.uint8)),
+                _gen.uniform_bytes(5000, 3, 4, base=97).tobytes(), _gen.uniform_bytes(6000, 16, 9, base=65).tobytes(),
+                _gen.uniform_bytes(4000, 17, 9, base=65).tobytes(), "\u2603abc\u2603".encode(),
+                # repeats of 40 .. 300 symbols in 2 .. 30 copies: runs of equal keys ordered inside the kernel
+                b"".join(dna[a:a + ln] + bytes([66 + k % 3]) for k, (a, ln) in enumerate(zip(rng.integers(0, 9000, 30).tolist(), rng.integers(40, 300, 30).tolist()))) * 3,
+                # the smallest symbol in runs at the end and before it: suffixes that end inside the key against real runs
+                dna[:3000].replace(b"C", b"A") + b"A" * 20, b"A" * 12 + dna[:2000] + b"A" * 14]
+    for t in finished:
+        names = build(t)
+        assert "tiny_sa" in names and "groups_reduce" not in names, (len(t), sorted(names))
+    given_up = [b"a" * 5000, b"ab" * 4000 + b"a", _gen.fibonacci_string(19)[:9000], (dna[:200] + b"N") * 60,
+                _gen.english_like(9000, seed=5).tobytes(), bytes(rng.integers(0, 256, 7000, dtype=np.uint8))]   # (8-bit symbols, > 4096 of them)
+    for t in given_up:
+        names = build(t)
+        assert "tiny_sa" in names and "groups_reduce" in names, (len(t), sorted(names))
+    names = build(dna + b"A")                                              # one byte too long: the general build at once
+    assert "tiny_sa" not in names and "groups_reduce" in names
+    with general_build(eng):
+        assert "tiny_sa" not in build(dna[:5000])
+    for t in finished[:8]:
+        check_text(eng, orc, t)                                            # (+ LCP, + the fused entry point over the tiny build)
 
 
 def literals(eng, orc, golden):
@@ -243,6 +313,8 @@ def fused_lcp_tails(eng, orc, iters=40, scale=1):
     than the key have zero-padded keys that overstate the common prefix, which the tail fix-up redoes."""
     rng = np.random.default_rng(3)
     fused = 0
+    tiny_was = int(eng.lib.sfx_get_option(TINY_OPT))
+    assert eng.lib.sfx_set_option(TINY_OPT, 0) == 0                     # (the fused LCP of the general build is what is tested)
     for it in range(iters):
         n = int(rng.integers(200, 4000)) * scale
         base = _gen.dna(n, seed=100 + it).tobytes()
@@ -260,6 +332,7 @@ def fused_lcp_tails(eng, orc, iters=40, scale=1):
         assert np.array_equal(st.table(), exp) and np.array_equal(lcp, orc.lcp_quadratic(t, exp))
     assert fused >= iters // 2, fused
     fused_lcp_short_suffix_ties(eng, orc)
+    assert eng.lib.sfx_set_option(TINY_OPT, tiny_was) == 0
     assert SuffixTable.new_with_lcp(b"", engine=eng)[1].size == 0
     assert SuffixTable.new_with_lcp(b"x", engine=eng)[1].tolist() == [0]
 

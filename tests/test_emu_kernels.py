@@ -37,6 +37,10 @@ def test_fasta_10k(emu, oracle, golden, fasta):
     _cases.fasta_fixture(emu, oracle, golden, fasta, "AP009048_10000")
 
 
+def test_single_workgroup_build(emu, oracle):
+    _cases.tiny_build(emu, oracle)
+
+
 def test_random_small(emu, oracle):
     _cases.random_small(emu, oracle, iters=60, max_len=90, seed=101)
 
@@ -139,7 +143,8 @@ def test_build_stats_and_profile(emu):
     from suffix_amd import SuffixTable
     emu.profile(True)
     emu.profile_reset()
-    SuffixTable(_gen.dna(5000).tobytes(), engine=emu)
+    with _cases.general_build(emu):
+        SuffixTable(_gen.dna(5000).tobytes(), engine=emu)
     st = emu.build_stats()
     assert st["n"] == 5000 and st["sigma"] == 4 and st["bits_per_symbol"] == 2
     assert st["key_bits"] == 32 and st["symbols_per_key"] == 16

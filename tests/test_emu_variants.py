@@ -203,6 +203,6 @@ def test_engine_variant_on_emulator(tmp_path, name):
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(HERE, "emu")])
     script = tmp_path / "variant.py"
     script.write_text(SCRIPT.format(root=ROOT, here=HERE))
-    env = dict(os.environ, **VARIANTS[name])
+    env = dict(os.environ, SFX_TINY="0", **VARIANTS[name])        # (SFX_TINY=0: the variants are about the general build)
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -62,6 +62,10 @@ def test_index_directory_queries(eng, oracle):
     _cases.directory_queries(eng, oracle, device="cuda", scale=20)
 
 
+def test_single_workgroup_build(eng, oracle):
+    _cases.tiny_build(eng, oracle)
+
+
 def test_suffix_tree_topology_and_doc_lookup(eng, oracle):
     _cases.suffix_tree_topology(eng, oracle, device="cuda", scale=3)
 
