@@ -183,23 +183,20 @@ struct PackedText {
     int spw;            // symbols per word
     int kbits;          // bits * spw  (<= 32)
     double inv_spw;     // 1.0 / spw
-    int spw_log2 = -1;  // log2(spw) when spw is a power of two (bits in {1, 2, 4, 8}: DNA, bytes), else -1
 };
-__host__ __device__ inline int packed_spw_log2(int spw) { return (spw & (spw - 1)) == 0 ? 31 - __builtin_clz((unsigned)spw) : -1; }
 
 // p / spw for any spw in 1..32, exact for p < 2^52: (p + 0.5) / spw is at least
 // 0.5/32 away from every integer, far more than the rounding error of the product.
-// (power-of-two spw: a shift -- the double-precision form is ~10 VALU instructions, several of them quarter-rate, per key,
-// and the text-fed radix pass extracts 16 keys per thread and tile)
+// (Round 4 tried a shift for power-of-two spw behind a uniform branch: the text-fed radix pass gained 2 % (0.449 -> 0.440 ms),
+// but the branch puts every key's loads into a basic block of their own, the gathers of k_small_groups no longer overlap,
+// and the direct pass lost 30 % at 8 virtual ranks (0.55 -> 0.72 ms) -- A/B against round 3's library.  Branch-free it stays.)
 __device__ __forceinline__ uint64_t packed_word_index(const PackedText& t, uint64_t p)
 {
-    if (t.spw_log2 >= 0) return p >> t.spw_log2;
     return (uint64_t)(((double)p + 0.5) * t.inv_spw);
 }
 
 __device__ __forceinline__ unsigned packed_word_offset(const PackedText& t, uint64_t p, uint64_t q)
 {
-    if (t.spw_log2 >= 0) return (unsigned)p & ((unsigned)t.spw - 1u);
     return (unsigned)(p - q * (uint64_t)t.spw);
 }
 // the spw symbols starting at position p, as a kbits-bit big-endian number

@@ -1582,7 +1582,6 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
         pt->spw = alpha->spw;
         pt->kbits = alpha->kbits;
         pt->inv_spw = 1.0 / alpha->spw;
-        pt->spw_log2 = packed_spw_log2(alpha->spw);
         return SFX_OK;
     }
     uint64_t nw = n_words_out ? n_words_out : packed_words(n, alpha);
@@ -1611,7 +1610,6 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
     pt->spw = alpha->spw;
     pt->kbits = alpha->kbits;
     pt->inv_spw = 1.0 / alpha->spw;
-    pt->spw_log2 = packed_spw_log2(alpha->spw);
     return SFX_OK;
 }
 
