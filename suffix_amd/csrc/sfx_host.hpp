@@ -158,6 +158,7 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
 // > 0: an E64 sort of m elements on bits [bit_lo, bit_hi) takes digit counts from its producer,
 // from at most this many workgroups
 unsigned radix_e64_presort_hist(uint64_t m, int bit_lo, int bit_hi);
+bool radix_e64_hybrid_expected(uint64_t m, int key_bits);
 inline uint32_t* radix_partial(uint32_t* scratch) { return scratch; }
 int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, int bit_lo,
                     int bit_hi, uint32_t* scratch, hipStream_t st, int* result_in_1,

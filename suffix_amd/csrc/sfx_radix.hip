@@ -1234,6 +1234,14 @@ constexpr int kBucketNW = 16, kBucketKPT = 16;                // the largest geo
 // (k_range_filter stores key - first key of the range): the sub-bucket of an element is its key >> (elem_bits - 16), the
 // histogram is counted from the elements (k_hist16_e64), both device-wide passes read elements (e0 -> e1 -> e0) and the
 // LDS sort reads e0; when the route gives way nothing has been touched but e1 and the scratch.
+// will a slice of m explicit elements whose keys fit key_bits bits take the hybrid route (hybrid_sort_e64_text's own entry test)?
+// Then its sub-bucket histogram supplies the digit totals and the producer of the elements need not count digits.
+bool radix_e64_hybrid_expected(uint64_t m, int key_bits)
+{
+    static const int enabled = [] { const char* e = dev_env("SFX_HYBRID"); return e ? atoi(e) : 1; }();
+    static const uint64_t min_m = [] { const char* e = dev_env("SFX_HYBRID_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 25); }();
+    return enabled && key_bits >= 24 && m >= min_m && m <= (1ull << 28);
+}
 static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, const RadixScratch& scr,
                                 hipStream_t st, sfx_build_stats* stats, const PackedText& text, uint32_t* split_v,
                                 uint32_t** split_k_out, bool* done, bool* windows_ready, int elem_bits = 0)

@@ -2161,7 +2161,13 @@ static int range_build(const PackedText& pt, int cpk, int top_bits, uint32_t bin
     // 32-bit keys: the emit pass also counts the digits for the one-sweep sort of its output
     unsigned hist_blocks = 0;
     uint32_t* digit_partial = nullptr;
-    if (sizeof(KeyT) == 4 && ch.blocks <= radix_e64_presort_hist(host_total, 32, 32 + pt.bits * cpk)) {
+    // (the keys of the slice, less its first key, fit elem_bits bits)
+    const uint64_t width = (uint64_t)(bin_hi - bin_lo) << (pt.bits * cpk - top_bits);
+    const int elem_bits = bits_for(width > 1 ? width - 1 : 1);
+    // (a slice the hybrid route will take gets its digit totals from the sub-bucket histogram: four LDS atomics per kept
+    // element saved; should the route give way after all, the sort counts for itself)
+    if (sizeof(KeyT) == 4 && !radix_e64_hybrid_expected(host_total, elem_bits) &&
+        ch.blocks <= radix_e64_presort_hist(host_total, 32, 32 + pt.bits * cpk)) {
         hist_blocks = ch.blocks;
         digit_partial = radix_partial(b.hist);
     }
@@ -2173,9 +2179,6 @@ static int range_build(const PackedText& pt, int cpk, int top_bits, uint32_t bin
         SFX_LAUNCH("range_emit", (double)n * pt.bits / 8.0 + (double)host_total * (sizeof(KeyT) + 4),
                    (k_range_filter<KeyT, 0>), ch.blocks, kBlock, st, pt, pt.bits * cpk, top_bits, bin_lo, bin_hi,
                    chunk, 1, block_counts, capacity, k0, b.VA, digit_partial);
-    // (the keys of the slice, less its first key, fit elem_bits bits)
-    const uint64_t width = (uint64_t)(bin_hi - bin_lo) << (pt.bits * cpk - top_bits);
-    const int elem_bits = bits_for(width > 1 ? width - 1 : 1);
     return sort_and_refine<KeyT>(pt, cpk, host_total, false, b, d_sa_part, nullptr, st, stats, hist_blocks, nullptr, nullptr,
                                  sizeof(KeyT) == 4 ? elem_bits : 0);
 }
