@@ -146,23 +146,7 @@ __global__ void k_cmp32(const uint32_t* a, const uint32_t* b, uint64_t n, unsign
     if (c) atomicAdd(bad, c);
 }
 
-// 16-bit per-wave digit counts (a wave sees at most 64 * KPT <= 1408 elements of a tile)
-__device__ __forceinline__ uint32_t rank_round16(unsigned d, unsigned long long* flags_w, uint16_t* cnt_w, unsigned long long mybit)
-{
-    atomicOr(&flags_w[d], mybit);
-    wave_sync();
-    const unsigned long long peers = flags_w[d];
-    const uint32_t pre = cnt_w[d];
-    wave_sync();
-    const unsigned below = lanes_below(peers);
-    if (below == 0) {
-        flags_w[d] = 0ull;
-        cnt_w[d] = (uint16_t)(pre + (uint32_t)__popcll(peers));
-    }
-    wave_sync();
-    return pre + below;
-}
-
+// (rank_round16 -- the match-mask ranking with 16-bit counts -- started here and now lives in sfx_device.hpp)
 template <int KPT, bool HAS_VAL, int NW>
 struct LeanSmem {
     uint64_t stage[NW * kWave * KPT];                    // (match masks of the ranking alias its first NW * 2 KiB)
