@@ -925,7 +925,25 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
 #pragma unroll
                 for (int j = 0; j < kGroupItems; j++)
                     if (((k8 >> j) & 1u) && (j == 0 || !((k8 >> (j - 1)) & 1u) || k64[j] != k64[j - 1])) want |= 1u << j;
-                ht_depth_n<kGroupItems>(k64, want, reinterpret_cast<const uint16_t*>(s_t12), dep);
+                // (one key at a time: a thread wants 1.7 of its 8 on English-like text, and the kernel is VALU-bound -- 92 % of the
+                // SIMD cycles on the 10^9-element pass of config 3 -- so decoding all eight side by side, wanted or not, until the
+                // slowest of a wave's 512 is done cost more than walking the set bits)
+#pragma unroll
+                for (int j = 0; j < kGroupItems; j++) dep[j] = 0;
+                unsigned todo = want;
+                while (todo) {
+                    const unsigned j = (unsigned)__ffs((int)todo) - 1u;
+                    todo &= todo - 1u;
+                    uint64_t kx = k64[0];
+#pragma unroll
+                    for (int q = 1; q < kGroupItems; q++) kx = j == (unsigned)q ? k64[q] : kx;
+                    const uint64_t one[1] = {kx};
+                    const unsigned all[1] = {(unsigned)kHtKeyBits};
+                    uint32_t d1[1];
+                    ht_common_n<1>(one, all, reinterpret_cast<const uint16_t*>(s_t12), d1);
+#pragma unroll
+                    for (int q = 0; q < kGroupItems; q++) dep[q] = j == (unsigned)q ? d1[0] : dep[q];
+                }
 #pragma unroll
                 for (int j = 1; j < kGroupItems; j++)
                     if (((k8 >> j) & 1u) && !((want >> j) & 1u)) dep[j] = dep[j - 1];
