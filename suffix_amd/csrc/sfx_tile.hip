@@ -514,21 +514,34 @@ __device__ __forceinline__ uint32_t lcp_deep(const LcpEmit& L, uint32_t depth, u
     return v < lb ? v : lb;
 }
 
-// One element of the wave's window during a sort: key (the 64 gathered bits), and pk = start of its sub-bucket << 16 |
-// the position it came from.  Order: sub-bucket, then key, then origin (a strict total order: ties cannot make the
-// two sides of a compare-exchange disagree).
-__device__ __forceinline__ bool deep_less(uint64_t ka, uint32_t pa, uint64_t kb, uint32_t pb)
+// One element of the wave's window during a sort: (sub-bucket tag, the 64 gathered key bits, the slot it came from), ordered by
+// the three in turn -- a strict total order: ties cannot make the two sides of a compare-exchange disagree.  For the network the
+// 96 bits travel as hi = tag << 48 | key >> 16 and lo = (key & 0xFFFF) << 16 | origin: one 64-bit and one 32-bit compare per
+// compare-exchange instead of three compares with their selects (the kernel is VALU-bound: SQ counters, 75 % of the SIMD cycles).
+struct DeepElem { uint64_t hi; uint32_t lo; };
+__device__ __forceinline__ DeepElem deep_pack(uint64_t key, uint32_t pk)
 {
-    const uint32_t ba = pa >> 16, bb = pb >> 16;
-    return ba != bb ? ba < bb : (ka != kb ? ka < kb : pa < pb);
+    return DeepElem{((uint64_t)(pk >> 16) << 48) | (key >> 16), ((uint32_t)(key & 0xFFFFull) << 16) | (pk & 0xFFFFu)};
+}
+__device__ __forceinline__ void deep_unpack(const DeepElem& x, uint64_t& key, uint32_t& pk)
+{
+    key = (x.hi << 16) | (uint64_t)(x.lo >> 16);
+    pk = ((uint32_t)(x.hi >> 48) << 16) | (x.lo & 0xFFFFu);
+}
+__device__ __forceinline__ bool deep_less(const DeepElem& a, const DeepElem& b)
+{
+    return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo;
 }
 // Bitonic sort of the 64 * E elements of a wave, E consecutive ones per lane (element i = lane * E + e): the
 // compare-exchanges at distance < E stay inside a lane's registers, the others swap with lane ^ (distance / E).
-// No LDS, no divergence, the same ~40 instructions per element whatever the bucket sizes are.
+// No LDS, no divergence, the same instructions per element whatever the bucket sizes are.
 template <int E>
 __device__ __forceinline__ void deep_bitonic(uint64_t (&key)[E], uint32_t (&pk)[E])
 {
     const unsigned lane = lane_id();
+    DeepElem x[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) x[e] = deep_pack(key[e], pk[e]);
 #pragma unroll
     for (int k = 2; k <= kWave * E; k <<= 1) {
 #pragma unroll
@@ -539,10 +552,11 @@ __device__ __forceinline__ void deep_bitonic(uint64_t (&key)[E], uint32_t (&pk)[
                 const bool keep_min = asc == ((lane & lm) == 0u);
 #pragma unroll
                 for (int e = 0; e < E; e++) {
-                    const uint64_t ok = __shfl_xor(key[e], (int)lm);
-                    const uint32_t op = __shfl_xor(pk[e], (int)lm);
-                    const bool mine_less = deep_less(key[e], pk[e], ok, op);
-                    if (mine_less != keep_min) { key[e] = ok; pk[e] = op; }
+                    DeepElem o;
+                    o.hi = __shfl_xor(x[e].hi, (int)lm);
+                    o.lo = __shfl_xor(x[e].lo, (int)lm);
+                    const bool mine_less = deep_less(x[e], o);
+                    if (mine_less != keep_min) x[e] = o;
                 }
             } else {
 #pragma unroll
@@ -550,15 +564,16 @@ __device__ __forceinline__ void deep_bitonic(uint64_t (&key)[E], uint32_t (&pk)[
                     const int f = e ^ j;
                     if (f > e) {
                         const bool asc = k >= E ? ((lane * (unsigned)E) & (unsigned)k) == 0u : (e & k) == 0;
-                        if (deep_less(key[f], pk[f], key[e], pk[e]) == asc) {
-                            const uint64_t tk = key[e]; key[e] = key[f]; key[f] = tk;
-                            const uint32_t tp = pk[e]; pk[e] = pk[f]; pk[f] = tp;
+                        if (deep_less(x[f], x[e]) == asc) {
+                            const DeepElem t = x[e]; x[e] = x[f]; x[f] = t;
                         }
                     }
                 }
             }
         }
     }
+#pragma unroll
+    for (int e = 0; e < E; e++) deep_unpack(x[e], key[e], pk[e]);
 }
 
 // counters[1] += buckets announced to the large path (the returned value is the bucket's place in `segs`); the members
@@ -613,6 +628,10 @@ __device__ __forceinline__ unsigned deep_step(const DeepTextKey& keyfn, DeepSmem
     }
 #pragma unroll
     for (int e = 0; e < E; e++) key[e] = j0 + (unsigned)e < cnt ? keyfn(suf[e], (uint32_t)hd[e] + it * (uint32_t)keyfn.wsym) : ~0ull;
+    // (Ordering by all-pairs comparison inside the sub-buckets when none of the wave's has more than 8 / 16 / 32 members -- keys
+    // through LDS, ~11 instructions per member and step against the network's 15 per member and stage -- was measured on config 3:
+    // 22.3 / 21.9 / 23.5 ms against 17.8.  The 3 KB of LDS per wave it needs cost a quarter of the occupancy (20.3 ms with the
+    // network alone and the larger LDS footprint), and the kernel lives on both: 75 % VALU-busy AND waiting on its gathers.)
     deep_bitonic<E>(key, pk);
     wave_sync();
 #pragma unroll
