@@ -905,8 +905,11 @@ k_oversize_return(const uint64_t* __restrict__ T, const OversizeEntry* __restric
 constexpr uint32_t kPairLimit = 32;
 constexpr int kGroupBits = 10;
 constexpr int kGroups = 1 << kGroupBits;
+// (The 256 x 8 geometry asks for six workgroups per CU -- 80 registers instead of the 88 the compiler takes unasked, five
+// workgroups: the sort waits on LDS round trips 62 % of its wave cycles (scripts/gpu_sq_dna.sh), and one more workgroup to
+// switch to is worth 10 %, 0.40 -> 0.36 ms on 100 MB of DNA; seven (72 registers) gives it back, 0.41.)
 template <int NW, int KPT>
-__global__ void __launch_bounds__(NW * kWave)
+__global__ void __launch_bounds__(NW * kWave) SFX_WAVES_PER_EU(NW == 4 && KPT == 8 ? 6 : 1, 8)
 k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstart, uint32_t nbuckets, int low_bits,
               uint32_t lo, uint32_t hi, uint32_t* __restrict__ K, uint32_t* __restrict__ V)
 {
