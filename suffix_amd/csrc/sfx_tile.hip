@@ -706,10 +706,11 @@ __device__ __forceinline__ unsigned deep_step(const DeepTextKey& keyfn, DeepSmem
 // large path.  (A second pass of the same kernel over the classes the large path makes of its buckets was measured:
 // it finishes most of them a round earlier, but the large buckets stay large for as many levels as before and the
 // extra scan of the list costs what the shorter lists save -- 222 against 177 ms on 1 GB of English-like text.)
-// (the kernel waits on its gathers: at 8 waves per SIMD -- 64 registers, no spill with windows of up to 256 positions --
-// config 3's deep rounds take 19.4 ms, at the 6 the compiler picks by itself 21.6)
+// (the kernel waits on its gathers: at 8 waves per SIMD -- 64 registers -- config 3's deep rounds took 19.4 ms in round 3, at the
+// 6 the compiler picks by itself 21.6; with round 4's packed sort elements 64 registers spill three words, and 7 waves -- 72
+// registers, no spill -- is the better point: 17.3 against 17.8 ms)
 template <int KPT, bool EMIT>
-__global__ void __launch_bounds__(kBlock) SFX_WAVES_PER_EU(KPT <= 4 ? 8 : 4, 8)
+__global__ void __launch_bounds__(kBlock) SFX_WAVES_PER_EU(KPT <= 4 ? 7 : 4, 8)
 k_deep_wave(DeepTextKey keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* __restrict__ V, uint8_t* __restrict__ F8,
             uint16_t* __restrict__ Hd, unsigned long long* __restrict__ counters,
             unsigned long long* __restrict__ slots, uint2* __restrict__ segs, LcpEmit emit, int max_iter)
