@@ -8,4 +8,4 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_SA
 cd $ROOT
 python scripts/pmc_summary.py $OUT/sq $OUT/sq2 > $OUT/sq_summary.csv
 find $OUT -name "*.csv" -size +5M -delete
-grep -E "deep_wave|seg_single|groups_apply|k_radix_sweep<sfx::SrcKV|kernel" $OUT/sq_summary.csv | cut -c1-400 | head -60
+python scripts/sq_table.py $OUT/sq_summary.csv

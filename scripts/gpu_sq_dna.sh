@@ -8,4 +8,4 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_SA
 cd $ROOT
 python scripts/pmc_summary.py $OUT/sq $OUT/sq2 > $OUT/sq_summary.csv
 find $OUT -name "*.csv" -size +5M -delete
-grep -E "bucket_sort|kernel" $OUT/sq_summary.csv | cut -c1-300 | head -40
+python scripts/sq_table.py $OUT/sq_summary.csv
