@@ -1881,7 +1881,9 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
             if (kept * 3 > m * 2) stalled += kept + (4u << 20);
             // (the depths of the deep rounds are 16-bit; a text that deep is a repeat anyway)
             const bool too_deep = h + 2 * (uint64_t)wsym > 60000;
-            if (isa && force != 1 && (stalled * 2 > n || force == 2 || too_deep)) {
+            // SFX_TEXT_ROUNDS_MIN=<k> (development): at least k text rounds before the switch
+            static const uint32_t min_text = [] { const char* e = dev_env("SFX_TEXT_ROUNDS_MIN"); return e ? (uint32_t)atoi(e) : 0u; }();
+            if (isa && force != 1 && (stalled * 2 > n || force == 2 || too_deep) && (too_deep || stats.text_rounds >= min_text)) {
                 // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
                 uint32_t md = 0;
                 SFX_TRY(read_back(&md, b.ht + 256, sizeof(md), st));
