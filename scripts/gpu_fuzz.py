@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off randomized parity run on the GPU beyond the sizes of the test suite: python scripts/gpu_fuzz.py [iters] [max_len] [seed]
+"""One-off randomized parity run on the GPU beyond the sizes of the test suite: python scripts/gpu_fuzz.py [iters] [max_len] [seed] [min_len]
 Random length, alphabet, symbol distribution (uniform / Zipf / two dominant symbols) and repeat structure (planted copies,
 periodic stretches, trailing runs, few distinct words); every text through new(), lcp_lens(), the one-call entry and a few
 queries, all compared with the oracle (tests/_cases.check_text; Kasai instead of the quadratic LCP for speed)."""
@@ -14,9 +14,10 @@ eng = suffix_amd.default_engine(); eng.require_device()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 max_len = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
 rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 1234)
+min_len = int(sys.argv[4]) if len(sys.argv) > 4 else 50_000          # (below 16 KiB: the single-workgroup build)
 t0 = time.time()
 for it in range(iters):
-    n = int(rng.integers(50_000, max_len))
+    n = int(rng.integers(min_len, max_len))
     sigma = int(rng.choice([2, 4, 5, 17, 20, 64, 66, 100, 141, 256]))
     dist = it % 3
     if dist == 0 or sigma < 5:
