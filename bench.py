@@ -113,11 +113,12 @@ def _sha_u32(t):
 
 
 def running_commit():
-    """The commit this code was built from: git where there is a checkout, else the stamp __graft_entry__.build() leaves
-    next to the library (the GPU boxes get a snapshot without .git)."""
+    """The last commit that touched the engine's sources (suffix_amd/csrc, include): git where there is a checkout, else the
+    stamp __graft_entry__.build() leaves next to the library (the GPU boxes get a snapshot without .git)."""
     try:
         import subprocess
-        out = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5)
+        out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "suffix_amd/csrc", "include"], capture_output=True,
+                             text=True, timeout=5)
         if out.returncode == 0 and out.stdout.strip():
             return out.stdout.strip()
     except (OSError, ValueError, Exception):
