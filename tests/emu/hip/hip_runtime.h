@@ -27,6 +27,7 @@
 #define __launch_bounds__(...)
 #define __shared__ static
 #define SFX_WAVES_PER_EU(lo, hi)                 /* occupancy requests mean nothing to the emulator */
+#define SFX_EMULATED 1                            /* (read_back: a copy, no polled host word) */
 
 struct dim3 {
     unsigned x, y, z;
