@@ -643,8 +643,8 @@ __device__ __forceinline__ void query_write(uint64_t qi, uint64_t start, uint64_
 // cost ten times as many lines; with `work` they are appended to a list (query, lo, hi) for phase 2, so that a
 // wave never idles 60 lanes while 4 of them bisect on the text; without it they are finished in place.
 struct LongQuery { uint32_t qi, lo, hi; };
-// (6 waves per SIMD: measured the same as 8, which spills)
-__global__ void __launch_bounds__(kBlock, 6)
+// (4 workgroups per CU is what its 38 KB of LDS allow; asking for 6 or 8 -- fewer registers -- measured the same, 8 spills)
+__global__ void __launch_bounds__(kBlock, 4)
 k_query_batch_tree(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, KeyTree tree,
                    const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, uint64_t nq,
                    uint32_t* __restrict__ start_out, uint32_t* __restrict__ end_out,

@@ -1296,12 +1296,6 @@ static uint64_t packed_words(uint64_t n, const Alphabet* a)
     return (n + spw - 1) / spw + 3;
 }
 
-// A full build whose initial sort leaves at most 1/kTextFirstDivisor of the suffixes
-// unresolved, over an alphabet small enough that one packed word carries >= 8 symbols
-// (sigma <= 16), spends its first refinement round on text symbols: that round needs no
-// rank array, so the n-element ISA scatter is skipped unless a further round is needed.
-constexpr uint64_t kTextFirstDivisor = 4;
-
 // ---- order-preserving code of the dense symbols (k_ht_keys, sfx_radix.hip) -------------------------
 // Optimal alphabetic binary tree over the symbol counts (dynamic programme over symbol ranges with Knuth's bounds on the
 // roots, O(sigma^2) on the host); counts are floored so that no code is longer than kHtMaxLen bits.  Returns false when the code would
@@ -1734,7 +1728,7 @@ static int build_ranks(SaBuffers& b, const uint32_t* sa, uint64_t n, const uint3
 //   rank round: key2 = rank of the suffix h symbols on (needs ISA), h doubles
 //   text round: key2 = the next spw symbols (needs only the packed text), h += spw
 // The partitioned build (isa == nullptr) only has text rounds.  A full build runs
-// `text_rounds` text rounds first (0 or 1, see kTextFirstDivisor) and rank rounds after.
+// `text_rounds` text rounds first (0 or 1) and rank rounds after.
 static int refine_composite(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uint32_t* isa,
                             int text_rounds, uint32_t* S_cur, uint32_t* V_cur, uint64_t m, uint64_t id_bound,
                             hipStream_t st, sfx_build_stats& stats, uint64_t h0)
