@@ -26,7 +26,8 @@ elif args and args[0] == "--fullsize":
     full_out, full_key, full_builds, args = args[1], args[2], int(args[3]), args[4:]
 
 # profile name of the engine (sfx_kernel_stat.name) for each kernel symbol
-NAMES = [("k_radix_sweep<sfx::SrcE64", "radix_scatter_u32"), ("k_radix_sweep<sfx::SrcText32", "radix_scatter_text_u32"),
+NAMES = [("k_partition<sfx::SrcText32", "radix_scatter_text_u32"), ("k_partition<sfx::SrcE64", "radix_scatter_u32"),
+         ("k_radix_sweep<sfx::SrcE64", "radix_scatter_u32"), ("k_radix_sweep<sfx::SrcText32", "radix_scatter_text_u32"),
          ("k_radix_sweep<sfx::SrcKV", "radix_scatter_u64"), ("k_radix_sweep<sfx::SrcKeyIota", "radix_scatter_u64"),
          ("k_radix_sweep<sfx::SrcText64", "radix_scatter_text_u64"), ("k_tiny_sa", "tiny_sa"),
          ("k_radix_pass<sfx::SrcE64, sfx::DstE64, 11, true, true, 16, false", "radix_scatter_u32"), ("k_radix_pass<sfx::SrcE64, sfx::DstSplit32", "radix_scatter_u32"), ("k_radix_pass<sfx::SrcText32", "radix_scatter_text_u32"),

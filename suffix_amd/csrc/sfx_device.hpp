@@ -110,6 +110,25 @@ __device__ __forceinline__ uint32_t block_scan_excl_1b(uint32_t v, uint32_t (*pa
     return base + incl - v;
 }
 
+// ... and the sum of all of them
+template <int NW>
+__device__ __forceinline__ uint32_t block_scan_excl_1b_total(uint32_t v, uint32_t (*part)[NW], unsigned& par, uint32_t& total)
+{
+    const uint32_t incl = wave_scan_add(v);
+    if (lane_id() == 63) part[par][wave_id()] = incl;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (unsigned k = 0; k < (unsigned)NW; k++) {
+        const uint32_t q = part[par][k];
+        if (k < wave_id()) base += q;
+        all += q;
+    }
+    par ^= 1u;
+    total = all;
+    return base + incl - v;
+}
+
 __device__ __forceinline__ unsigned lanes_below(unsigned long long peers)
 {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
@@ -172,6 +191,13 @@ __device__ __forceinline__ uint32_t rank_round16(unsigned d, unsigned long long*
 // fetched at any position < n with 2-3 aligned loads and a funnel shift.
 // Occupancy request of a kernel (waves per SIMD: the compiler fits the registers to it).  The CPU emulator of the tests
 // (tests/emu/hip/hip_runtime.h) defines it away.
+// A per-lane value the compiler must not reason about (it stops loop-invariant address arithmetic from being hoisted out of
+// a tile loop that has no registers to keep it in).  Nothing to the CPU emulator.
+#ifdef SFX_EMULATED
+#define SFX_OPAQUE_VGPR(x) ((void)0)
+#else
+#define SFX_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
+#endif
 #ifndef SFX_WAVES_PER_EU
 #define SFX_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 #endif

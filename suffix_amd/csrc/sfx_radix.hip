@@ -679,6 +679,172 @@ k_radix_sweep(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const uint
     }
 }
 
+// ---- partition passes: when the order inside a bucket does not matter ------------------------------------------------------
+// The two device-wide passes of the hybrid route only have to bring the elements of every sub-bucket (top 16 key bits)
+// together: the LDS sort that follows orders each sub-bucket by the whole 64-bit element, whatever order it arrives in.
+// Without stability a pass needs neither tickets nor a look-back nor the match-mask ranking (half of a one-sweep tile's time:
+// DESIGN.md section 9): an element's place inside its tile's bucket is the return value of ONE LDS atomic (all of a thread's
+// atomics in flight together), and the tile's run of bucket d goes wherever a returning global atomic on bucket d's cursor
+// says -- the cursors start at the bucket starts, which the 65536-bin histogram of the route has.  MSD order, so that both
+// passes are free: the first splits by the top 8 bits (256 cursors, one per 128-byte line: a tile's 256 atomics would
+// otherwise queue up on eight lines), the second splits every top-8 bucket by the next 8 bits (cursor = the sub-bucket's own
+// start: 65536 of them, a few dozen atomics each).  Tiles of the second pass never straddle two top-8 buckets: tile v of the
+// pass is tile (v - first tile of b) of bucket b, found by bisecting the running tile counts.
+constexpr unsigned kCursorPad = 32;                                  // words between two cursors of the first pass
+#ifndef SFX_PART_ABL
+#define SFX_PART_ABL 0                                               // lab/partition_lab.hip: 1 no LDS atomics, 2 no global atomics, 4 no stores, 8 no loads
+#endif
+template <int KPT, int NW>
+struct PartSmem {
+    uint64_t stage[NW * kWave * KPT];                                // (the match masks of the ranking alias its first NW x 2 KiB)
+    uint16_t cnt[NW][kRadix];                                        // per-wave digit counts, then per-wave tile-local bases
+    uint32_t off[kRadix];                                            // global start of the tile's run of bucket d minus its tile-local start
+    uint32_t tiles_before[kRadix + 1];                               // SUB: tiles of the top-8 buckets before b
+    uint32_t part[2][NW];
+};
+// SUB = false: the elements src.key(0 .. m), bucket = bits [shift, shift + 8), cursor[d * kCursorPad].
+// SUB = true:  src = the output of the first pass; bstart16[b << 8] = start of top-8 bucket b in it (bstart16[65536] = m);
+//              bucket = bits [shift, shift + 8) inside top-8 bucket b, cursor[(b << 8) | d].
+// (Ranking: the match masks of the one-sweep pass.  One returning LDS atomic per element was the first version -- the LDS
+// retires about one of them per clock and CU: 8.4 us per 16384-element tile against 4.6 for the masks, lab/partition_lab.hip.)
+template <class Src, int KPT, int NW, bool SUB>
+__global__ void __launch_bounds__(NW * kWave, 1)
+k_partition(Src src, uint64_t* __restrict__ out, uint64_t m, int shift, uint32_t* __restrict__ cursor,
+            const uint32_t* __restrict__ bstart16)
+{
+    constexpr int kThreads = NW * kWave;
+    constexpr uint32_t kTile = kThreads * KPT;
+    static_assert(kThreads >= kRadix, "thread d owns bucket d");
+    static_assert(kWave * KPT >= kRadix, "the match masks must fit the staging buffer");
+    static_assert(kTile < 65536, "16-bit tile positions");
+    __shared__ PartSmem<KPT, NW> s;
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const unsigned long long mybit = 1ull << lane;
+    const bool owner = tid < (unsigned)kRadix;
+    unsigned par = 0;
+    unsigned long long* const my_flags = reinterpret_cast<unsigned long long*>(s.stage) + w * kRadix;
+    uint64_t ntiles = (m + kTile - 1) / kTile;
+    if (SUB) {
+        const uint32_t tb = owner ? (bstart16[(tid + 1u) << 8] - bstart16[tid << 8] + kTile - 1u) / kTile : 0u;
+        uint32_t total;
+        const uint32_t ex = block_scan_excl_1b_total<NW>(tb, s.part, par, total);
+        if (owner) s.tiles_before[tid] = ex;
+        if (tid == 0) s.tiles_before[kRadix] = total;
+        ntiles = total;
+    }
+    if (owner) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0;
+    }
+    __syncthreads();
+    // where tile v lies: its first element, its length, its top-8 bucket (SUB)
+    auto locate = [&](uint64_t v, uint64_t& begin, unsigned& nvalid, unsigned& top) {
+        begin = v * kTile;
+        nvalid = 0;
+        top = 0;
+        if (v >= ntiles) return;
+        if (SUB) {
+            unsigned lo = 0, hi = kRadix;                            // largest b with tiles_before[b] <= v (uniform)
+            while (hi - lo > 1u) {
+                const unsigned mid = (lo + hi) / 2u;
+                if ((uint64_t)s.tiles_before[mid] <= v) lo = mid; else hi = mid;
+            }
+            top = lo;
+            const uint32_t b0 = bstart16[top << 8], b1 = bstart16[(top + 1u) << 8];
+            begin = (uint64_t)b0 + (v - (uint64_t)s.tiles_before[top]) * kTile;
+            nvalid = (unsigned)dmin<uint64_t>(kTile, (uint64_t)b1 - begin);
+        } else {
+            nvalid = (unsigned)dmin<uint64_t>(kTile, m - begin);
+        }
+    };
+    // (wave-striped loads, 64 consecutive elements per round; the padding of a short tile carries the largest digit and is
+    // ranked behind the real elements of its wave's last rounds: it stays out of the counts and is never stored.  Requesting
+    // the next tile's elements before this one leaves was measured: the 32 registers it takes spill into the ranking loop.)
+    for (uint64_t v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        uint64_t begin;
+        unsigned nvalid, top;
+        locate(v, begin, nvalid, top);
+        uint64_t key[KPT];
+        uint32_t pos[KPT];
+        if (nvalid == kTile) {                                       // (a whole tile: one address, sixteen offsets)
+            const uint64_t first = begin + w * (kWave * KPT) + lane;
+#pragma unroll
+            for (int r = 0; r < KPT; r++) key[r] = src.key(first + (unsigned)(r * kWave));
+        } else {
+#pragma unroll
+            for (int r = 0; r < KPT; r++) {
+                const unsigned idx = w * (kWave * KPT) + r * kWave + lane;
+                key[r] = idx < nvalid ? src.key(begin + idx) : ~0ull;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kRadix / kWave; k++) my_flags[k * kWave + lane] = 0ull;
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < KPT; r++) pos[r] = (SFX_PART_ABL & 1) ? 0u : rank_round16(digit_of(key[r], shift, 255u), my_flags, s.cnt[w], mybit);
+        __syncthreads();
+        uint32_t real_count = 0, tile_ex = 0, mine = 0;
+        {
+            uint32_t c[NW], tile_count = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                c[k] = owner ? s.cnt[k][tid] : 0u;
+                tile_count += c[k];
+            }
+            const uint32_t ex = block_scan_excl_1b<NW>(tile_count, s.part, par);
+            if (owner) {
+                uint32_t run = ex;
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    s.cnt[k][tid] = (uint16_t)run;
+                    run += c[k];
+                }
+                real_count = tile_count - ((tid == 255u) ? (uint32_t)(kTile - nvalid) : 0u);
+                tile_ex = ex;
+                // (the reservation is in flight while the tile is staged)
+                if (SFX_PART_ABL & 2) mine = (uint32_t)begin + ex;
+                else if (real_count) mine = atomicAdd(&cursor[SUB ? ((top << 8) | tid) : tid * kCursorPad], real_count);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < KPT; r++) s.stage[pos[r] + s.cnt[w][digit_of(key[r], shift, 255u)]] = key[r];
+        if (owner) s.off[tid] = mine - tile_ex;
+        __syncthreads();
+        constexpr int kOut = (KPT % 4 == 0) ? 4 : ((KPT % 2 == 0) ? 2 : 1);
+        // (the thread index, made opaque: the compiler otherwise computes the sixteen LDS addresses of this loop once, before the
+        // tile loop, finds no registers to keep them in and reloads them from scratch in every tile)
+        unsigned t = tid;
+        SFX_OPAQUE_VGPR(t);
+#pragma unroll
+        for (int r0 = 0; r0 < KPT; r0 += kOut) {
+#pragma unroll
+            for (int r = r0; r < r0 + kOut; r++) key[r] = s.stage[r * kThreads + t];
+#pragma unroll
+            for (int r = r0; r < r0 + kOut; r++) pos[r] = s.off[digit_of(key[r], shift, 255u)] + ((unsigned)r * kThreads + t);
+#pragma unroll
+            for (int r = r0; r < r0 + kOut; r++)
+                if (!(SFX_PART_ABL & 4) && (unsigned)r * kThreads + t < nvalid) out[(SFX_PART_ABL ? pos[r] % m : pos[r])] = key[r];
+        }
+        if (owner) {
+#pragma unroll
+            for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0;
+        }
+        __syncthreads();
+    }
+}
+// the cursors of both passes from the sub-bucket starts
+__global__ void __launch_bounds__(kBlock)
+k_partition_cursors(const uint32_t* __restrict__ bstart16, uint32_t* __restrict__ cursor16, uint32_t* __restrict__ cursor8)
+{
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < (unsigned)(1 << 16)) {
+        const uint32_t b = bstart16[i];
+        cursor16[i] = b;
+        if ((i & 255u) == 0u) cursor8[(i >> 8) * kCursorPad] = b;
+    }
+}
+
 // ---- hybrid initial sort: two device-wide passes on the top 16 key bits, the rest in LDS ----------
 // An LSD sort moves every element once per 8 key bits through the CU write path (0.41 of HBM peak, §9 of
 // DESIGN.md).  When the text is large enough that the 65536 sub-buckets of the top 16 key bits hold a few
@@ -1313,7 +1479,40 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
         return SFX_OK;
     }
     const bool sweep = true;
-    if (from_elems) {
+    static const int partition = [] { const char* e = dev_env("SFX_HYBRID_PARTITION"); return e ? atoi(e) : 1; }();
+    if (partition) {
+        // two partition passes (k_partition: no order inside a sub-bucket, none needed): top 8 bits, then the next 8 inside
+        // every top-8 bucket; cursors behind the oversize list
+        constexpr int kPKpt = 16, kPNw = 16;
+        uint32_t* cursor16 = bins + kH16Bins + 128 + 4 * kOversizeMax;
+        uint32_t* cursor8 = cursor16 + kH16Bins;
+        static_assert(kH16Bins + 128 + 4 * kOversizeMax + kH16Bins + kRadix * kCursorPad <= kReserve, "the reserve holds the cursors too");
+        SFX_LAUNCH("partition_cursors", (double)kH16Bins * 8, k_partition_cursors, kH16Bins / kBlock, kBlock, st, (const uint32_t*)bins,
+                   cursor16, cursor8);
+        const uint64_t tile = (uint64_t)kPKpt * kPNw * kWave;
+        // (one workgroup per CU, each striding over the tiles: 128 KB of LDS leave room for no second one)
+        static const unsigned cus = [] {
+            const char* e = dev_env("SFX_PARTITION_GRID");
+            if (e && atoi(e) > 0) return (unsigned)atoi(e);
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            return (unsigned)n;
+        }();
+        const unsigned grid1 = (unsigned)dmin<uint64_t>((m + tile - 1) / tile, dmin(cus, grid_cap()));
+        const unsigned grid2 = (unsigned)dmin<uint64_t>((m + tile - 1) / tile + kRadix, dmin(cus, grid_cap()));
+        if (from_elems) {
+            SFX_LAUNCH("radix_scatter_u32", (double)m * 16.0, (k_partition<SrcE64, kPKpt, kPNw, false>), grid1, kPNw * kWave, st, SrcE64{e0}, e1,
+                       m, top_hi - 8, cursor8, (const uint32_t*)bins);
+            SFX_LAUNCH("radix_scatter_u32", (double)m * 16.0, (k_partition<SrcE64, kPKpt, kPNw, true>), grid2, kPNw * kWave, st, SrcE64{e1}, e0,
+                       m, top_hi - 16, cursor16, (const uint32_t*)bins);
+            uint64_t* t = e0; e0 = e1; e1 = t;                 // (from here on: e1 = the array grouped by its top 16 bits, e0 = free)
+        } else {
+            SFX_LAUNCH("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), (k_partition<SrcText32, kPKpt, kPNw, false>), grid1,
+                       kPNw * kWave, st, SrcText32{text}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins);
+            SFX_LAUNCH("radix_scatter_u32", (double)m * 16.0, (k_partition<SrcE64, kPKpt, kPNw, true>), grid2, kPNw * kWave, st, SrcE64{e0}, e1,
+                       m, top_hi - 16, cursor16, (const uint32_t*)bins);
+        }
+    } else if (from_elems) {
         SFX_TRY(run_pass("radix_scatter_u32", (double)m * 16.0, SrcE64{e0}, DstE64{e1}, m, top_hi - 16, 255u, scr, 0, sweep, st));
         SFX_TRY(run_pass("radix_scatter_u32", (double)m * 16.0, SrcE64{e1}, DstE64{e0}, m, top_hi - 8, 255u, scr, 1, sweep, st));
         uint64_t* t = e0; e0 = e1; e1 = t;                     // (from here on: e1 = the array sorted by its top 16 bits, e0 = free)

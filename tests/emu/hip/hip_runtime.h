@@ -58,6 +58,8 @@ const char* hipGetErrorString(hipError_t e);
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int* d);
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }   /* a 4-CU device: grids of the persistent kernels */
 hipError_t hipStreamCreate(hipStream_t* st);
 constexpr unsigned hipStreamNonBlocking = 1;
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned) { return hipStreamCreate(st); }
