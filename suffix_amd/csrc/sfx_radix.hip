@@ -610,9 +610,11 @@ k_radix_sweep(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const uint
         uint64_t key[KPT];
         uint32_t val[HAS_VAL ? KPT : 1];
         uint32_t pos[KPT];
+        unsigned first = w * (kWave * KPT) + lane;                  // (opaque, like t below)
+        SFX_OPAQUE_VGPR(first);
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
-            const unsigned idx = w * (kWave * KPT) + r * kWave + lane;
+            const unsigned idx = first + r * kWave;
             key[r] = (idx < nvalid) ? src.key(tile + idx) : ~0ull;
             if (HAS_VAL) val[r] = (idx < nvalid) ? src.val(tile + idx) : 0u;
         }
@@ -658,18 +660,22 @@ k_radix_sweep(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const uint
         __syncthreads();
         // small batches: all LDS reads of a batch are in flight together; batches of 1 .. KPT tie as long as nothing spills
         constexpr int kOut = (KPT % 4 == 0) ? 4 : ((KPT % 3 == 0) ? 3 : ((KPT % 2 == 0) ? 2 : 1));
+        // (the thread index, made opaque: the compiler otherwise computes the LDS addresses of this loop once, before the tile
+        // loop, has no registers to keep them in and reloads them from scratch in every tile -- see k_partition)
+        unsigned t = tid;
+        SFX_OPAQUE_VGPR(t);
 #pragma unroll
         for (int r0 = 0; r0 < KPT; r0 += kOut) {
 #pragma unroll
             for (int r = r0; r < r0 + kOut; r++) {
-                key[r] = s.stage[r * kThreads + tid];
-                if (HAS_VAL) val[r] = s.stage_v[r * kThreads + tid];
+                key[r] = s.stage[r * kThreads + t];
+                if (HAS_VAL) val[r] = s.stage_v[r * kThreads + t];
             }
 #pragma unroll
-            for (int r = r0; r < r0 + kOut; r++) pos[r] = s.off[digit_of(key[r], shift, mask)] + (r * kThreads + tid);
+            for (int r = r0; r < r0 + kOut; r++) pos[r] = s.off[digit_of(key[r], shift, mask)] + (r * kThreads + t);
 #pragma unroll
             for (int r = r0; r < r0 + kOut; r++)
-                if ((unsigned)(r * kThreads) + tid < nvalid) dst.store(pos[r], key[r], HAS_VAL ? val[r] : 0u);
+                if ((unsigned)(r * kThreads) + t < nvalid) dst.store(pos[r], key[r], HAS_VAL ? val[r] : 0u);
         }
         if (owner) {
 #pragma unroll
@@ -766,16 +772,12 @@ k_partition(Src src, uint64_t* __restrict__ out, uint64_t m, int shift, uint32_t
         locate(v, begin, nvalid, top);
         uint64_t key[KPT];
         uint32_t pos[KPT];
-        if (nvalid == kTile) {                                       // (a whole tile: one address, sixteen offsets)
-            const uint64_t first = begin + w * (kWave * KPT) + lane;
+        unsigned first = w * (kWave * KPT) + lane;                   // (opaque, like t below)
+        SFX_OPAQUE_VGPR(first);
 #pragma unroll
-            for (int r = 0; r < KPT; r++) key[r] = src.key(first + (unsigned)(r * kWave));
-        } else {
-#pragma unroll
-            for (int r = 0; r < KPT; r++) {
-                const unsigned idx = w * (kWave * KPT) + r * kWave + lane;
-                key[r] = idx < nvalid ? src.key(begin + idx) : ~0ull;
-            }
+        for (int r = 0; r < KPT; r++) {
+            const unsigned idx = first + r * kWave;
+            key[r] = idx < nvalid ? src.key(begin + idx) : ~0ull;
         }
 #pragma unroll
         for (int k = 0; k < kRadix / kWave; k++) my_flags[k * kWave + lane] = 0ull;
@@ -1248,13 +1250,13 @@ struct RadixTuning { int sweep, kpt, rank, nw, kpt_text, kpt_kv; };
 static RadixTuning radix_tuning()
 {
     static const RadixTuning t = [] {
-        RadixTuning r = {1, 16, 1, 16, 16, 10};         // measured best on MI355X (round 4, lab/radix_lab2.hip): 1024-thread
-                                                // workgroups, 16384-element E64 tiles (512-byte runs), 10240-element KV tiles
+        RadixTuning r = {1, 16, 1, 16, 16, 12};         // measured best on MI355X (round 4, lab/radix_lab2.hip): 1024-thread
+                                                // workgroups, 16384-element E64 tiles (512-byte runs), 12288-element KV tiles
         if (const char* e = dev_env("SFX_RADIX_SWEEP")) r.sweep = atoi(e) ? 1 : 0;
         if (const char* e = dev_env("SFX_RADIX_KPT")) r.kpt = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 8;
         if (const char* e = dev_env("SFX_RADIX_RANK")) r.rank = atoi(e) ? 1 : 0;
         if (const char* e = dev_env("SFX_RADIX_KPT_TEXT")) r.kpt_text = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 16;
-        if (const char* e = dev_env("SFX_RADIX_KPT_KV")) r.kpt_kv = (atoi(e) >= 8 && atoi(e) <= 10) ? atoi(e) : 8;
+        if (const char* e = dev_env("SFX_RADIX_KPT_KV")) r.kpt_kv = (atoi(e) >= 8 && atoi(e) <= 12) ? atoi(e) : 8;
         if (const char* e = dev_env("SFX_RADIX_NW")) r.nw = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 4);
         return r;
     }();
@@ -1288,7 +1290,7 @@ static int launch_pass(const char* name, double algo_bytes, const Src& src, cons
 {
     constexpr int kThreads = NW * kWave;
     constexpr int kTile = kThreads * KPT;
-    if (ONESWEEP) {
+    if constexpr (ONESWEEP) {
         const uint64_t tiles = (m + kTile - 1) / kTile;
         const unsigned grid = (unsigned)dmin<uint64_t>(tiles, kMaxGrid);
         SFX_HIP(hipMemsetAsync(scr.status, 0, tiles * kRadix * sizeof(uint32_t), st));
@@ -1334,9 +1336,14 @@ static int run_pass(const char* name, double algo_bytes, const Src& src, const D
             if (kk == 11) SFX_PASS_NW(11, 16);
         }
         if constexpr (Src::kHasVal && !Src::kFromText) {
-            // KV passes (12-byte elements): 10 per thread is the largest tile without spills in k_radix_sweep
+            // KV passes (12-byte elements): 10 per thread was the largest tile without spills in k_radix_sweep until its output
+            // loop stopped leaving sixteen hoisted LDS addresses in scratch (SFX_OPAQUE_VGPR); 12 is what the LDS holds.  Config 3's
+            // eight passes: 53.8 / 52.2 / 51.9 ms at 10 / 11 / 12.
             // (round 3's kernel: 9; 8 / 9 / 10 measured 106.2 / 102.0 / 105.1 ms over the 23 KV passes of config 3 then)
-            if (t.kpt_kv == 10) SFX_PASS_NW(10, 16);
+            // (11 and 12: the one-sweep kernel only -- the tile of the other schedules' kernel does not fit the LDS)
+            if (t.kpt_kv == 12 && sweep && t.rank) return SFX_PASS(12, true, true, 16);
+            if (t.kpt_kv == 11 && sweep && t.rank) return SFX_PASS(11, true, true, 16);
+            if (t.kpt_kv >= 10) SFX_PASS_NW(10, 16);
             if (t.kpt_kv == 9) SFX_PASS_NW(9, 16);
         }
         SFX_PASS_NW(8, 16);
