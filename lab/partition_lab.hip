@@ -3,6 +3,9 @@
 // 4 no stores, 8 no loads), next to the one-sweep pass on the same elements.
 #include <stdio.h>
 #include <vector>
+#ifndef LAB_NW
+#define LAB_NW 16
+#endif
 #ifndef LAB_KPT
 #define LAB_KPT 16
 #endif
@@ -50,7 +53,7 @@ int main(int argc, char** argv)
         for (int d = 0; d < 256; d++) pad[d * kCursorPad] = start[d];
         hipMemcpy(cur, pad.data(), pad.size() * 4, hipMemcpyHostToDevice);
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((k_partition<SrcE64, LAB_KPT, 16, false>), dim3(grid), dim3(1024), 0, 0, SrcE64{a}, b, m, 56, cur, (const uint32_t*)bst);
+        hipLaunchKernelGGL((k_partition<SrcE64, LAB_KPT, LAB_NW, false>), dim3(grid), dim3(LAB_NW * 64), 0, 0, SrcE64{a}, b, m, 56, cur, (const uint32_t*)bst);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms = 0; hipEventElapsedTime(&ms, e0, e1);
         if (rep) printf("k_partition (top 8 bits, abl %d, grid %d): %.3f ms\n", (int)SFX_PART_ABL, grid, ms);
