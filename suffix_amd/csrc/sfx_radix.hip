@@ -423,9 +423,11 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
     uint32_t nval[HAS_VAL ? KPT : 1];
     auto load_tile = [&](uint64_t tile) {
         const unsigned nv = (unsigned)dmin<uint64_t>(kTile, limit - tile);
+        unsigned first = w * (kWave * KPT) + lane;                  // (opaque: see k_partition)
+        SFX_OPAQUE_VGPR(first);
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
-            const unsigned idx = w * (kWave * KPT) + r * kWave + lane;
+            const unsigned idx = first + r * kWave;
             nkey[r] = (idx < nv) ? src.key(tile + idx) : ~0ull;
             if (HAS_VAL) nval[r] = (idx < nv) ? src.val(tile + idx) : 0u;
         }
@@ -536,18 +538,20 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
         // batches of 8 slots: within a batch all LDS reads of a kind are in flight together;
         // more than 8 at once only costs registers (16-element threads spilled)
         constexpr int kOut = (KPT % 8 == 0) ? 8 : ((KPT % 4 == 0) ? 4 : KPT);
+        unsigned t = tid;                                           // (opaque: see k_partition)
+        SFX_OPAQUE_VGPR(t);
 #pragma unroll
         for (int r0 = 0; r0 < KPT; r0 += kOut) {
 #pragma unroll
             for (int r = r0; r < r0 + kOut; r++) {
-                key[r] = s.stage[r * kThreads + tid];
-                if (HAS_VAL) val[r] = s.stage_v[r * kThreads + tid];
+                key[r] = s.stage[r * kThreads + t];
+                if (HAS_VAL) val[r] = s.stage_v[r * kThreads + t];
             }
 #pragma unroll
-            for (int r = r0; r < r0 + kOut; r++) pos[r] = s.off[digit_of(key[r], shift, mask)] + (r * kThreads + tid);
+            for (int r = r0; r < r0 + kOut; r++) pos[r] = s.off[digit_of(key[r], shift, mask)] + (r * kThreads + t);
 #pragma unroll
             for (int r = r0; r < r0 + kOut; r++)
-                if ((unsigned)(r * kThreads) + tid < nvalid) dst.store(pos[r], key[r], HAS_VAL ? val[r] : 0u);
+                if ((unsigned)(r * kThreads) + t < nvalid) dst.store(pos[r], key[r], HAS_VAL ? val[r] : 0u);
         }
         if (owner) {
 #pragma unroll
@@ -1331,7 +1335,9 @@ static int run_pass(const char* name, double algo_bytes, const Src& src, const D
         if constexpr (!Src::kHasVal) {                           // (KV elements: 8 per thread, LDS)
             // elements per thread swept from 8 to 16 on hardware (profiles/r1c_radix_variants.txt):
             // 11 wins for the E64 passes, 16 for the text-fed pass; the other sizes are not built
-            const int kk = Src::kFromText ? t.kpt_text : t.kpt;
+            // (the chunked schedule keeps the next tile's elements in registers as well: 16 per thread spill there -- 2 * 10^9 bytes
+            // of DNA 107.9 ms at 16, 84.1 at 11, 88.7 at 8)
+            const int kk = !sweep ? (t.kpt > 11 ? 11 : t.kpt) : (Src::kFromText ? t.kpt_text : t.kpt);
             if (kk == 16) SFX_PASS_NW(16, 16);
             if (kk == 11) SFX_PASS_NW(11, 16);
         }
@@ -1343,8 +1349,12 @@ static int run_pass(const char* name, double algo_bytes, const Src& src, const D
             // (11 and 12: the one-sweep kernel only -- the tile of the other schedules' kernel does not fit the LDS)
             if (t.kpt_kv == 12 && sweep && t.rank) return SFX_PASS(12, true, true, 16);
             if (t.kpt_kv == 11 && sweep && t.rank) return SFX_PASS(11, true, true, 16);
-            if (t.kpt_kv >= 10) SFX_PASS_NW(10, 16);
-            if (t.kpt_kv == 9) SFX_PASS_NW(9, 16);
+            // (chunked schedule, m >= 2^30: 8 per thread -- the prefetched tile's registers again; 1.5 * 10^9 bytes of English-like
+            // text 204.7 / 186.4 / 185.9 ms at 10 / 9 / 8)
+            static const int kv_chunked = [] { const char* e = dev_env("SFX_RADIX_KPT_KV_CHUNKED"); return e ? atoi(e) : 8; }();
+            if (sweep && t.kpt_kv >= 10) SFX_PASS_NW(10, 16);
+            if (!sweep && kv_chunked >= 10) SFX_PASS_NW(10, 16);
+            if (sweep ? t.kpt_kv == 9 : kv_chunked == 9) SFX_PASS_NW(9, 16);
         }
         SFX_PASS_NW(8, 16);
     }
