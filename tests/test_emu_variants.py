@@ -6,7 +6,7 @@ environment variables are read once per process, so every variant runs in a subp
   SFX_LCP_DIRECT_MIN                     sampled choice between direct and Phi/PLCP LCP, cap + fallback
   SFX_TILE_SMALL / SFX_FORCE_KEY64       small LDS windows of the refinement rounds; 64-bit initial keys
   SFX_SEG_SMALL                          small tiles in the segmented sort of the large buckets
-  SFX_HYBRID_MIN / _GEOM / _CAP          hybrid initial sort (two device-wide passes + LDS sort of the sub-buckets)
+  SFX_HYBRID_MIN / _GEOM / _CAP / _PARTITION   hybrid initial sort (two device-wide passes + LDS sort of the sub-buckets)
 Every run compares SA and LCP with the oracle on a few texts that exercise the path."""
 import os
 import subprocess
@@ -173,6 +173,8 @@ VARIANTS = {
     "key64": {"SFX_FORCE_KEY64": "1"},
     # hybrid initial sort forced on small inputs
     "hybrid-initial-sort": {"SFX_HYBRID_MIN": "1"},
+    # ... with the stable one-sweep passes of rounds 2-3 instead of the partition passes (k_partition)
+    "hybrid-initial-sort-one-sweep-passes": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_PARTITION": "0"},
     # a few oversized sub-buckets (gathered, sorted device-wide, copied back), the 256 x 16 geometry, several sub-buckets
     # per workgroup
     "hybrid-initial-sort-oversized": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_CAP": "100", "SFX_MAX_GRID": "3", "SFX_HYBRID_GEOM": "1"},
