@@ -709,7 +709,8 @@ struct PartSmem {
     uint64_t stage[NW * kWave * KPT];                                // (the match masks of the ranking alias its first NW x 2 KiB)
     uint16_t cnt[NW][kRadix];                                        // per-wave digit counts, then per-wave tile-local bases
     uint32_t off[kRadix];                                            // global start of the tile's run of bucket d minus its tile-local start
-    uint32_t tiles_before[kRadix + 1];                               // SUB: tiles of the top-8 buckets before b
+    uint32_t tiles_before[kRadix];                                   // SUB: tiles of the top-8 buckets of b's class (b mod 8) before b
+    uint32_t class_tiles[8];                                         // SUB: tiles of each class
     uint32_t part[2][NW];
 };
 // SUB = false: the elements src.key(0 .. m), bucket = bits [shift, shift + 8), cursor[d * kCursorPad].
@@ -735,12 +736,27 @@ k_partition(Src src, uint64_t* __restrict__ out, uint64_t m, int shift, uint32_t
     unsigned long long* const my_flags = reinterpret_cast<unsigned long long*>(s.stage) + w * kRadix;
     uint64_t ntiles = (m + kTile - 1) / kTile;
     if (SUB) {
-        const uint32_t tb = owner ? (bstart16[(tid + 1u) << 8] - bstart16[tid << 8] + kTile - 1u) / kTile : 0u;
-        uint32_t total;
-        const uint32_t ex = block_scan_excl_1b_total<NW>(tb, s.part, par, total);
-        if (owner) s.tiles_before[tid] = ex;
-        if (tid == 0) s.tiles_before[kRadix] = total;
-        ntiles = total;
+        // Tile v = 8 u + x is tile u of class x = the top-8 buckets b with b mod 8 == x, in order.  Workgroup j takes v = j,
+        // j + gridDim, ...: with a grid that is a multiple of 8 all its tiles are of class j mod 8 -- and workgroups are dealt to
+        // the 8 XCDs round robin, so all tiles of a top-8 bucket are sorted on ONE XCD: the runs that consecutive tiles append to
+        // a sub-bucket meet in that XCD's L2, and the 64-byte blocks at their seams leave it whole (the store model of DESIGN.md
+        // section 9: a partial block costs three whole ones on the memory side).
+        if (owner) s.tiles_before[tid] = (bstart16[(tid + 1u) << 8] - bstart16[tid << 8] + kTile - 1u) / kTile;
+        __syncthreads();
+        if (tid < 8u) {
+            uint32_t run = 0;
+            for (unsigned b = tid; b < (unsigned)kRadix; b += 8u) {
+                const uint32_t tb = s.tiles_before[b];
+                s.tiles_before[b] = run;
+                run += tb;
+            }
+            s.class_tiles[tid] = run;
+        }
+        __syncthreads();
+        uint32_t most = 0;
+#pragma unroll
+        for (int x = 0; x < 8; x++) most = dmax(most, s.class_tiles[x]);
+        ntiles = (uint64_t)most * 8u;
     }
     if (owner) {
 #pragma unroll
@@ -754,14 +770,17 @@ k_partition(Src src, uint64_t* __restrict__ out, uint64_t m, int shift, uint32_t
         top = 0;
         if (v >= ntiles) return;
         if (SUB) {
-            unsigned lo = 0, hi = kRadix;                            // largest b with tiles_before[b] <= v (uniform)
+            const unsigned x = (unsigned)(v & 7u);
+            const uint32_t u = (uint32_t)(v >> 3);
+            if (u >= s.class_tiles[x]) return;                       // (a class with fewer tiles than the largest one)
+            unsigned lo = 0, hi = kRadix / 8;                        // largest i with tiles_before[x + 8 i] <= u (uniform)
             while (hi - lo > 1u) {
                 const unsigned mid = (lo + hi) / 2u;
-                if ((uint64_t)s.tiles_before[mid] <= v) lo = mid; else hi = mid;
+                if (s.tiles_before[x + 8u * mid] <= u) lo = mid; else hi = mid;
             }
-            top = lo;
+            top = x + 8u * lo;
             const uint32_t b0 = bstart16[top << 8], b1 = bstart16[(top + 1u) << 8];
-            begin = (uint64_t)b0 + (v - (uint64_t)s.tiles_before[top]) * kTile;
+            begin = (uint64_t)b0 + (uint64_t)(u - s.tiles_before[top]) * kTile;
             nvalid = (unsigned)dmin<uint64_t>(kTile, (uint64_t)b1 - begin);
         } else {
             nvalid = (unsigned)dmin<uint64_t>(kTile, m - begin);
@@ -774,6 +793,7 @@ k_partition(Src src, uint64_t* __restrict__ out, uint64_t m, int shift, uint32_t
         uint64_t begin;
         unsigned nvalid, top;
         locate(v, begin, nvalid, top);
+        if (nvalid == 0u) continue;                                  // (SUB: this class has fewer tiles than the largest)
         uint64_t key[KPT];
         uint32_t pos[KPT];
         unsigned first = w * (kWave * KPT) + lane;                   // (opaque, like t below)
