@@ -174,7 +174,7 @@ VARIANTS = {
     # hybrid initial sort forced on small inputs
     "hybrid-initial-sort": {"SFX_HYBRID_MIN": "1"},
     # ... with the stable one-sweep passes of rounds 2-3 instead of the partition passes (k_partition)
-    "hybrid-initial-sort-one-sweep-passes": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_PARTITION": "0"},
+    "hybrid-initial-sort-one-sweep-passes": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_PARTITION": "0", "TEST_TEXTS": "2"},
     # a few oversized sub-buckets (gathered, sorted device-wide, copied back), the 256 x 16 geometry, several sub-buckets
     # per workgroup
     "hybrid-initial-sort-oversized": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_CAP": "100", "SFX_MAX_GRID": "3", "SFX_HYBRID_GEOM": "1"},
