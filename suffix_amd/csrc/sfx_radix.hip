@@ -700,7 +700,8 @@ k_radix_sweep(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const uint
 // otherwise queue up on eight lines), the second splits every top-8 bucket by the next 8 bits (cursor = the sub-bucket's own
 // start: 65536 of them, a few dozen atomics each).  Tiles of the second pass never straddle two top-8 buckets: tile v of the
 // pass is tile (v - first tile of b) of bucket b, found by bisecting the running tile counts.
-constexpr unsigned kCursorPad = 32;                                  // words between two cursors of the first pass
+constexpr unsigned kCursorPad = 16;                                  // words between two cursors of the first pass
+constexpr unsigned kPartClasses = 8;                                 // stretches of the input of the first pass = XCDs
 #ifndef SFX_PART_ABL
 #define SFX_PART_ABL 0                                               // lab/partition_lab.hip: 1 no LDS atomics, 2 no global atomics, 4 no stores, 8 no loads
 #endif
@@ -713,7 +714,9 @@ struct PartSmem {
     uint32_t class_tiles[8];                                         // SUB: tiles of each class
     uint32_t part[2][NW];
 };
-// SUB = false: the elements src.key(0 .. m), bucket = bits [shift, shift + 8), cursor[d * kCursorPad].
+// SUB = false: the elements src.key(0 .. m), bucket = bits [shift, shift + 8); the input is cut into kPartClasses stretches of
+//              class_len elements, tile v = 8 u + x is tile u of stretch x, cursor[(x * 256 + d) * kCursorPad] -- as in the second
+//              pass, the workgroups of one XCD then append to cursors of their own, and the seams of their runs meet in its L2.
 // SUB = true:  src = the output of the first pass; bstart16[b << 8] = start of top-8 bucket b in it (bstart16[65536] = m);
 //              bucket = bits [shift, shift + 8) inside top-8 bucket b, cursor[(b << 8) | d].
 // (Ranking: the match masks of the one-sweep pass.  One returning LDS atomic per element was the first version -- the LDS
@@ -721,7 +724,7 @@ struct PartSmem {
 template <class Src, int KPT, int NW, bool SUB>
 __global__ void __launch_bounds__(NW * kWave, 1)
 k_partition(Src src, uint64_t* __restrict__ out, uint64_t m, int shift, uint32_t* __restrict__ cursor,
-            const uint32_t* __restrict__ bstart16)
+            const uint32_t* __restrict__ bstart16, uint64_t class_len)
 {
     constexpr int kThreads = NW * kWave;
     constexpr uint32_t kTile = kThreads * KPT;
@@ -734,7 +737,12 @@ k_partition(Src src, uint64_t* __restrict__ out, uint64_t m, int shift, uint32_t
     const bool owner = tid < (unsigned)kRadix;
     unsigned par = 0;
     unsigned long long* const my_flags = reinterpret_cast<unsigned long long*>(s.stage) + w * kRadix;
-    uint64_t ntiles = (m + kTile - 1) / kTile;
+    uint64_t ntiles;
+    {
+        // (the longest stretch is the first; the last may be short or empty)
+        const uint64_t first = dmin<uint64_t>(m, class_len);
+        ntiles = ((first + kTile - 1) / kTile) * kPartClasses;
+    }
     if (SUB) {
         // Tile v = 8 u + x is tile u of class x = the top-8 buckets b with b mod 8 == x, in order.  Workgroup j takes v = j,
         // j + gridDim, ...: with a grid that is a multiple of 8 all its tiles are of class j mod 8 -- and workgroups are dealt to
@@ -783,7 +791,11 @@ k_partition(Src src, uint64_t* __restrict__ out, uint64_t m, int shift, uint32_t
             begin = (uint64_t)b0 + (uint64_t)(u - s.tiles_before[top]) * kTile;
             nvalid = (unsigned)dmin<uint64_t>(kTile, (uint64_t)b1 - begin);
         } else {
-            nvalid = (unsigned)dmin<uint64_t>(kTile, m - begin);
+            const unsigned x = (unsigned)(v % kPartClasses);
+            const uint64_t p0 = dmin<uint64_t>(m, (uint64_t)x * class_len), p1 = dmin<uint64_t>(m, p0 + class_len);
+            begin = p0 + (v / kPartClasses) * kTile;
+            top = x;
+            if (begin < p1) nvalid = (unsigned)dmin<uint64_t>(kTile, p1 - begin);
         }
     };
     // (wave-striped loads, 64 consecutive elements per round; the padding of a short tile carries the largest digit and is
@@ -829,7 +841,7 @@ k_partition(Src src, uint64_t* __restrict__ out, uint64_t m, int shift, uint32_t
                 tile_ex = ex;
                 // (the reservation is in flight while the tile is staged)
                 if (SFX_PART_ABL & 2) mine = (uint32_t)begin + ex;
-                else if (real_count) mine = atomicAdd(&cursor[SUB ? ((top << 8) | tid) : tid * kCursorPad], real_count);
+                else if (real_count) mine = atomicAdd(&cursor[SUB ? ((top << 8) | tid) : (top * kRadix + tid) * kCursorPad], real_count);
             }
         }
         __syncthreads();
@@ -859,15 +871,23 @@ k_partition(Src src, uint64_t* __restrict__ out, uint64_t m, int shift, uint32_t
         __syncthreads();
     }
 }
-// the cursors of both passes from the sub-bucket starts
+// the cursors of both passes from the sub-bucket starts: second pass = the sub-bucket starts themselves; first pass = one per
+// (stretch of the input x, top-8 bucket b): the bucket's start + what the stretches before x put into it
 __global__ void __launch_bounds__(kBlock)
-k_partition_cursors(const uint32_t* __restrict__ bstart16, uint32_t* __restrict__ cursor16, uint32_t* __restrict__ cursor8)
+k_partition_cursors(const uint32_t* __restrict__ bstart16, const uint32_t* __restrict__ class_top8, uint32_t* __restrict__ cursor16,
+                    uint32_t* __restrict__ cursor8)
 {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i < (unsigned)(1 << 16)) {
         const uint32_t b = bstart16[i];
         cursor16[i] = b;
-        if ((i & 255u) == 0u) cursor8[(i >> 8) * kCursorPad] = b;
+        if ((i & 255u) == 0u) {
+            uint32_t run = b;
+            for (unsigned x = 0; x < kPartClasses; x++) {
+                cursor8[(x * kRadix + (i >> 8)) * kCursorPad] = run;
+                run += class_top8[x * kRadix + (i >> 8)];
+            }
+        }
     }
 }
 
@@ -949,13 +969,19 @@ k_hist16_e64(const uint64_t* __restrict__ E, uint64_t m, int shift, uint64_t per
 // from 1024 x (2 KB of every partial, one 8-byte load per thread) and the partials y, y + split, ...
 constexpr int kH16ReduceBins = 1024;
 constexpr unsigned kH16ReduceSplit = 8;
+// (The rows are split among the kH16ReduceSplit = 8 block groups in contiguous stretches of `rows_per_class`: group x sums the
+// workgroups that counted the x-th stretch of the text, and a wave's 256 bins are one top-8 bucket -- so the sum over a wave is
+// the number of suffixes of that stretch in that bucket: class_top8[x * 256 + bucket], which the first partition pass turns
+// into one cursor per (stretch, bucket), k_partition.)
 __global__ void __launch_bounds__(kBlock)
-k_hist16_reduce(const uint32_t* __restrict__ partial, unsigned nblocks, uint32_t* __restrict__ bins)
+k_hist16_reduce(const uint32_t* __restrict__ partial, unsigned nblocks, uint32_t* __restrict__ bins, unsigned rows_per_class,
+                uint32_t* __restrict__ class_top8)
 {
     const unsigned bx = blockIdx.x % (kH16Bins / kH16ReduceBins), by = blockIdx.x / (kH16Bins / kH16ReduceBins);
     const unsigned w0 = bx * (kH16ReduceBins / 2) + threadIdx.x * 2;              // this thread's two counter words = 4 bins
     uint32_t c[4] = {0, 0, 0, 0};
-    for (unsigned g = by; g < nblocks; g += kH16ReduceSplit) {
+    const unsigned g1 = dmin(nblocks, (by + 1u) * rows_per_class);
+    for (unsigned g = by * rows_per_class; g < g1; g++) {
         const uint2 v = *reinterpret_cast<const uint2*>(partial + (uint64_t)g * kH16Words + w0);
         c[0] += v.x & 0xFFFFu;
         c[1] += v.x >> 16;
@@ -965,6 +991,10 @@ k_hist16_reduce(const uint32_t* __restrict__ partial, unsigned nblocks, uint32_t
 #pragma unroll
     for (int k = 0; k < 4; k++)
         if (c[k]) atomicAdd(&bins[2 * w0 + k], c[k]);
+    uint32_t all = c[0] + c[1] + c[2] + c[3];
+    for (int d = 32; d >= 1; d >>= 1) all += __shfl_xor(all, d);
+    static_assert(kWave * 4 == kRadix, "a wave's bins are one top-8 bucket");
+    if (lane_id() == 0) class_top8[by * kRadix + (2u * w0) / (unsigned)kRadix] = all;
 }
 // totals_lo[d] = sum over the high digits of bin (j, d), totals_hi[j] = sum over the low digits; bins[b] -> first
 // position of sub-bucket b (in place), bins[65536] = m.  stat_out (zeroed by the caller) = {largest bin, sum of all
@@ -1488,8 +1518,16 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     else
         SFX_LAUNCH("radix_hist16_text", (double)m * text.bits / 8.0, k_hist16_text, ch.blocks, kH16Threads, st, text, low_bits,
                    ch.tiles_per_block * kH16Threads, partial);
+    // (the rows of the partial counts in kPartClasses contiguous stretches: k_partition's first pass wants the top-8 counts of each)
+    static_assert(kH16ReduceSplit == kPartClasses, "one block group of the reduction per stretch");
+    const unsigned rows_per_class = (ch.blocks + kPartClasses - 1) / kPartClasses;
+    const uint64_t class_len = (uint64_t)rows_per_class * ch.tiles_per_block * kH16Threads * (from_elems ? 1u : (uint64_t)text.spw);
+    uint32_t* cursor16 = bins + kH16Bins + 128 + 4 * kOversizeMax;     // (behind the oversize list)
+    uint32_t* class_top8 = cursor16 + kH16Bins;
+    uint32_t* cursor8 = class_top8 + kPartClasses * kRadix;
+    static_assert(kH16Bins + 128 + 4 * kOversizeMax + kH16Bins + kPartClasses * kRadix * (1 + kCursorPad) <= kReserve, "the reserve holds the cursors too");
     SFX_LAUNCH("radix_hist16_reduce", (double)ch.blocks * kH16Words * 4, k_hist16_reduce, (kH16Bins / kH16ReduceBins) * kH16ReduceSplit, kBlock, st,
-               (const uint32_t*)partial, ch.blocks, bins);
+               (const uint32_t*)partial, ch.blocks, bins, rows_per_class, class_top8);
     SFX_LAUNCH("radix_hist16_scan", (double)kH16Bins * 8, k_hist16_scan, 1, kH16Threads, st, bins, scr.totals, scr.totals + kRadix,
                stat, cap, dmin(cap, 4096u));
     uint32_t host_stat[5] = {0, 0, 0, 0, 0};
@@ -1521,11 +1559,8 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
         // two partition passes (k_partition: no order inside a sub-bucket, none needed): top 8 bits, then the next 8 inside
         // every top-8 bucket; cursors behind the oversize list
         constexpr int kPKpt = 16, kPNw = 16;
-        uint32_t* cursor16 = bins + kH16Bins + 128 + 4 * kOversizeMax;
-        uint32_t* cursor8 = cursor16 + kH16Bins;
-        static_assert(kH16Bins + 128 + 4 * kOversizeMax + kH16Bins + kRadix * kCursorPad <= kReserve, "the reserve holds the cursors too");
         SFX_LAUNCH("partition_cursors", (double)kH16Bins * 8, k_partition_cursors, kH16Bins / kBlock, kBlock, st, (const uint32_t*)bins,
-                   cursor16, cursor8);
+                   (const uint32_t*)class_top8, cursor16, cursor8);
         const uint64_t tile = (uint64_t)kPKpt * kPNw * kWave;
         // (one workgroup per CU, each striding over the tiles: 128 KB of LDS leave room for no second one)
         static const unsigned cus = [] {
@@ -1539,15 +1574,15 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
         const unsigned grid2 = (unsigned)dmin<uint64_t>((m + tile - 1) / tile + kRadix, dmin(cus, grid_cap()));
         if (from_elems) {
             SFX_LAUNCH("radix_scatter_u32", (double)m * 16.0, (k_partition<SrcE64, kPKpt, kPNw, false>), grid1, kPNw * kWave, st, SrcE64{e0}, e1,
-                       m, top_hi - 8, cursor8, (const uint32_t*)bins);
+                       m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len);
             SFX_LAUNCH("radix_scatter_u32", (double)m * 16.0, (k_partition<SrcE64, kPKpt, kPNw, true>), grid2, kPNw * kWave, st, SrcE64{e1}, e0,
-                       m, top_hi - 16, cursor16, (const uint32_t*)bins);
+                       m, top_hi - 16, cursor16, (const uint32_t*)bins, class_len);
             uint64_t* t = e0; e0 = e1; e1 = t;                 // (from here on: e1 = the array grouped by its top 16 bits, e0 = free)
         } else {
             SFX_LAUNCH("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), (k_partition<SrcText32, kPKpt, kPNw, false>), grid1,
-                       kPNw * kWave, st, SrcText32{text}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins);
+                       kPNw * kWave, st, SrcText32{text}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len);
             SFX_LAUNCH("radix_scatter_u32", (double)m * 16.0, (k_partition<SrcE64, kPKpt, kPNw, true>), grid2, kPNw * kWave, st, SrcE64{e0}, e1,
-                       m, top_hi - 16, cursor16, (const uint32_t*)bins);
+                       m, top_hi - 16, cursor16, (const uint32_t*)bins, class_len);
         }
     } else if (from_elems) {
         SFX_TRY(run_pass("radix_scatter_u32", (double)m * 16.0, SrcE64{e0}, DstE64{e1}, m, top_hi - 16, 255u, scr, 0, sweep, st));
