@@ -136,26 +136,34 @@ static __global__ void __launch_bounds__(64) k_post_words(const uint32_t* __rest
 #endif
 inline int read_back(void* dst, const void* d_src, size_t bytes, hipStream_t st)
 {
-    constexpr size_t kStage = 4096;
+    // One pinned allocation per thread, two disjoint areas: [0, kStage) stages the copies of the fallback below (and of every
+    // read above 256 bytes: the 2 KiB of byte bins), [kStage, kStage + 512) is the posted area -- payload + sequence word.  They
+    // must not overlap: a staged copy that left a stale value where the sequence word lives would end a later poll before its
+    // kernel has run (the bins of a text with spaces wrote 1 over the word, the first post polled for 1).
+    // Portable + coherent + mapped: kernels of whichever device is current later write the page, and the host sees the words
+    // without a flush.
+    constexpr size_t kStage = 4096, kPostArea = 512;
     thread_local void* stage = nullptr;
     thread_local bool tried = false;
     if (!tried) {
         tried = true;
-        if (hipHostMalloc(&stage, kStage, hipHostMallocDefault) != hipSuccess) {
+        if (hipHostMalloc(&stage, kStage + kPostArea, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
             stage = nullptr;
             (void)hipGetLastError();
         }
-        if (stage) std::memset(stage, 0, kStage);
+        if (stage) std::memset(stage, 0, kStage + kPostArea);
     }
 #ifndef SFX_EMULATED
     thread_local uint32_t seq = 0;
     if (stage && bytes > 0 && bytes <= detail::kPostWords * 4 && (bytes & 3u) == 0 && (reinterpret_cast<uintptr_t>(d_src) & 3u) == 0) {
-        volatile uint32_t* const host = static_cast<volatile uint32_t*>(stage);
+        static_assert((detail::kPostWords + 16) * 4 <= kPostArea, "payload + the sequence word's own 64-byte block");
+        volatile uint32_t* const host = reinterpret_cast<volatile uint32_t*>(static_cast<char*>(stage) + kStage);
         if (++seq == 0) seq = 1;
         hipLaunchKernelGGL(detail::k_post_words, dim3(1), dim3(64), 0, st, static_cast<const uint32_t*>(d_src), (unsigned)(bytes / 4), host, seq);
         SFX_HIP(hipGetLastError());
         for (unsigned spins = 1;; spins++) {
             if (host[detail::kPostWords] == seq) break;
+            __builtin_ia32_pause();
             if ((spins & 0xFFFu) == 0) {
                 const hipError_t q = hipStreamQuery(st);
                 if (q == hipErrorNotReady) continue;

@@ -41,6 +41,7 @@
 //   reorder elements go to their tile-local slot in LDS, are read back in slot
 //           order and leave as one contiguous run per bucket.
 // No MFMA anywhere: pure scan/scatter, HBM-bound by design.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "sfx_host.hpp"
@@ -113,6 +114,33 @@ struct DstKV {
     {
         k[d] = key;
         v[d] = val;
+    }
+};
+
+// KV12: key and suffix of one element side by side, 12 bytes (4-byte aligned).  The passes BETWEEN the first and the last pass
+// of a 64-bit-key sort move their elements in this form: a bucket's share of a tile then leaves as ONE run of 12 x count bytes
+// instead of an 8 x count-byte key run and a 4 x count-byte value run.  What a pass pays for on the store side is the partial
+// 64-byte block at either end of every run (~46 ps against ~14 ps for a whole block), and one run has two
+// ends where two runs have four: a 12288-element tile over 256 buckets writes 576-byte runs (8 whole + 2 partial blocks: 204 ps
+// per 48 elements) instead of 384 + 192 bytes (7 whole + 4 partial: 282 ps).
+struct KV12 { uint32_t lo, hi, v; };
+static_assert(sizeof(KV12) == 12 && alignof(KV12) == 4, "three words, word-aligned");
+struct SrcKV12 {
+    static constexpr bool kHasVal = true;
+    static constexpr bool kFromText = false;
+    const KV12* in;
+    __device__ __forceinline__ uint64_t key(uint64_t i) const { return ((uint64_t)in[i].hi << 32) | in[i].lo; }
+    __device__ __forceinline__ uint32_t val(uint64_t i) const { return in[i].v; }
+};
+struct DstKV12 {
+    KV12* out;
+    __device__ __forceinline__ void store(uint32_t d, uint64_t key, uint32_t val) const
+    {
+        KV12 e;
+        e.lo = (uint32_t)key;
+        e.hi = (uint32_t)(key >> 32);
+        e.v = val;
+        out[d] = e;
     }
 };
 
@@ -1300,17 +1328,18 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
 //   SFX_RADIX_KPT_TEXT  ... of the text-fed pass: 16 (default), 11 or 8
 //   SFX_RADIX_RANK   1 = LDS match masks (default), 0 = 8-ballot match
 //   SFX_RADIX_NW     waves per workgroup: 4, 8 or 16 (default); tile = 64 * NW * KPT elements
-struct RadixTuning { int sweep, kpt, rank, nw, kpt_text, kpt_kv; };
+struct RadixTuning { int sweep, kpt, rank, nw, kpt_text, kpt_kv, kv12; };
 static RadixTuning radix_tuning()
 {
     static const RadixTuning t = [] {
-        RadixTuning r = {1, 16, 1, 16, 16, 12};         // measured best on MI355X (round 4, lab/radix_lab2.hip): 1024-thread
+        RadixTuning r = {1, 16, 1, 16, 16, 12, 1};      // measured best on MI355X (round 4, lab/radix_lab2.hip): 1024-thread
                                                 // workgroups, 16384-element E64 tiles (512-byte runs), 12288-element KV tiles
         if (const char* e = dev_env("SFX_RADIX_SWEEP")) r.sweep = atoi(e) ? 1 : 0;
         if (const char* e = dev_env("SFX_RADIX_KPT")) r.kpt = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 8;
         if (const char* e = dev_env("SFX_RADIX_RANK")) r.rank = atoi(e) ? 1 : 0;
         if (const char* e = dev_env("SFX_RADIX_KPT_TEXT")) r.kpt_text = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 16;
         if (const char* e = dev_env("SFX_RADIX_KPT_KV")) r.kpt_kv = (atoi(e) >= 8 && atoi(e) <= 12) ? atoi(e) : 8;
+        if (const char* e = dev_env("SFX_RADIX_KV12")) r.kv12 = atoi(e) ? 1 : 0;         // 0: (key array, value array) in every pass
         if (const char* e = dev_env("SFX_RADIX_NW")) r.nw = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 4);
         return r;
     }();
@@ -1603,6 +1632,10 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
         const unsigned g = (unsigned)dmin<uint64_t>(nover, kMaxGrid);
         SFX_LAUNCH("oversize_gather", (double)nlarge * 16, k_oversize_gather, g, kBlock, st, (const uint64_t*)e1, (const OversizeEntry*)over,
                    nover, low_bits, T);
+        // (sorted on the key bits alone: the members of one key come out in the order the partition passes left them in, which
+        // depends on atomic timing -- unlike k_bucket_sort, which orders by the whole element.  Nothing downstream reads an order
+        // into a run of equal keys: k_groups_reduce compares keys only, the direct pass and the rounds order a bucket's members
+        // from the text / the ranks whatever order they arrive in, the fused LCP leaves such pairs pending.  ADVICE round 4.)
         int in1 = 0;
         SFX_TRY(radix_sort_e64(T, T2, nlarge, 32, 32 + low_bits + bits_for(nover > 1 ? nover - 1 : 1), scr.partial, st, &in1, stats,
                                nullptr, nullptr, nullptr, 0));
@@ -1823,6 +1856,27 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
         for (int p = 0; p < npass; p++) partial[((uint64_t)p * kRadix + tid) * gridDim.x + blockIdx.x] = h[p][tid];
 }
 
+// ---- 64-bit keys: the passes between the first and the last move 12-byte (key, suffix) elements (KV12 above) -----------------
+// (k, v) can serve as ONE array of m 12-byte elements when v starts right behind k's m keys (the arena carves them in that
+// order; up to one alignment gap in between belongs to nobody)
+static bool kv12_region(const uint64_t* k, const uint32_t* v, uint64_t m)
+{
+    const uintptr_t ke = reinterpret_cast<uintptr_t>(k + m), vb = reinterpret_cast<uintptr_t>(v);
+    return vb >= ke && vb - ke <= 256;
+}
+static void kv_trace(uint64_t m, int npass, bool e12)                  // SFX_TRACE=1 (development)
+{
+    static const bool trace = [] { const char* e = dev_env("SFX_TRACE"); return e && atoi(e) != 0; }();
+    if (trace) fprintf(stderr, "[sfx] 64-bit-key sort: m=%llu passes=%d elements=%s\n", (unsigned long long)m, npass, e12 ? "kv12" : "k+v");
+}
+template <class Src>
+static int kv_pass_out(const char* name, double algo, const Src& src, bool out12, KV12* out_e, uint64_t* out_k, uint32_t* out_v,
+                       uint64_t m, int shift, unsigned mask, const RadixScratch& scr, int pass, bool sweep, hipStream_t st)
+{
+    if (out12) return run_pass(name, algo, src, DstKV12{out_e}, m, shift, mask, scr, pass, sweep, st);
+    return run_pass(name, algo, src, DstKV{out_k, out_v}, m, shift, mask, scr, pass, sweep, st);
+}
+
 // Sort of all m = text.n suffixes by their compressed 64-bit keys (eight passes); (k0, v0) / (k1, v1) as
 // radix_sort_kv64, the keys are made here.
 // last_v (both sorts): the suffixes of the LAST pass go there instead of into v0 / v1 (the caller's SA: every suffix
@@ -1846,14 +1900,23 @@ int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
             SFX_LAUNCH("radix_scan", (double)npass * kRadix * ch.blocks * 8, k_radix_scan, npass * kRadix, kBlock, st, scr.partial,
                        ch.blocks, scr.totals);
     }
+    // passes 1 .. npass - 2 read and write 12-byte elements, the first writes them, the last reads them (and leaves the sorted
+    // keys as an array of their own, the suffixes in last_v / the value array of that side): region "0" = k0 + v0, "1" = k1 + v1
+    const bool e12 = radix_tuning().kv12 && npass >= 2 && kv12_region(k0, v0, m) && kv12_region(k1, v1, m);
+    kv_trace(m, npass, e12);
     uint64_t* kin = k0; uint32_t* vin = v0;
     uint64_t* kout = k1; uint32_t* vout = v1;
     int flips = 0;
     for (int p = 0; p < npass; p++) {
         const double algo = (double)m * ((p == 0 ? 8.0 : 12.0) + 12.0);
         uint32_t* vdst = (last_v && p == npass - 1) ? last_v : vout;
-        if (p == 0) SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKeyIota{kin}, DstKV{kout, vdst}, m, bit0 + 8 * p, 255u, scr, p, sweep, st));
-        else SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKV{kin, vin}, DstKV{kout, vdst}, m, bit0 + 8 * p, 255u, scr, p, sweep, st));
+        const bool out12 = e12 && p < npass - 1;
+        KV12* const ein = reinterpret_cast<KV12*>(kin);
+        KV12* const eout = reinterpret_cast<KV12*>(kout);
+        const int shift = bit0 + 8 * p;
+        if (p == 0) SFX_TRY(kv_pass_out("radix_scatter_u64", algo, SrcKeyIota{kin}, out12, eout, kout, vdst, m, shift, 255u, scr, p, sweep, st));
+        else if (e12) SFX_TRY(kv_pass_out("radix_scatter_u64", algo, SrcKV12{ein}, out12, eout, kout, vdst, m, shift, 255u, scr, p, sweep, st));
+        else SFX_TRY(kv_pass_out("radix_scatter_u64", algo, SrcKV{kin, vin}, false, eout, kout, vdst, m, shift, 255u, scr, p, sweep, st));
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
         flips ^= 1;
@@ -1878,6 +1941,9 @@ int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
         if (text) SFX_TRY(prepare_sweep("radix_hist_all_text_u64", (double)m * text->bits / 8.0, tsrc, m, bit_lo, bit_hi, npass, scr, st));
         else SFX_TRY(prepare_sweep("radix_hist_all_u64", (double)m * 8.0, SrcKV{k0, v0}, m, bit_lo, bit_hi, npass, scr, st));
     }
+    // (12-byte elements between the first and the last pass: see radix_sort_ht64)
+    const bool e12 = radix_tuning().kv12 && npass >= 2 && kv12_region(k0, v0, m) && kv12_region(k1, v1, m);
+    kv_trace(m, npass, e12);
     uint64_t* kin = k0; uint32_t* vin = v0;
     uint64_t* kout = k1; uint32_t* vout = v1;
     int flips = 0;
@@ -1889,10 +1955,15 @@ int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
         const double in_bytes = first_text ? text->bits / 8.0 : 12.0;
         const double algo = (double)m * (in_bytes + 12.0);
         uint32_t* vdst = (last_v && p == npass - 1) ? last_v : vout;
+        const bool out12 = e12 && p < npass - 1;
+        KV12* const ein = reinterpret_cast<KV12*>(kin);
+        KV12* const eout = reinterpret_cast<KV12*>(kout);
         if (first_text) {
-            SFX_TRY(run_pass("radix_scatter_text_u64", algo, tsrc, DstKV{kout, vdst}, m, shift, mask, scr, p, sweep, st));
+            SFX_TRY(kv_pass_out("radix_scatter_text_u64", algo, tsrc, out12, eout, kout, vdst, m, shift, mask, scr, p, sweep, st));
+        } else if (e12 && p > 0) {
+            SFX_TRY(kv_pass_out("radix_scatter_u64", algo, SrcKV12{ein}, out12, eout, kout, vdst, m, shift, mask, scr, p, sweep, st));
         } else {
-            SFX_TRY(run_pass("radix_scatter_u64", algo, SrcKV{kin, vin}, DstKV{kout, vdst}, m, shift, mask, scr, p, sweep, st));
+            SFX_TRY(kv_pass_out("radix_scatter_u64", algo, SrcKV{kin, vin}, out12, eout, kout, vdst, m, shift, mask, scr, p, sweep, st));
         }
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;

@@ -1424,9 +1424,11 @@ struct SizerArena : ArenaSizer {
 template <class A>
 static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffers* b)
 {
+    // (K0, VA) and (K1, VB) back to back: each pair doubles as one array of 12-byte (key, suffix) elements for the middle
+    // passes of the 64-bit-key sorts (kv12_region, sfx_radix.hip)
     uint64_t* K0 = ar.template take<uint64_t>(cap);
-    uint64_t* K1 = ar.template take<uint64_t>(cap);
     uint32_t* VA = ar.template take<uint32_t>(cap);
+    uint64_t* K1 = ar.template take<uint64_t>(cap);
     uint32_t* VB = ar.template take<uint32_t>(cap);
     uint32_t* S0 = ar.template take<uint32_t>(cap);
     uint32_t* S1 = ar.template take<uint32_t>(cap);

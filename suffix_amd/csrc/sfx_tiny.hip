@@ -27,7 +27,7 @@ constexpr uint32_t kTinyMaxBytes8 = 4096;              // more than 16 different
 constexpr uint32_t kTinyStepCap = 1u << 13;
 
 struct TinySmem {
-    uint8_t raw[kTinyMax + 16];                     // the text as it came (one coalesced load per thread)
+    alignas(16) uint8_t raw[kTinyMax + 16];                     // the text as it came (one coalesced load per thread)
     uint32_t stream[kTinyMax / 4 + 8];              // symbol codes, `bits` each, as one bit stream: word k = bits [32 k, 32 k + 32), first bit on top; zero tail
     uint16_t idx[2][kTinyMax];                      // suffix indices, ping-pong
     unsigned long long flags[kTinyNW][kRadix];      // match masks of the ranking; afterwards: one head flag byte per rank

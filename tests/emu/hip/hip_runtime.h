@@ -74,6 +74,7 @@ hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 template <class T> hipError_t hipMalloc(T** p, size_t bytes) { return hipMalloc((void**)p, bytes); }
 constexpr unsigned hipHostMallocDefault = 0;
+constexpr unsigned hipHostMallocPortable = 1, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000;
 inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned = 0) { return hipMalloc(p, bytes); }
 inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 

@@ -171,6 +171,10 @@ VARIANTS = {
     "small-tiles-small-segments": {"SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
     "small-tiles-key64-multi-tile": {"SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "3", "SFX_SEG_SMALL": "1"},
     "key64": {"SFX_FORCE_KEY64": "1"},
+    # 64-bit keys: the middle passes move 12-byte (key, suffix) elements (KV12, round 5) -- here through the chunked schedule's
+    # kernel with multi-tile chunks, and the (key array, value array) form of rounds 1-4 in every pass
+    "key64-chunked-multi-tile": {"SFX_FORCE_KEY64": "1", "SFX_RADIX_SWEEP": "0", "SFX_MAX_GRID": "2", "TEST_TEXTS": "3"},
+    "key64-split-arrays": {"SFX_FORCE_KEY64": "1", "SFX_RADIX_KV12": "0", "TEST_TEXTS": "3"},
     # hybrid initial sort forced on small inputs
     "hybrid-initial-sort": {"SFX_HYBRID_MIN": "1"},
     # ... with the stable one-sweep passes of rounds 2-3 instead of the partition passes (k_partition)
