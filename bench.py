@@ -69,12 +69,17 @@ def verify_sa_on_device(torch, sdev, text, sa, n_samples=20000, seed=1):
     return True, "permutation + adjacent-order (all pairs) + sampled LCP bytes"
 
 
-def verify_sa_chunked(torch, sdev, text, sa, chunk=200_000_000):
+def verify_sa_chunked(torch, sdev, text, sa, chunk=200_000_000, n_samples=2000, seed=1):
     """verify_sa_on_device for inputs whose int64 temporaries would not fit next to the data:
     the permutation test counts in place, and the adjacent-order test walks the suffix array in
     slices, taking each slice's LCP from the engine's per-slice routine (direct comparison,
-    src/table.rs:348-361) -- every adjacent pair is still checked."""
+    src/table.rs:348-361) -- every adjacent pair is still checked.  As in verify_sa_on_device the
+    LCP values the order test leans on are re-checked on the host, byte by byte, for n_samples
+    pairs of every slice: an overstated LCP would let the next-symbol compare look past the first
+    mismatch (an understated one fails the compare itself: the symbols at that offset are equal)."""
     n = text.numel()
+    rng = np.random.default_rng(seed)
+    t_host = text.cpu().numpy()
     cnt = torch.zeros(n, dtype=torch.int8, device=text.device)
     for lo in range(0, n, chunk):
         idx = sa[lo:lo + chunk].to(torch.int64) & 0xFFFFFFFF
@@ -101,9 +106,14 @@ def verify_sa_chunked(torch, sdev, text, sa, chunk=200_000_000):
         cb = text[pb].to(torch.int32)
         if not bool(((pa >= n) | (ca < cb)).all()):
             return False, "adjacent suffixes out of order"
+        if cur.numel() > skip_first:
+            rs = torch.from_numpy(rng.integers(skip_first, cur.numel(), size=min(n_samples, cur.numel() - skip_first))).to(text.device)
+            for x, y, l in zip(before[rs].cpu().tolist(), cur[rs].cpu().tolist(), h[rs].cpu().tolist()):
+                if x + l > n or y + l > n or t_host[x:x + l].tobytes() != t_host[y:y + l].tobytes():
+                    return False, "LCP overstates a common prefix"
         prev = int(cur[-1])
         del lcp, cur, h, before, pa, pb, ca, cb
-    return True, "permutation + adjacent-order (all pairs, in slices of %d)" % chunk
+    return True, "permutation + adjacent-order (all pairs, in slices of %d) + sampled LCP bytes per slice" % chunk
 
 
 def _sha_u32(t):

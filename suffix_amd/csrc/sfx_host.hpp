@@ -314,6 +314,7 @@ struct TileRound {
     uint8_t* F8;                  // m bytes (+ 8), scratch
     uint16_t* Hd;                 // deep text rounds: symbols the members of p's bucket share, per list position (in / out)
     uint32_t wsym;                // ... and what a split by the large-bucket path adds to it (text_round_symbols)
+    uint32_t h;                   // symbols every bucket of the list shares at least (the round's h)
     uint16_t* F;
     uint32_t* part_head; uint32_t* part_keep; uint32_t* part_ghead;
     uint32_t* block_counts;       // kMaxGrid

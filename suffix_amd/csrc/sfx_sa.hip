@@ -1826,6 +1826,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         const bool deep_round = !rank_mode;
         tr.Hd = deep_round ? hd_of(b, S_cur) : nullptr;
         tr.wsym = (uint32_t)wsym;
+        tr.h = (uint32_t)(h > 0xFFFFFFFFull ? 0xFFFFFFFFull : h);
         tr.part_head = b.part_head; tr.part_keep = b.part_keep; tr.part_ghead = b.part_ghead;
         tr.block_counts = b.block_counts; tr.totals = b.totals; tr.counters = b.counters; tr.deep_slots = b.deep_slots;
         tr.part_pairs = rank_mode ? b.block_counts : nullptr;   // (idle during a round)

@@ -717,7 +717,7 @@ template <int KPT, bool EMIT>
 __global__ void __launch_bounds__(kBlock) SFX_WAVES_PER_EU(KPT <= 4 ? 7 : 4, 8)
 k_deep_wave(DeepTextKey keyfn, const uint32_t* __restrict__ G, uint64_t m, uint32_t* __restrict__ V, uint8_t* __restrict__ F8,
             uint16_t* __restrict__ Hd, unsigned long long* __restrict__ counters,
-            unsigned long long* __restrict__ slots, uint2* __restrict__ segs, LcpEmit emit, int max_iter)
+            unsigned long long* __restrict__ slots, uint2* __restrict__ segs, LcpEmit emit, int max_iter, uint32_t max_depth)
 {
     constexpr int W = kWave * KPT, H = W / 2, kOwn = W - H;
     static_assert((KPT & (KPT - 1)) == 0 && KPT >= 2 && KPT <= 8 && W <= 32768, "bitonic network up to 8 per lane; positions fit 15 bits");
@@ -804,10 +804,42 @@ k_deep_wave(DeepTextKey keyfn, const uint32_t* __restrict__ G, uint64_t m, uint3
     unsigned n_gather = 0;
     uint32_t it = 0;
     while (cnt > 0 && (int)it < max_iter) {
-        {   // the depth must stay representable
+        {   // the depth must stay representable: the buckets that another key would take past the 16 bits of Hd leave now, as
+            // buckets of the list with the depth they have reached (the rank rounds' job) -- the wave's other buckets go on
+            // (until round 5 one such bucket ended the whole wave's round: ADVICE round 3)
+            const uint32_t next_add = (it + 1u) * (uint32_t)keyfn.wsym;
             bool over = false;
-            for (unsigned j = lane; j < cnt; j += kWave) over |= (uint32_t)s.hd[j] + (it + 1u) * (uint32_t)keyfn.wsym > kDeepMaxDepth;
-            if (__any(over)) break;
+            for (unsigned j = lane; j < cnt; j += kWave) over |= (uint32_t)s.hd[j] + next_add > max_depth;
+            if (__any(over)) {
+                unsigned kept = 0;                                      // slots [0, kept): the members that stay, whole sub-buckets, in order
+                for (unsigned j0 = 0; j0 < cnt; j0 += kWave) {          // (a chunk writes below what later chunks still have to read)
+                    const unsigned j = j0 + lane;
+                    const bool valid = j < cnt;
+                    const uint32_t suf = valid ? s.suf[j] : 0u;
+                    const uint16_t pos = valid ? s.pos[j] : (uint16_t)0, hd = valid ? s.hd[j] : (uint16_t)0, tag = valid ? s.tag[j] : (uint16_t)0;
+                    const bool out = valid && (uint32_t)hd + next_add > max_depth;
+                    const bool stay = valid && !out;
+                    if (out) {
+                        const uint64_t p = wbase + pos;
+                        V[p] = suf;
+                        F8[p] = (uint8_t)((tag == j ? 1u : 0u) | 4u);
+                        Hd[p] = (uint16_t)((uint32_t)hd + it * (uint32_t)keyfn.wsym);
+                    }
+                    const unsigned long long bal = __ballot(stay);
+                    const unsigned at = kept + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+                    wave_sync();
+                    if (stay) {
+                        s.suf[at] = suf;
+                        s.pos[at] = pos;
+                        s.hd[at] = hd;
+                        s.tag[at] = (uint16_t)(at - (j - tag));          // (a sub-bucket stays or leaves as a whole: one depth)
+                    }
+                    kept += (unsigned)__popcll(bal);
+                    wave_sync();
+                }
+                cnt = kept;
+                if (cnt == 0) break;
+            }
         }
         n_gather += cnt;
         unsigned left;
@@ -1016,6 +1048,13 @@ static int deep_max_iter()
     static const int v = [] { const char* e = dev_env("SFX_DEEP_ITERS"); int x = e ? atoi(e) : 24; return x >= 1 && x <= 4096 ? x : 24; }();
     return v;
 }
+// SFX_DEEP_MAX_DEPTH (tests): a lower bound on the depth from which a bucket leaves the deep kernel for good (the 16-bit
+// limit of Hd otherwise), so that small inputs have buckets that leave beside buckets that go on in the same wave
+static uint32_t deep_max_depth()
+{
+    static const uint32_t v = [] { const char* e = dev_env("SFX_DEEP_MAX_DEPTH"); int x = e ? atoi(e) : 0; return x >= 1 && x < (int)kDeepMaxDepth ? (uint32_t)x : kDeepMaxDepth; }();
+    return v;
+}
 int deep_text_symbols(const PackedText& pt) { return text_key64_symbols(pt); }
 
 template <int KPT>
@@ -1028,12 +1067,19 @@ static int launch_deep(const DeepTextKey& keyfn, const TileRound& r, uint64_t m,
     SFX_HIP(hipMemsetAsync(r.deep_slots, 0, (size_t)kDeepSlotWords * sizeof(unsigned long long), st));
     // read G (+ V + Hd of what it takes), write V + F8 (+ Hd of what stays tied); the gathers are counted by the kernel
     const double algo = (double)m * (4 + 4);
+    // A bucket that leaves without another key must still be deeper than the h the NEXT round assumes of every bucket
+    // (h + r.wsym, refine): the limit never lies below h + r.wsym + one key.  (The 16-bit limit itself is far above that: the
+    // build switches to ranks before h + 2 wsym reaches 60000.)
+    uint32_t max_depth = deep_max_depth();
+    const uint64_t floor_depth = (uint64_t)r.h + r.wsym + (uint64_t)keyfn.wsym;
+    if (floor_depth > kDeepMaxDepth) return SFX_ERR_INTERNAL;
+    if (max_depth < floor_depth) max_depth = (uint32_t)floor_depth;
     if (r.emit.lcp)
         SFX_LAUNCH("deep_wave", algo, (k_deep_wave<KPT, true>), (unsigned)blocks, kBlock, st, keyfn, r.G, m, r.V, r.F8, r.Hd,
-                   r.counters, r.deep_slots, reinterpret_cast<uint2*>(r.seg.segs), r.emit, deep_max_iter());
+                   r.counters, r.deep_slots, reinterpret_cast<uint2*>(r.seg.segs), r.emit, deep_max_iter(), max_depth);
     else
         SFX_LAUNCH("deep_wave", algo, (k_deep_wave<KPT, false>), (unsigned)blocks, kBlock, st, keyfn, r.G, m, r.V, r.F8, r.Hd,
-                   r.counters, r.deep_slots, reinterpret_cast<uint2*>(r.seg.segs), r.emit, deep_max_iter());
+                   r.counters, r.deep_slots, reinterpret_cast<uint2*>(r.seg.segs), r.emit, deep_max_iter(), max_depth);
     SFX_LAUNCH("deep_totals", 0.0, k_deep_totals, 1, kBlock, st, (const unsigned long long*)r.deep_slots, r.counters, 1);
     return SFX_OK;
 }

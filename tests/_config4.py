@@ -4,8 +4,10 @@ the range filter, slices of 10^9 suffixes -- above the hybrid route's 2^28 and i
 plan_ranges), every range built by sfx_build_sa_range_packed_u32_dev as one rank would build it, one after another.
 Checks: every slice equals its stretch of ONE single-GPU build of the same text (whose own gate is permutation + every
 adjacent pair in order, boundaries included: bench.verify_sa_chunked); the slices' sizes sum to n; sha256 of the concatenated
-slices = sha256 of the single-GPU array; the u64 widening of a slice holds the same positions.  Returns one record per rank
-(+ one for the whole)."""
+slices = sha256 of the single-GPU array; the u64 widening of a slice holds the same positions; and (round 5) sha256 of the
+complete array = the pin that scripts/cpu_config4_oracle.py made from oracle.sais over the same 4 * 10^9 bytes (u32 positions
+fit: SURVEY 8(d)'s "u32-oracle cross-check"), with per-2^28-entry chunk hashes to localise a difference.  Returns one record
+per rank (+ one for the whole)."""
 import ctypes
 import hashlib
 import os
@@ -18,6 +20,12 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def _pins():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "fullsize_pins.json")) as f:
+        return json.load(f)
 
 
 def rehearse(n, world=4, tb=14, seed=0x5AF1C5 + 4, full_gate=True):
@@ -34,6 +42,7 @@ def rehearse(n, world=4, tb=14, seed=0x5AF1C5 + 4, full_gate=True):
     recs = []
     t0 = time.perf_counter()
     host = _gen.dna_fast(n, seed=seed)
+    sha_text = hashlib.sha256(memoryview(host)).hexdigest()
     text = torch.from_numpy(host).to(dev)
     del host
     gen_s = time.perf_counter() - t0
@@ -106,14 +115,28 @@ def rehearse(n, world=4, tb=14, seed=0x5AF1C5 + 4, full_gate=True):
         del part, wsr
         torch.cuda.empty_cache()
     assert total == n
-    sha_full = hashlib.sha256(memoryview(full.cpu().numpy())).hexdigest()
+    full_host = full.cpu().numpy()
+    sha_full = hashlib.sha256(memoryview(full_host)).hexdigest()
     assert h_slices.hexdigest() == sha_full
+    # the ORACLE's array of the same text (scripts/cpu_config4_oracle.py: oracle.sais over all n bytes, u32 positions since
+    # n < 2^32 -- SURVEY 8(d)'s "u32-oracle cross-check"), pinned as sha256 of the whole array and of every 2^28-entry chunk
+    pin = _pins().get("c4", {}).get(str(n))
+    oracle_pinned = False
+    if pin is not None:
+        assert sha_text == pin["sha256_text"], "the generator no longer makes the pinned text"
+        if sha_full != pin["sha256_sa"]:
+            bad = [k for k, want in enumerate(pin["sha256_sa_chunks_2p28"])
+                   if hashlib.sha256(memoryview(full_host[k << 28:(k + 1) << 28])).hexdigest() != want]
+            raise AssertionError("config 4: suffix array differs from the oracle's in 2^28-entry chunks %r" % bad)
+        oracle_pinned = True
+    del full_host
     per = [r["range_build_ms"] for r in recs]
     recs.append({"summary": "config 4 input, %d virtual ranks on one GPU" % world, "n": n, "gen_s": round(gen_s, 1),
                  "single_gpu_build_ms": round(single_ms, 1), "single_gpu_gate": how, "range_build_ms_per_rank": per,
                  "max_rank_ms": max(per), "sum_rank_ms": round(sum(per), 1),
                  "compute_efficiency_vs_single_gpu_share": round(single_ms / world / max(per), 3),
-                 "sha256_sa": sha_full, "sha256_of_concatenated_slices_equal": True})
+                 "sha256_sa": sha_full, "sha256_of_concatenated_slices_equal": True, "sha256_text": sha_text,
+                 "sa_equals_oracle_pin": oracle_pinned})
     del full, text, packed
     torch.cuda.empty_cache()
     return recs

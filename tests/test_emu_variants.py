@@ -197,6 +197,14 @@ VARIANTS = {
     "deep-two-iterations-small-windows": {"SFX_DEEP_ITERS": "2", "SFX_TILE_SMALL": "1", "SFX_SEG_SMALL": "1"},
     "deep-small-windows-key64": {"SFX_DEEP_ITERS": "24", "SFX_TILE_SMALL": "1", "SFX_FORCE_KEY64": "1"},
     "deep-512-position-windows": {"SFX_DEEP_KPT": "8", "SFX_DEEP_ITERS": "3"},
+    # buckets that would pass the depth limit leave the deep kernel (evicted from the wave's slots with the depth they have
+    # reached) while the wave's other buckets go on.  Compressed keys start the buckets of one wave at different depths, so with
+    # the limit lowered to 24 / 18 symbols a wave evicts SOME of its buckets (checked once with a counter: 106 / 21 partial
+    # evictions on the doubled English-like text, 3 / 109 complete ones); fixed-width keys evict a wave's buckets together
+    "deep-buckets-past-the-depth-limit-compressed-keys": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24", "SFX_DEEP_MAX_DEPTH": "24"},
+    "deep-buckets-past-the-depth-limit-compressed-keys-small-windows": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24",
+                                                                       "SFX_DEEP_MAX_DEPTH": "18", "SFX_TILE_SMALL": "1"},
+    "deep-buckets-past-the-depth-limit": {"SFX_DEEP_ITERS": "24", "SFX_DEEP_MAX_DEPTH": "48"},
     # 64-bit initial keys in an order-preserving prefix code (k_ht_keys): buckets of different depths from the first list on
     "compressed-keys": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24"},
     "compressed-keys-small-windows-one-iteration": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "1", "SFX_TILE_SMALL": "1",

@@ -175,7 +175,7 @@ def test_config4_virtual_ranks(eng):
     another by sfx_build_sa_range_packed_u32_dev (what each of the 4 ranks would run), every slice equal to its stretch of
     one single-GPU build of the same text (itself gated: permutation + every adjacent pair in order), sizes summing to n,
     sha256 of the concatenation equal, u64 widening checked; per-rank milliseconds go to gpurun_out/ (copied to
-    profiles/r4_config4_virtual.jsonl).  tests/_config4.py."""
+    profiles/r5_config4_virtual.jsonl).  Round 5: the complete array's sha256 is pinned to an oracle run.  tests/_config4.py."""
     import _config4
     n = 4_000_000_000
     free, _total = torch.cuda.mem_get_info()
@@ -183,10 +183,13 @@ def test_config4_virtual_ranks(eng):
         pytest.skip("needs ~230 GB of free HBM for the single-GPU comparison build")
     recs = _config4.rehearse(n, world=4)
     assert len(recs) == 5 and all(r["equals_single_gpu_slice"] for r in recs[:4])
+    # (round 5) the array is the ORACLE's: sha256 of the complete suffix array = the pin of scripts/cpu_config4_oracle.py
+    # (oracle.sais over all 4 * 10^9 bytes, u32 positions: tests/golden/fullsize_pins.json "c4")
+    assert recs[4]["sa_equals_oracle_pin"] is True, recs[4]
     assert max(r["largest_position"] for r in recs[:4]) >= (1 << 31)          # positions beyond 2^31 were placed
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "r4_config4_virtual.jsonl"), "w") as f:
+        with open(os.path.join(ROOT, "gpurun_out", "r5_config4_virtual.jsonl"), "w") as f:
             for r in recs:
                 f.write(json.dumps(r) + "\n")
     except OSError:
