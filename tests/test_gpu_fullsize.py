@@ -196,23 +196,67 @@ def test_config4_virtual_ranks(eng):
         pass
 
 
-def test_two_gpu_bench_over_rccl():
-    """bench.py --gpus 2 under torch.distributed.run with the nccl (= RCCL) backend, one rank per GPU: the
-    partitioned build's first contact with RCCL.  Skipped on 1-GPU boxes (the driver's multi-GPU node runs it)."""
-    import subprocess
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs >= 2 visible GPUs")
+def _bench_over_rccl(extra, size="20000000", share_gpu=False):
     import socket
+    import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if share_gpu:
+        env["SFX_BENCH_SHARE_GPU"] = "1"                 # both ranks on cuda:0, gloo instead of RCCL (bench.py's rehearsal hook)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "20000000"],
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", size, "--configs", "", "--cpu-sample", "0"] + extra,
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["verified"] is True, rec
-    assert rec["config"]["partitioned_phases_ms"]["range_build"] > 0
+    return rec
+
+
+@pytest.mark.parametrize("case", ["even-packed", "ragged-packed", "replicated-fallback"])
+def test_two_gpu_bench_over_rccl(case):
+    """bench.py --gpus 2 under torch.distributed.run with the nccl (= RCCL) backend, one rank per GPU: the partitioned build's
+    first contact with RCCL, one sub-case per branch of suffix_amd/dist.py -- shards of equal length (packed exchange on the
+    global word grid), ragged shards (lengths that are no multiple of the symbols per word: the straddling words are assembled
+    from the halos), and a periodic text (the range build reports SFX_ERR_NEEDS_RANKS, the ranks agree with one all-reduce and
+    every rank builds the whole array: the replicated fallback).  The gate of every sub-case is verify_partitioned (permutation
+    + every adjacent pair, slice boundaries included).  Skipped on 1-GPU boxes (the driver's multi-GPU node runs it); the same
+    three shapes run over gloo in tests/test_dist_gloo.py."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    if case == "even-packed":
+        rec = _bench_over_rccl([])
+        ph = rec["config"]["partitioned_phases_ms"]
+        assert ph["range_build"] > 0 and "fallback" not in ph, ph
+        assert rec["config"]["text_bytes_total"] == 40000000
+    elif case == "ragged-packed":
+        rec = _bench_over_rccl(["--ragged"])
+        ph = rec["config"]["partitioned_phases_ms"]
+        assert ph["range_build"] > 0 and "fallback" not in ph, ph
+        assert rec["config"]["text_bytes_total"] == 2 * 20000000 - 1 - 4098
+        assert "packed" in str(ph.get("text_exchange", "packed")), ph
+    else:
+        rec = _bench_over_rccl(["--input", "periodic"], size="3000000")
+        ph = rec["config"]["partitioned_phases_ms"]
+        assert "fallback" in ph, ph
+
+
+@pytest.mark.parametrize("case", ["even-packed", "ragged-packed", "replicated-fallback"])
+def test_two_rank_bench_rehearsal_on_one_gpu(case):
+    """The same three sub-cases as test_two_gpu_bench_over_rccl on the 1-GPU boxes of this pool: both ranks on cuda:0, gloo in
+    place of RCCL (which refuses two ranks on one device) -- bench.py's N > 1 code, its --ragged / --input flags and every
+    branch of suffix_amd/dist.py on device memory.  Not a multi-GPU measurement."""
+    if case == "even-packed":
+        rec = _bench_over_rccl([], size="3000000", share_gpu=True)
+        assert "fallback" not in rec["config"]["partitioned_phases_ms"] and rec["config"]["text_bytes_total"] == 6000000
+    elif case == "ragged-packed":
+        rec = _bench_over_rccl(["--ragged"], size="3000000", share_gpu=True)
+        ph = rec["config"]["partitioned_phases_ms"]
+        assert "fallback" not in ph and rec["config"]["text_bytes_total"] == 6000000 - 1 - 4098, rec["config"]
+        assert "packed" in str(ph.get("text_exchange", "")), ph
+    else:
+        rec = _bench_over_rccl(["--input", "periodic"], size="1000000", share_gpu=True)
+        assert "fallback" in rec["config"]["partitioned_phases_ms"], rec["config"]

@@ -21,6 +21,46 @@ def eng():
     return e
 
 
+def test_first_build_on_a_fresh_thread_with_spaces(eng, oracle):
+    """the polled read-back kept its sequence word inside the page that also staged the 2 KiB copy of the
+    byte bins -- bins[0x20] of a text with spaces left 1 (or the count of spaces) where the next post polled for its sequence
+    number, the poll ended before the kernel had run and the build went on with stale round totals.  Deterministic for the first
+    general build of a thread (sequence number 1) on a text with spaces below 65536 bytes, and whenever the count of spaces
+    met the running sequence number.  Fresh threads (fresh thread-local state), general build forced, texts with 1 .. 12 spaces
+    and ordinary text; through the host-pointer entry point and through the device entry point."""
+    import threading
+    rng = np.random.default_rng(20)
+    texts = [_gen.english_like(20000, seed=77).tobytes()]
+    for spaces in range(1, 13):
+        body = bytearray(rng.integers(97, 123, 17000 + 371 * spaces, dtype=np.uint8).tobytes())
+        for pos in rng.choice(len(body), size=spaces, replace=False).tolist():
+            body[pos] = 0x20
+        texts.append(bytes(body))
+    errors = []
+
+    def work(t, dev_entry):
+        try:
+            from suffix_amd import SuffixTable
+            exp = oracle.sais(t)
+            if dev_entry:
+                from suffix_amd import device as sdev
+                got = sdev.build_sa(torch.frombuffer(bytearray(t), dtype=torch.uint8).cuda(), engine=eng).cpu().numpy().view(np.uint32)
+            else:
+                got = SuffixTable(t, engine=eng).table()
+            if not np.array_equal(got, exp):
+                errors.append(("SA differs", len(t), t.count(b" "), dev_entry))
+        except Exception as exc:                                       # noqa: BLE001
+            errors.append((repr(exc), len(t), dev_entry))
+
+    with _cases.general_build(eng):
+        for t in texts:
+            for dev_entry in (False, True):
+                th = threading.Thread(target=work, args=(t, dev_entry))
+                th.start()
+                th.join()
+    assert not errors, errors
+
+
 def test_literals(eng, oracle, golden):
     _cases.literals(eng, oracle, golden)
 
