@@ -197,27 +197,32 @@ k_lcp_gather(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ plcp,
     }
 }
 
-// first 16 bytes of suffix s, zero-padded past the end of the text
-__device__ __forceinline__ void load_window(const uint8_t* __restrict__ text, uint64_t n, uint64_t s, uint64_t& w0,
-                                            uint64_t& w1)
+// first 8 * NWORDS bytes of suffix s, zero-padded past the end of the text
+template <int NWORDS>
+__device__ __forceinline__ void load_window(const uint8_t* __restrict__ text, uint64_t n, uint64_t s, uint64_t (&w)[NWORDS])
 {
-    if (s + 16 <= n) {
-        __builtin_memcpy(&w0, text + s, 8);
-        __builtin_memcpy(&w1, text + s + 8, 8);
+    if (s + 8 * NWORDS <= n) {
+#pragma unroll
+        for (int k = 0; k < NWORDS; k++) __builtin_memcpy(&w[k], text + s + 8 * k, 8);
     } else {
-        w0 = w1 = 0;
-        for (unsigned k = 0; k < 16 && s + k < n; k++) {
-            const uint64_t b = (uint64_t)text[s + k] << (8 * (k & 7u));
-            if (k < 8) w0 |= b; else w1 |= b;
+#pragma unroll
+        for (int k = 0; k < NWORDS; k++) {
+            uint64_t x = 0;
+            for (unsigned b = 0; b < 8 && s + 8u * (unsigned)k + b < n; b++) x |= (uint64_t)text[s + 8u * (unsigned)k + b] << (8 * b);
+            w[k] = x;
         }
     }
 }
-__device__ __forceinline__ unsigned match_windows(uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1)
+template <int NWORDS>
+__device__ __forceinline__ unsigned match_windows(const uint64_t (&a)[NWORDS], const uint64_t (&b)[NWORDS])
 {
-    const uint64_t d0 = a0 ^ b0, d1 = a1 ^ b1;
-    if (d0) return (unsigned)(__ffsll((long long)d0) - 1) / 8u;
-    if (d1) return 8u + (unsigned)(__ffsll((long long)d1) - 1) / 8u;
-    return 16u;
+    unsigned l = 8u * NWORDS;
+#pragma unroll
+    for (int k = NWORDS - 1; k >= 0; k--) {
+        const uint64_t d = a[k] ^ b[k];
+        if (d) l = 8u * (unsigned)k + (unsigned)(__ffsll((long long)d) - 1) / 8u;
+    }
+    return l;
 }
 // extend_match that gives up at `cap` bytes (returns a value >= cap then)
 __device__ __forceinline__ uint64_t extend_match_capped(const uint8_t* __restrict__ text, uint64_t n, uint64_t a,
@@ -259,11 +264,17 @@ k_lcp_sample(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __res
     if (lane_id() == 0 && l) atomicAdd(&counters[0], (unsigned long long)l);
 }
 
-// lcp[r] for every r; counters[1] counts the pairs that reached the cap (their lcp[r] is not final)
+// lcp[r] for every r; counters[1] counts the pairs that reached the cap (their lcp[r] is not final).
+// NWORDS: 8-byte words of a suffix's window.  The window is what a pair is decided on without leaving the wave's lock step:
+// a pair that agrees on all of it walks on alone (extend_match_capped: a dependent load-compare loop in one lane while the
+// wave waits).  With 16 bytes about a third of the pairs of natural-language text walk on (mean LCP 13.7), with 32 a few per
+// cent -- and the second half of a window lies in the line the first half fetched, or the next one.
+template <int NWORDS>
 __global__ void __launch_bounds__(kBlock)
 k_lcp_windows(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa,
               uint32_t* __restrict__ lcp, unsigned long long* __restrict__ counters)
 {
+    constexpr unsigned kBytes = 8u * NWORDS;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const unsigned lane = lane_id();
     uint32_t capped = 0;
@@ -273,21 +284,25 @@ k_lcp_windows(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __re
         const bool live = r < n;
         uint64_t cur = live ? (uint64_t)sa[r] : 0;
         if (cur >= n) { atomicAdd(&counters[2], 1ull); cur = 0; }
-        uint64_t c0 = 0, c1 = 0;
-        if (live) load_window(text, n, cur, c0, c1);
-        uint64_t prev = __shfl_up(cur, 1u), p0 = __shfl_up(c0, 1u), p1 = __shfl_up(c1, 1u);
+        uint64_t c[NWORDS], p[NWORDS];
+#pragma unroll
+        for (int k = 0; k < NWORDS; k++) c[k] = 0;
+        if (live) load_window<NWORDS>(text, n, cur, c);
+        uint64_t prev = __shfl_up(cur, 1u);
+#pragma unroll
+        for (int k = 0; k < NWORDS; k++) p[k] = __shfl_up(c[k], 1u);
         if (lane == 0 && live && r > 0) {
             prev = (uint64_t)sa[r - 1];
             if (prev >= n) prev = 0;                                 // (counted by the lane that owns r - 1)
-            load_window(text, n, prev, p0, p1);
+            load_window<NWORDS>(text, n, prev, p);
         }
         if (!live) continue;
         uint64_t l = 0;
         if (r > 0) {
             const uint64_t room = n - (cur > prev ? cur : prev);          // bytes the shorter suffix has
-            l = match_windows(p0, p1, c0, c1);
+            l = match_windows<NWORDS>(p, c);
             if (l > room) l = room;
-            if (l == 16) l = extend_match_capped(text, n, prev, cur, 16, kDirectCap);
+            if (l == kBytes) l = extend_match_capped(text, n, prev, cur, kBytes, kDirectCap);
             if (l >= kDirectCap) capped++;
         }
         lcp[r] = (uint32_t)l;
@@ -520,8 +535,16 @@ int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, u
             if (packed)
                 SFX_LAUNCH("lcp_windows_packed", (double)n * 24, k_lcp_windows_packed, grid, kBlock, st, pt, d_sa, d_lcp,
                            counters);
-            else
-                SFX_LAUNCH("lcp_windows", (double)n * 24, k_lcp_windows, grid, kBlock, st, d_text, n, d_sa, d_lcp, counters);
+            else {
+                // window of 32 bytes where the sample says a 16-byte window would leave many pairs to walk on alone
+                // (SFX_LCP_WINDOW=2 / 4, development: force 16 / 32 bytes)
+                static const int forced = [] { const char* e = dev_env("SFX_LCP_WINDOW"); return e ? atoi(e) : 0; }();
+                const bool wide = forced ? forced == 4 : host[0] >= 6ull * samples;
+                if (wide)
+                    SFX_LAUNCH("lcp_windows", (double)n * 24, k_lcp_windows<4>, grid, kBlock, st, d_text, n, d_sa, d_lcp, counters);
+                else
+                    SFX_LAUNCH("lcp_windows", (double)n * 24, k_lcp_windows<2>, grid, kBlock, st, d_text, n, d_sa, d_lcp, counters);
+            }
             SFX_TRY(read_back(host, counters, sizeof(host), st));
             if (host[2]) return SFX_ERR_ARG;
             if (host[1] == 0) return SFX_OK;

@@ -131,6 +131,13 @@ struct SrcKV12 {
     const KV12* in;
     __device__ __forceinline__ uint64_t key(uint64_t i) const { return ((uint64_t)in[i].hi << 32) | in[i].lo; }
     __device__ __forceinline__ uint32_t val(uint64_t i) const { return in[i].v; }
+    // key and value of element i with ONE 12-byte load (a wave's 64 consecutive elements: 768 contiguous bytes per instruction)
+    __device__ __forceinline__ void fetch(uint64_t i, uint64_t& k, uint32_t& v) const
+    {
+        const KV12 e = in[i];
+        k = ((uint64_t)e.hi << 32) | e.lo;
+        v = e.v;
+    }
 };
 struct DstKV12 {
     KV12* out;
@@ -143,6 +150,20 @@ struct DstKV12 {
         out[d] = e;
     }
 };
+
+// element i of a source: its own one-load form where it has one (SrcKV12), key() + val() otherwise
+template <class Src, class = void> struct SrcHasFetch { static constexpr bool value = false; };
+template <class Src> struct SrcHasFetch<Src, decltype((void)&Src::fetch)> { static constexpr bool value = true; };
+template <class Src>
+__device__ __forceinline__ void src_fetch(const Src& src, uint64_t i, uint64_t& k, uint32_t& v)
+{
+    if constexpr (SrcHasFetch<Src>::value) {
+        src.fetch(i, k, v);
+    } else {
+        k = src.key(i);
+        v = Src::kHasVal ? src.val(i) : 0u;
+    }
+}
 
 __device__ __forceinline__ unsigned digit_of(uint64_t key, int shift, unsigned mask)
 {
@@ -456,8 +477,11 @@ k_radix_pass(Src src, Dst dst, uint64_t m, int shift, unsigned mask, uint64_t ch
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
             const unsigned idx = first + r * kWave;
-            nkey[r] = (idx < nv) ? src.key(tile + idx) : ~0ull;
-            if (HAS_VAL) nval[r] = (idx < nv) ? src.val(tile + idx) : 0u;
+            uint64_t k = ~0ull;
+            uint32_t v = 0u;
+            if (idx < nv) src_fetch(src, tile + idx, k, v);
+            nkey[r] = k;
+            if (HAS_VAL) nval[r] = v;
         }
     };
     if (!ONESWEEP && next < limit) load_tile(next);
@@ -647,8 +671,11 @@ k_radix_sweep(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const uint
 #pragma unroll
         for (int r = 0; r < KPT; r++) {
             const unsigned idx = first + r * kWave;
-            key[r] = (idx < nvalid) ? src.key(tile + idx) : ~0ull;
-            if (HAS_VAL) val[r] = (idx < nvalid) ? src.val(tile + idx) : 0u;
+            uint64_t k = ~0ull;
+            uint32_t v = 0u;
+            if (idx < nvalid) src_fetch(src, tile + idx, k, v);
+            key[r] = k;
+            if (HAS_VAL) val[r] = v;
         }
 #pragma unroll
         for (int k = 0; k < kRadix / kWave; k++) my_flags[k * kWave + lane] = 0ull;

@@ -165,6 +165,9 @@ VARIANTS = {
     "one-sweep-8-waves-kpt8": {"SFX_RADIX_NW": "8", "SFX_RADIX_KPT": "8", "SFX_MAX_GRID": "3", "TEST_TEXTS": "2"},
     "partitioned-scatter": {"SFX_PARTITION_MIN": "1"},
     "direct-lcp": {"SFX_LCP_DIRECT_MIN": "8"},
+    # the byte-window kernel at both window widths (round 5: 32 bytes where the sample's mean LCP is >= 6), whatever the sample says
+    "direct-lcp-32-byte-windows": {"SFX_LCP_DIRECT_MIN": "8", "SFX_LCP_WINDOW": "4"},
+    "direct-lcp-16-byte-windows": {"SFX_LCP_DIRECT_MIN": "8", "SFX_LCP_WINDOW": "2"},
     # 256-element LDS windows: buckets cross tile boundaries, > 128 members take the large-bucket path
     "small-tiles": {"SFX_TILE_SMALL": "1"},
     # ... and 4096-element tiles in the segmented sort of the large buckets: multi-tile segments, look-back inside a segment
