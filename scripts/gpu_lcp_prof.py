@@ -22,13 +22,15 @@ GENS = {
     "dna100m": lambda: _gen.dna(100_000_000),
     "eng400m": lambda: _gen.english_like(400_000_000, seed=3),
     "utf400m": lambda: _gen.utf8_mixed(400_000_000),
+    "eng1g": lambda: _gen.english_like(1_000_000_000),
+    "utf1g": lambda: _gen.utf8_mixed(1_000_000_000),
 }
 for name in (sys.argv[1:] or ["dna1g", "eng400m"]):
     t = torch.from_numpy(GENS[name]()).to(dev)
     n = t.numel()
     sa = sdev.build_sa(t)
     torch.cuda.synchronize()
-    out = {"text": name, "n": n}
+    out = {"text": name, "n": n, "env": {a: b for a, b in os.environ.items() if a.startswith("SFX_")}}
     for label, fn in (("lcp", lambda: sdev.build_lcp(t, sa)), ("lcp_direct_slice", lambda: sdev.build_lcp_range(t, sa))):
         fn()
         torch.cuda.synchronize()
