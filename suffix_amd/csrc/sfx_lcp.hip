@@ -536,10 +536,12 @@ int build_lcp_u32_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_sa, u
                 SFX_LAUNCH("lcp_windows_packed", (double)n * 24, k_lcp_windows_packed, grid, kBlock, st, pt, d_sa, d_lcp,
                            counters);
             else {
-                // window of 32 bytes where the sample says a 16-byte window would leave many pairs to walk on alone
-                // (SFX_LCP_WINDOW=2 / 4, development: force 16 / 32 bytes)
+                // window of 32 bytes where the sample says a 16-byte window would leave most pairs to walk on alone: sampled mean
+                // LCP >= 16 bytes.  Measured on 10^9 bytes (round 5, profiles/r5_lcp_window_ab.jsonl): mixed-script UTF-8 (mean
+                // 21.7) 37.0 -> 33.0 ms, English-like text (mean 13.7) 28.9 -> 29.6 ms -- below the threshold the second half of
+                // the window is two more load instructions for nothing.  (SFX_LCP_WINDOW=2 / 4, development: force 16 / 32 bytes)
                 static const int forced = [] { const char* e = dev_env("SFX_LCP_WINDOW"); return e ? atoi(e) : 0; }();
-                const bool wide = forced ? forced == 4 : host[0] >= 6ull * samples;
+                const bool wide = forced ? forced == 4 : host[0] >= 16ull * samples;
                 if (wide)
                     SFX_LAUNCH("lcp_windows", (double)n * 24, k_lcp_windows<4>, grid, kBlock, st, d_text, n, d_sa, d_lcp, counters);
                 else

@@ -190,6 +190,11 @@ VARIANTS = {
     # without the (opt-in) ordering of the batch
     "index-two-phase-queries": {"SFX_QUERY_PHASE_MIN": "1", "TEST_TEXTS": "0"},
     "index-two-phase-ordered": {"SFX_QUERY_PHASE_MIN": "1", "SFX_QUERY_ORDER": "1", "TEST_TEXTS": "0"},
+    # rank rounds from the first round on (round 5: what a build does whose 64-bit keys leave >= 95 % of the suffixes tied),
+    # over 32-bit, 64-bit and compressed keys; with the fused LCP (the deep-round texts) the values are bounds from the start
+    "start-with-rank-rounds": {"SFX_START_RANKS": "1"},
+    "start-with-rank-rounds-key64": {"SFX_START_RANKS": "1", "SFX_FORCE_KEY64": "1", "SFX_DEEP_ITERS": "24"},
+    "start-with-rank-rounds-compressed-keys": {"SFX_START_RANKS": "1", "SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24"},
     # rank rounds through round 1's composite-key sort (the fallback for key2 = rank + h beyond 32 bits)
     "composite-rank-rounds": {"SFX_FORCE_COMPOSITE": "1"},
     "tile-1024x4-pair32": {"SFX_TILE_GEOM": "1", "SFX_TILE_PAIR": "32"},
