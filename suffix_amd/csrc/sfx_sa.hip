@@ -1799,7 +1799,6 @@ static int refine_composite(const PackedText& pt, int cpk, SaBuffers& b, uint32_
 // to ranks (prefix doubling).  The partitioned build (isa == nullptr) only has text rounds and
 // reports SFX_ERR_NEEDS_RANKS when they do not converge.
 constexpr int kMaxTextOnlyRounds = 4096;
-constexpr uint64_t kStartRanksPercent = 95;               // tied after the initial 64-bit key: straight to rank rounds (sort_and_refine)
 static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uint32_t* isa, uint32_t* S_cur,
                   uint32_t* V_cur, uint64_t m, hipStream_t st, sfx_build_stats& stats, uint32_t* lcp = nullptr,
                   bool start_with_ranks = false)
@@ -1815,7 +1814,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
     bool any_deep = false;
     if (m > 0) SFX_HIP(hipMemsetAsync(b.counters, 0, 4 * sizeof(unsigned long long), st));
     if (start_with_ranks && isa && m > 0) {
-        // (sort_and_refine: nearly every suffix is still tied after a 64-bit key -- a repetitive text, whose text rounds stall)
+        // (development route, SFX_START_RANKS=1: see sort_and_refine)
         SFX_TRY(build_ranks(b, sa, n, V_cur, S_cur, m, isa, st, stats));
         rank_mode = true;
     }
@@ -1998,15 +1997,14 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         const unsigned grid = (unsigned)dmin<uint64_t>((kept + kBlock * 4 - 1) / (kBlock * 4), kMaxGrid);
         SFX_LAUNCH("depth_fill", (double)kept * 2, k_fill_u16, grid, kBlock, st, hd_of(b, S_cur), kept, (uint16_t)cpk);
     }
-    // A text nearly all of whose suffixes are still tied after a 64-bit key (near-duplicate documents: 97 %) is a repetitive one:
-    // its first text round resolves a few per cent of what it is given, leaves the minimum depth where it was -- the rank rounds
-    // start from the same h with or without it -- and costs a deep round over everything (24 + 5 ms per 10^9 on the high-LCP
-    // text).  Such a build goes to rank rounds at once.  (Mixed-script UTF-8, 86 % tied, keeps its text round: it takes the
-    // minimum depth from 5 to 10 symbols, a whole rank round's worth.)  SFX_START_RANKS=0 / 1 (development): never / whenever
-    // there is a rank array.
-    static const int start_ranks = [] { const char* e = dev_env("SFX_START_RANKS"); return e ? atoi(e) : -1; }();
-    const bool to_ranks = isa && kept > 0 &&
-                          (start_ranks >= 0 ? start_ranks == 1 : (sizeof(KeyT) == 8 && kept * 100 >= count * kStartRanksPercent));
+    // Rank rounds from the first round on, for a text nearly all of whose suffixes are still tied after the initial key, were
+    // measured in round 5 and do NOT pay (profiles/r5_start_ranks_ab.jsonl, 10^9 bytes each): near-duplicate documents (97 %
+    // tied) 358.2 -> 368.4 ms, mixed-script UTF-8 (86 %) 208.2 -> 213.4 ms.  The first text round is not wasted on them: it lifts
+    // the minimum depth the rank rounds start from (6 -> 13 and 5 -> 10 symbols) for the price of a deep round, where a rank round
+    // at h = 6 pays a rank gather per member and a rank update for the same step.  SFX_START_RANKS=1 (development) keeps the
+    // route reachable for the tests.
+    static const int start_ranks = [] { const char* e = dev_env("SFX_START_RANKS"); return e ? atoi(e) : 0; }();
+    const bool to_ranks = isa && kept > 0 && start_ranks == 1;
     return refine(pt, (int)h0, b, sa, isa, S_cur, V_next, kept, st, stats, lcp_fuse, to_ranks);
 }
 

@@ -167,7 +167,6 @@ VARIANTS = {
     "direct-lcp": {"SFX_LCP_DIRECT_MIN": "8"},
     # the byte-window kernel at both window widths (round 5: 32 bytes where the sample's mean LCP is >= 6), whatever the sample says
     "direct-lcp-32-byte-windows": {"SFX_LCP_DIRECT_MIN": "8", "SFX_LCP_WINDOW": "4"},
-    "direct-lcp-16-byte-windows": {"SFX_LCP_DIRECT_MIN": "8", "SFX_LCP_WINDOW": "2"},
     # 256-element LDS windows: buckets cross tile boundaries, > 128 members take the large-bucket path
     "small-tiles": {"SFX_TILE_SMALL": "1"},
     # ... and 4096-element tiles in the segmented sort of the large buckets: multi-tile segments, look-back inside a segment
@@ -192,7 +191,6 @@ VARIANTS = {
     "index-two-phase-ordered": {"SFX_QUERY_PHASE_MIN": "1", "SFX_QUERY_ORDER": "1", "TEST_TEXTS": "0"},
     # rank rounds from the first round on (round 5: what a build does whose 64-bit keys leave >= 95 % of the suffixes tied),
     # over 32-bit, 64-bit and compressed keys; with the fused LCP (the deep-round texts) the values are bounds from the start
-    "start-with-rank-rounds": {"SFX_START_RANKS": "1"},
     "start-with-rank-rounds-key64": {"SFX_START_RANKS": "1", "SFX_FORCE_KEY64": "1", "SFX_DEEP_ITERS": "24"},
     "start-with-rank-rounds-compressed-keys": {"SFX_START_RANKS": "1", "SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24"},
     # rank rounds through round 1's composite-key sort (the fallback for key2 = rank + h beyond 32 bits)
@@ -212,7 +210,6 @@ VARIANTS = {
     "deep-buckets-past-the-depth-limit-compressed-keys": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24", "SFX_DEEP_MAX_DEPTH": "24"},
     "deep-buckets-past-the-depth-limit-compressed-keys-small-windows": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24",
                                                                        "SFX_DEEP_MAX_DEPTH": "18", "SFX_TILE_SMALL": "1"},
-    "deep-buckets-past-the-depth-limit": {"SFX_DEEP_ITERS": "24", "SFX_DEEP_MAX_DEPTH": "48"},
     # 64-bit initial keys in an order-preserving prefix code (k_ht_keys): buckets of different depths from the first list on
     "compressed-keys": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24"},
     "compressed-keys-small-windows-one-iteration": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "1", "SFX_TILE_SMALL": "1",
