@@ -141,7 +141,7 @@ def running_commit():
 
 # kernels whose cost is one random 128-byte line per key they fetch, not the bytes they stream: (statistics field that counts
 # their fetches).  The chip's ceiling for that access shape is the random 4-byte gather probe (sfx_microbench MB_GATHER4,
-# 210 GB/s of payload = 52.5 G fetches/s, profiles/r1c_microbench.jsonl; PMC: 128 bytes fetched per read, r4_pmc_fullsize.json)
+# 210 GB/s of payload = 52.5 G fetches/s, profiles/r1c_microbench.jsonl; PMC: 128 bytes fetched per read, r5_pmc_fullsize.json)
 GATHER_BOUND = {"deep_wave": "deep_gathers", "tile_sort": None}      # (tile_sort: one fetch per member = algorithmic bytes / 17)
 GATHER_PROBE_GPS = 52.5
 
@@ -245,7 +245,7 @@ def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
     eng.profile(False)
     rec["top_kernels_ms"] = {r["name"]: round(r["total_ms"], 2) for r in prof[:8]}
     engine_algo = sum(r["algo_bytes"] for r in prof)
-    pmc_cfg = load_pmc("r4_pmc_fullsize.json").get(key, {})
+    pmc_cfg = (load_pmc("r5_pmc_fullsize.json") or load_pmc("r4_pmc_fullsize.json")).get(key, {})
     del ws
     lws = sdev.lcp_workspace(n, dev)
     lcp = torch.empty(n, dtype=torch.int32, device=dev)
