@@ -341,8 +341,8 @@ def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=100_000_000, help="bytes of text per GPU")
     ap.add_argument("--input", choices=("dna", "periodic"), default="dna",
                     help="dna: BASELINE config 2's uniform DNA (the bench line); periodic: shards of one periodic text -- a "
