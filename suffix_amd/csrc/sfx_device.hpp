@@ -201,6 +201,13 @@ __device__ __forceinline__ uint32_t rank_round16(unsigned d, unsigned long long*
 #ifndef SFX_WAVES_PER_EU
 #define SFX_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 #endif
+// A value every lane of the wave holds alike (a ticket read from LDS), moved to a scalar register: addresses built on it take a
+// scalar base and leave the vector registers to the data.  The value itself to the CPU emulator.
+#ifdef SFX_EMULATED
+#define SFX_WAVE_UNIFORM(x) (x)
+#else
+#define SFX_WAVE_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#endif
 
 struct PackedText {
     const uint32_t* words;

@@ -744,6 +744,160 @@ k_radix_sweep(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const uint
     }
 }
 
+// ---- the one-sweep pass with TWO workgroups per CU (round 5) ------------------------------------------------------------------
+// k_radix_sweep keeps one 12288-element KV tile per CU: its elements in registers, its staging copy in 147 KB of LDS.  One
+// workgroup per CU means nothing overlaps a tile's phases -- while it ranks, scans and waits for its look-back the CU asks the
+// memory system for nothing (a tile takes 18.8 us, of which its 295 KB need 12 at the CU's fair share of HBM: DESIGN.md section
+// 9).  Here a tile is held by 512 threads and staged through LDS in two halves of sorted places, so that a workgroup needs half
+// the LDS of its tile and TWO of them share a CU: one loads and ranks while the other writes.  Registers: 16 waves per CU
+// either way, 128 per thread.  Same tickets, same look-back, same stable ranking order (wave, round, lane) as k_radix_sweep;
+// only the elements' way out differs: a sorted place p of the tile leaves in half p / (tile / 2), and a run that straddles the
+// middle is written in two pieces.
+// Measured (profiles/r5_duo_ab.jsonl, the eight KV passes of config 3): k_radix_sweep 47.1 ms; two workgroups of 512 threads x 14
+// elements (7168-element tiles, 336-byte runs, 128 registers, no scratch) 44.9; x 16 (8192-element tiles: 44 bytes of scratch)
+// 50.0.  The whole 12288-element tile (24 per thread) needs 236 bytes of scratch under the 128 registers that two workgroups
+// per CU leave a thread, 10- and 12-wave workgroups spill at 14 per thread: 14 x 8 is the geometry.
+constexpr int kDuoKPT = 14, kDuoNW = 8;
+template <int KPT, int NW>
+struct DuoSmem {
+    static constexpr int kHalf = NW * kWave * KPT / 2;
+    uint64_t stage[kHalf];                              // (the match masks of the ranking alias its first NW x 2 KiB)
+    uint32_t stage_v[kHalf];
+    uint16_t cnt[NW][kRadix];
+    uint32_t off[kRadix];
+    uint32_t part[2][NW];
+    uint32_t ticket;
+};
+template <class Src, class Dst, int KPT, int NW>
+__global__ void __launch_bounds__(NW * kWave) SFX_WAVES_PER_EU(NW / 2, NW / 2)      // (two workgroups per CU: 2 NW / 4 waves per SIMD)
+k_radix_sweep_duo(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const uint32_t* __restrict__ digit_total,
+                  uint32_t* __restrict__ status, uint32_t* __restrict__ ticket)
+{
+    static_assert(Src::kHasVal, "key + value elements");
+    constexpr int kThreads = NW * kWave;
+    constexpr int kTile = kThreads * KPT;
+    constexpr int kHalf = kTile / 2;
+    static_assert(kThreads >= kRadix && KPT % 2 == 0 && kHalf % kThreads == 0, "an owner thread per bucket; whole output rounds per half");
+    static_assert(kHalf * 8 >= NW * kRadix * 8, "the match masks must fit the staging buffer");
+    static_assert(kTile < 65536, "16-bit tile positions");
+    __shared__ DuoSmem<KPT, NW> s;
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const unsigned long long mybit = 1ull << lane;
+    const bool owner = tid < (unsigned)kRadix;
+    unsigned par = 0;
+    unsigned long long* const my_flags = reinterpret_cast<unsigned long long*>(s.stage) + w * kRadix;
+    if (owner) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0;
+    }
+    const uint32_t my_head = block_scan_excl_1b<NW>(owner ? digit_total[tid] : 0u, s.part, par);
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) s.ticket = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const uint32_t tile_no = SFX_WAVE_UNIFORM(s.ticket);
+        const uint64_t tile = (uint64_t)tile_no * kTile;
+        if (tile >= m) break;
+        const unsigned nvalid = (unsigned)dmin<uint64_t>(kTile, m - tile);
+        uint64_t key[KPT];
+        uint32_t val[KPT];
+        uint32_t pos2[KPT / 2];                              // sorted places, two 16-bit values per register
+        unsigned first = w * (kWave * KPT) + lane;
+        SFX_OPAQUE_VGPR(first);
+#pragma unroll
+        for (int r = 0; r < KPT; r++) {
+            const unsigned idx = first + r * kWave;
+            uint64_t k = ~0ull;
+            uint32_t v = 0u;
+            if (idx < nvalid) src_fetch(src, tile + idx, k, v);
+            key[r] = k;
+            val[r] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < kRadix / kWave; k++) my_flags[k * kWave + lane] = 0ull;
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < KPT; r += 2) {
+            const uint32_t a = rank_round16(digit_of(key[r], shift, mask), my_flags, s.cnt[w], mybit);
+            const uint32_t b = rank_round16(digit_of(key[r + 1], shift, mask), my_flags, s.cnt[w], mybit);
+            pos2[r / 2] = a | (b << 16);
+        }
+        __syncthreads();
+        LookBack lb;
+        uint32_t real_count = 0, tile_ex = 0;
+        {
+            // (the bucket's column of the count table through an opaque index: its NW addresses are otherwise computed once,
+            // before the tile loop, and kept -- in scratch, for want of registers)
+            unsigned col = tid;
+            SFX_OPAQUE_VGPR(col);
+            uint32_t c[NW], tile_count = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                c[k] = owner ? s.cnt[k][col] : 0u;
+                tile_count += c[k];
+            }
+            const uint32_t ex = block_scan_excl_1b<NW>(tile_count, s.part, par);
+            if (owner) {
+                uint32_t run = ex;
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    s.cnt[k][col] = (uint16_t)run;
+                    run += c[k];
+                }
+                real_count = tile_count - ((tid == mask) ? (uint32_t)(kTile - nvalid) : 0u);
+                tile_ex = ex;
+                lookback_begin(status, tile_no, tid, real_count, lb, tile_no == 0);
+            }
+        }
+        __syncthreads();
+        // sorted place of every element in the tile (16 bits), then the two halves through LDS
+#pragma unroll
+        for (int r = 0; r < KPT; r += 2)
+            pos2[r / 2] += (uint32_t)s.cnt[w][digit_of(key[r], shift, mask)] | ((uint32_t)s.cnt[w][digit_of(key[r + 1], shift, mask)] << 16);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            __syncthreads();                                    // (h = 0: every thread has read its bases; h = 1: the first half has left)
+#pragma unroll
+            for (int r = 0; r < KPT; r++) {
+                const unsigned p = (r & 1) ? (pos2[r / 2] >> 16) : (pos2[r / 2] & 0xFFFFu);
+                if ((p >= (unsigned)kHalf) == (h == 1)) {
+                    s.stage[p - (unsigned)(h * kHalf)] = key[r];
+                    s.stage_v[p - (unsigned)(h * kHalf)] = val[r];
+                }
+            }
+            // (the look-back's loads were in flight during the staging of the first half)
+            if (h == 0 && owner) s.off[tid] = my_head + lookback_finish(status, tile_no, tid, real_count, lb, tile_no == 0) - tile_ex;
+            __syncthreads();
+            unsigned t = tid;
+            SFX_OPAQUE_VGPR(t);
+            constexpr int kRounds = kHalf / kThreads;               // 12
+            constexpr int kOut = (kRounds % 4 == 0) ? 4 : ((kRounds % 3 == 0) ? 3 : ((kRounds % 2 == 0) ? 2 : 1));
+#pragma unroll
+            for (int j0 = 0; j0 < kRounds; j0 += kOut) {
+                uint64_t ok[kOut];
+                uint32_t ov[kOut], od[kOut];
+#pragma unroll
+                for (int j = 0; j < kOut; j++) {
+                    ok[j] = s.stage[(j0 + j) * kThreads + t];
+                    ov[j] = s.stage_v[(j0 + j) * kThreads + t];
+                }
+#pragma unroll
+                for (int j = 0; j < kOut; j++) od[j] = s.off[digit_of(ok[j], shift, mask)] + (unsigned)(h * kHalf + (j0 + j) * kThreads) + t;
+#pragma unroll
+                for (int j = 0; j < kOut; j++)
+                    if ((unsigned)(h * kHalf + (j0 + j) * kThreads) + t < nvalid) dst.store(od[j], ok[j], ov[j]);
+            }
+        }
+        if (owner) {
+            unsigned col = tid;
+            SFX_OPAQUE_VGPR(col);
+#pragma unroll
+            for (int k = 0; k < NW; k++) s.cnt[k][col] = 0;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- partition passes: when the order inside a bucket does not matter ------------------------------------------------------
 // The two device-wide passes of the hybrid route only have to bring the elements of every sub-bucket (top 16 key bits)
 // together: the LDS sort that follows orders each sub-bucket by the whole 64-bit element, whatever order it arrives in.
@@ -1355,11 +1509,11 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
 //   SFX_RADIX_KPT_TEXT  ... of the text-fed pass: 16 (default), 11 or 8
 //   SFX_RADIX_RANK   1 = LDS match masks (default), 0 = 8-ballot match
 //   SFX_RADIX_NW     waves per workgroup: 4, 8 or 16 (default); tile = 64 * NW * KPT elements
-struct RadixTuning { int sweep, kpt, rank, nw, kpt_text, kpt_kv, kv12; };
+struct RadixTuning { int sweep, kpt, rank, nw, kpt_text, kpt_kv, kv12, duo; };
 static RadixTuning radix_tuning()
 {
     static const RadixTuning t = [] {
-        RadixTuning r = {1, 16, 1, 16, 16, 12, 1};      // measured best on MI355X (round 4, lab/radix_lab2.hip): 1024-thread
+        RadixTuning r = {1, 16, 1, 16, 16, 12, 1, 1};   // measured best on MI355X (round 4, lab/radix_lab2.hip): 1024-thread
                                                 // workgroups, 16384-element E64 tiles (512-byte runs), 12288-element KV tiles
         if (const char* e = dev_env("SFX_RADIX_SWEEP")) r.sweep = atoi(e) ? 1 : 0;
         if (const char* e = dev_env("SFX_RADIX_KPT")) r.kpt = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 8;
@@ -1367,6 +1521,7 @@ static RadixTuning radix_tuning()
         if (const char* e = dev_env("SFX_RADIX_KPT_TEXT")) r.kpt_text = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 16;
         if (const char* e = dev_env("SFX_RADIX_KPT_KV")) r.kpt_kv = (atoi(e) >= 8 && atoi(e) <= 12) ? atoi(e) : 8;
         if (const char* e = dev_env("SFX_RADIX_KV12")) r.kv12 = atoi(e) ? 1 : 0;         // 0: (key array, value array) in every pass
+        if (const char* e = dev_env("SFX_RADIX_DUO")) r.duo = atoi(e) ? 1 : 0;           // 0: the KV passes by k_radix_sweep (one workgroup per CU)
         if (const char* e = dev_env("SFX_RADIX_NW")) r.nw = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 4);
         return r;
     }();
@@ -1404,6 +1559,18 @@ static int launch_pass(const char* name, double algo_bytes, const Src& src, cons
         const uint64_t tiles = (m + kTile - 1) / kTile;
         const unsigned grid = (unsigned)dmin<uint64_t>(tiles, kMaxGrid);
         SFX_HIP(hipMemsetAsync(scr.status, 0, tiles * kRadix * sizeof(uint32_t), st));
+        if constexpr (RANK_ATOMIC && NW == 16 && KPT == 12 && Src::kHasVal && !Src::kFromText) {
+            // (the same 12288-element tiles held by 512 threads, two workgroups per CU: k_radix_sweep_duo)
+            if (radix_tuning().duo) {
+                const uint64_t dtile = (uint64_t)kDuoKPT * kDuoNW * kWave;
+                const uint64_t dtiles = (m + dtile - 1) / dtile;
+                const unsigned dgrid = (unsigned)dmin<uint64_t>(dtiles, kMaxGrid);
+                if (dtiles > tiles) SFX_HIP(hipMemsetAsync(scr.status, 0, dtiles * kRadix * sizeof(uint32_t), st));
+                SFX_LAUNCH(name, algo_bytes, (k_radix_sweep_duo<Src, Dst, kDuoKPT, kDuoNW>), dgrid, kDuoNW * kWave, st, src, dst, m, shift,
+                           mask, (const uint32_t*)(scr.totals + pass * kRadix), scr.status, scr.tickets + pass);
+                return SFX_OK;
+            }
+        }
         if constexpr (RANK_ATOMIC && NW == 16 && kTile < 65536) {
             SFX_LAUNCH(name, algo_bytes, (k_radix_sweep<Src, Dst, KPT, NW>), grid, kThreads, st, src, dst, m, shift, mask,
                        (const uint32_t*)(scr.totals + pass * kRadix), scr.status, scr.tickets + pass);

@@ -177,6 +177,10 @@ VARIANTS = {
     # kernel with multi-tile chunks, and the (key array, value array) form of rounds 1-4 in every pass
     "key64-chunked-multi-tile": {"SFX_FORCE_KEY64": "1", "SFX_RADIX_SWEEP": "0", "SFX_MAX_GRID": "2", "TEST_TEXTS": "3"},
     "key64-split-arrays": {"SFX_FORCE_KEY64": "1", "SFX_RADIX_KV12": "0", "TEST_TEXTS": "3"},
+    # ... and k_radix_sweep (one workgroup per CU) instead of k_radix_sweep_duo (two, the default of the one-sweep KV passes since
+    # round 5); the duo kernel with multi-tile inputs: 64-bit keys on every text with the grid capped
+    "key64-one-workgroup-per-cu": {"SFX_FORCE_KEY64": "1", "SFX_RADIX_DUO": "0", "TEST_TEXTS": "3"},
+    "key64-duo-multi-tile": {"SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "2"},
     # hybrid initial sort forced on small inputs
     "hybrid-initial-sort": {"SFX_HYBRID_MIN": "1"},
     # ... with the stable one-sweep passes of rounds 2-3 instead of the partition passes (k_partition)
