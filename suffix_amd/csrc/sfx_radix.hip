@@ -42,6 +42,7 @@
 //           order and leave as one contiguous run per bucket.
 // No MFMA anywhere: pure scan/scatter, HBM-bound by design.
 #include <stdio.h>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "sfx_host.hpp"
@@ -758,11 +759,12 @@ k_radix_sweep(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const uint
 // 50.0.  The whole 12288-element tile (24 per thread) needs 236 bytes of scratch under the 128 registers that two workgroups
 // per CU leave a thread, 10- and 12-wave workgroups spill at 14 per thread: 14 x 8 is the geometry.
 constexpr int kDuoKPT = 14, kDuoNW = 8;
-template <int KPT, int NW>
+constexpr int kDuoKPTE64 = 16;                                     // 8-byte elements: 8192-element tiles (18 and 20 per thread spill)
+template <int KPT, int NW, bool HAS_VAL>
 struct DuoSmem {
     static constexpr int kHalf = NW * kWave * KPT / 2;
     uint64_t stage[kHalf];                              // (the match masks of the ranking alias its first NW x 2 KiB)
-    uint32_t stage_v[kHalf];
+    uint32_t stage_v[HAS_VAL ? kHalf : 1];
     uint16_t cnt[NW][kRadix];
     uint32_t off[kRadix];
     uint32_t part[2][NW];
@@ -773,14 +775,14 @@ __global__ void __launch_bounds__(NW * kWave) SFX_WAVES_PER_EU(NW / 2, NW / 2)  
 k_radix_sweep_duo(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const uint32_t* __restrict__ digit_total,
                   uint32_t* __restrict__ status, uint32_t* __restrict__ ticket)
 {
-    static_assert(Src::kHasVal, "key + value elements");
+    constexpr bool HAS_VAL = Src::kHasVal;
     constexpr int kThreads = NW * kWave;
     constexpr int kTile = kThreads * KPT;
     constexpr int kHalf = kTile / 2;
     static_assert(kThreads >= kRadix && KPT % 2 == 0 && kHalf % kThreads == 0, "an owner thread per bucket; whole output rounds per half");
     static_assert(kHalf * 8 >= NW * kRadix * 8, "the match masks must fit the staging buffer");
     static_assert(kTile < 65536, "16-bit tile positions");
-    __shared__ DuoSmem<KPT, NW> s;
+    __shared__ DuoSmem<KPT, NW, HAS_VAL> s;
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const unsigned long long mybit = 1ull << lane;
     const bool owner = tid < (unsigned)kRadix;
@@ -800,7 +802,7 @@ k_radix_sweep_duo(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const 
         if (tile >= m) break;
         const unsigned nvalid = (unsigned)dmin<uint64_t>(kTile, m - tile);
         uint64_t key[KPT];
-        uint32_t val[KPT];
+        uint32_t val[HAS_VAL ? KPT : 1];
         uint32_t pos2[KPT / 2];                              // sorted places, two 16-bit values per register
         unsigned first = w * (kWave * KPT) + lane;
         SFX_OPAQUE_VGPR(first);
@@ -811,7 +813,7 @@ k_radix_sweep_duo(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const 
             uint32_t v = 0u;
             if (idx < nvalid) src_fetch(src, tile + idx, k, v);
             key[r] = k;
-            val[r] = v;
+            if (HAS_VAL) val[r] = v;
         }
 #pragma unroll
         for (int k = 0; k < kRadix / kWave; k++) my_flags[k * kWave + lane] = 0ull;
@@ -862,7 +864,7 @@ k_radix_sweep_duo(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const 
                 const unsigned p = (r & 1) ? (pos2[r / 2] >> 16) : (pos2[r / 2] & 0xFFFFu);
                 if ((p >= (unsigned)kHalf) == (h == 1)) {
                     s.stage[p - (unsigned)(h * kHalf)] = key[r];
-                    s.stage_v[p - (unsigned)(h * kHalf)] = val[r];
+                    if (HAS_VAL) s.stage_v[p - (unsigned)(h * kHalf)] = val[r];
                 }
             }
             // (the look-back's loads were in flight during the staging of the first half)
@@ -879,7 +881,7 @@ k_radix_sweep_duo(Src src, Dst dst, uint64_t m, int shift, unsigned mask, const 
 #pragma unroll
                 for (int j = 0; j < kOut; j++) {
                     ok[j] = s.stage[(j0 + j) * kThreads + t];
-                    ov[j] = s.stage_v[(j0 + j) * kThreads + t];
+                    ov[j] = HAS_VAL ? s.stage_v[(j0 + j) * kThreads + t] : 0u;
                 }
 #pragma unroll
                 for (int j = 0; j < kOut; j++) od[j] = s.off[digit_of(ok[j], shift, mask)] + (unsigned)(h * kHalf + (j0 + j) * kThreads) + t;
@@ -1509,11 +1511,11 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
 //   SFX_RADIX_KPT_TEXT  ... of the text-fed pass: 16 (default), 11 or 8
 //   SFX_RADIX_RANK   1 = LDS match masks (default), 0 = 8-ballot match
 //   SFX_RADIX_NW     waves per workgroup: 4, 8 or 16 (default); tile = 64 * NW * KPT elements
-struct RadixTuning { int sweep, kpt, rank, nw, kpt_text, kpt_kv, kv12, duo; };
+struct RadixTuning { int sweep, kpt, rank, nw, kpt_text, kpt_kv, kv12, duo, duo_e64; };
 static RadixTuning radix_tuning()
 {
     static const RadixTuning t = [] {
-        RadixTuning r = {1, 16, 1, 16, 16, 12, 1, 1};   // measured best on MI355X (round 4, lab/radix_lab2.hip): 1024-thread
+        RadixTuning r = {1, 16, 1, 16, 16, 12, 1, 1, 0}; // measured best on MI355X (round 4, lab/radix_lab2.hip): 1024-thread
                                                 // workgroups, 16384-element E64 tiles (512-byte runs), 12288-element KV tiles
         if (const char* e = dev_env("SFX_RADIX_SWEEP")) r.sweep = atoi(e) ? 1 : 0;
         if (const char* e = dev_env("SFX_RADIX_KPT")) r.kpt = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 8;
@@ -1521,6 +1523,7 @@ static RadixTuning radix_tuning()
         if (const char* e = dev_env("SFX_RADIX_KPT_TEXT")) r.kpt_text = (atoi(e) >= 8 && atoi(e) <= 16) ? atoi(e) : 16;
         if (const char* e = dev_env("SFX_RADIX_KPT_KV")) r.kpt_kv = (atoi(e) >= 8 && atoi(e) <= 12) ? atoi(e) : 8;
         if (const char* e = dev_env("SFX_RADIX_KV12")) r.kv12 = atoi(e) ? 1 : 0;         // 0: (key array, value array) in every pass
+        if (const char* e = dev_env("SFX_RADIX_DUO_E64")) r.duo_e64 = atoi(e) ? 1 : 0;   // 1: the E64 -> E64 one-sweep passes by k_radix_sweep_duo (development)
         if (const char* e = dev_env("SFX_RADIX_DUO")) r.duo = atoi(e) ? 1 : 0;           // 0: the KV passes by k_radix_sweep (one workgroup per CU)
         if (const char* e = dev_env("SFX_RADIX_NW")) r.nw = atoi(e) == 16 ? 16 : (atoi(e) == 8 ? 8 : 4);
         return r;
@@ -1559,8 +1562,9 @@ static int launch_pass(const char* name, double algo_bytes, const Src& src, cons
         const uint64_t tiles = (m + kTile - 1) / kTile;
         const unsigned grid = (unsigned)dmin<uint64_t>(tiles, kMaxGrid);
         SFX_HIP(hipMemsetAsync(scr.status, 0, tiles * kRadix * sizeof(uint32_t), st));
-        if constexpr (RANK_ATOMIC && NW == 16 && KPT == 12 && Src::kHasVal && !Src::kFromText) {
-            // (the same 12288-element tiles held by 512 threads, two workgroups per CU: k_radix_sweep_duo)
+        if constexpr (RANK_ATOMIC && NW == 16 && KPT == 12 && Src::kHasVal && !Src::kFromText && !std::is_same<Src, SrcKeyIota>::value) {
+            // (7168-element tiles held by 512 threads, two workgroups per CU: k_radix_sweep_duo.  Not the first pass of a compressed-key
+            // sort, which reads 8 bytes per element where the others read 12: 5.31 ms with k_radix_sweep, 5.57 with this)
             if (radix_tuning().duo) {
                 const uint64_t dtile = (uint64_t)kDuoKPT * kDuoNW * kWave;
                 const uint64_t dtiles = (m + dtile - 1) / dtile;
@@ -1568,6 +1572,21 @@ static int launch_pass(const char* name, double algo_bytes, const Src& src, cons
                 if (dtiles > tiles) SFX_HIP(hipMemsetAsync(scr.status, 0, dtiles * kRadix * sizeof(uint32_t), st));
                 SFX_LAUNCH(name, algo_bytes, (k_radix_sweep_duo<Src, Dst, kDuoKPT, kDuoNW>), dgrid, kDuoNW * kWave, st, src, dst, m, shift,
                            mask, (const uint32_t*)(scr.totals + pass * kRadix), scr.status, scr.tickets + pass);
+                return SFX_OK;
+            }
+        }
+        if constexpr (RANK_ATOMIC && NW == 16 && KPT == 16 && std::is_same<Src, SrcE64>::value && std::is_same<Dst, DstE64>::value) {
+            // (8-byte elements in, 8-byte elements out: 8192-element tiles held by 512 threads, two workgroups per CU -- development
+            // only, SFX_RADIX_DUO_E64=1.  Measured on 10^9 bytes each (profiles/r5_duo_e64_ab.jsonl): the rank-update partition passes
+            // of the near-duplicate documents 70.8 -> 67.0 ms, but the E64 passes of 1 GB of DNA 12.6 -> 13.2 and those of config 5
+            // 23.2 -> 25.2: 8 bytes per element leave a 8192-element tile 256-byte runs, and that costs what the overlap gives)
+            if (radix_tuning().duo_e64) {
+                const uint64_t dtile = (uint64_t)kDuoKPTE64 * kDuoNW * kWave;
+                const uint64_t dtiles = (m + dtile - 1) / dtile;
+                const unsigned dgrid = (unsigned)dmin<uint64_t>(dtiles, kMaxGrid);
+                if (dtiles > tiles) SFX_HIP(hipMemsetAsync(scr.status, 0, dtiles * kRadix * sizeof(uint32_t), st));
+                SFX_LAUNCH(name, algo_bytes, (k_radix_sweep_duo<Src, Dst, kDuoKPTE64, kDuoNW>), dgrid, kDuoNW * kWave, st, src, dst, m,
+                           shift, mask, (const uint32_t*)(scr.totals + pass * kRadix), scr.status, scr.tickets + pass);
                 return SFX_OK;
             }
         }

@@ -181,6 +181,8 @@ VARIANTS = {
     # round 5); the duo kernel with multi-tile inputs: 64-bit keys on every text with the grid capped
     "key64-one-workgroup-per-cu": {"SFX_FORCE_KEY64": "1", "SFX_RADIX_DUO": "0", "TEST_TEXTS": "3"},
     "key64-duo-multi-tile": {"SFX_FORCE_KEY64": "1", "SFX_MAX_GRID": "2"},
+    # the same kernel over 8-byte elements (development route: measured, not adopted), incl. the rank-update partition passes
+    "e64-duo-multi-tile": {"SFX_RADIX_DUO_E64": "1", "SFX_MAX_GRID": "2", "SFX_PARTITION_MIN": "1", "SFX_HYBRID": "0"},
     # hybrid initial sort forced on small inputs
     "hybrid-initial-sort": {"SFX_HYBRID_MIN": "1"},
     # ... with the stable one-sweep passes of rounds 2-3 instead of the partition passes (k_partition)
