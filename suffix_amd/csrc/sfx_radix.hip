@@ -933,7 +933,7 @@ struct PartSmem {
 // (Ranking: the match masks of the one-sweep pass.  One returning LDS atomic per element was the first version -- the LDS
 // retires about one of them per clock and CU: 8.4 us per 16384-element tile against 4.6 for the masks, lab/partition_lab.hip.)
 template <class Src, int KPT, int NW, bool SUB>
-__global__ void __launch_bounds__(NW * kWave, 1)
+__global__ void __launch_bounds__(NW * kWave) SFX_WAVES_PER_EU(4, 4)      // (16 waves per CU: one workgroup of 16 or two of 8)
 k_partition(Src src, uint64_t* __restrict__ out, uint64_t m, int shift, uint32_t* __restrict__ cursor,
             const uint32_t* __restrict__ bstart16, uint64_t class_len)
 {
@@ -1814,6 +1814,37 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
         }();
         const unsigned grid1 = (unsigned)dmin<uint64_t>((m + tile - 1) / tile, dmin(cus, grid_cap()));
         const unsigned grid2 = (unsigned)dmin<uint64_t>((m + tile - 1) / tile + kRadix, dmin(cus, grid_cap()));
+        // A full build's two passes run as TWO workgroups of 8 waves per CU (round 5): 8192-element tiles, 72 KB of LDS each, the
+        // same 128 registers per thread -- one workgroup loads and ranks while the other writes (what k_radix_sweep_duo does for the
+        // stable passes; here the whole tile fits the LDS and the kernel is the same template).  Headline, 50 steps each
+        // (profiles/r5_partition_duo_bench.jsonl): 1.566 / 1.577 ms with one workgroup of 16 waves, 1.523 / 1.523 with two of 8 (the
+        // text-fed pass 0.400 -> 0.353 ms, the element-fed one 0.400 -> 0.373); the runs of consecutive tiles meet in one XCD's L2
+        // either way, so the shorter run of a smaller tile costs little here.  SFX_PARTITION_WAVES=16 / 8 / 4 (development).
+        static const int pwaves = [] { const char* e = dev_env("SFX_PARTITION_WAVES"); const int v = e ? atoi(e) : 8; return (v == 16 || v == 4) ? v : 8; }();
+        if (pwaves != 16) {
+#define SFX_PARTITION_PAIR(DNW)                                                                                                         \
+            do {                                                                                                                            \
+                const uint64_t dtile = (uint64_t)kPKpt * (DNW) * kWave;                                                                     \
+                const unsigned per_cu = 16u / (DNW);                                                                                        \
+                const unsigned g1 = (unsigned)dmin<uint64_t>((m + dtile - 1) / dtile, dmin(per_cu * cus, grid_cap()));                     \
+                const unsigned g2 = (unsigned)dmin<uint64_t>((m + dtile - 1) / dtile + kRadix, dmin(per_cu * cus, grid_cap()));            \
+                if (from_elems) {                                                                                                           \
+                    SFX_LAUNCH("radix_scatter_u32", (double)m * 16.0, (k_partition<SrcE64, kPKpt, DNW, false>), g1, (DNW) * kWave, st,      \
+                               SrcE64{e0}, e1, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len);                                   \
+                    SFX_LAUNCH("radix_scatter_u32", (double)m * 16.0, (k_partition<SrcE64, kPKpt, DNW, true>), g2, (DNW) * kWave, st,       \
+                               SrcE64{e1}, e0, m, top_hi - 16, cursor16, (const uint32_t*)bins, class_len);                                 \
+                    uint64_t* t = e0; e0 = e1; e1 = t;     /* (from here on: e1 = the array grouped by its top 16 bits, e0 = free) */      \
+                } else {                                                                                                                    \
+                    SFX_LAUNCH("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), (k_partition<SrcText32, kPKpt, DNW, false>),  \
+                               g1, (DNW) * kWave, st, SrcText32{text}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len);        \
+                    SFX_LAUNCH("radix_scatter_u32", (double)m * 16.0, (k_partition<SrcE64, kPKpt, DNW, true>), g2, (DNW) * kWave, st,       \
+                               SrcE64{e0}, e1, m, top_hi - 16, cursor16, (const uint32_t*)bins, class_len);                                 \
+                }                                                                                                                           \
+            } while (0)
+            if (pwaves == 4) SFX_PARTITION_PAIR(4);
+            else SFX_PARTITION_PAIR(8);
+#undef SFX_PARTITION_PAIR
+        } else
         if (from_elems) {
             SFX_LAUNCH("radix_scatter_u32", (double)m * 16.0, (k_partition<SrcE64, kPKpt, kPNw, false>), grid1, kPNw * kWave, st, SrcE64{e0}, e1,
                        m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len);

@@ -18,6 +18,10 @@ CONFIGS = {
     # mean LCP 275: the quadratic routine would need half an hour; Kasai's array is the same array (test_oracle.py checks
     # the two routines against each other on every parity text)
     "dup": ("near_duplicates", "lcp_kasai"),
+    # configs 3 / 5 on ROUND 1's inputs (tests/_gen_r1.py: the numpy generators, 17 + 27 s): their pins dated from a round-1 run
+    # until round 5 put the complete comparison into every -m gpu session as well
+    "c3r1": ("_gen_r1:english_like", "lcp_quadratic"),
+    "c5r1": ("_gen_r1:utf8_mixed", "lcp_quadratic"),
 }
 
 
@@ -27,7 +31,12 @@ def _run(key, n, out):
     gen, lcp_fn = CONFIGS[key]
     try:
         t0 = time.time()
-        host = getattr(_gen, gen)(n)
+        if ":" in gen:
+            import importlib
+            mod, fn = gen.split(":")
+            host = getattr(importlib.import_module(mod), fn)(n)
+        else:
+            host = getattr(_gen, gen)(n)
         out["text"] = host
         sa = oracle.sais(host)
         out["sa_seconds"] = round(time.time() - t0, 1)
@@ -40,7 +49,7 @@ def _run(key, n, out):
         out["error"] = repr(e)
 
 
-def start(n=1_000_000_000, keys=("c3", "c5", "dup")):
+def start(n=1_000_000_000, keys=("c3", "c5", "dup", "c3r1", "c5r1")):
     import oracle
     oracle.build()
     with _lock:

@@ -1,4 +1,5 @@
-"""The COMPLETE suffix and LCP arrays of the three 1 GB configs (BASELINE config 3, config 5, the high-LCP text) against
+"""The COMPLETE suffix and LCP arrays of the 1 GB configs (BASELINE config 3, config 5, the high-LCP text, and configs 3 / 5 on
+round 1's inputs) against
 the oracle's, element by element, on a real MI355X (run with -m gpu).  The oracle needs ~110 s for a 1 GB suffix array
 and 80-95 s for the quadratic LCP array on one core: tests/conftest.py starts the three runs in background threads when
 the session is collected (tests/_full_oracle.py), this module sorts last, and the comparisons cost ~3.5 minutes together
@@ -73,3 +74,13 @@ def test_dup_full_oracle(eng):
     _full_oracle_compare(eng, "dup")
 
 
+
+
+def test_c3r1_full_oracle(eng):
+    """Config 3 on round 1's input: the pin of bench.py's `c3r1` record, re-derived against the oracle in this run."""
+    _full_oracle_compare(eng, "c3r1")
+
+
+def test_c5r1_full_oracle(eng):
+    """Config 5 on round 1's input (no refinement round at all: the direct pass finishes what the 64-bit keys leave tied)."""
+    _full_oracle_compare(eng, "c5r1")
