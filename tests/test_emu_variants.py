@@ -196,8 +196,7 @@ VARIANTS = {
     "index-two-phase-queries": {"SFX_QUERY_PHASE_MIN": "1", "TEST_TEXTS": "0"},
     "index-two-phase-ordered": {"SFX_QUERY_PHASE_MIN": "1", "SFX_QUERY_ORDER": "1", "TEST_TEXTS": "0"},
     # rank rounds from the first round on (round 5: what a build does whose 64-bit keys leave >= 95 % of the suffixes tied),
-    # over 32-bit, 64-bit and compressed keys; with the fused LCP (the deep-round texts) the values are bounds from the start
-    "start-with-rank-rounds-key64": {"SFX_START_RANKS": "1", "SFX_FORCE_KEY64": "1", "SFX_DEEP_ITERS": "24"},
+    # over compressed 64-bit keys; with the fused LCP (the deep-round texts) the values are bounds from the start
     "start-with-rank-rounds-compressed-keys": {"SFX_START_RANKS": "1", "SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24"},
     # rank rounds through round 1's composite-key sort (the fallback for key2 = rank + h beyond 32 bits)
     "composite-rank-rounds": {"SFX_FORCE_COMPOSITE": "1"},
@@ -211,11 +210,9 @@ VARIANTS = {
     "deep-512-position-windows": {"SFX_DEEP_KPT": "8", "SFX_DEEP_ITERS": "3"},
     # buckets that would pass the depth limit leave the deep kernel (evicted from the wave's slots with the depth they have
     # reached) while the wave's other buckets go on.  Compressed keys start the buckets of one wave at different depths, so with
-    # the limit lowered to 24 / 18 symbols a wave evicts SOME of its buckets (checked once with a counter: 106 / 21 partial
-    # evictions on the doubled English-like text, 3 / 109 complete ones); fixed-width keys evict a wave's buckets together
+    # the limit lowered to 24 symbols a wave evicts SOME of its buckets (checked once with a counter: 106 partial
+    # evictions on the doubled English-like text, 3 complete ones); fixed-width keys evict a wave's buckets together
     "deep-buckets-past-the-depth-limit-compressed-keys": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24", "SFX_DEEP_MAX_DEPTH": "24"},
-    "deep-buckets-past-the-depth-limit-compressed-keys-small-windows": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24",
-                                                                       "SFX_DEEP_MAX_DEPTH": "18", "SFX_TILE_SMALL": "1"},
     # 64-bit initial keys in an order-preserving prefix code (k_ht_keys): buckets of different depths from the first list on
     "compressed-keys": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24"},
     "compressed-keys-small-windows-one-iteration": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "1", "SFX_TILE_SMALL": "1",
