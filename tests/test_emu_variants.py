@@ -220,11 +220,33 @@ VARIANTS = {
 }
 
 
-@pytest.mark.parametrize("name", sorted(VARIANTS))
-def test_engine_variant_on_emulator(tmp_path, name):
-    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(HERE, "emu")])
-    script = tmp_path / "variant.py"
-    script.write_text(SCRIPT.format(root=ROOT, here=HERE))
+def _run_variant(name, script_path):
     env = dict(os.environ, SFX_TINY="0", **VARIANTS[name])        # (SFX_TINY=0: the variants are about the general build)
-    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    return subprocess.run([sys.executable, script_path], env=env, capture_output=True, text=True, timeout=1500)
+
+
+@pytest.fixture(scope="module")
+def variant_runs(request, tmp_path_factory):
+    """Every selected variant is an independent subprocess (its own emulator library instance, its own environment): they are
+    started together, a few at a time, when the first of them is asked for, and each test waits for its own -- the 30-odd
+    variants cost the wall time of the longest few instead of their sum."""
+    import concurrent.futures
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(HERE, "emu")])
+    script = tmp_path_factory.mktemp("variants") / "variant.py"
+    script.write_text(SCRIPT.format(root=ROOT, here=HERE))
+    wanted = []
+    for item in request.session.items:
+        if item.name.startswith("test_engine_variant_on_emulator[") and item.name.endswith("]"):
+            wanted.append(item.name[len("test_engine_variant_on_emulator["):-1])
+    workers = max(1, min(4, (os.cpu_count() or 2) // 2))
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers)
+    futures = {name: pool.submit(_run_variant, name, str(script)) for name in wanted if name in VARIANTS}
+    yield futures, str(script)
+    pool.shutdown(wait=False, cancel_futures=True)
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_engine_variant_on_emulator(variant_runs, name):
+    futures, script = variant_runs
+    out = futures[name].result() if name in futures else _run_variant(name, script)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
