@@ -185,6 +185,9 @@ VARIANTS = {
     "e64-duo-multi-tile": {"SFX_RADIX_DUO_E64": "1", "SFX_MAX_GRID": "2", "SFX_PARTITION_MIN": "1", "SFX_HYBRID": "0"},
     # hybrid initial sort forced on small inputs
     "hybrid-initial-sort": {"SFX_HYBRID_MIN": "1"},
+    # ... with the partition passes as one 16-wave workgroup per CU (round 4's geometry) / four 4-wave ones instead of two 8-wave ones
+    "hybrid-initial-sort-16-wave-partition": {"SFX_HYBRID_MIN": "1", "SFX_PARTITION_WAVES": "16", "TEST_TEXTS": "2"},
+    "hybrid-initial-sort-4-wave-partition": {"SFX_HYBRID_MIN": "1", "SFX_PARTITION_WAVES": "4", "SFX_MAX_GRID": "3", "TEST_TEXTS": "2"},
     # ... with the stable one-sweep passes of rounds 2-3 instead of the partition passes (k_partition)
     "hybrid-initial-sort-one-sweep-passes": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_PARTITION": "0", "TEST_TEXTS": "2"},
     # a few oversized sub-buckets (gathered, sorted device-wide, copied back), the 256 x 16 geometry, several sub-buckets
