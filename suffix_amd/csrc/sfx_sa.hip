@@ -173,12 +173,13 @@ k_pack_text(const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restr
 // text: a thread makes one word from spw consecutive bytes fetched with one or two wide
 // loads -- consecutive threads read consecutive bytes, no LDS staging, only the LUT lives
 // in LDS.  The last word (< spw bytes left) and the zero tail take the guarded path.
-template <int SPW>
+// (round 5: also 7-bit codes, four to a word -- natural-language ASCII: the LDS-staged general kernel took 1.2 ms per 10^9)
+template <int SPW, int BITS = 32 / SPW>
 __global__ void __launch_bounds__(kBlock)
 k_pack_text_pow2(const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ lut,
                  uint64_t n_words_total, uint32_t* __restrict__ words)
 {
-    constexpr int BITS = 32 / SPW;
+    static_assert(BITS * SPW <= 32, "a word holds SPW codes of BITS bits in its low bits");
     __shared__ uint8_t s_lut[256];
     s_lut[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
@@ -1600,11 +1601,13 @@ static int prepare_text(const uint8_t* d_text, uint64_t n, const unsigned long l
     }
     uint64_t nw = n_words_out ? n_words_out : packed_words(n, alpha);
     const double pack_bytes = (double)n * (1.0 + alpha->bits / 8.0);
-    const bool pow2 = alpha->bits * alpha->spw == 32 &&          // bits in {1, 2, 4, 8}
+    const bool pow2 = (alpha->bits * alpha->spw == 32 || (alpha->bits == 7 && alpha->spw == 4)) &&   // bits in {1, 2, 4, 8}, or 7
                       (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0;
     if (pow2) {
         const unsigned grid = (unsigned)dmin<uint64_t>((nw + kBlock - 1) / kBlock, 4 * kMaxGrid);
-        if (alpha->spw == 4) {
+        if (alpha->bits == 7) {
+            SFX_LAUNCH("pack_text", pack_bytes, (k_pack_text_pow2<4, 7>), grid, kBlock, st, d_text, n, d_lut, nw, d_packed);
+        } else if (alpha->spw == 4) {
             SFX_LAUNCH("pack_text", pack_bytes, (k_pack_text_pow2<4>), grid, kBlock, st, d_text, n, d_lut, nw, d_packed);
         } else if (alpha->spw == 8) {
             SFX_LAUNCH("pack_text", pack_bytes, (k_pack_text_pow2<8>), grid, kBlock, st, d_text, n, d_lut, nw, d_packed);
