@@ -175,6 +175,19 @@ def kernel_rooflines(rep, pmc_kernels=None, min_share=0.15, stats=None):
     return out
 
 
+def dominant_kernel(rep, within=0.02):
+    """The dominant kernel of a profiled build by accumulated time.  Kernels within `within` of it on time are tied with it,
+    and of a tie the one with the LOWER fraction of the HBM peak is the one named (round-4 verdict: the text-fed partition
+    pass and the element-fed one took the same 0.39 ms at 0.26 and 0.51 of the peak -- naming the flattering one of a tie
+    says nothing).  Returns (record, [{kernel, ms_per_step, frac} of every tied kernel, lowest fraction first])."""
+    def frac_of(r):
+        ms = r["total_ms"] / max(r["launches"], 1)
+        return (r["algo_bytes"] / max(r["launches"], 1)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0
+    top_ms = max(r["total_ms"] for r in rep)
+    tied = sorted([r for r in rep if r["total_ms"] >= (1.0 - within) * top_ms], key=frac_of)
+    return tied[0], [{"kernel": r["name"], "ms_per_step": round(r["total_ms"], 4), "frac": round(frac_of(r), 4)} for r in tied]
+
+
 def load_pmc(name):
     try:
         return json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -559,16 +572,7 @@ def main():
     eng.profile(False)
     kernels = {r["name"]: r for r in rep}
     total_ms = sum(r["total_ms"] for r in rep) or 1.0
-    # the dominant kernel by accumulated time; kernels within 2 % of it on time are tied with it, and of a tie the one with the
-    # LOWER fraction of the peak is the one named (round-4 verdict: the text-fed partition pass and the element-fed one take
-    # the same 0.39 ms at 0.26 and 0.51 of the peak)
-    def _frac_of(r):
-        ms = r["total_ms"] / max(r["launches"], 1)
-        return (r["algo_bytes"] / max(r["launches"], 1)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0
-    top_ms = max(r["total_ms"] for r in rep)
-    tied = sorted([r for r in rep if r["total_ms"] >= 0.98 * top_ms], key=_frac_of)
-    dom = tied[0]
-    kernels_tied = [{"kernel": r["name"], "ms_per_step": round(r["total_ms"], 4), "frac": round(_frac_of(r), 4)} for r in tied]
+    dom, kernels_tied = dominant_kernel(rep)
     per_launch_bytes = dom["algo_bytes"] / max(dom["launches"], 1)
     per_launch_ms = dom["total_ms"] / max(dom["launches"], 1)
     achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
