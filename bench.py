@@ -376,6 +376,9 @@ def main():
                          "configs 3 / 5 on round 1's easier inputs, for a like-for-like comparison with round 1 -- their "
                          "numpy generators take ~1 min each, so they are skipped once the run is past --config-budget seconds); "
                          "'' = none")
+    ap.add_argument("--dev-lib", default=None,
+                    help="development A/B runs only (scripts/gpu_ab.sh): bind this build of the C ABI (libsuffix_hip_dev.so, hooks "
+                         "compiled in) instead of the product library; the line then carries config.dev_lib")
     ap.add_argument("--config-budget", type=float, default=150.0)
     ap.add_argument("--config-size", type=int, default=1_000_000_000)
     args = ap.parse_args()
@@ -397,6 +400,9 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.dev_lib:
+        from suffix_amd import _lib as slib
+        slib.set_default_engine(suffix_amd.Engine(lib_path=os.path.abspath(args.dev_lib)))
     eng = suffix_amd.default_engine()
     eng.require_device()                       # no CPU fallback: fail loudly without a GPU
     # test hook for 1-GPU boxes: SFX_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and swaps RCCL
@@ -757,7 +763,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": workload, "text_bytes_total": n_total, "partitioned_phases_ms": phases},
+            "config": {"workload": workload, "text_bytes_total": n_total, "partitioned_phases_ms": phases,
+                       **({"dev_lib": os.path.basename(args.dev_lib)} if args.dev_lib else {})},
             "roofline": short_roof, "cpu_baseline": short_cpu, "lcp": short_lcp,
             # the metric's own words, "SuffixTable::new (SA-IS+LCP)": `value` is new() alone (config 2 is SA-only, and new() builds
             # no LCP array, src/table.rs:78-85); new() + lcp_lens() as ONE engine call, both arrays device-resident, is here

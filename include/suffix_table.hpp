@@ -5,13 +5,14 @@
 // compiled-language host side; rust/suffix-hip/src/lib.rs shows the Rust binding.
 //
 // Same names, argument meaning and error behaviour as the Rust API:
-//   new_ / new_naive(absent: the naive path is the CPU oracle's business) /
-//   from_parts / into_parts / lcp_lens / table / text / len / is_empty /
+//   new_ / new_naive (doc-hidden upstream, :93-100: the definition, sorted on the host -- the reference's own test oracle,
+//   tests/tests.rs:18-20; never a fallback of new_) / from_parts / into_parts / lcp_lens / table / text / len / is_empty /
 //   suffix / suffix_bytes / contains / positions / any_position,
 // plus the additive positions_batch / contains_batch.  Errors that are panics
 // in the reference (assert! :380, assert_eq! :117) are std::runtime_error /
 // std::length_error here.  Text is indexed by BYTES (:379).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <memory>
 #include <mutex>
@@ -35,6 +36,20 @@ public:
         st.text_ = std::move(text);
         st.table_.assign(st.text_.size(), 0u);                       // vec![0u32; n] (:381)
         check(sfx_build_sa_u32(bytes(st.text_), st.text_.size(), st.table_.data()), "SuffixTable::new");
+        return st;
+    }
+    // SuffixTable::new_naive (:93-100, #[doc(hidden)]) -> naive_table (:367-376): the definition -- all byte suffixes sorted by
+    // comparison on the host, O(n^2 log n).  Upstream keeps it as the oracle of its own tests (tests/tests.rs:18-20); it is the same
+    // here: what a caller compares new_() against, never something new_() falls back to.
+    static SuffixTable new_naive(std::string text)
+    {
+        SuffixTable st;
+        st.text_ = std::move(text);
+        if (st.text_.size() > 0xFFFFFFFFull) throw std::length_error("SuffixTable::new_naive: text longer than u32::MAX");
+        st.table_.resize(st.text_.size());
+        for (size_t i = 0; i < st.table_.size(); i++) st.table_[i] = (uint32_t)i;
+        const std::string_view t(st.text_);
+        std::sort(st.table_.begin(), st.table_.end(), [t](uint32_t a, uint32_t b) { return t.substr(a) < t.substr(b); });
         return st;
     }
     // SuffixTable::from_parts (:111-119): unchecked except for the lengths.

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Round 5, closing call: smoke, the whole GPU suite, the default bench (what the driver runs), the host-path probe.
+# The closing call of a round: smoke(), the whole `pytest -m gpu`, the default bench (what the driver runs) and a headline-only
+# bench.    gpu_final.sh [TAG=r6]   -> gpurun_out/TAG_final/ -> profiles/TAG_bench_100MB_dna*.txt, profiles/TAG_pytest_gpu.log
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/r5e
+TAG=${1:-r6}; OUT=gpurun_out/${TAG}_final
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?" | tee "$OUT/summary.txt"

@@ -13,9 +13,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _gen  # noqa: E402
 import suffix_amd  # noqa: E402
+import _devlib
 from suffix_amd import device as sdev  # noqa: E402
 
-eng = suffix_amd.default_engine()
+eng = _devlib.engine()
 dev = torch.device("cuda", 0)
 N = int(os.environ.get("SFX_N", "1000000000"))
 GENS = {"c3": lambda: _gen.english_like(N), "c5": lambda: _gen.utf8_mixed(N), "dup": lambda: _gen.near_duplicates(N),

@@ -8,9 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle, suffix_amd
+import _devlib
 from suffix_amd import SuffixTable
 oracle.build()
-eng = suffix_amd.default_engine(); eng.require_device()
+eng = _devlib.engine(); eng.require_device()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 max_len = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
 rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 1234)

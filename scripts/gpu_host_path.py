@@ -14,8 +14,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _gen  # noqa: E402
 import suffix_amd  # noqa: E402
+import _devlib
 
-eng = suffix_amd.default_engine()
+eng = _devlib.engine()
 eng.require_device()
 n = 100_000_000
 text = _gen.dna(n, seed=0x5AF1C5 + 1)

@@ -6,7 +6,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np, torch, suffix_amd
     from suffix_amd import device as sdev
-    eng = suffix_amd.default_engine(); eng.require_device()
+    import _devlib
+    eng = _devlib.engine(); eng.require_device()
     n = 100_000_000
     rng = np.random.default_rng(3)
     letters = np.frombuffer(b"ACGT", dtype=np.uint8)

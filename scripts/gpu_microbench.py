@@ -8,8 +8,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import suffix_amd  # noqa: E402
+import _devlib
 
-eng = suffix_amd.default_engine()
+eng = _devlib.engine()
 eng.require_device()
 E = eng
 rows = []

@@ -6,9 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import _gen, suffix_amd
+import _devlib
 from suffix_amd import device as sdev
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
-eng = suffix_amd.default_engine(); eng.require_device()
+eng = _devlib.engine(); eng.require_device()
 dev = torch.device("cuda", 0)
 host = _gen.utf8_mixed(n)
 text = torch.from_numpy(host).to(dev)

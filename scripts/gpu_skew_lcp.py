@@ -5,9 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import _gen, oracle, suffix_amd
+import _devlib
 from suffix_amd import device as sdev
 oracle.build()
-eng = suffix_amd.default_engine(); eng.require_device()
+eng = _devlib.engine(); eng.require_device()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40_000_000
 rng = np.random.default_rng(12)
 host = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, size=n, p=[0.55, 0.05, 0.05, 0.35])]

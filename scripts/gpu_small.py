@@ -12,9 +12,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import suffix_amd  # noqa: E402
+import _devlib
 from suffix_amd import device as sdev  # noqa: E402
 
-eng = suffix_amd.default_engine()
+eng = _devlib.engine()
 eng.require_device()
 z = np.load(os.path.join(ROOT, "tests", "golden", "fasta_fixtures.npz"))
 for name in ("AP009048_10000", "AP009048_100000"):

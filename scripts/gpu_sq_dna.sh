@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the headline's kernels (100 MB of DNA): SFX_LIB / SFX_TIE_ROUTE select the variant; $1 = output tag
+# SQ counters of the headline's kernels (100 MB of DNA): SFX_DEV_LIB / SFX_TIE_ROUTE select the variant; $1 = output tag
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 ROOT=$PWD; TAG=${1:-dna}; OUT=$ROOT/gpurun_out/sq_$TAG; mkdir -p $OUT; export TMPDIR=/tmp TIME_SHA=0
 cd /tmp

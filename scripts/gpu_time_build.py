@@ -1,20 +1,21 @@
 #!/usr/bin/env python3
-"""Development timing of one full-size build: python scripts/gpu_time_build.py <eng|utf8|dup|dna|engr1> [n]
+"""Development timing of one full-size build: python scripts/gpu_time_build.py <eng|utf8|dup|dna|engr1|utf8r1> [n]
 Prints one JSON line: sa_ms (best of 2), build stats, per-kernel ms, sha256 of the SA (compare across variants)."""
 import hashlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import _gen, suffix_amd
+import _devlib
 from suffix_amd import device as sdev
 kind = sys.argv[1]; n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000_000
-if kind == "engr1":
+if kind in ("engr1", "utf8r1"):
     import _gen_r1
-    host = _gen_r1.english_like(n)
+    host = (_gen_r1.english_like if kind == "engr1" else _gen_r1.utf8_mixed)(n)
 else:
     host = {"eng": _gen.english_like, "utf8": _gen.utf8_mixed, "dup": _gen.near_duplicates,
             "dna": lambda k: _gen.dna_fast(k, seed=0x5AF1C5 + 4)}[kind](n)
-eng = suffix_amd.default_engine(); eng.require_device()
+eng = _devlib.engine(); eng.require_device()
 dev = torch.device("cuda", 0)
 text = torch.from_numpy(host).to(dev)
 ws = sdev.sa_workspace(n, dev); sa = torch.empty(n, dtype=torch.int32, device=dev)

@@ -1,9 +1,10 @@
 import os, sys, ctypes, numpy as np, torch
 sys.path.insert(0,'/root/repo')
 import suffix_amd
+import _devlib
 from suffix_amd import device as sdev
 from suffix_amd.device import _p
-eng = suffix_amd.default_engine()
+eng = _devlib.engine()
 z = np.load('/root/repo/tests/golden/fasta_fixtures.npz')
 host = np.ascontiguousarray(z['AP009048_10000'])
 text = torch.from_numpy(host).cuda()

@@ -1,8 +1,9 @@
 import os, sys, time, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import _gen, suffix_amd
+import _devlib
 from suffix_amd import device as sdev
-eng = suffix_amd.default_engine()
+eng = _devlib.engine()
 dev = torch.device('cuda', 0)
 name = sys.argv[1]
 gen = {'c5': _gen.utf8_mixed, 'c3': _gen.english_like, 'dup': _gen.near_duplicates}[name]

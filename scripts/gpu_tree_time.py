@@ -5,8 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import _gen, suffix_amd
+import _devlib
 from suffix_amd import device as sdev
-eng = suffix_amd.default_engine(); eng.require_device()
+eng = _devlib.engine(); eng.require_device()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
 for name, host in (("english", _gen.english_like(n)), ("dna", _gen.dna_fast(n, seed=0x5AF1C5 + 2))):
     text = torch.from_numpy(host).cuda()

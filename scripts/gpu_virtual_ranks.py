@@ -16,10 +16,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _gen  # noqa: E402
 import suffix_amd  # noqa: E402
+import _devlib
 from suffix_amd import dist as sdist  # noqa: E402
 from suffix_amd.device import _p  # noqa: E402
 
-eng = suffix_amd.default_engine()
+eng = _devlib.engine()
 eng.require_device()
 dev = torch.device("cuda", 0)
 m = 100_000_000

@@ -6,8 +6,9 @@ There is NO CPU fallback: if the library is missing, or no HIP device is
 visible, every compute entry point raises.
 
 `Engine(lib_path=...)` exists so the test-suite can bind the same ABI exported
-by the kernel-logic emulator (tests/emu/libsuffix_emu.so); product code never
-passes it.
+by the kernel-logic emulator (tests/emu/libsuffix_emu.so) and development
+scripts the hook-enabled build (scripts/_devlib.py); product code never passes
+it, and the package reads no environment variable.
 """
 import ctypes
 import os
@@ -98,7 +99,7 @@ class Engine:
     """One loaded copy of the C ABI."""
 
     def __init__(self, lib_path=None):
-        path = lib_path or os.environ.get("SFX_LIB") or DEFAULT_LIB      # SFX_LIB: development builds (lab/)
+        path = lib_path or DEFAULT_LIB
         if not os.path.exists(path):
             raise SuffixHipError(
                 f"{path} not found: the HIP extension is not built (run "
@@ -176,3 +177,9 @@ def default_engine():
     if _default is None:
         _default = Engine()
     return _default
+
+
+def set_default_engine(engine):
+    """Development and test harnesses only (scripts/_devlib.py): every later `default_engine()` returns `engine`."""
+    global _default
+    _default = engine

@@ -34,6 +34,7 @@ void note_hip_error(hipError_t e, const char* what, const char* file, int line);
 // All device scratch comes from one caller-provided allocation (torch tensor in
 // bench.py, hipMalloc in the host-pointer entry points): nothing is allocated
 // inside a build, so the build is a pure kernel/memcpy sequence on one stream.
+constexpr uint64_t kArenaAlign = 256;       // every carve starts on a multiple of it; the gap behind a carve belongs to nobody
 struct Arena {
     char* base = nullptr;
     uint64_t size = 0, used = 0;
@@ -42,7 +43,7 @@ struct Arena {
     Arena(void* p, uint64_t bytes) : base((char*)p), size(bytes) {}
     template <class T> T* take(uint64_t count)
     {
-        uint64_t bytes = (count * sizeof(T) + 255) & ~uint64_t(255);   // 256-B aligned carves
+        uint64_t bytes = (count * sizeof(T) + kArenaAlign - 1) & ~(kArenaAlign - 1);
         if (used + bytes > size) { overflow = true; return nullptr; }
         T* p = (T*)(base + used);
         used += bytes;
@@ -52,7 +53,7 @@ struct Arena {
 // same arithmetic without memory, for *_workspace_bytes()
 struct ArenaSizer {
     uint64_t used = 0;
-    template <class T> void take(uint64_t count) { used += (count * sizeof(T) + 255) & ~uint64_t(255); }
+    template <class T> void take(uint64_t count) { used += (count * sizeof(T) + kArenaAlign - 1) & ~(kArenaAlign - 1); }
 };
 
 // ---- development hooks -----------------------------------------------------------
@@ -163,7 +164,9 @@ inline int read_back(void* dst, const void* d_src, size_t bytes, hipStream_t st)
         SFX_HIP(hipGetLastError());
         for (unsigned spins = 1;; spins++) {
             if (host[detail::kPostWords] == seq) break;
-            __builtin_ia32_pause();
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();                                  // (neutral on every latency measured: profiles/r5_post_page_ab.txt)
+#endif
             if ((spins & 0xFFFu) == 0) {
                 const hipError_t q = hipStreamQuery(st);
                 if (q == hipErrorNotReady) continue;
@@ -209,12 +212,16 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
 unsigned radix_e64_presort_hist(uint64_t m, int bit_lo, int bit_hi);
 bool radix_e64_hybrid_expected(uint64_t m, int key_bits);
 inline uint32_t* radix_partial(uint32_t* scratch) { return scratch; }
+// kv12_cap: the caller's statement that (k0, v0) and (k1, v1) are two DISJOINT regions each carved as "kv12_cap keys, then
+// (behind at most one arena alignment gap that belongs to nobody) kv12_cap values" (carve_sa) -- such a pair also serves as one
+// array of up to kv12_cap 12-byte (key, suffix) elements for the middle passes.  0 = separate arrays, never reinterpreted.
 int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, int bit_lo,
                     int bit_hi, uint32_t* scratch, hipStream_t st, int* result_in_1,
-                    sfx_build_stats* stats, const PackedText* text, uint32_t* last_v = nullptr);
+                    sfx_build_stats* stats, const PackedText* text, uint32_t* last_v = nullptr, uint64_t kv12_cap = 0);
 // the same over the compressed keys (k_ht_keys) of all m = text.n suffixes; ht = the code table on the device
 int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, uint32_t* scratch, hipStream_t st,
-                    int* result_in_1, sfx_build_stats* stats, const PackedText& text, const uint32_t* ht, uint32_t* last_v = nullptr);
+                    int* result_in_1, sfx_build_stats* stats, const PackedText& text, const uint32_t* ht, uint32_t* last_v = nullptr,
+                    uint64_t kv12_cap = 0);
 // Segmented sort of the large buckets of a refinement round (sfx_radix.hip).  Scratch:
 //   segs      8 B per segment, filled by the caller          tiles    32 B per tile (<= nlarge / tile + nseg)
 //   tilehist  4 KiB per tile of a multi-tile segment (<= 2 * nlarge / tile)

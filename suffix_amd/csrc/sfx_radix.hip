@@ -1561,7 +1561,8 @@ static int launch_pass(const char* name, double algo_bytes, const Src& src, cons
     if constexpr (ONESWEEP) {
         const uint64_t tiles = (m + kTile - 1) / kTile;
         const unsigned grid = (unsigned)dmin<uint64_t>(tiles, kMaxGrid);
-        SFX_HIP(hipMemsetAsync(scr.status, 0, tiles * kRadix * sizeof(uint32_t), st));
+        // (the status words are zeroed once, for the tile count of the kernel that runs: the two-workgroup kernels have smaller tiles)
+        auto zero_status = [&](uint64_t t) { return hipMemsetAsync(scr.status, 0, t * kRadix * sizeof(uint32_t), st); };
         if constexpr (RANK_ATOMIC && NW == 16 && KPT == 12 && Src::kHasVal && !Src::kFromText && !std::is_same<Src, SrcKeyIota>::value) {
             // (7168-element tiles held by 512 threads, two workgroups per CU: k_radix_sweep_duo.  Not the first pass of a compressed-key
             // sort, which reads 8 bytes per element where the others read 12: 5.31 ms with k_radix_sweep, 5.57 with this)
@@ -1569,7 +1570,7 @@ static int launch_pass(const char* name, double algo_bytes, const Src& src, cons
                 const uint64_t dtile = (uint64_t)kDuoKPT * kDuoNW * kWave;
                 const uint64_t dtiles = (m + dtile - 1) / dtile;
                 const unsigned dgrid = (unsigned)dmin<uint64_t>(dtiles, kMaxGrid);
-                if (dtiles > tiles) SFX_HIP(hipMemsetAsync(scr.status, 0, dtiles * kRadix * sizeof(uint32_t), st));
+                SFX_HIP(zero_status(dtiles));
                 SFX_LAUNCH(name, algo_bytes, (k_radix_sweep_duo<Src, Dst, kDuoKPT, kDuoNW>), dgrid, kDuoNW * kWave, st, src, dst, m, shift,
                            mask, (const uint32_t*)(scr.totals + pass * kRadix), scr.status, scr.tickets + pass);
                 return SFX_OK;
@@ -1584,12 +1585,13 @@ static int launch_pass(const char* name, double algo_bytes, const Src& src, cons
                 const uint64_t dtile = (uint64_t)kDuoKPTE64 * kDuoNW * kWave;
                 const uint64_t dtiles = (m + dtile - 1) / dtile;
                 const unsigned dgrid = (unsigned)dmin<uint64_t>(dtiles, kMaxGrid);
-                if (dtiles > tiles) SFX_HIP(hipMemsetAsync(scr.status, 0, dtiles * kRadix * sizeof(uint32_t), st));
+                SFX_HIP(zero_status(dtiles));
                 SFX_LAUNCH(name, algo_bytes, (k_radix_sweep_duo<Src, Dst, kDuoKPTE64, kDuoNW>), dgrid, kDuoNW * kWave, st, src, dst, m,
                            shift, mask, (const uint32_t*)(scr.totals + pass * kRadix), scr.status, scr.tickets + pass);
                 return SFX_OK;
             }
         }
+        SFX_HIP(zero_status(tiles));
         if constexpr (RANK_ATOMIC && NW == 16 && kTile < 65536) {
             SFX_LAUNCH(name, algo_bytes, (k_radix_sweep<Src, Dst, KPT, NW>), grid, kThreads, st, src, dst, m, shift, mask,
                        (const uint32_t*)(scr.totals + pass * kRadix), scr.status, scr.tickets + pass);
@@ -2101,12 +2103,22 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
 }
 
 // ---- 64-bit keys: the passes between the first and the last move 12-byte (key, suffix) elements (KV12 above) -----------------
-// (k, v) can serve as ONE array of m 12-byte elements when v starts right behind k's m keys (the arena carves them in that
-// order; up to one alignment gap in between belongs to nobody)
-static bool kv12_region(const uint64_t* k, const uint32_t* v, uint64_t m)
+// (k, v) can serve as ONE array of m <= cap 12-byte elements when the caller carved it as cap keys followed by cap values
+// (kv12_cap of radix_sort_kv64 / radix_sort_ht64: a statement of the caller, not something inferred from pointer distances --
+// ADVICE round 5).  What is checked here is that the statement holds: v behind k's cap keys with at most one arena alignment
+// gap, and the two regions [k0, v0 + cap) and [k1, v1 + cap) disjoint.
+static bool kv12_pair(const uint64_t* k0, const uint32_t* v0, const uint64_t* k1, const uint32_t* v1, uint64_t m, uint64_t cap)
 {
-    const uintptr_t ke = reinterpret_cast<uintptr_t>(k + m), vb = reinterpret_cast<uintptr_t>(v);
-    return vb >= ke && vb - ke <= 256;
+    if (cap == 0 || m > cap) return false;
+    auto region = [cap](const uint64_t* k, const uint32_t* v, uintptr_t* lo, uintptr_t* hi) {
+        const uintptr_t ke = reinterpret_cast<uintptr_t>(k + cap), vb = reinterpret_cast<uintptr_t>(v);
+        *lo = reinterpret_cast<uintptr_t>(k);
+        *hi = reinterpret_cast<uintptr_t>(v + cap);
+        return vb >= ke && vb - ke < kArenaAlign;
+    };
+    uintptr_t lo0, hi0, lo1, hi1;
+    if (!region(k0, v0, &lo0, &hi0) || !region(k1, v1, &lo1, &hi1)) return false;
+    return hi0 <= lo1 || hi1 <= lo0;
 }
 static void kv_trace(uint64_t m, int npass, bool e12)                  // SFX_TRACE=1 (development)
 {
@@ -2126,7 +2138,8 @@ static int kv_pass_out(const char* name, double algo, const Src& src, bool out12
 // last_v (both sorts): the suffixes of the LAST pass go there instead of into v0 / v1 (the caller's SA: every suffix
 // lands in its slot without a copy); the keys still end in k0 / k1 as *result_in_1 says.
 int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, uint32_t* scratch, hipStream_t st,
-                    int* result_in_1, sfx_build_stats* stats, const PackedText& text, const uint32_t* ht, uint32_t* last_v)
+                    int* result_in_1, sfx_build_stats* stats, const PackedText& text, const uint32_t* ht, uint32_t* last_v,
+                    uint64_t kv12_cap)
 {
     *result_in_1 = 0;
     if (m == 0) return SFX_OK;
@@ -2146,7 +2159,7 @@ int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
     }
     // passes 1 .. npass - 2 read and write 12-byte elements, the first writes them, the last reads them (and leaves the sorted
     // keys as an array of their own, the suffixes in last_v / the value array of that side): region "0" = k0 + v0, "1" = k1 + v1
-    const bool e12 = radix_tuning().kv12 && npass >= 2 && kv12_region(k0, v0, m) && kv12_region(k1, v1, m);
+    const bool e12 = radix_tuning().kv12 && npass >= 2 && kv12_pair(k0, v0, k1, v1, m, kv12_cap);
     kv_trace(m, npass, e12);
     uint64_t* kin = k0; uint32_t* vin = v0;
     uint64_t* kout = k1; uint32_t* vout = v1;
@@ -2172,7 +2185,7 @@ int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
 
 int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, int bit_lo, int bit_hi,
                     uint32_t* scratch, hipStream_t st, int* result_in_1, sfx_build_stats* stats,
-                    const PackedText* text, uint32_t* last_v)
+                    const PackedText* text, uint32_t* last_v, uint64_t kv12_cap)
 {
     *result_in_1 = 0;
     if (m == 0 || bit_hi <= bit_lo) return last_v ? SFX_ERR_INTERNAL : SFX_OK;
@@ -2186,7 +2199,7 @@ int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
         else SFX_TRY(prepare_sweep("radix_hist_all_u64", (double)m * 8.0, SrcKV{k0, v0}, m, bit_lo, bit_hi, npass, scr, st));
     }
     // (12-byte elements between the first and the last pass: see radix_sort_ht64)
-    const bool e12 = radix_tuning().kv12 && npass >= 2 && kv12_region(k0, v0, m) && kv12_region(k1, v1, m);
+    const bool e12 = radix_tuning().kv12 && npass >= 2 && kv12_pair(k0, v0, k1, v1, m, kv12_cap);
     kv_trace(m, npass, e12);
     uint64_t* kin = k0; uint32_t* vin = v0;
     uint64_t* kout = k1; uint32_t* vout = v1;

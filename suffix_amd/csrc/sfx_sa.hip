@@ -1393,6 +1393,7 @@ static bool ht_build(const unsigned long long* counts256, int fixed_bits, HtHost
 }
 
 struct SaBuffers {
+    uint64_t kv_cap;                                    // (K0, VA) and (K1, VB) are each "kv_cap keys, then kv_cap values": radix_sort_kv64's kv12_cap
     uint64_t* K0; uint64_t* K1;                         // key ping-pong (8 B per element)
     uint32_t* VA; uint32_t* VB;                         // suffix ping-pong
     uint32_t* S0; uint32_t* S1;                         // slot lists
@@ -1457,6 +1458,7 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint32_t* ht = ar.template take<uint32_t>(kHtTableWords + (1u << kHtFastBits) / 2);
     if (b) {
         b->ht = ht;
+        b->kv_cap = cap;
         b->K0 = K0; b->K1 = K1; b->VA = VA; b->VB = VB; b->S0 = S0; b->S1 = S1; b->G = G; b->G1 = G1; b->F = F; b->F8 = F8;
         b->Hd0 = Hd0; b->Hd1 = Hd1;
         b->counters = counters; b->deep_slots = deep_slots; b->block_counts = bc; b->R = R;
@@ -1764,7 +1766,7 @@ static int refine_composite(const PackedText& pt, int cpk, SaBuffers& b, uint32_
         uint32_t* V_other = (V_cur == b.VA) ? b.VB : b.VA;
         int in1 = 0;
         SFX_TRY(radix_sort_kv64(b.K0, V_cur, b.K1, V_other, m, 0, key2_bits + gid_bits, b.hist, st, &in1,
-                                &stats, nullptr));
+                                &stats, nullptr, nullptr, V_cur == b.VA ? b.kv_cap : 0));
         const uint64_t* Kr = in1 ? b.K1 : b.K0;
         uint32_t* Vr = in1 ? V_other : V_cur;
         uint32_t* V_next = in1 ? V_cur : V_other;
@@ -1889,7 +1891,8 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
             const bool too_deep = h + 2 * (uint64_t)wsym > 60000;
             // SFX_TEXT_ROUNDS_MIN=<k> (development): at least k text rounds before the switch
             static const uint32_t min_text = [] { const char* e = dev_env("SFX_TEXT_ROUNDS_MIN"); return e ? (uint32_t)atoi(e) : 0u; }();
-            if (isa && force != 1 && (stalled * 2 > n || force == 2 || too_deep) && (too_deep || stats.text_rounds >= min_text)) {
+            // (too_deep overrides SFX_SWITCH=text: the depths are 16-bit whatever the hook asks for -- ADVICE round 5)
+            if (isa && (force != 1 || too_deep) && (stalled * 2 > n || force == 2 || too_deep) && (too_deep || stats.text_rounds >= min_text)) {
                 // switching to ranks: slot = rank for resolved suffixes, head slot for the rest
                 uint32_t md = 0;
                 SFX_TRY(read_back(&md, b.ht + 256, sizeof(md), st));
@@ -1947,10 +1950,10 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     } else {
         // (the last pass drops every suffix straight into its SA slot, as the E64 sort does)
         if (ht && from_text && count == pt.n)
-            SFX_TRY(radix_sort_ht64(b.K0, b.VA, b.K1, b.VB, count, b.hist, st, &in1, &stats, pt, b.ht, sa));
+            SFX_TRY(radix_sort_ht64(b.K0, b.VA, b.K1, b.VB, count, b.hist, st, &in1, &stats, pt, b.ht, sa, b.kv_cap));
         else
             SFX_TRY(radix_sort_kv64(b.K0, b.VA, b.K1, b.VB, count, 0, pt.bits * cpk, b.hist, st, &in1, &stats,
-                                    from_text ? &pt : nullptr, sa));
+                                    from_text ? &pt : nullptr, sa, b.kv_cap));
         Kr = (const KeyT*)(in1 ? b.K1 : b.K0);
         Vr = sa;
         V_next = b.VA;

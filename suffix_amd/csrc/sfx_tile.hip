@@ -1072,7 +1072,7 @@ static int launch_deep(const DeepTextKey& keyfn, const TileRound& r, uint64_t m,
     // build switches to ranks before h + 2 wsym reaches 60000.)
     uint32_t max_depth = deep_max_depth();
     const uint64_t floor_depth = (uint64_t)r.h + r.wsym + (uint64_t)keyfn.wsym;
-    if (floor_depth > kDeepMaxDepth) return SFX_ERR_INTERNAL;
+    if (floor_depth > kDeepMaxDepth) return SFX_ERR_NEEDS_RANKS;      // (refine switches to ranks long before: h + 2 wsym > 60000)
     if (max_depth < floor_depth) max_depth = (uint32_t)floor_depth;
     if (r.emit.lcp)
         SFX_LAUNCH("deep_wave", algo, (k_deep_wave<KPT, true>), (unsigned)blocks, kBlock, st, keyfn, r.G, m, r.V, r.F8, r.Hd,

@@ -5,6 +5,7 @@ Same method names, argument meaning and error behaviour as the Rust API:
 
     reference (Rust)                         here
     SuffixTable::new(text)            :78    SuffixTable.new(text) / SuffixTable(text)
+    SuffixTable::new_naive(text)      :93    SuffixTable.new_naive(text)   (doc-hidden upstream: the definition, on the host)
     SuffixTable::from_parts(t, sa)    :111   SuffixTable.from_parts(text, table)
     .into_parts()                     :125   .into_parts()
     .lcp_lens()                       :130   .lcp_lens()
@@ -66,6 +67,18 @@ class SuffixTable:
     @classmethod
     def new(cls, text, engine=None):
         return cls(text, engine=engine)
+
+    @classmethod
+    def new_naive(cls, text, engine=None):
+        """SuffixTable::new_naive (:93-100, #[doc(hidden)]) -> naive_table (:367-376): the definition -- every byte suffix
+        sorted by comparison on the host, O(n^2 log n).  Upstream keeps it as the known answer of its own tests
+        (tests/tests.rs:18-20) and so does this mirror: it is what a caller compares new() against, never a fallback of
+        new() (which has none: it raises without the HIP library or a device)."""
+        t = _as_bytes(text)
+        if len(t) > 0xFFFFFFFF:
+            raise OverflowError("SuffixTable::new_naive: text longer than u32::MAX")      # the table is Vec<u32> (:57)
+        table = np.array(sorted(range(len(t)), key=lambda i: t[i:]), dtype=np.uint32)
+        return cls(text, _table=table, engine=engine)
 
     @classmethod
     def new_with_lcp(cls, text, engine=None):

@@ -122,6 +122,7 @@ def literals(eng, orc, golden):
         assert st.lcp_lens().tolist() == exp["lcp"], s
         naive = SuffixTable.from_parts(s, orc.naive_sa(s), engine=eng)   # new == new_naive
         assert st == naive
+        assert st == SuffixTable.new_naive(s, engine=eng)                # ... as tests/tests.rs:18-20 writes it (host mirror's own)
 
 
 def search_known_answers(eng, golden):

@@ -55,6 +55,9 @@ int main()
     auto ap = q.any_position("quick");
     EXPECT(ap && (*ap == 4 || *ap == 29));
     EXPECT((pos(SuffixTable::new_("\xe2\x98\x83" "abc" "\xe2\x98\x83"), "\xe2\x98\x83") == std::vector<uint32_t>{6, 0}));
+    // tests.rs:18-20: sais(text) == naive(text), through the mirror's own new_naive (:93-100)
+    for (const char* lit : {"banana", "mississippi", "aaaaaa", "abracadabra", "\xe2\x98\x83" "abc" "\xe2\x98\x83"})
+        EXPECT(SuffixTable::new_(lit) == SuffixTable::new_naive(lit));
     // tests.rs:170-179 parts()
     SuffixTable a = SuffixTable::new_("po\xc3\xabzie");
     SuffixTable b = a;

@@ -165,7 +165,8 @@ VARIANTS = {
     "one-sweep-8-waves-kpt8": {"SFX_RADIX_NW": "8", "SFX_RADIX_KPT": "8", "SFX_MAX_GRID": "3", "TEST_TEXTS": "2"},
     "partitioned-scatter": {"SFX_PARTITION_MIN": "1"},
     "direct-lcp": {"SFX_LCP_DIRECT_MIN": "8"},
-    # the byte-window kernel at both window widths (round 5: 32 bytes where the sample's mean LCP is >= 6), whatever the sample says
+    # the byte-window kernel at both window widths (round 5: 32 bytes where the sample's mean LCP is >= 16 bytes, sfx_lcp.hip), whatever
+    # the sample says
     "direct-lcp-32-byte-windows": {"SFX_LCP_DIRECT_MIN": "8", "SFX_LCP_WINDOW": "4"},
     # 256-element LDS windows: buckets cross tile boundaries, > 128 members take the large-bucket path
     "small-tiles": {"SFX_TILE_SMALL": "1"},
@@ -198,8 +199,9 @@ VARIANTS = {
     # without the (opt-in) ordering of the batch
     "index-two-phase-queries": {"SFX_QUERY_PHASE_MIN": "1", "TEST_TEXTS": "0"},
     "index-two-phase-ordered": {"SFX_QUERY_PHASE_MIN": "1", "SFX_QUERY_ORDER": "1", "TEST_TEXTS": "0"},
-    # rank rounds from the first round on (round 5: what a build does whose 64-bit keys leave >= 95 % of the suffixes tied),
-    # over compressed 64-bit keys; with the fused LCP (the deep-round texts) the values are bounds from the start
+    # rank rounds from the first round on (SFX_START_RANKS: a development route -- measured in round 5 on texts whose 64-bit keys leave
+    # >= 95 % of the suffixes tied and NOT adopted, sort_and_refine), over compressed 64-bit keys; with the fused LCP (the deep-round
+    # texts) the values are bounds from the start
     "start-with-rank-rounds-compressed-keys": {"SFX_START_RANKS": "1", "SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24"},
     # rank rounds through round 1's composite-key sort (the fallback for key2 = rank + h beyond 32 bits)
     "composite-rank-rounds": {"SFX_FORCE_COMPOSITE": "1"},

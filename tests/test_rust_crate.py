@@ -116,3 +116,40 @@ def test_patches_apply_to_the_reference():
                              capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "FAILED" not in out.stdout and "fuzz" not in out.stdout, out.stdout
+
+
+# ---- the upstream suite through the FFI, wherever a Rust toolchain exists ----------------
+# /root/reference/tests/tests.rs:14-96 (SA = naive_table on 10 literals + 2 QuickCheck properties), :100-243 (positions / contains
+# known answers + 3 properties) and Cargo.toml:25-37 ([[test]] tests, dev-dependency quickcheck 0.9).  Needs: cargo, an upstream
+# checkout (SUFFIX_REFERENCE_DIR, default /root/reference), a built libsuffix_hip.so and a GPU.  The image this repository is
+# built in has no cargo and its GPU boxes have neither cargo nor the checkout: the test is collected under `-m gpu` and skips there.
+def _reference_dir():
+    return os.environ.get("SUFFIX_REFERENCE_DIR", "/root/reference")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("cargo") is None, reason="no cargo on this box (the build image and the pool's GPU boxes have none)")
+@pytest.mark.skipif(not os.path.isdir(os.path.join(_reference_dir(), "src")), reason="no upstream checkout (SUFFIX_REFERENCE_DIR)")
+def test_upstream_cargo_tests_through_the_ffi(tmp_path):
+    lib_dir = os.path.join(ROOT, "suffix_amd")
+    assert os.path.exists(os.path.join(lib_dir, "libsuffix_hip.so")), "build the engine first (__graft_entry__.build())"
+    work = tmp_path / "suffix"
+    shutil.copytree(_reference_dir(), work, ignore=shutil.ignore_patterns("target", ".git"))
+    for p in ("table.rs.patch", "Cargo.toml.patch"):
+        subprocess.run(["patch", "-p1", "-d", str(work), "-i", os.path.join(CRATE, p)], check=True, capture_output=True)
+    # Cargo.toml.patch assumes sibling checkouts; point the dependency at this tree
+    manifest = (work / "Cargo.toml").read_text().replace('path = "../suffix_amd/rust/suffix-hip"', f'path = "{CRATE}"')
+    (work / "Cargo.toml").write_text(manifest)
+    env = dict(os.environ, SUFFIX_HIP_LIB_DIR=lib_dir, CARGO_TARGET_DIR=str(tmp_path / "target"))
+    # offline boxes: `cargo vendor` output or a primed ~/.cargo/registry is used as is (rust/suffix-hip/README.md)
+    offline = ["--offline"] if os.environ.get("CARGO_NET_OFFLINE") == "true" else []
+    out = subprocess.run(["cargo", "test", "--features", "hip-always", *offline, "--", "--test-threads", "4"], cwd=work, env=env,
+                         capture_output=True, text=True, timeout=3000)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
+    # all 31 upstream tests ran (tests/tests.rs) and every one crossed extern "C" (the `always` feature: threshold 0)
+    m = re.search(r"test result: ok\. (\d+) passed; 0 failed", out.stdout)
+    assert m and int(m.group(1)) >= 31, out.stdout[-2000:]
+    # the benches compile against the patched crate too (tests/bench.rs:9-133); not run here
+    out = subprocess.run(["cargo", "bench", "--features", "hip", *offline, "--no-run"], cwd=work, env=env, capture_output=True,
+                         text=True, timeout=3000)
+    assert out.returncode == 0, out.stderr[-4000:]
