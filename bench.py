@@ -163,7 +163,11 @@ def kernel_rooflines(rep, pmc_kernels=None, min_share=0.15, stats=None):
                "algo_bytes_per_launch": per_b, "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                "traffic": None}
         pk = (pmc_kernels or {}).get(r["name"])
-        if pk:
+        if pk and pk.get("launches") not in (None, r["launches"]):
+            # a PMC record of another launch sequence (collected before the code changed): no figure rather than a wrong one
+            ent["traffic_note"] = f"PMC record holds {pk['launches']} launches of this kernel, this build made {r['launches']}"
+        elif pk:
+            # (all symbols of the profile name summed over the build / its launches: scripts/pmc_summary.py)
             ent["traffic"] = round(pk["hbm_bytes_per_launch"])
         if r["name"] in GATHER_BOUND:
             fld = GATHER_BOUND[r["name"]]
@@ -193,6 +197,19 @@ def load_pmc(name):
         return json.load(open(os.path.join(ROOT, "profiles", name)))
     except (OSError, ValueError):
         return {}
+
+
+def load_pmc_fullsize():
+    """The newest committed per-config PMC record (profiles/rN_pmc_fullsize.json, scripts/gpu_pmc_fullsize.sh): every entry is
+    recomputable from profiles/rN_pmc_summary_<config>.csv with scripts/pmc_summary.py (tests/test_bench_logic.py does it)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fullsize.json")):
+        m = re.match(r"r(\d+)_pmc_fullsize\.json$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), os.path.basename(f))
+    return load_pmc(best[1]) if best else {}
 
 
 def compact_config(key, rec):
@@ -258,7 +275,7 @@ def fullsize_config(torch, eng, sdev, _gen, key, size, pins, dev):
     eng.profile(False)
     rec["top_kernels_ms"] = {r["name"]: round(r["total_ms"], 2) for r in prof[:8]}
     engine_algo = sum(r["algo_bytes"] for r in prof)
-    pmc_cfg = (load_pmc("r5_pmc_fullsize.json") or load_pmc("r4_pmc_fullsize.json")).get(key, {})
+    pmc_cfg = load_pmc_fullsize().get(key, {})
     del ws
     lws = sdev.lcp_workspace(n, dev)
     lcp = torch.empty(n, dtype=torch.int32, device=dev)

@@ -50,3 +50,111 @@ def test_kernel_rooflines_share_and_traffic():
 def test_compact_config_of_an_error_record():
     assert bench.compact_config("c3", {"config": "c3", "error": "RuntimeError: x"}) == {"key": "c3", "error": "RuntimeError: x"}
     assert bench.compact_config("c5r1", {"config": "c5r1", "skipped": "time budget"})["error"] == "time budget"
+
+
+# ---- PMC records: every per-config roofline must be reproducible from what profiles/ holds -------------
+import csv      # noqa: E402
+import glob     # noqa: E402
+import json     # noqa: E402
+import re       # noqa: E402
+import subprocess  # noqa: E402
+
+import pytest  # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import pmc_summary  # noqa: E402
+
+
+def test_kernel_rooflines_refuse_a_pmc_record_of_another_launch_sequence():
+    rep = [_k("radix_scatter_u64", 44.8, 8, 8 * 23.5)]
+    out = bench.kernel_rooflines(rep, {"radix_scatter_u64": {"hbm_bytes_per_launch": 21.45e9, "launches": 1}}, 0.15)
+    assert out[0]["traffic"] is None and "1 launches" in out[0]["traffic_note"]           # round 5's mis-filed record
+    out = bench.kernel_rooflines(rep, {"radix_scatter_u64": {"hbm_bytes_per_launch": 25.6e9, "launches": 8}}, 0.15)
+    assert out[0]["traffic"] == 25_600_000_000
+
+
+def test_every_engine_kernel_has_a_profile_name():
+    """rocprofv3 names kernel symbols, the engine's profiler names launches: scripts/pmc_summary.py must know every
+    `__global__` kernel of the engine, or a PMC summary silently drops it (round 5: k_radix_sweep_duo, 46 % of config 3)."""
+    csrc = os.path.join(ROOT, "suffix_amd", "csrc")
+    kernels = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp")):
+            src = open(os.path.join(csrc, f)).read()
+            for m in re.finditer(r"__global__[^;{]*?\b(k_[a-z0-9_]+)\s*\(", src, flags=re.S):
+                kernels.add(m.group(1))
+    assert len(kernels) > 80, len(kernels)
+    syms = [sym for sym, _ in pmc_summary.NAMES]
+    # (a template kernel is known when an entry names one of its instances; a plain one when an entry is a prefix of its name)
+    missing = sorted(k for k in kernels
+                     if not any(sym.startswith(k + "<") or k.startswith(sym) or sym == "detail::" + k for sym in syms))
+    assert not missing, missing
+    # the symbols as rocprofv3 prints them
+    assert pmc_summary.profile_name("void sfx::k_radix_sweep_duo<sfx::SrcKV12, sfx::DstKV12, 14, 8>(sfx::SrcKV12, ...)") == "radix_scatter_u64"
+    assert pmc_summary.profile_name("sfx::k_radix_sweep_duo<sfx::SrcKV12, sfx::DstKV, 14, 8>") == "radix_scatter_u64"
+    assert pmc_summary.profile_name("sfx::k_radix_sweep<sfx::SrcKeyIota, sfx::DstKV12, 12, 16>") == "radix_scatter_u64"
+    assert pmc_summary.profile_name("sfx::k_radix_pass<sfx::SrcE64, sfx::DstE64, 11, true, true, 16, true>") == "seg_radix_pass"
+    assert pmc_summary.profile_name("sfx::k_radix_pass<sfx::SrcE64, sfx::DstE64, 11, true, true, 16, false>") == "radix_scatter_u32"
+    assert pmc_summary.profile_name("sfx::k_lcp_intervals_open") == "tree_intervals_open"
+    assert pmc_summary.profile_name("at::native::vectorized_elementwise_kernel<4>") is None
+
+
+def _newest(pattern):
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", pattern)):
+        m = re.match(r"r(\d+)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best
+
+
+def test_fullsize_pmc_record_is_recomputable_from_the_committed_summaries(tmp_path):
+    rnd, path = _newest("r*_pmc_fullsize.json")
+    if rnd < 6:
+        pytest.skip("no per-config PMC record of round 6 or later under profiles/ yet (scripts/gpu_profiles.sh)")
+    rec = json.load(open(path))
+    assert set(rec) >= {"c3", "c5", "dup", "c3r1", "c5r1"}, (path, sorted(rec))
+    out = str(tmp_path / "re.json")
+    for key, ent in rec.items():
+        summary = os.path.join(ROOT, "profiles", f"r{rnd}_pmc_summary_{key}.csv")
+        assert os.path.exists(summary), summary
+        subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_summary.py"), "--fullsize", out, key, str(ent["builds"]), summary],
+                       check=True, capture_output=True)
+        again = json.load(open(out))[key]
+        assert not ent["unmapped_symbols"], (key, ent["unmapped_symbols"])
+        assert again["kernels"] == ent["kernels"], key
+        # the raw counters are in KiB: the dominant pass's traffic straight from the CSV (FETCH x the copy calibration + WRITE)
+        tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+        n = 0
+        for row in csv.DictReader(open(summary)):
+            if pmc_summary.profile_name(row["Kernel"]) == "radix_scatter_u64" and row["Counter"] in tot:
+                tot[row["Counter"]] += float(row["MeanPerDispatch"]) * int(row["Dispatches"])
+                n += int(row["Dispatches"]) if row["Counter"] == "FETCH_SIZE" else 0
+        by_hand = (tot["FETCH_SIZE"] * ent["fetch_calibration_copy"] + tot["WRITE_SIZE"] * ent["write_calibration_copy"]) * 1024.0 / ent["builds"]
+        k = ent["kernels"]["radix_scatter_u64"]
+        assert abs(by_hand - k["hbm_bytes_per_build"]) <= 8 and k["launches"] == n // ent["builds"] == 8, key
+
+
+def test_committed_bench_record_has_a_measured_traffic_for_every_large_kernel():
+    """The bench line of the round (profiles/rN_bench_100MB_dna.txt, a copy of what the driver's command prints): every kernel
+    with >= 15 % of its build carries PMC traffic of at least 0.98 x its algorithmic bytes -- never null, never below what
+    the kernel must move."""
+    rnd, path = _newest("r*_bench_100MB_dna.txt")
+    if rnd < 6:
+        pytest.skip("no bench record of round 6 or later under profiles/ yet (scripts/gpu_final.sh)")
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import _benchout
+    final, details = _benchout.load(open(path))
+    for k in final["roofline"]["kernels"]:
+        if k["share"] >= 0.15:
+            assert k["traffic_ratio"] is not None and k["traffic_ratio"] >= 0.98, ("headline", k)
+    seen = set()
+    for c in final["configs"]:
+        assert c.get("dominant"), c
+        seen.add(c["key"])
+        assert c["dominant"]["traffic_ratio"] is not None and c["dominant"]["traffic_ratio"] >= 0.98, c
+    assert seen >= {"c3", "c5", "dup", "c3r1", "c5r1"}, seen
+    for name, d in details.items():
+        for k in (d.get("roofline") or {}).get("kernels") or []:
+            if name in seen and k["share_of_build"] >= 0.15:
+                assert k.get("traffic") and k["traffic"] >= 0.98 * k["algo_bytes_per_launch"], (name, k)
