@@ -201,12 +201,26 @@ struct BuildStats;   // = sfx_build_stats
 //  - KV: u64 keys + u32 values, (k0,v0)/(k1,v1) ping-pong; with `text` the first pass
 //    reads (packed_key64(text, i), i) instead of (k0, v0).
 uint64_t radix_scratch_words(uint64_t m);
+//    `ties` (with split_v; round 6): a caller that only needs to know WHICH elements share their whole key with a neighbour, not
+//    the sorted keys.  When the hybrid route runs and no sub-bucket is oversized, its LDS sort (k_bucket_sort<.., true>) writes no
+//    keys (*split_k_out = nullptr) and leaves, per sub-bucket b of the top 16 key bits, counts[b] = tied elements | runs of
+//    equal keys << 16 and the records rec[bstart[b] + i], i-th tied element in sorted order:
+//        suffix << 32 | place inside the sub-bucket << 16 | place of the first member of its run
+//    (slot of an element = bstart[b] + place; split_v holds every suffix at its slot).  produced = false: the sorted keys are in
+//    *split_k_out as always.  All pointers stay valid until the scratch or e0 / e1 are written again.
+struct TieRecords {
+    bool produced;
+    const uint64_t* rec;
+    const uint32_t* bstart;        // nbuckets + 1 starts
+    uint32_t* counts;              // nbuckets
+    uint32_t nbuckets;
+};
 //    A producer that had the keys in registers anyway (the range filter) may have counted the
 //    digits itself: `hist_blocks` workgroups' counts at radix_partial(scratch)[(pass * 256 +
 //    digit) * hist_blocks + workgroup]; only honoured when radix_e64_presort_hist() said so.
 int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, uint32_t* scratch,
                    hipStream_t st, int* result_in_1, sfx_build_stats* stats, const PackedText* text,
-                   uint32_t* split_v, uint32_t** split_k_out, unsigned hist_blocks = 0, int elem_bits = 0);
+                   uint32_t* split_v, uint32_t** split_k_out, unsigned hist_blocks = 0, int elem_bits = 0, TieRecords* ties = nullptr);
 // > 0: an E64 sort of m elements on bits [bit_lo, bit_hi) takes digit counts from its producer,
 // from at most this many workgroups
 unsigned radix_e64_presort_hist(uint64_t m, int bit_lo, int bit_hi);

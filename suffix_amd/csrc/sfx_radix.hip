@@ -1341,21 +1341,45 @@ constexpr int kGroups = 1 << kGroupBits;
 // (The 256 x 8 geometry asks for six workgroups per CU -- 80 registers instead of the 88 the compiler takes unasked, five
 // workgroups: the sort waits on LDS round trips 62 % of its wave cycles (scripts/gpu_sq_dna.sh), and one more workgroup to
 // switch to is worth 10 %, 0.40 -> 0.36 ms on 100 MB of DNA; seven (72 registers) gives it back, 0.41.)
-template <int NW, int KPT>
+// TIES (round 6): the sort also says which of its elements share their whole key with a neighbour -- the members of the buckets
+// the refinement has to go on with -- so that nobody reads the sorted keys again (k_groups_reduce / k_groups_apply re-read 4 + 8
+// bytes per suffix that this kernel had in LDS a moment before: 0.19 of the headline's 1.50 ms).  Keys are not written at all.
+// Every tied element leaves a record, REC[begin + i] for the i-th tied element of the sub-bucket in sorted order:
+//     suffix << 32 | place in the sub-bucket << 16 | place of the first member of its run of equal keys
+// and the sub-bucket its counts, tcount[b] = tied elements | runs << 16.  The places come from two LDS bit masks over the
+// sub-bucket's places (tied, first of its run): the index of a tied element among the tied ones is a population count below
+// its bit, the head of its run the highest `first` bit at or below it.  k_tie_scan / k_tie_collect (sfx_sa.hip) turn the records
+// of all sub-buckets into the first active list.
+// The fast path keeps no per-thread state for this (80 registers, six workgroups per CU): a tied element appends (suffix, place)
+// to a list in the part of the staging buffer that the sub-bucket leaves free (kCap - size entries); a sub-bucket whose tied
+// elements do not fit there has its groups scanned a second time instead.
+template <int WORDS, bool ON>
+struct TieSmem {
+    uint32_t tmask[2][WORDS], hmask[2][WORDS];                      // (double-buffered: a sub-bucket's masks are cleared while the next one's fill)
+    uint32_t wpre[WORDS];
+    uint32_t nlist;
+};
+template <int WORDS>
+struct TieSmem<WORDS, false> {};
+template <int NW, int KPT, bool TIES = false>
 __global__ void __launch_bounds__(NW * kWave) SFX_WAVES_PER_EU(NW == 4 && KPT == 8 ? 6 : 1, 8)
 k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstart, uint32_t nbuckets, int low_bits,
-              uint32_t lo, uint32_t hi, uint32_t* __restrict__ K, uint32_t* __restrict__ V)
+              uint32_t lo, uint32_t hi, uint32_t* __restrict__ K, uint32_t* __restrict__ V, uint64_t* __restrict__ REC = nullptr,
+              uint32_t* __restrict__ tcount = nullptr)
 {
     constexpr int kThreads = NW * kWave;
     constexpr uint32_t kCap = kThreads * KPT;
+    constexpr int kMaskWords = (int)(kCap / 32u);
     static_assert(kWave * KPT >= kRadix, "the match masks must fit the staging buffer");
     static_assert(NW * kRadix >= kGroups && kGroups % (NW * kWave) == 0, "the group counts of the fast path live in cnt");
+    static_assert(kCap <= 16384u && kMaskWords <= kThreads, "a record holds 14-bit places; one thread per mask word");
     __shared__ struct {
         uint32_t cnt[NW][kRadix];                                   // LSD rounds: per-wave digit counts; fast path: the group counts
         uint16_t gstart[kGroups];                                   // (sub-buckets hold at most 4096 elements)
         uint32_t part[2][NW];
         uint32_t big;
         uint64_t stage[NW * kWave * KPT];
+        TieSmem<kMaskWords, TIES> tie;
     } s;
     const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const unsigned long long mybit = 1ull << lane;
@@ -1366,6 +1390,11 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
     if (owner) {
 #pragma unroll
         for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0u;
+    }
+    unsigned tpar = 0;                                              // which pair of masks the current sub-bucket fills
+    if constexpr (TIES) {
+        if (tid < (unsigned)kMaskWords) s.tie.tmask[0][tid] = s.tie.hmask[0][tid] = s.tie.tmask[1][tid] = s.tie.hmask[1][tid] = 0u;
+        if (tid == 0) s.tie.nlist = 0u;
     }
     __syncthreads();
     // Two sub-buckets ahead: the bounds of bucket b + 2 G and the elements of bucket b + G are requested before
@@ -1399,6 +1428,70 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
         const unsigned kpt = (size + kThreads - 1) / kThreads;                  // rounds in use, <= KPT
         const unsigned per = kpt * kWave;
         bool pairs = false;
+        // TIES: the records of this sub-bucket's tied elements, once their masks are complete.  from_groups: after the fast path
+        // (the tied elements are listed behind the sub-bucket in the staging buffer, or -- when they did not fit -- found by a second
+        // scan of the groups); otherwise after the LSD rounds (the sorted sub-bucket lies in the staging buffer and in key[]).
+        auto tie_records = [&](bool from_groups, int gshift, unsigned gmask) {
+          if constexpr (TIES) {
+            __syncthreads();
+            // tied elements before each mask word; the other pair of masks (the previous sub-bucket's) is cleared on the way
+            uint32_t tc = 0, hc = 0;
+            if (tid < (unsigned)kMaskWords) {
+                tc = (uint32_t)__popc(s.tie.tmask[tpar][tid]);
+                hc = (uint32_t)__popc(s.tie.hmask[tpar][tid]);
+                s.tie.tmask[tpar ^ 1u][tid] = 0u;
+                s.tie.hmask[tpar ^ 1u][tid] = 0u;
+            }
+            uint32_t total;
+            const uint32_t ex = block_scan_excl_1b_total<NW>(tc | (hc << 16), s.part, par, total);   // (tied <= 16384 < 2^16: no carry into the runs)
+            if (tid < (unsigned)kMaskWords) s.tie.wpre[tid] = ex & 0xFFFFu;
+            if (tid == 0) tcount[b] = total;                                    // tied | runs << 16
+            __syncthreads();
+            const uint32_t ntied = total & 0xFFFFu;
+            auto record = [&](uint32_t suffix, uint32_t place) {
+                const uint32_t wd = place >> 5, bit = place & 31u;
+                const uint32_t i = s.tie.wpre[wd] + (uint32_t)__popc(s.tie.tmask[tpar][wd] & ((1u << bit) - 1u));
+                uint32_t hw = wd, hm = s.tie.hmask[tpar][wd] & (0xFFFFFFFFu >> (31u - bit));
+                while (hm == 0u) hm = s.tie.hmask[tpar][--hw];                  // (a run starts at its first member: there is a bit at or below)
+                const uint32_t head = hw * 32u + 31u - (uint32_t)__clz((int)hm);
+                REC[(uint64_t)begin + i] = ((uint64_t)suffix << 32) | (uint64_t)((place << 16) | head);
+            };
+            if (ntied != 0u && from_groups) {
+                if (ntied <= kCap - size) {
+                    for (unsigned i = tid; i < ntied; i += kThreads) {
+                        const uint64_t ent = s.stage[size + i];
+                        record((uint32_t)(ent >> 32), (uint32_t)ent);
+                    }
+                } else {
+                    const uint32_t* const gcount = &s.cnt[0][0];
+                    for (unsigned q = tid; q < size; q += kThreads) {
+                        const uint64_t e = s.stage[q];
+                        const unsigned d = digit_of(e, gshift, gmask);
+                        const unsigned gb = s.gstart[d], ge = gb + gcount[d];
+                        unsigned rank = 0, same = 0;
+                        for (unsigned j = gb; j < ge; j++) {
+                            const uint64_t x = s.stage[j];
+                            rank += x < e ? 1u : 0u;
+                            same += (uint32_t)(x >> 32) == (uint32_t)(e >> 32) ? 1u : 0u;
+                        }
+                        if (same > 1u) record((uint32_t)e, gb + rank);
+                    }
+                }
+            } else if (ntied != 0u) {
+#pragma unroll
+                for (int r = 0; r < KPT; r++) {
+                    const unsigned idx = w * per + r * kWave + lane;
+                    if ((unsigned)r < kpt && idx < size) {
+                        const uint32_t k32 = (uint32_t)(key[r] >> 32);
+                        const bool eq_prev = idx > 0u && (uint32_t)(s.stage[idx - 1u] >> 32) == k32;
+                        const bool eq_next = idx + 1u < size && (uint32_t)(s.stage[idx + 1u] >> 32) == k32;
+                        if (eq_prev || eq_next) record((uint32_t)key[r], idx);
+                    }
+                }
+            }
+            tpar ^= 1u;
+          }
+        };
         if (size > 1) {
             // group by the top bits of the low key part: place inside the group from a returning atomic, group starts by a scan
             const int gbits = low_bits < kGroupBits ? low_bits : kGroupBits;
@@ -1432,6 +1525,31 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                     if ((unsigned)r < kpt && w * per + r * kWave + lane < size)
                         s.stage[s.gstart[digit_of(key[r], gshift, gmask)] + pos[r]] = key[r];
                 __syncthreads();
+                if constexpr (TIES) {
+                    const unsigned room = kCap - size;                          // free entries of the staging buffer behind the sub-bucket
+                    for (unsigned q = tid; q < size; q += kThreads) {
+                        const uint64_t e = s.stage[q];
+                        const unsigned d = digit_of(e, gshift, gmask);
+                        const unsigned gb = s.gstart[d], ge = gb + gcount[d];
+                        unsigned rank = 0, same = 0, same_below = 0;
+                        for (unsigned j = gb; j < ge; j++) {
+                            const uint64_t x = s.stage[j];
+                            const bool below = x < e, eq = (uint32_t)(x >> 32) == (uint32_t)(e >> 32);
+                            rank += below ? 1u : 0u;
+                            same += eq ? 1u : 0u;                                  // (counts e itself)
+                            same_below += (eq && below) ? 1u : 0u;
+                        }
+                        const unsigned place = gb + rank;
+                        V[(uint64_t)begin + place] = (uint32_t)e;
+                        if (same > 1u) {
+                            atomicOr(&s.tie.tmask[tpar][place >> 5], 1u << (place & 31u));
+                            if (same_below == 0u) atomicOr(&s.tie.hmask[tpar][place >> 5], 1u << (place & 31u));
+                            const unsigned at = atomicAdd(&s.tie.nlist, 1u);
+                            if (at < room) s.stage[size + at] = (e << 32) | (uint64_t)place;
+                        }
+                    }
+                    tie_records(true, gshift, gmask);
+                } else {
                 for (unsigned q = tid; q < size; q += kThreads) {
                     const uint64_t e = s.stage[q];
                     const unsigned d = digit_of(e, gshift, gmask);
@@ -1441,11 +1559,15 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                     K[(uint64_t)begin + gb + rank] = (uint32_t)(e >> 32);
                     V[(uint64_t)begin + gb + rank] = (uint32_t)e;
                 }
+                }
             }
             __syncthreads();                                                    // (stage and the counts are read to the end)
 #pragma unroll
             for (int k = 0; k < kPerThread; k++) gcount[tid * kPerThread + k] = 0u;
             if (tid == 0) s.big = 0u;
+            if constexpr (TIES) {
+                if (tid == 0) s.tie.nlist = 0u;
+            }
             __syncthreads();
         }
         for (int pass = 0; pass < 2 && size > 1 && !pairs; pass++) {
@@ -1495,9 +1617,25 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
         for (int r = 0; r < KPT; r++) {
             const unsigned idx = w * per + r * kWave + lane;
             if ((unsigned)r < kpt && idx < size && !pairs) {
-                K[(uint64_t)begin + idx] = (uint32_t)(key[r] >> 32);
                 V[(uint64_t)begin + idx] = (uint32_t)key[r];
+                if constexpr (TIES) {
+                    // (after the LSD rounds the sub-bucket lies sorted in the staging buffer: a run of equal keys is a run of neighbours)
+                    if (size > 1u) {
+                        const uint32_t k32 = (uint32_t)(key[r] >> 32);
+                        const bool eq_prev = idx > 0u && (uint32_t)(s.stage[idx - 1u] >> 32) == k32;
+                        const bool eq_next = idx + 1u < size && (uint32_t)(s.stage[idx + 1u] >> 32) == k32;
+                        if (eq_prev || eq_next) {
+                            atomicOr(&s.tie.tmask[tpar][idx >> 5], 1u << (idx & 31u));
+                            if (!eq_prev) atomicOr(&s.tie.hmask[tpar][idx >> 5], 1u << (idx & 31u));
+                        }
+                    }
+                } else {
+                    K[(uint64_t)begin + idx] = (uint32_t)(key[r] >> 32);
+                }
             }
+        }
+        if constexpr (TIES) {
+            if (size > 1u && !pairs) tie_records(false, 0, 0u);                 // (block-uniform; the fast path did it before it let go of the groups)
         }
         begin = begin1; size = size1;
         begin1 = begin2; size1 = size2;
@@ -1724,8 +1862,9 @@ bool radix_e64_hybrid_expected(uint64_t m, int key_bits)
 }
 static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, const RadixScratch& scr,
                                 hipStream_t st, sfx_build_stats* stats, const PackedText& text, uint32_t* split_v,
-                                uint32_t** split_k_out, bool* done, bool* windows_ready, int elem_bits = 0)
+                                uint32_t** split_k_out, bool* done, bool* windows_ready, int elem_bits = 0, TieRecords* ties = nullptr)
 {
+    if (ties) ties->produced = false;
     *done = false;
     *windows_ready = false;
     const bool from_elems = elem_bits > 0;
@@ -1895,19 +2034,41 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     const uint32_t top = dmin(host_max, cap);                  // the largest sub-bucket the LDS sort takes
     const uint32_t c1 = force_geom >= 1 ? 0u : dmin(2048u, cap), c2 = force_geom == 2 ? c1 : dmin(4096u, cap);
     const unsigned grid = (unsigned)dmin<uint64_t>(kH16Bins, (uint64_t)grid_cap() * 2);
+    // With no oversized sub-bucket the LDS sort can name the tied elements itself (k_bucket_sort<.., true>): no sorted keys are
+    // written, the caller builds its first active list from the records (TieRecords, sfx_host.hpp).  SFX_HYBRID_TIES=0
+    // (development): the sorted keys, as rounds 3-5.
+    static const int ties_on = [] { const char* e = dev_env("SFX_HYBRID_TIES"); return e ? atoi(e) : 1; }();
+    const bool tie_mode = ties && ties_on && nover == 0;
+    uint32_t* tcount = reinterpret_cast<uint32_t*>(over);      // (the oversize list is idle: 4 * kOversizeMax = 65536 words)
+    static_assert(4 * kOversizeMax >= kH16Bins, "the tie counts of all sub-buckets fit the oversize list");
+    if (tie_mode) SFX_HIP(hipMemsetAsync(tcount, 0, kH16Bins * sizeof(uint32_t), st));
 #define SFX_BUCKET_SORT(NW, KPT, LO, HI, GRID)                                                                              \
-    SFX_LAUNCH("bucket_sort_lds", (double)m * 16.0, (k_bucket_sort<NW, KPT>), GRID, NW * kWave, st, (const uint64_t*)e1,    \
-               (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, (uint32_t)(LO), (uint32_t)(HI), split_k, split_v)
+    do {                                                                                                                    \
+        if (tie_mode)                                                                                                       \
+            SFX_LAUNCH("bucket_sort_lds", (double)m * 12.0, (k_bucket_sort<NW, KPT, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
+                       (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, (uint32_t)(LO), (uint32_t)(HI), (uint32_t*)nullptr, split_v, \
+                       e0, tcount);                                                                                         \
+        else                                                                                                                \
+            SFX_LAUNCH("bucket_sort_lds", (double)m * 16.0, (k_bucket_sort<NW, KPT>), GRID, NW * kWave, st, (const uint64_t*)e1, \
+                       (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, (uint32_t)(LO), (uint32_t)(HI), split_k, split_v); \
+    } while (0)
     if (c1 > 0) SFX_BUCKET_SORT(4, 8, 0u, c1, grid);
     if (c2 > c1 && top > c1) SFX_BUCKET_SORT(4, 16, c1, c2, grid);
     if (cap > c2 && top > c2) SFX_BUCKET_SORT(16, 16, c2, cap, dmin(grid, grid_cap()));
 #undef SFX_BUCKET_SORT
+    if (tie_mode) {
+        ties->produced = true;
+        ties->rec = e0;
+        ties->bstart = bins;
+        ties->counts = tcount;
+        ties->nbuckets = (uint32_t)kH16Bins;
+    }
     if (nover) {
         const unsigned g = (unsigned)dmin<uint64_t>(nover, kMaxGrid);
         SFX_LAUNCH("oversize_return", (double)nlarge * 16, k_oversize_return, g, kBlock, st, over_sorted, (const OversizeEntry*)over, nover,
                    low_bits, split_k, split_v);
     }
-    if (split_k_out) *split_k_out = split_k;
+    if (split_k_out) *split_k_out = tie_mode ? (uint32_t*)nullptr : split_k;
     if (stats) { stats->radix_passes += 2; stats->elements_sorted += 2 * m; }
     *done = true;
     return SFX_OK;
@@ -1944,8 +2105,9 @@ unsigned scatter_pairs_presort_hist(uint64_t m, uint64_t n, int* lo_out, int* nb
 
 int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_hi, uint32_t* scratch, hipStream_t st,
                    int* result_in_1, sfx_build_stats* stats, const PackedText* text, uint32_t* split_v,
-                   uint32_t** split_k_out, unsigned hist_blocks, int elem_bits)
+                   uint32_t** split_k_out, unsigned hist_blocks, int elem_bits, TieRecords* ties)
 {
+    if (ties) ties->produced = false;
     // elem_bits (with split_v, without text): the keys of the elements in e0 are all below 2^elem_bits -- a slice of the
     // partitioned build; lets the hybrid route take it
     *result_in_1 = 0;
@@ -1959,13 +2121,13 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
     bool windows_ready = false;                                  // the digit totals of all passes are in place already
     if (sweep && text && split_v && npass >= 3) {
         bool done = false;
-        SFX_TRY(hybrid_sort_e64_text(e0, e1, m, bit_lo, bit_hi, scr, st, stats, *text, split_v, split_k_out, &done, &windows_ready));
+        SFX_TRY(hybrid_sort_e64_text(e0, e1, m, bit_lo, bit_hi, scr, st, stats, *text, split_v, split_k_out, &done, &windows_ready, 0, ties));
         if (done) return SFX_OK;
     }
     if (sweep && !text && split_v && npass >= 3 && elem_bits > 0) {
         bool done = false, unused = false;
         SFX_TRY(hybrid_sort_e64_text(e0, e1, m, bit_lo, bit_hi, scr, st, stats, PackedText{nullptr, 0, 0, 1, 0, 1.0}, split_v, split_k_out,
-                                     &done, &unused, elem_bits));
+                                     &done, &unused, elem_bits, ties));
         if (done) return SFX_OK;
     }
     SrcText32 tsrc = {text ? *text : PackedText{nullptr, 0, 0, 1, 0, 1.0}};

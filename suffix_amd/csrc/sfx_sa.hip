@@ -740,6 +740,64 @@ k_groups_scan(uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep
     if (threadIdx.x == 0) { totals[0] = c_keep; totals[1] = c_ghead; totals[2] = c_pairs; }
 }
 
+// ---- the first active list from the tie records of the hybrid initial sort (TieRecords, sfx_host.hpp; round 6) ----------------
+// The LDS sort of a sub-bucket knows which of its elements share their whole key with a neighbour; k_groups_reduce /
+// k_groups_apply found the same out by reading the sorted keys and suffixes again (12 bytes per suffix for the 2.3 % of them
+// that stay tied on uniform DNA).  k_tie_scan: counts[b] = tied | runs << 16 per sub-bucket -> where the sub-bucket's tied
+// elements start in the list (in place; totals[0] = list length, totals[1] = buckets).  One workgroup, nb <= 65536.
+__global__ void __launch_bounds__(1024)
+k_tie_scan(uint32_t* __restrict__ counts, uint32_t nb, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t part[2][16];
+    unsigned par = 0;
+    uint32_t carry_t = 0, carry_r = 0;
+    for (uint32_t base = 0; base < nb; base += 1024u * 4u) {
+        // four consecutive sub-buckets per thread
+        const uint32_t i0 = base + threadIdx.x * 4u;
+        uint32_t c[4], t = 0, r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c[k] = i0 + k < nb ? counts[i0 + k] : 0u;
+            t += c[k] & 0xFFFFu;
+            r += c[k] >> 16;
+        }
+        uint32_t tot_t, tot_r;
+        uint32_t ex = block_scan_excl_1b_total<16>(t, part, par, tot_t);
+        (void)block_scan_excl_1b_total<16>(r, part, par, tot_r);
+        ex += carry_t;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < nb) counts[i0 + k] = ex;
+            ex += c[k] & 0xFFFFu;
+        }
+        carry_t += tot_t;
+        carry_r += tot_r;
+    }
+    if (threadIdx.x == 0) { totals[0] = carry_t; totals[1] = carry_r; }
+}
+// k_tie_collect: one wave per sub-bucket at a time; list position L = base[b] + i of record i: suffix, slot = bstart[b] + place,
+// bucket id = list position of the head of its run (the members of a run are consecutive records).
+__global__ void __launch_bounds__(kBlock)
+k_tie_collect(const uint64_t* __restrict__ rec, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ base, uint32_t nb,
+              const uint32_t* __restrict__ totals, uint32_t* __restrict__ S, uint32_t* __restrict__ V, uint32_t* __restrict__ G)
+{
+    const unsigned lane = lane_id();
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock, total = totals[0];
+    for (uint32_t b = blockIdx.x * kWavesPerBlock + wave_id(); b < nb; b += nwaves) {
+        const uint32_t at = base[b], cnt = (b + 1u < nb ? base[b + 1u] : total) - at;
+        if (cnt == 0u) continue;
+        const uint32_t begin = bstart[b];
+        for (uint32_t i = lane; i < cnt; i += kWave) {
+            const uint64_t r = rec[(uint64_t)begin + i];
+            const uint32_t place = ((uint32_t)r >> 16) & 0xFFFFu, head = (uint32_t)r & 0xFFFFu;
+            const uint32_t L = at + i;
+            V[L] = (uint32_t)(r >> 32);
+            S[L] = begin + place;
+            G[L] = L - (place - head);
+        }
+    }
+}
+
 // K,V: sorted keys / suffixes of the m active elements; S: their SA slots in
 // ascending order (nullptr = identity).  Writes SA[slot] = suffix (skipped when
 // sa_in_place: V IS the SA and slots are the identity -- the last radix pass of the
@@ -1937,12 +1995,15 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     uint32_t* V_next;
     bool in_place = false;
     int in1 = 0;
+    TieRecords ties = {false, nullptr, nullptr, nullptr, 0};
     if (sizeof(KeyT) == 4) {
         // E64 elements; the last pass drops every suffix straight into its SA slot and
         // leaves the sorted 32-bit keys in the element buffer it did not read
         uint32_t* k32 = nullptr;
+        // (without the fused LCP, which reads the common prefix of neighbours off the sorted keys, nobody needs them: the hybrid
+        // route may leave the records of the tied elements instead -- TieRecords)
         SFX_TRY(radix_sort_e64(b.K0, b.K1, count, 32, 32 + pt.bits * cpk, b.hist, st, &in1, &stats,
-                               from_text ? &pt : nullptr, sa, &k32, hist_blocks, from_text ? 0 : elem_bits));
+                               from_text ? &pt : nullptr, sa, &k32, hist_blocks, from_text ? 0 : elem_bits, lcp_fuse ? nullptr : &ties));
         Kr = (const KeyT*)k32;
         Vr = sa;
         V_next = b.VA;
@@ -1969,6 +2030,30 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         fuse.inv_bits = (65536u + (unsigned)pt.bits - 1u) / (unsigned)pt.bits;
         for (unsigned x = 0; x < 64; x++)
             if (((x * fuse.inv_bits) >> 16) != x / (unsigned)pt.bits) return SFX_ERR_INTERNAL;
+    }
+    if (ties.produced) {
+        // every suffix sits in its slot of the array; the tied ones (slot, suffix, bucket) are listed from the sort's own records
+        if (ht || lcp_fuse) return SFX_ERR_INTERNAL;
+        SFX_LAUNCH("tie_scan", (double)ties.nbuckets * 8, k_tie_scan, 1, 1024, st, ties.counts, ties.nbuckets, b.totals);
+        uint32_t host_totals[2] = {0, 0};
+        SFX_TRY(read_back(host_totals, b.totals, sizeof(host_totals), st));
+        kept = host_totals[0];
+        groups = host_totals[1];
+        if (kept > count || groups * 2 > kept) return SFX_ERR_INTERNAL;
+        stats.active_after_initial = kept;
+        if (kept > 0) {
+            const unsigned grid = (unsigned)dmin<uint64_t>((ties.nbuckets + kWavesPerBlock - 1) / kWavesPerBlock, kMaxGrid);
+            SFX_LAUNCH("tie_collect", (double)ties.nbuckets * 8 + (double)kept * 20, k_tie_collect, grid, kBlock, st, ties.rec, ties.bstart,
+                       (const uint32_t*)ties.counts, ties.nbuckets, (const uint32_t*)b.totals, b.S0, V_next, b.G);
+        }
+        uint32_t* S_cur = b.S0;
+        if (small_groups_pay(kept, groups))
+            SFX_TRY(small_groups_pass(pt, (uint64_t)cpk, b, sa, nullptr, &S_cur, &V_next, &kept, st, stats, nullptr, false));
+        if (kept > 0) {
+            const unsigned grid = (unsigned)dmin<uint64_t>((kept + kBlock * 4 - 1) / (kBlock * 4), kMaxGrid);
+            SFX_LAUNCH("depth_fill", (double)kept * 2, k_fill_u16, grid, kBlock, st, hd_of(b, S_cur), kept, (uint16_t)cpk);
+        }
+        return refine(pt, cpk, b, sa, isa, S_cur, V_next, kept, st, stats, nullptr, false);
     }
     SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups, fuse));
     stats.active_after_initial = kept;

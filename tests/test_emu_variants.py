@@ -51,6 +51,18 @@ if os.environ.get("SFX_HYBRID_MIN"):
     texts.append(b"".join(blocks[int(k)] + bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for k in rngh.integers(0, 4, 3600)))
     texts += [_gen.uniform_bytes(12000, 5, 2, base=65).tobytes(), _gen.uniform_bytes(12000, 16, 3, base=65).tobytes(),
               _gen.uniform_bytes(14000, 2, 4, base=65).tobytes()]
+    # one 13-symbol block, each copy followed by 3 random symbols: a sub-bucket of ~700 suffixes that all fall into ONE group of
+    # the LDS sort's fast path (the group is the top 10 of the 16 low key bits) -> the stable LSD rounds, with runs of ~11 equal
+    # 16-symbol keys: the tie records (round 6) from neighbours in the staging buffer instead of from the group scan
+    # one 8-symbol block followed by one of 700 8-symbol tails, every tail twice: a sub-bucket of ~1400 suffixes in 700 runs of
+    # two equal keys, spread over the groups of the fast path -- more tied elements than the staging buffer has room behind the
+    # sub-bucket (2048 - 1400), so the groups are scanned a second time for the records
+    b8 = bytes(rngh.choice(list(b"ACGT"), 8).tolist())
+    tails = [bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for _ in range(700)]
+    order = rngh.permutation(1400) % 700
+    texts.append(b"".join(b8 + tails[int(k)] + bytes(rngh.choice(list(b"ACGT"), 9).tolist()) for k in order))
+    b13 = bytes(rngh.choice(list(b"ACGT"), 13).tolist())
+    texts.append(_gen.dna(9000, seed=21).tobytes() + b"".join(b13 + bytes(rngh.choice(list(b"ACGT"), 3).tolist()) for _ in range(700)))
     from suffix_amd import device as sdev
     for t in texts[:1]:                                 # the fused SA + LCP entry over the same initial sort
         import torch
@@ -70,11 +82,15 @@ if os.environ.get("SFX_HYBRID_MIN"):
         eng.profile(False)
         return names
     cap = int(os.environ.get("SFX_HYBRID_CAP", "100000"))
+    ties_on = os.environ.get("SFX_HYBRID_TIES", "1") != "0"
     names = kernels_of(texts[0])
     # (cap 3: 6 % of that text sits in sub-buckets of more than 3 suffixes -- above the 1/64 the route tolerates)
     assert ("bucket_sort_lds" in names) == (cap > 10) and "oversize_gather" not in names, names
+    # round 6: with no oversized sub-bucket the LDS sort names the tied elements itself -- no keys written, none read back
+    assert ("tie_scan" in names) == (cap > 10 and ties_on) and ("groups_reduce" in names) != ("tie_scan" in names), names
     names = kernels_of(planted)                                       # 0.8 % of it in the three planted sub-buckets
     assert ("bucket_sort_lds" in names) == (cap > 10) and ("oversize_gather" in names) == (10 < cap < 400), names
+    assert ("tie_scan" in names) == (cap >= 400 and ties_on), names   # (an oversized sub-bucket: the sorted keys, as before)
     # most of the suffixes in oversized sub-buckets: the four-pass sort
     skewed = np.frombuffer(b"ACGT", dtype=np.uint8)[rngh.choice(4, size=20000, p=[0.85, 0.05, 0.05, 0.05])].tobytes()
     texts.append(skewed)
@@ -93,6 +109,7 @@ if os.environ.get("SFX_HYBRID_MIN"):
         # (one rank = the whole key space: no filter, the text-fed route of the full build)
         assert ("radix_hist16_elems" in seen) == (nr == 3) and ("radix_hist16_text" in seen) == (nr == 1), (nr, seen)
         assert ("bucket_sort_lds" in seen) == (cap > 10 and nr < 7) and ("range_emit" in seen) == (nr > 1), (nr, seen)
+        assert ("tie_scan" in seen) == (cap > 10 and nr < 7 and ties_on), (nr, seen)         # (slices take the records too)
     if cap < 400:
         _cases.range_slices(eng, oracle, planted, 3, packed=True)
         _cases.range_slices(eng, oracle, skewed, 2, packed=True)
@@ -191,6 +208,10 @@ VARIANTS = {
     "hybrid-initial-sort-4-wave-partition": {"SFX_HYBRID_MIN": "1", "SFX_PARTITION_WAVES": "4", "SFX_MAX_GRID": "3", "TEST_TEXTS": "2"},
     # ... with the stable one-sweep passes of rounds 2-3 instead of the partition passes (k_partition)
     "hybrid-initial-sort-one-sweep-passes": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_PARTITION": "0", "TEST_TEXTS": "2"},
+    # ... with the sorted keys written and read back by the bucket pass, as rounds 3-5 (round 6: the LDS sort leaves tie records)
+    "hybrid-initial-sort-sorted-keys": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_TIES": "0"},
+    # ... the tie records from the 1024 x 16 geometry (sub-buckets of up to 16384), several sub-buckets per workgroup
+    "hybrid-initial-sort-1024x16": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_GEOM": "2", "SFX_MAX_GRID": "2"},
     # a few oversized sub-buckets (gathered, sorted device-wide, copied back), the 256 x 16 geometry, several sub-buckets
     # per workgroup
     "hybrid-initial-sort-oversized": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_CAP": "100", "SFX_MAX_GRID": "3", "SFX_HYBRID_GEOM": "1"},
