@@ -1344,20 +1344,20 @@ constexpr int kGroups = 1 << kGroupBits;
 // TIES (round 6): the sort also says which of its elements share their whole key with a neighbour -- the members of the buckets
 // the refinement has to go on with -- so that nobody reads the sorted keys again (k_groups_reduce / k_groups_apply re-read 4 + 8
 // bytes per suffix that this kernel had in LDS a moment before: 0.19 of the headline's 1.50 ms).  Keys are not written at all.
-// Every tied element leaves a record, REC[begin + i] for the i-th tied element of the sub-bucket in sorted order:
+// Every tied element leaves a record somewhere in REC[begin, begin + tied elements of the sub-bucket):
 //     suffix << 32 | place in the sub-bucket << 16 | place of the first member of its run of equal keys
-// and the sub-bucket its counts, tcount[b] = tied elements | runs << 16.  The places come from two LDS bit masks over the
-// sub-bucket's places (tied, first of its run): the index of a tied element among the tied ones is a population count below
-// its bit, the head of its run the highest `first` bit at or below it.  k_tie_scan / k_tie_collect (sfx_sa.hip) turn the records
-// of all sub-buckets into the first active list.
-// The fast path keeps no per-thread state for this (80 registers, six workgroups per CU): a tied element appends (suffix, place)
-// to a list in the part of the staging buffer that the sub-bucket leaves free (kCap - size entries); a sub-bucket whose tied
-// elements do not fit there has its groups scanned a second time instead.
+// and the sub-bucket its counts, tcount[b] = tied elements | runs << 16.  On the fast path the thread that places an element has
+// seen every member of its group, hence of its run: the head of the run is its own place minus the members of the run below it,
+// and the record goes where a returning LDS atomic says -- no order among the records of a sub-bucket, no barrier, no state.
+// After the LSD rounds (skewed sub-buckets) a run is a run of neighbours in the staging buffer: two bit masks over the places
+// (tied, first of its run) give every tied element its index among them and the head of its run.  k_tie_direct (sfx_sa.hip)
+// orders the runs on the text where they are; what it cannot finish goes through k_tie_scan / k_tie_collect into the first
+// active list.
 template <int WORDS, bool ON>
 struct TieSmem {
-    uint32_t tmask[2][WORDS], hmask[2][WORDS];                      // (double-buffered: a sub-bucket's masks are cleared while the next one's fill)
+    uint32_t tmask[WORDS], hmask[WORDS];                            // (the LSD path only)
     uint32_t wpre[WORDS];
-    uint32_t nlist;
+    uint32_t nrec;                                                  // fast path: tied | runs << 16 so far
 };
 template <int WORDS>
 struct TieSmem<WORDS, false> {};
@@ -1391,10 +1391,9 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
 #pragma unroll
         for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0u;
     }
-    unsigned tpar = 0;                                              // which pair of masks the current sub-bucket fills
     if constexpr (TIES) {
-        if (tid < (unsigned)kMaskWords) s.tie.tmask[0][tid] = s.tie.hmask[0][tid] = s.tie.tmask[1][tid] = s.tie.hmask[1][tid] = 0u;
-        if (tid == 0) s.tie.nlist = 0u;
+        if (tid < (unsigned)kMaskWords) s.tie.tmask[tid] = s.tie.hmask[tid] = 0u;
+        if (tid == 0) s.tie.nrec = 0u;
     }
     __syncthreads();
     // Two sub-buckets ahead: the bounds of bucket b + 2 G and the elements of bucket b + G are requested before
@@ -1428,56 +1427,22 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
         const unsigned kpt = (size + kThreads - 1) / kThreads;                  // rounds in use, <= KPT
         const unsigned per = kpt * kWave;
         bool pairs = false;
-        // TIES: the records of this sub-bucket's tied elements, once their masks are complete.  from_groups: after the fast path
-        // (the tied elements are listed behind the sub-bucket in the staging buffer, or -- when they did not fit -- found by a second
-        // scan of the groups); otherwise after the LSD rounds (the sorted sub-bucket lies in the staging buffer and in key[]).
-        auto tie_records = [&](bool from_groups, int gshift, unsigned gmask) {
+        // TIES, after the LSD rounds: the records of this sub-bucket's tied elements once their masks are complete (the sorted
+        // sub-bucket lies in the staging buffer and in key[])
+        auto tie_records_lsd = [&]() {
           if constexpr (TIES) {
             __syncthreads();
-            // tied elements before each mask word; the other pair of masks (the previous sub-bucket's) is cleared on the way
             uint32_t tc = 0, hc = 0;
             if (tid < (unsigned)kMaskWords) {
-                tc = (uint32_t)__popc(s.tie.tmask[tpar][tid]);
-                hc = (uint32_t)__popc(s.tie.hmask[tpar][tid]);
-                s.tie.tmask[tpar ^ 1u][tid] = 0u;
-                s.tie.hmask[tpar ^ 1u][tid] = 0u;
+                tc = (uint32_t)__popc(s.tie.tmask[tid]);
+                hc = (uint32_t)__popc(s.tie.hmask[tid]);
             }
             uint32_t total;
             const uint32_t ex = block_scan_excl_1b_total<NW>(tc | (hc << 16), s.part, par, total);   // (tied <= 16384 < 2^16: no carry into the runs)
             if (tid < (unsigned)kMaskWords) s.tie.wpre[tid] = ex & 0xFFFFu;
             if (tid == 0) tcount[b] = total;                                    // tied | runs << 16
             __syncthreads();
-            const uint32_t ntied = total & 0xFFFFu;
-            auto record = [&](uint32_t suffix, uint32_t place) {
-                const uint32_t wd = place >> 5, bit = place & 31u;
-                const uint32_t i = s.tie.wpre[wd] + (uint32_t)__popc(s.tie.tmask[tpar][wd] & ((1u << bit) - 1u));
-                uint32_t hw = wd, hm = s.tie.hmask[tpar][wd] & (0xFFFFFFFFu >> (31u - bit));
-                while (hm == 0u) hm = s.tie.hmask[tpar][--hw];                  // (a run starts at its first member: there is a bit at or below)
-                const uint32_t head = hw * 32u + 31u - (uint32_t)__clz((int)hm);
-                REC[(uint64_t)begin + i] = ((uint64_t)suffix << 32) | (uint64_t)((place << 16) | head);
-            };
-            if (ntied != 0u && from_groups) {
-                if (ntied <= kCap - size) {
-                    for (unsigned i = tid; i < ntied; i += kThreads) {
-                        const uint64_t ent = s.stage[size + i];
-                        record((uint32_t)(ent >> 32), (uint32_t)ent);
-                    }
-                } else {
-                    const uint32_t* const gcount = &s.cnt[0][0];
-                    for (unsigned q = tid; q < size; q += kThreads) {
-                        const uint64_t e = s.stage[q];
-                        const unsigned d = digit_of(e, gshift, gmask);
-                        const unsigned gb = s.gstart[d], ge = gb + gcount[d];
-                        unsigned rank = 0, same = 0;
-                        for (unsigned j = gb; j < ge; j++) {
-                            const uint64_t x = s.stage[j];
-                            rank += x < e ? 1u : 0u;
-                            same += (uint32_t)(x >> 32) == (uint32_t)(e >> 32) ? 1u : 0u;
-                        }
-                        if (same > 1u) record((uint32_t)e, gb + rank);
-                    }
-                }
-            } else if (ntied != 0u) {
+            if ((total & 0xFFFFu) != 0u) {
 #pragma unroll
                 for (int r = 0; r < KPT; r++) {
                     const unsigned idx = w * per + r * kWave + lane;
@@ -1485,11 +1450,19 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                         const uint32_t k32 = (uint32_t)(key[r] >> 32);
                         const bool eq_prev = idx > 0u && (uint32_t)(s.stage[idx - 1u] >> 32) == k32;
                         const bool eq_next = idx + 1u < size && (uint32_t)(s.stage[idx + 1u] >> 32) == k32;
-                        if (eq_prev || eq_next) record((uint32_t)key[r], idx);
+                        if (eq_prev || eq_next) {
+                            const uint32_t wd = idx >> 5, bit = idx & 31u;
+                            const uint32_t i = s.tie.wpre[wd] + (uint32_t)__popc(s.tie.tmask[wd] & ((1u << bit) - 1u));
+                            uint32_t hw = wd, hm = s.tie.hmask[wd] & (0xFFFFFFFFu >> (31u - bit));
+                            while (hm == 0u) hm = s.tie.hmask[--hw];            // (a run starts at its first member: there is a bit at or below)
+                            const uint32_t head = hw * 32u + 31u - (uint32_t)__clz((int)hm);
+                            REC[(uint64_t)begin + i] = ((uint64_t)(uint32_t)key[r] << 32) | (uint64_t)((idx << 16) | head);
+                        }
                     }
                 }
+                __syncthreads();
+                if (tid < (unsigned)kMaskWords) s.tie.tmask[tid] = s.tie.hmask[tid] = 0u;   // (clean for the next skewed sub-bucket)
             }
-            tpar ^= 1u;
           }
         };
         if (size > 1) {
@@ -1526,7 +1499,6 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                         s.stage[s.gstart[digit_of(key[r], gshift, gmask)] + pos[r]] = key[r];
                 __syncthreads();
                 if constexpr (TIES) {
-                    const unsigned room = kCap - size;                          // free entries of the staging buffer behind the sub-bucket
                     for (unsigned q = tid; q < size; q += kThreads) {
                         const uint64_t e = s.stage[q];
                         const unsigned d = digit_of(e, gshift, gmask);
@@ -1542,13 +1514,11 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                         const unsigned place = gb + rank;
                         V[(uint64_t)begin + place] = (uint32_t)e;
                         if (same > 1u) {
-                            atomicOr(&s.tie.tmask[tpar][place >> 5], 1u << (place & 31u));
-                            if (same_below == 0u) atomicOr(&s.tie.hmask[tpar][place >> 5], 1u << (place & 31u));
-                            const unsigned at = atomicAdd(&s.tie.nlist, 1u);
-                            if (at < room) s.stage[size + at] = (e << 32) | (uint64_t)place;
+                            // (equal keys are neighbours in the sorted order: the run starts same_below places below)
+                            const uint32_t at = atomicAdd(&s.tie.nrec, same_below == 0u ? 0x10001u : 1u) & 0xFFFFu;
+                            REC[(uint64_t)begin + at] = (e << 32) | (uint64_t)((place << 16) | (place - same_below));
                         }
                     }
-                    tie_records(true, gshift, gmask);
                 } else {
                 for (unsigned q = tid; q < size; q += kThreads) {
                     const uint64_t e = s.stage[q];
@@ -1566,7 +1536,10 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
             for (int k = 0; k < kPerThread; k++) gcount[tid * kPerThread + k] = 0u;
             if (tid == 0) s.big = 0u;
             if constexpr (TIES) {
-                if (tid == 0) s.tie.nlist = 0u;
+                if (tid == 0 && pairs) {
+                    tcount[b] = s.tie.nrec;                                     // tied | runs << 16
+                    s.tie.nrec = 0u;
+                }
             }
             __syncthreads();
         }
@@ -1625,8 +1598,8 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                         const bool eq_prev = idx > 0u && (uint32_t)(s.stage[idx - 1u] >> 32) == k32;
                         const bool eq_next = idx + 1u < size && (uint32_t)(s.stage[idx + 1u] >> 32) == k32;
                         if (eq_prev || eq_next) {
-                            atomicOr(&s.tie.tmask[tpar][idx >> 5], 1u << (idx & 31u));
-                            if (!eq_prev) atomicOr(&s.tie.hmask[tpar][idx >> 5], 1u << (idx & 31u));
+                            atomicOr(&s.tie.tmask[idx >> 5], 1u << (idx & 31u));
+                            if (!eq_prev) atomicOr(&s.tie.hmask[idx >> 5], 1u << (idx & 31u));
                         }
                     }
                 } else {
@@ -1635,7 +1608,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
             }
         }
         if constexpr (TIES) {
-            if (size > 1u && !pairs) tie_records(false, 0, 0u);                 // (block-uniform; the fast path did it before it let go of the groups)
+            if (size > 1u && !pairs) tie_records_lsd();                         // (block-uniform; the fast path left its records as it went)
         }
         begin = begin1; size = size1;
         begin1 = begin2; size1 = size2;

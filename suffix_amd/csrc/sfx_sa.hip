@@ -740,64 +740,6 @@ k_groups_scan(uint32_t* __restrict__ part_head, uint32_t* __restrict__ part_keep
     if (threadIdx.x == 0) { totals[0] = c_keep; totals[1] = c_ghead; totals[2] = c_pairs; }
 }
 
-// ---- the first active list from the tie records of the hybrid initial sort (TieRecords, sfx_host.hpp; round 6) ----------------
-// The LDS sort of a sub-bucket knows which of its elements share their whole key with a neighbour; k_groups_reduce /
-// k_groups_apply found the same out by reading the sorted keys and suffixes again (12 bytes per suffix for the 2.3 % of them
-// that stay tied on uniform DNA).  k_tie_scan: counts[b] = tied | runs << 16 per sub-bucket -> where the sub-bucket's tied
-// elements start in the list (in place; totals[0] = list length, totals[1] = buckets).  One workgroup, nb <= 65536.
-__global__ void __launch_bounds__(1024)
-k_tie_scan(uint32_t* __restrict__ counts, uint32_t nb, uint32_t* __restrict__ totals)
-{
-    __shared__ uint32_t part[2][16];
-    unsigned par = 0;
-    uint32_t carry_t = 0, carry_r = 0;
-    for (uint32_t base = 0; base < nb; base += 1024u * 4u) {
-        // four consecutive sub-buckets per thread
-        const uint32_t i0 = base + threadIdx.x * 4u;
-        uint32_t c[4], t = 0, r = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            c[k] = i0 + k < nb ? counts[i0 + k] : 0u;
-            t += c[k] & 0xFFFFu;
-            r += c[k] >> 16;
-        }
-        uint32_t tot_t, tot_r;
-        uint32_t ex = block_scan_excl_1b_total<16>(t, part, par, tot_t);
-        (void)block_scan_excl_1b_total<16>(r, part, par, tot_r);
-        ex += carry_t;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (i0 + k < nb) counts[i0 + k] = ex;
-            ex += c[k] & 0xFFFFu;
-        }
-        carry_t += tot_t;
-        carry_r += tot_r;
-    }
-    if (threadIdx.x == 0) { totals[0] = carry_t; totals[1] = carry_r; }
-}
-// k_tie_collect: one wave per sub-bucket at a time; list position L = base[b] + i of record i: suffix, slot = bstart[b] + place,
-// bucket id = list position of the head of its run (the members of a run are consecutive records).
-__global__ void __launch_bounds__(kBlock)
-k_tie_collect(const uint64_t* __restrict__ rec, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ base, uint32_t nb,
-              const uint32_t* __restrict__ totals, uint32_t* __restrict__ S, uint32_t* __restrict__ V, uint32_t* __restrict__ G)
-{
-    const unsigned lane = lane_id();
-    const uint32_t nwaves = gridDim.x * kWavesPerBlock, total = totals[0];
-    for (uint32_t b = blockIdx.x * kWavesPerBlock + wave_id(); b < nb; b += nwaves) {
-        const uint32_t at = base[b], cnt = (b + 1u < nb ? base[b + 1u] : total) - at;
-        if (cnt == 0u) continue;
-        const uint32_t begin = bstart[b];
-        for (uint32_t i = lane; i < cnt; i += kWave) {
-            const uint64_t r = rec[(uint64_t)begin + i];
-            const uint32_t place = ((uint32_t)r >> 16) & 0xFFFFu, head = (uint32_t)r & 0xFFFFu;
-            const uint32_t L = at + i;
-            V[L] = (uint32_t)(r >> 32);
-            S[L] = begin + place;
-            G[L] = L - (place - head);
-        }
-    }
-}
-
 // K,V: sorted keys / suffixes of the m active elements; S: their SA slots in
 // ascending order (nullptr = identity).  Writes SA[slot] = suffix (skipped when
 // sa_in_place: V IS the SA and slots are the identity -- the last radix pass of the
@@ -1212,6 +1154,153 @@ k_small_groups(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, c
         flag[pos] = ties ? 1u : 0u;
         sa[S[pos]] = my;                                         // keeps sa a permutation even where unresolved
         if (isa) isa[my] = S[cls];                               // final slot, or the tie class's head slot
+    }
+}
+
+// ---- the tie records of the hybrid initial sort (TieRecords, sfx_host.hpp; round 6) ----------------------------------------
+// The LDS sort of a sub-bucket knows which of its elements share their whole key with a neighbour; k_groups_reduce /
+// k_groups_apply found the same out by reading the sorted keys and suffixes again (12 bytes per suffix for the 2.3 % of them
+// that stay tied on uniform DNA).  A record: suffix << 32 | place in the sub-bucket << 16 | place of the head of its run; the
+// records of sub-bucket b lie in rec[bstart[b] ..) in no particular order, counts[b] = tied | runs << 16.
+//
+// k_tie_direct: one wave per sub-bucket orders the runs of up to kSmallCap members on the text, as k_small_groups does for
+// the buckets of an active list -- every member to its place among the run's places (members that tie with each other on
+// kSmallDepthWords more words keep adjacent places, in record order: the array stays a permutation).  totals[0] = tied elements,
+// [1] = runs, [2] = elements left unresolved (ties beyond the depth, runs above kSmallCap, sub-buckets with more than
+// kTieDirectMax records).  Uniform DNA leaves none: the build is done.  Otherwise the records -- untouched here -- become the first
+// active list (k_tie_scan, k_tie_collect) and the direct pass of the list does the same comparisons again, to the same places.
+constexpr uint32_t kTieDirectMax = 4 * kWave;                     // records of a sub-bucket one wave stages in LDS
+__global__ void __launch_bounds__(kBlock)
+k_tie_direct(const uint64_t* __restrict__ rec, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ counts, uint32_t nb,
+             PackedText t, uint64_t h, uint32_t* __restrict__ sa, uint32_t* __restrict__ totals)
+{
+    __shared__ uint64_t s_rec[kWavesPerBlock][kTieDirectMax];
+    const unsigned lane = lane_id(), w = wave_id();
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    uint32_t n_tied = 0, n_runs = 0, n_left = 0;                  // (per lane; summed over the wave at the end)
+    uint32_t b = blockIdx.x * kWavesPerBlock + w;
+    uint32_t c_next = b < nb ? counts[b] : 0u, begin_next = b < nb ? bstart[b] : 0u;
+    for (; b < nb; b += nwaves) {
+        const uint32_t c = c_next, begin = begin_next;
+        if (b + nwaves < nb) { c_next = counts[b + nwaves]; begin_next = bstart[b + nwaves]; }
+        const uint32_t cnt = c & 0xFFFFu;
+        if (cnt == 0u) continue;
+        if (lane == 0) { n_tied += cnt; n_runs += c >> 16; }
+        if (cnt > kTieDirectMax) {
+            if (lane == 0) n_left += cnt;
+            continue;
+        }
+        for (uint32_t i = lane; i < cnt; i += kWave) s_rec[w][i] = rec[(uint64_t)begin + i];
+        wave_sync();
+        for (uint32_t i = lane; i < cnt; i += kWave) {
+            const uint64_t mine = s_rec[w][i];
+            const uint32_t my = (uint32_t)(mine >> 32), head = (uint32_t)mine & 0xFFFFu;
+            uint32_t members = 0, smaller = 0, ties = 0, ties_before = 0;
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint64_t o = s_rec[w][j];
+                if (((uint32_t)o & 0xFFFFu) != head) continue;
+                members++;
+                if (j == i || members > (uint32_t)kSmallCap) continue;
+                const int cmp = direct_compare(t, (uint64_t)my, (uint64_t)(o >> 32), h);
+                if (cmp > 0) smaller++;
+                else if (cmp == 0) { ties++; if (j < i) ties_before++; }
+            }
+            if (members > (uint32_t)kSmallCap) { n_left++; continue; }          // (a large run: untouched)
+            sa[(uint64_t)begin + head + smaller + ties_before] = my;
+            if (ties) n_left++;
+        }
+        wave_sync();                                                            // (the staged records are read to the end)
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        n_tied += (uint32_t)__shfl_xor(n_tied, d);
+        n_runs += (uint32_t)__shfl_xor(n_runs, d);
+        n_left += (uint32_t)__shfl_xor(n_left, d);
+    }
+    if (lane == 0) {
+        if (n_tied) atomicAdd(&totals[0], n_tied);
+        if (n_runs) atomicAdd(&totals[1], n_runs);
+        if (n_left) atomicAdd(&totals[2], n_left);
+    }
+}
+// k_tie_scan: counts[b] -> where the sub-bucket's tied elements start in the list (in place; totals[0] = list length,
+// totals[1] = buckets).  One workgroup, nb <= 65536.
+__global__ void __launch_bounds__(1024)
+k_tie_scan(uint32_t* __restrict__ counts, uint32_t nb, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t part[2][16];
+    unsigned par = 0;
+    uint32_t carry_t = 0, carry_r = 0;
+    for (uint32_t base = 0; base < nb; base += 1024u * 4u) {
+        // four consecutive sub-buckets per thread
+        const uint32_t i0 = base + threadIdx.x * 4u;
+        uint32_t c[4], t = 0, r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c[k] = i0 + k < nb ? counts[i0 + k] : 0u;
+            t += c[k] & 0xFFFFu;
+            r += c[k] >> 16;
+        }
+        uint32_t tot_t, tot_r;
+        uint32_t ex = block_scan_excl_1b_total<16>(t, part, par, tot_t);
+        (void)block_scan_excl_1b_total<16>(r, part, par, tot_r);
+        ex += carry_t;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < nb) counts[i0 + k] = ex;
+            ex += c[k] & 0xFFFFu;
+        }
+        carry_t += tot_t;
+        carry_r += tot_r;
+    }
+    if (threadIdx.x == 0) { totals[0] = carry_t; totals[1] = carry_r; }
+}
+// k_tie_collect: one workgroup per sub-bucket at a time.  The records of a sub-bucket are in no order, the list is in slot
+// order: a bit mask over the sub-bucket's places (16384 at most) ranks the tied places; list position L = base[b] + rank of
+// the record's place: suffix, slot = bstart[b] + place, bucket id = list position of the head of its run.
+constexpr int kTieMaskWords = 16384 / 32;
+__global__ void __launch_bounds__(kBlock)
+k_tie_collect(const uint64_t* __restrict__ rec, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ base, uint32_t nb,
+              const uint32_t* __restrict__ totals, uint32_t* __restrict__ S, uint32_t* __restrict__ V, uint32_t* __restrict__ G)
+{
+    __shared__ uint32_t mask[kTieMaskWords];
+    __shared__ uint32_t wpre[kTieMaskWords];
+    __shared__ uint32_t part[2][kWavesPerBlock];
+    const unsigned tid = threadIdx.x;
+    unsigned par = 0;
+    const uint32_t total = totals[0];
+    for (unsigned i = tid; i < (unsigned)kTieMaskWords; i += kBlock) mask[i] = 0u;
+    __syncthreads();
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const uint32_t at = base[b], cnt = (b + 1u < nb ? base[b + 1u] : total) - at;
+        if (cnt == 0u) continue;                                                // (block-uniform)
+        const uint32_t begin = bstart[b], size = bstart[b + 1u] - begin;
+        const uint32_t words = (size + 31u) / 32u;                              // <= kTieMaskWords: the LDS sort holds 16384 at most
+        for (uint32_t i = tid; i < cnt; i += kBlock) {
+            const uint32_t place = ((uint32_t)rec[(uint64_t)begin + i] >> 16) & 0xFFFFu;
+            atomicOr(&mask[place >> 5], 1u << (place & 31u));
+        }
+        __syncthreads();
+        uint32_t carry = 0;
+        for (uint32_t w0 = 0; w0 < words; w0 += kBlock) {                       // (block-uniform trip count)
+            const uint32_t wd = w0 + tid;
+            const uint32_t c = wd < words ? (uint32_t)__popc(mask[wd]) : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_scan_excl_1b_total<kWavesPerBlock>(c, part, par, tot);
+            if (wd < words) wpre[wd] = carry + ex;
+            carry += tot;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += kBlock) {
+            const uint64_t r = rec[(uint64_t)begin + i];
+            const uint32_t place = ((uint32_t)r >> 16) & 0xFFFFu, head = (uint32_t)r & 0xFFFFu;
+            const uint32_t L = at + wpre[place >> 5] + (uint32_t)__popc(mask[place >> 5] & ((1u << (place & 31u)) - 1u));
+            V[L] = (uint32_t)(r >> 32);
+            S[L] = begin + place;
+            G[L] = L - (place - head);                                          // (every place of a run is tied: its members are consecutive)
+        }
+        __syncthreads();
+        for (uint32_t wd = tid; wd < words; wd += kBlock) mask[wd] = 0u;
+        __syncthreads();
     }
 }
 
@@ -2032,18 +2121,30 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
             if (((x * fuse.inv_bits) >> 16) != x / (unsigned)pt.bits) return SFX_ERR_INTERNAL;
     }
     if (ties.produced) {
-        // every suffix sits in its slot of the array; the tied ones (slot, suffix, bucket) are listed from the sort's own records
+        // every suffix sits in a slot of its run of equal keys; the runs are ordered on the text where they are (k_tie_direct) ...
         if (ht || lcp_fuse) return SFX_ERR_INTERNAL;
-        SFX_LAUNCH("tie_scan", (double)ties.nbuckets * 8, k_tie_scan, 1, 1024, st, ties.counts, ties.nbuckets, b.totals);
-        uint32_t host_totals[2] = {0, 0};
+        SFX_HIP(hipMemsetAsync(b.totals, 0, 4 * sizeof(uint32_t), st));
+        {
+            const unsigned grid = (unsigned)dmin<uint64_t>((ties.nbuckets + kWavesPerBlock - 1) / kWavesPerBlock, kMaxGrid);
+            SFX_LAUNCH("tie_direct", (double)ties.nbuckets * 8, k_tie_direct, grid, kBlock, st, ties.rec, ties.bstart, (const uint32_t*)ties.counts,
+                       ties.nbuckets, pt, (uint64_t)cpk, sa, b.totals);
+        }
+        uint32_t host_totals[3] = {0, 0, 0};
         SFX_TRY(read_back(host_totals, b.totals, sizeof(host_totals), st));
         kept = host_totals[0];
         groups = host_totals[1];
-        if (kept > count || groups * 2 > kept) return SFX_ERR_INTERNAL;
+        if (kept > count || groups * 2 > kept || host_totals[2] > kept) return SFX_ERR_INTERNAL;
         stats.active_after_initial = kept;
-        if (kept > 0) {
-            const unsigned grid = (unsigned)dmin<uint64_t>((ties.nbuckets + kWavesPerBlock - 1) / kWavesPerBlock, kMaxGrid);
-            SFX_LAUNCH("tie_collect", (double)ties.nbuckets * 8 + (double)kept * 20, k_tie_collect, grid, kBlock, st, ties.rec, ties.bstart,
+        if (host_totals[2] == 0) {
+            stats.small_bucket_resolved += kept;
+            return SFX_OK;
+        }
+        // ... and what that leaves tied (repeats beyond the direct pass's depth, large runs) goes on as the first active list: ALL
+        // the tied elements, from the records -- its direct pass redoes the runs that k_tie_direct finished, to the same places
+        SFX_LAUNCH("tie_scan", (double)ties.nbuckets * 8, k_tie_scan, 1, 1024, st, ties.counts, ties.nbuckets, b.totals);
+        {
+            const unsigned grid = (unsigned)dmin<uint64_t>(ties.nbuckets, kMaxGrid);
+            SFX_LAUNCH("tie_collect", (double)ties.nbuckets * 8 + (double)kept * 28, k_tie_collect, grid, kBlock, st, ties.rec, ties.bstart,
                        (const uint32_t*)ties.counts, ties.nbuckets, (const uint32_t*)b.totals, b.S0, V_next, b.G);
         }
         uint32_t* S_cur = b.S0;

@@ -51,16 +51,17 @@ if os.environ.get("SFX_HYBRID_MIN"):
     texts.append(b"".join(blocks[int(k)] + bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for k in rngh.integers(0, 4, 3600)))
     texts += [_gen.uniform_bytes(12000, 5, 2, base=65).tobytes(), _gen.uniform_bytes(12000, 16, 3, base=65).tobytes(),
               _gen.uniform_bytes(14000, 2, 4, base=65).tobytes()]
-    # one 13-symbol block, each copy followed by 3 random symbols: a sub-bucket of ~700 suffixes that all fall into ONE group of
-    # the LDS sort's fast path (the group is the top 10 of the 16 low key bits) -> the stable LSD rounds, with runs of ~11 equal
-    # 16-symbol keys: the tie records (round 6) from neighbours in the staging buffer instead of from the group scan
     # one 8-symbol block followed by one of 700 8-symbol tails, every tail twice: a sub-bucket of ~1400 suffixes in 700 runs of
-    # two equal keys, spread over the groups of the fast path -- more tied elements than the staging buffer has room behind the
-    # sub-bucket (2048 - 1400), so the groups are scanned a second time for the records
+    # two equal keys, spread over the groups of the fast path -- more records than k_tie_direct stages per sub-bucket (256): the
+    # whole sub-bucket is left to the first active list (k_tie_scan, k_tie_collect: unordered records -> slot order)
     b8 = bytes(rngh.choice(list(b"ACGT"), 8).tolist())
     tails = [bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for _ in range(700)]
     order = rngh.permutation(1400) % 700
-    texts.append(b"".join(b8 + tails[int(k)] + bytes(rngh.choice(list(b"ACGT"), 9).tolist()) for k in order))
+    runs_of_two = b"".join(b8 + tails[int(k)] + bytes(rngh.choice(list(b"ACGT"), 9).tolist()) for k in order)
+    texts.append(runs_of_two)
+    # one 13-symbol block, each copy followed by 3 random symbols: a sub-bucket of ~700 suffixes that all fall into ONE group of
+    # the LDS sort's fast path (the group is the top 10 of the 16 low key bits) -> the stable LSD rounds, with runs of ~11 equal
+    # 16-symbol keys: the tie records (round 6) from neighbours in the staging buffer instead of from the group scan
     b13 = bytes(rngh.choice(list(b"ACGT"), 13).tolist())
     texts.append(_gen.dna(9000, seed=21).tobytes() + b"".join(b13 + bytes(rngh.choice(list(b"ACGT"), 3).tolist()) for _ in range(700)))
     from suffix_amd import device as sdev
@@ -87,10 +88,15 @@ if os.environ.get("SFX_HYBRID_MIN"):
     # (cap 3: 6 % of that text sits in sub-buckets of more than 3 suffixes -- above the 1/64 the route tolerates)
     assert ("bucket_sort_lds" in names) == (cap > 10) and "oversize_gather" not in names, names
     # round 6: with no oversized sub-bucket the LDS sort names the tied elements itself -- no keys written, none read back
-    assert ("tie_scan" in names) == (cap > 10 and ties_on) and ("groups_reduce" in names) != ("tie_scan" in names), names
+    assert ("tie_direct" in names) == (cap > 10 and ties_on) and ("groups_reduce" in names) != ("tie_direct" in names), names
+    if cap >= 100000 and ties_on:
+        # the sub-bucket of 700 runs of two: left to the list; random DNA: everything ordered where it is, no list at all
+        names2 = kernels_of(runs_of_two)
+        assert "tie_collect" in names2 and "small_groups" in names2, names2
+        assert "tie_collect" not in names and "small_groups" not in names, names
     names = kernels_of(planted)                                       # 0.8 % of it in the three planted sub-buckets
     assert ("bucket_sort_lds" in names) == (cap > 10) and ("oversize_gather" in names) == (10 < cap < 400), names
-    assert ("tie_scan" in names) == (cap >= 400 and ties_on), names   # (an oversized sub-bucket: the sorted keys, as before)
+    assert ("tie_direct" in names) == (cap >= 400 and ties_on), names   # (an oversized sub-bucket: the sorted keys, as before)
     # most of the suffixes in oversized sub-buckets: the four-pass sort
     skewed = np.frombuffer(b"ACGT", dtype=np.uint8)[rngh.choice(4, size=20000, p=[0.85, 0.05, 0.05, 0.05])].tobytes()
     texts.append(skewed)
@@ -109,7 +115,7 @@ if os.environ.get("SFX_HYBRID_MIN"):
         # (one rank = the whole key space: no filter, the text-fed route of the full build)
         assert ("radix_hist16_elems" in seen) == (nr == 3) and ("radix_hist16_text" in seen) == (nr == 1), (nr, seen)
         assert ("bucket_sort_lds" in seen) == (cap > 10 and nr < 7) and ("range_emit" in seen) == (nr > 1), (nr, seen)
-        assert ("tie_scan" in seen) == (cap > 10 and nr < 7 and ties_on), (nr, seen)         # (slices take the records too)
+        assert ("tie_direct" in seen) == (cap > 10 and nr < 7 and ties_on), (nr, seen)       # (slices take the records too)
     if cap < 400:
         _cases.range_slices(eng, oracle, planted, 3, packed=True)
         _cases.range_slices(eng, oracle, skewed, 2, packed=True)
