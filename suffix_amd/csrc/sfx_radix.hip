@@ -1344,35 +1344,32 @@ constexpr int kGroups = 1 << kGroupBits;
 // TIES (round 6): the sort also says which of its elements share their whole key with a neighbour -- the members of the buckets
 // the refinement has to go on with -- so that nobody reads the sorted keys again (k_groups_reduce / k_groups_apply re-read 4 + 8
 // bytes per suffix that this kernel had in LDS a moment before: 0.19 of the headline's 1.50 ms).  Keys are not written at all.
-// Every tied element leaves a record somewhere in REC[begin, begin + tied elements of the sub-bucket):
-//     suffix << 32 | place in the sub-bucket << 16 | place of the first member of its run of equal keys
-// and the sub-bucket its counts, tcount[b] = tied elements | runs << 16.  On the fast path the thread that places an element has
-// seen every member of its group, hence of its run: the head of the run is its own place minus the members of the run below it,
-// and the record goes where a returning LDS atomic says -- no order among the records of a sub-bucket, no barrier, no state.
-// After the LSD rounds (skewed sub-buckets) a run is a run of neighbours in the staging buffer: two bit masks over the places
-// (tied, first of its run) give every tied element its index among them and the head of its run.  k_tie_direct (sfx_sa.hip)
-// orders the runs on the text where they are; what it cannot finish goes through k_tie_scan / k_tie_collect into the first
-// active list.
+// What leaves instead is two bits per place of the sub-bucket, as two bit masks: `tied` (the element shares its key with another)
+// and `head` (it is the first of its run of equal keys: runs are runs of neighbours in the sorted order, so the masks say where
+// every run starts and ends, and the array itself holds the suffixes).  On the fast path the thread that places an element has
+// seen every member of its group, hence of its run: two fire-and-forget LDS atomics, no barrier of their own; after the LSD
+// rounds a run is a run of neighbours in the staging buffer.  The mask words of sub-bucket b go to word tie_mask_word(begin, b)
+// of two global arrays (a sub-bucket's words are its own: begin / 32 + b leaves every sub-bucket ceil(size / 32) words).
+// k_tie_direct (sfx_sa.hip) orders the runs on the text where they are; what it cannot finish goes through k_tie_scan /
+// k_tie_collect into the first active list.
 template <int WORDS, bool ON>
 struct TieSmem {
-    uint32_t tmask[WORDS], hmask[WORDS];                            // (the LSD path only)
-    uint32_t wpre[WORDS];
-    uint32_t nrec;                                                  // fast path: tied | runs << 16 so far
+    uint32_t tmask[WORDS], hmask[WORDS];
 };
 template <int WORDS>
 struct TieSmem<WORDS, false> {};
 template <int NW, int KPT, bool TIES = false>
 __global__ void __launch_bounds__(NW * kWave) SFX_WAVES_PER_EU(NW == 4 && KPT == 8 ? 6 : 1, 8)
 k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstart, uint32_t nbuckets, int low_bits,
-              uint32_t lo, uint32_t hi, uint32_t* __restrict__ K, uint32_t* __restrict__ V, uint64_t* __restrict__ REC = nullptr,
-              uint32_t* __restrict__ tcount = nullptr)
+              uint32_t lo, uint32_t hi, uint32_t* __restrict__ K, uint32_t* __restrict__ V, uint32_t* __restrict__ GT = nullptr,
+              uint32_t* __restrict__ GH = nullptr)
 {
     constexpr int kThreads = NW * kWave;
     constexpr uint32_t kCap = kThreads * KPT;
     constexpr int kMaskWords = (int)(kCap / 32u);
     static_assert(kWave * KPT >= kRadix, "the match masks must fit the staging buffer");
     static_assert(NW * kRadix >= kGroups && kGroups % (NW * kWave) == 0, "the group counts of the fast path live in cnt");
-    static_assert(kCap <= 16384u && kMaskWords <= kThreads, "a record holds 14-bit places; one thread per mask word");
+    static_assert(kMaskWords <= kThreads, "one thread per mask word");
     __shared__ struct {
         uint32_t cnt[NW][kRadix];                                   // LSD rounds: per-wave digit counts; fast path: the group counts
         uint16_t gstart[kGroups];                                   // (sub-buckets hold at most 4096 elements)
@@ -1393,7 +1390,6 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
     }
     if constexpr (TIES) {
         if (tid < (unsigned)kMaskWords) s.tie.tmask[tid] = s.tie.hmask[tid] = 0u;
-        if (tid == 0) s.tie.nrec = 0u;
     }
     __syncthreads();
     // Two sub-buckets ahead: the bounds of bucket b + 2 G and the elements of bucket b + G are requested before
@@ -1427,41 +1423,17 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
         const unsigned kpt = (size + kThreads - 1) / kThreads;                  // rounds in use, <= KPT
         const unsigned per = kpt * kWave;
         bool pairs = false;
-        // TIES, after the LSD rounds: the records of this sub-bucket's tied elements once their masks are complete (the sorted
-        // sub-bucket lies in the staging buffer and in key[])
-        auto tie_records_lsd = [&]() {
+        // TIES: the sub-bucket's mask words leave for the global arrays (and the LDS copies are cleared for the next sub-bucket);
+        // the caller has a barrier between the last atomic on the masks and this
+        auto tie_masks_out = [&]() {
           if constexpr (TIES) {
-            __syncthreads();
-            uint32_t tc = 0, hc = 0;
-            if (tid < (unsigned)kMaskWords) {
-                tc = (uint32_t)__popc(s.tie.tmask[tid]);
-                hc = (uint32_t)__popc(s.tie.hmask[tid]);
-            }
-            uint32_t total;
-            const uint32_t ex = block_scan_excl_1b_total<NW>(tc | (hc << 16), s.part, par, total);   // (tied <= 16384 < 2^16: no carry into the runs)
-            if (tid < (unsigned)kMaskWords) s.tie.wpre[tid] = ex & 0xFFFFu;
-            if (tid == 0) tcount[b] = total;                                    // tied | runs << 16
-            __syncthreads();
-            if ((total & 0xFFFFu) != 0u) {
-#pragma unroll
-                for (int r = 0; r < KPT; r++) {
-                    const unsigned idx = w * per + r * kWave + lane;
-                    if ((unsigned)r < kpt && idx < size) {
-                        const uint32_t k32 = (uint32_t)(key[r] >> 32);
-                        const bool eq_prev = idx > 0u && (uint32_t)(s.stage[idx - 1u] >> 32) == k32;
-                        const bool eq_next = idx + 1u < size && (uint32_t)(s.stage[idx + 1u] >> 32) == k32;
-                        if (eq_prev || eq_next) {
-                            const uint32_t wd = idx >> 5, bit = idx & 31u;
-                            const uint32_t i = s.tie.wpre[wd] + (uint32_t)__popc(s.tie.tmask[wd] & ((1u << bit) - 1u));
-                            uint32_t hw = wd, hm = s.tie.hmask[wd] & (0xFFFFFFFFu >> (31u - bit));
-                            while (hm == 0u) hm = s.tie.hmask[--hw];            // (a run starts at its first member: there is a bit at or below)
-                            const uint32_t head = hw * 32u + 31u - (uint32_t)__clz((int)hm);
-                            REC[(uint64_t)begin + i] = ((uint64_t)(uint32_t)key[r] << 32) | (uint64_t)((idx << 16) | head);
-                        }
-                    }
-                }
-                __syncthreads();
-                if (tid < (unsigned)kMaskWords) s.tie.tmask[tid] = s.tie.hmask[tid] = 0u;   // (clean for the next skewed sub-bucket)
+            const uint32_t words = (size + 31u) >> 5;
+            if (tid < words) {
+                const uint64_t at = tie_mask_word(begin, b) + tid;
+                GT[at] = s.tie.tmask[tid];
+                GH[at] = s.tie.hmask[tid];
+                s.tie.tmask[tid] = 0u;
+                s.tie.hmask[tid] = 0u;
             }
           }
         };
@@ -1514,9 +1486,8 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                         const unsigned place = gb + rank;
                         V[(uint64_t)begin + place] = (uint32_t)e;
                         if (same > 1u) {
-                            // (equal keys are neighbours in the sorted order: the run starts same_below places below)
-                            const uint32_t at = atomicAdd(&s.tie.nrec, same_below == 0u ? 0x10001u : 1u) & 0xFFFFu;
-                            REC[(uint64_t)begin + at] = (e << 32) | (uint64_t)((place << 16) | (place - same_below));
+                            atomicOr(&s.tie.tmask[place >> 5], 1u << (place & 31u));
+                            if (same_below == 0u) atomicOr(&s.tie.hmask[place >> 5], 1u << (place & 31u));
                         }
                     }
                 } else {
@@ -1535,12 +1506,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
 #pragma unroll
             for (int k = 0; k < kPerThread; k++) gcount[tid * kPerThread + k] = 0u;
             if (tid == 0) s.big = 0u;
-            if constexpr (TIES) {
-                if (tid == 0 && pairs) {
-                    tcount[b] = s.tie.nrec;                                     // tied | runs << 16
-                    s.tie.nrec = 0u;
-                }
-            }
+            if (pairs) tie_masks_out();
             __syncthreads();
         }
         for (int pass = 0; pass < 2 && size > 1 && !pairs; pass++) {
@@ -1608,7 +1574,10 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
             }
         }
         if constexpr (TIES) {
-            if (size > 1u && !pairs) tie_records_lsd();                         // (block-uniform; the fast path left its records as it went)
+            if (size > 1u && !pairs) {                                          // (block-uniform; the fast path wrote its masks before it let go of the groups)
+                __syncthreads();
+                tie_masks_out();
+            }
         }
         begin = begin1; size = size1;
         begin1 = begin2; size1 = size2;
@@ -2012,15 +1981,22 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     // (development): the sorted keys, as rounds 3-5.
     static const int ties_on = [] { const char* e = dev_env("SFX_HYBRID_TIES"); return e ? atoi(e) : 1; }();
     const bool tie_mode = ties && ties_on && nover == 0;
-    uint32_t* tcount = reinterpret_cast<uint32_t*>(over);      // (the oversize list is idle: 4 * kOversizeMax = 65536 words)
+    uint32_t* tcount = reinterpret_cast<uint32_t*>(over);      // (the oversize list is idle: 4 * kOversizeMax = 65536 words; k_tie_direct fills them)
     static_assert(4 * kOversizeMax >= kH16Bins, "the tie counts of all sub-buckets fit the oversize list");
-    if (tie_mode) SFX_HIP(hipMemsetAsync(tcount, 0, kH16Bins * sizeof(uint32_t), st));
+    // the mask words of all sub-buckets: two arrays of m / 32 + 65536 words -- in e0, which nobody needs once the elements are in
+    // e1; small inputs (the tests: e0 is shorter than that) keep them in the front part of the histogram scratch, idle without
+    // an oversized sub-bucket to sort
+    const uint64_t mask_words = m / 32 + kH16Bins + 64;
+    const bool masks_in_scratch = 2 * mask_words <= (uint64_t)kMaxPasses * kRadix * kHistAllGrid - kReserve;
+    uint32_t* const gt = masks_in_scratch ? scr.partial : reinterpret_cast<uint32_t*>(e0);
+    uint32_t* const gh = gt + mask_words;
+    if (!masks_in_scratch && 2 * mask_words * sizeof(uint32_t) > m * sizeof(uint64_t)) return SFX_ERR_INTERNAL;
 #define SFX_BUCKET_SORT(NW, KPT, LO, HI, GRID)                                                                              \
     do {                                                                                                                    \
         if (tie_mode)                                                                                                       \
-            SFX_LAUNCH("bucket_sort_lds", (double)m * 12.0, (k_bucket_sort<NW, KPT, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
+            SFX_LAUNCH("bucket_sort_lds", (double)m * 12.25, (k_bucket_sort<NW, KPT, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
                        (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, (uint32_t)(LO), (uint32_t)(HI), (uint32_t*)nullptr, split_v, \
-                       e0, tcount);                                                                                         \
+                       gt, gh);                                                                                             \
         else                                                                                                                \
             SFX_LAUNCH("bucket_sort_lds", (double)m * 16.0, (k_bucket_sort<NW, KPT>), GRID, NW * kWave, st, (const uint64_t*)e1, \
                        (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, (uint32_t)(LO), (uint32_t)(HI), split_k, split_v); \
@@ -2031,7 +2007,8 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
 #undef SFX_BUCKET_SORT
     if (tie_mode) {
         ties->produced = true;
-        ties->rec = e0;
+        ties->tmask = gt;
+        ties->hmask = gh;
         ties->bstart = bins;
         ties->counts = tcount;
         ties->nbuckets = (uint32_t)kH16Bins;

@@ -1157,59 +1157,108 @@ k_small_groups(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, c
     }
 }
 
-// ---- the tie records of the hybrid initial sort (TieRecords, sfx_host.hpp; round 6) ----------------------------------------
+// ---- the tie masks of the hybrid initial sort (TieRecords, sfx_host.hpp; round 6) -------------------------------------------
 // The LDS sort of a sub-bucket knows which of its elements share their whole key with a neighbour; k_groups_reduce /
 // k_groups_apply found the same out by reading the sorted keys and suffixes again (12 bytes per suffix for the 2.3 % of them
-// that stay tied on uniform DNA).  A record: suffix << 32 | place in the sub-bucket << 16 | place of the head of its run; the
-// records of sub-bucket b lie in rec[bstart[b] ..) in no particular order, counts[b] = tied | runs << 16.
+// that stay tied on uniform DNA).  Per sub-bucket b of at least two elements, from word tie_mask_word(bstart[b], b) on: tmask (bit
+// p: the element at place p shares its key with a neighbour), hmask (it is the first of its run).  A run = the tied places
+// from a head bit up to the next head bit or untied place; the array holds its suffixes at slots bstart[b] + place.
 //
-// k_tie_direct: one wave per sub-bucket orders the runs of up to kSmallCap members on the text, as k_small_groups does for
-// the buckets of an active list -- every member to its place among the run's places (members that tie with each other on
-// kSmallDepthWords more words keep adjacent places, in record order: the array stays a permutation).  totals[0] = tied elements,
-// [1] = runs, [2] = elements left unresolved (ties beyond the depth, runs above kSmallCap, sub-buckets with more than
-// kTieDirectMax records).  Uniform DNA leaves none: the build is done.  Otherwise the records -- untouched here -- become the first
-// active list (k_tie_scan, k_tie_collect) and the direct pass of the list does the same comparisons again, to the same places.
-constexpr uint32_t kTieDirectMax = 4 * kWave;                     // records of a sub-bucket one wave stages in LDS
+// k_tie_direct: one wave per sub-bucket; the lane that owns the mask word with a run's head bit orders the run on the text (runs
+// of up to kTieRunMax members: insertion sort with direct_compare, as k_small_groups orders the small buckets of an active
+// list) and writes it back in order.  A run it cannot finish -- longer, or two members equal for kSmallDepthWords more words --
+// stays as it is.  counts[b] = tied | runs << 16; totals[0] = tied elements, [1] = runs, [2] = members of unfinished runs.
+// Uniform DNA leaves none: the build is done.  Otherwise ALL runs become the first active list (k_tie_scan, k_tie_collect) and
+// the direct pass of the list redoes the finished ones, to the same places.
+constexpr uint32_t kTieRunMax = 8;
+constexpr int kTieMaskWords = 16384 / 32;                         // the LDS sort takes sub-buckets of 16384 at most
 __global__ void __launch_bounds__(kBlock)
-k_tie_direct(const uint64_t* __restrict__ rec, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ counts, uint32_t nb,
-             PackedText t, uint64_t h, uint32_t* __restrict__ sa, uint32_t* __restrict__ totals)
+k_tie_direct(const uint32_t* __restrict__ tmask, const uint32_t* __restrict__ hmask, const uint32_t* __restrict__ bstart, uint32_t nb,
+             PackedText t, uint64_t h, uint32_t* __restrict__ sa, uint32_t* __restrict__ counts, uint32_t* __restrict__ totals)
 {
-    __shared__ uint64_t s_rec[kWavesPerBlock][kTieDirectMax];
+    __shared__ uint32_t s_t[kWavesPerBlock][kTieMaskWords + 1], s_h[kWavesPerBlock][kTieMaskWords + 1];
     const unsigned lane = lane_id(), w = wave_id();
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
     uint32_t n_tied = 0, n_runs = 0, n_left = 0;                  // (per lane; summed over the wave at the end)
-    uint32_t b = blockIdx.x * kWavesPerBlock + w;
-    uint32_t c_next = b < nb ? counts[b] : 0u, begin_next = b < nb ? bstart[b] : 0u;
-    for (; b < nb; b += nwaves) {
-        const uint32_t c = c_next, begin = begin_next;
-        if (b + nwaves < nb) { c_next = counts[b + nwaves]; begin_next = bstart[b + nwaves]; }
-        const uint32_t cnt = c & 0xFFFFu;
-        if (cnt == 0u) continue;
-        if (lane == 0) { n_tied += cnt; n_runs += c >> 16; }
-        if (cnt > kTieDirectMax) {
-            if (lane == 0) n_left += cnt;
+    for (uint32_t b = blockIdx.x * kWavesPerBlock + w; b < nb; b += nwaves) {
+        const uint32_t begin = bstart[b], size = bstart[b + 1u] - begin;
+        if (size < 2u) {
+            if (lane == 0) counts[b] = 0u;
             continue;
         }
-        for (uint32_t i = lane; i < cnt; i += kWave) s_rec[w][i] = rec[(uint64_t)begin + i];
-        wave_sync();
-        for (uint32_t i = lane; i < cnt; i += kWave) {
-            const uint64_t mine = s_rec[w][i];
-            const uint32_t my = (uint32_t)(mine >> 32), head = (uint32_t)mine & 0xFFFFu;
-            uint32_t members = 0, smaller = 0, ties = 0, ties_before = 0;
-            for (uint32_t j = 0; j < cnt; j++) {
-                const uint64_t o = s_rec[w][j];
-                if (((uint32_t)o & 0xFFFFu) != head) continue;
-                members++;
-                if (j == i || members > (uint32_t)kSmallCap) continue;
-                const int cmp = direct_compare(t, (uint64_t)my, (uint64_t)(o >> 32), h);
-                if (cmp > 0) smaller++;
-                else if (cmp == 0) { ties++; if (j < i) ties_before++; }
-            }
-            if (members > (uint32_t)kSmallCap) { n_left++; continue; }          // (a large run: untouched)
-            sa[(uint64_t)begin + head + smaller + ties_before] = my;
-            if (ties) n_left++;
+        const uint32_t words = (size + 31u) >> 5;                 // <= kTieMaskWords
+        const uint64_t at = tie_mask_word(begin, b);
+        uint32_t c_t = 0, c_h = 0;
+        for (uint32_t i = lane; i < words; i += kWave) {
+            const uint32_t mt = tmask[at + i], mh = hmask[at + i];
+            s_t[w][i] = mt;
+            s_h[w][i] = mh;
+            c_t += (uint32_t)__popc(mt);
+            c_h += (uint32_t)__popc(mh);
         }
-        wave_sync();                                                            // (the staged records are read to the end)
+        if (lane == 0) { s_t[w][words] = 0u; s_h[w][words] = 0u; }               // (a run ends at the end of the sub-bucket)
+        for (int d = 32; d >= 1; d >>= 1) {
+            c_t += (uint32_t)__shfl_xor(c_t, d);
+            c_h += (uint32_t)__shfl_xor(c_h, d);
+        }
+        if (lane == 0) { counts[b] = c_t | (c_h << 16); n_tied += c_t; n_runs += c_h; }
+        wave_sync();
+        if (c_t != 0u) {
+            for (uint32_t i = lane; i < words; i += kWave) {
+                uint32_t heads = s_h[w][i];
+                while (heads != 0u) {
+                    const uint32_t bit = (uint32_t)__ffs((int)heads) - 1u;
+                    heads &= heads - 1u;
+                    const uint32_t p0 = i * 32u + bit;
+                    // the run: tied places behind the head up to the next head or untied place
+                    uint32_t len = 1;
+                    while (len <= kTieRunMax) {
+                        const uint32_t p = p0 + len;
+                        const bool tied = (s_t[w][p >> 5] >> (p & 31u)) & 1u, head = (s_h[w][p >> 5] >> (p & 31u)) & 1u;
+                        if (!tied || head) break;
+                        len++;
+                    }
+                    if (len > kTieRunMax) {
+                        // (its length is not needed here: count the members for the statistics)
+                        uint32_t p = p0 + len;
+                        while (((s_t[w][p >> 5] >> (p & 31u)) & 1u) && !((s_h[w][p >> 5] >> (p & 31u)) & 1u)) { len++; p++; }
+                        n_left += len;
+                        continue;
+                    }
+                    uint32_t suf[kTieRunMax];
+                    uint32_t* const slot = sa + (uint64_t)begin + p0;
+#pragma unroll
+                    for (uint32_t k = 0; k < kTieRunMax; k++) suf[k] = k < len ? slot[k] : 0u;
+                    // insertion sort on the text; a pair that stays equal leaves the run as it was
+                    bool undecided = false;
+#pragma unroll
+                    for (uint32_t k = 1; k < kTieRunMax; k++) {
+                        if (k < len && !undecided) {
+                            const uint32_t x = suf[k];
+                            uint32_t pos = k;
+#pragma unroll
+                            for (uint32_t q = kTieRunMax - 1; q >= 1; q--) {
+                                if (q <= k && pos == q && !undecided) {
+                                    const int cmp = direct_compare(t, (uint64_t)x, (uint64_t)suf[q - 1], h);
+                                    if (cmp == 0) undecided = true;
+                                    else if (cmp < 0) { suf[q] = suf[q - 1]; pos = q - 1; }
+                                }
+                            }
+                            if (!undecided) {
+#pragma unroll
+                                for (uint32_t q = 0; q < kTieRunMax; q++)
+                                    if (q == pos) suf[q] = x;
+                            }
+                        }
+                    }
+                    if (undecided) { n_left += len; continue; }
+#pragma unroll
+                    for (uint32_t k = 0; k < kTieRunMax; k++)
+                        if (k < len) slot[k] = suf[k];
+                }
+            }
+        }
+        wave_sync();                                                            // (the staged masks are read to the end)
     }
     for (int d = 32; d >= 1; d >>= 1) {
         n_tied += (uint32_t)__shfl_xor(n_tied, d);
@@ -1254,52 +1303,47 @@ k_tie_scan(uint32_t* __restrict__ counts, uint32_t nb, uint32_t* __restrict__ to
     }
     if (threadIdx.x == 0) { totals[0] = carry_t; totals[1] = carry_r; }
 }
-// k_tie_collect: one workgroup per sub-bucket at a time.  The records of a sub-bucket are in no order, the list is in slot
-// order: a bit mask over the sub-bucket's places (16384 at most) ranks the tied places; list position L = base[b] + rank of
-// the record's place: suffix, slot = bstart[b] + place, bucket id = list position of the head of its run.
-constexpr int kTieMaskWords = 16384 / 32;
+// k_tie_collect: one workgroup per sub-bucket at a time; the tied places in ascending order are the list: position L = base[b] +
+// tied places below: suffix = the array's entry, slot = bstart[b] + place, bucket id = list position of the head of its run
+// (every place of a run is tied: the distance to the head is the same in the list as in the array).
 __global__ void __launch_bounds__(kBlock)
-k_tie_collect(const uint64_t* __restrict__ rec, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ base, uint32_t nb,
-              const uint32_t* __restrict__ totals, uint32_t* __restrict__ S, uint32_t* __restrict__ V, uint32_t* __restrict__ G)
+k_tie_collect(const uint32_t* __restrict__ tmask, const uint32_t* __restrict__ hmask, const uint32_t* __restrict__ bstart,
+              const uint32_t* __restrict__ base, uint32_t nb, const uint32_t* __restrict__ totals, const uint32_t* __restrict__ sa,
+              uint32_t* __restrict__ S, uint32_t* __restrict__ V, uint32_t* __restrict__ G)
 {
-    __shared__ uint32_t mask[kTieMaskWords];
-    __shared__ uint32_t wpre[kTieMaskWords];
+    __shared__ uint32_t s_t[kTieMaskWords], s_h[kTieMaskWords], wpre[kTieMaskWords];
     __shared__ uint32_t part[2][kWavesPerBlock];
     const unsigned tid = threadIdx.x;
     unsigned par = 0;
     const uint32_t total = totals[0];
-    for (unsigned i = tid; i < (unsigned)kTieMaskWords; i += kBlock) mask[i] = 0u;
-    __syncthreads();
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const uint32_t at = base[b], cnt = (b + 1u < nb ? base[b + 1u] : total) - at;
         if (cnt == 0u) continue;                                                // (block-uniform)
         const uint32_t begin = bstart[b], size = bstart[b + 1u] - begin;
-        const uint32_t words = (size + 31u) / 32u;                              // <= kTieMaskWords: the LDS sort holds 16384 at most
-        for (uint32_t i = tid; i < cnt; i += kBlock) {
-            const uint32_t place = ((uint32_t)rec[(uint64_t)begin + i] >> 16) & 0xFFFFu;
-            atomicOr(&mask[place >> 5], 1u << (place & 31u));
-        }
-        __syncthreads();
+        const uint32_t words = (size + 31u) >> 5;
+        const uint64_t mw = tie_mask_word(begin, b);
         uint32_t carry = 0;
         for (uint32_t w0 = 0; w0 < words; w0 += kBlock) {                       // (block-uniform trip count)
             const uint32_t wd = w0 + tid;
-            const uint32_t c = wd < words ? (uint32_t)__popc(mask[wd]) : 0u;
+            uint32_t mt = 0;
+            if (wd < words) { mt = tmask[mw + wd]; s_t[wd] = mt; s_h[wd] = hmask[mw + wd]; }
             uint32_t tot;
-            const uint32_t ex = block_scan_excl_1b_total<kWavesPerBlock>(c, part, par, tot);
+            const uint32_t ex = block_scan_excl_1b_total<kWavesPerBlock>((uint32_t)__popc(mt), part, par, tot);
             if (wd < words) wpre[wd] = carry + ex;
             carry += tot;
         }
         __syncthreads();
-        for (uint32_t i = tid; i < cnt; i += kBlock) {
-            const uint64_t r = rec[(uint64_t)begin + i];
-            const uint32_t place = ((uint32_t)r >> 16) & 0xFFFFu, head = (uint32_t)r & 0xFFFFu;
-            const uint32_t L = at + wpre[place >> 5] + (uint32_t)__popc(mask[place >> 5] & ((1u << (place & 31u)) - 1u));
-            V[L] = (uint32_t)(r >> 32);
-            S[L] = begin + place;
-            G[L] = L - (place - head);                                          // (every place of a run is tied: its members are consecutive)
+        for (uint32_t p = tid; p < size; p += kBlock) {
+            const uint32_t wd = p >> 5, bit = p & 31u;
+            if (!((s_t[wd] >> bit) & 1u)) continue;
+            const uint32_t L = at + wpre[wd] + (uint32_t)__popc(s_t[wd] & ((1u << bit) - 1u));
+            uint32_t hw = wd, hm = s_h[wd] & (0xFFFFFFFFu >> (31u - bit));
+            while (hm == 0u) hm = s_h[--hw];                                    // (a run starts at its head: there is a bit at or below)
+            const uint32_t head = hw * 32u + 31u - (uint32_t)__clz((int)hm);
+            V[L] = sa[(uint64_t)begin + p];
+            S[L] = begin + p;
+            G[L] = L - (p - head);
         }
-        __syncthreads();
-        for (uint32_t wd = tid; wd < words; wd += kBlock) mask[wd] = 0u;
         __syncthreads();
     }
 }
@@ -2084,7 +2128,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     uint32_t* V_next;
     bool in_place = false;
     int in1 = 0;
-    TieRecords ties = {false, nullptr, nullptr, nullptr, 0};
+    TieRecords ties = {false, nullptr, nullptr, nullptr, nullptr, 0};
     if (sizeof(KeyT) == 4) {
         // E64 elements; the last pass drops every suffix straight into its SA slot and
         // leaves the sorted 32-bit keys in the element buffer it did not read
@@ -2126,8 +2170,8 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         SFX_HIP(hipMemsetAsync(b.totals, 0, 4 * sizeof(uint32_t), st));
         {
             const unsigned grid = (unsigned)dmin<uint64_t>((ties.nbuckets + kWavesPerBlock - 1) / kWavesPerBlock, kMaxGrid);
-            SFX_LAUNCH("tie_direct", (double)ties.nbuckets * 8, k_tie_direct, grid, kBlock, st, ties.rec, ties.bstart, (const uint32_t*)ties.counts,
-                       ties.nbuckets, pt, (uint64_t)cpk, sa, b.totals);
+            SFX_LAUNCH("tie_direct", (double)count * 0.25 + (double)ties.nbuckets * 8, k_tie_direct, grid, kBlock, st, ties.tmask, ties.hmask,
+                       ties.bstart, ties.nbuckets, pt, (uint64_t)cpk, sa, ties.counts, b.totals);
         }
         uint32_t host_totals[3] = {0, 0, 0};
         SFX_TRY(read_back(host_totals, b.totals, sizeof(host_totals), st));
@@ -2144,8 +2188,9 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         SFX_LAUNCH("tie_scan", (double)ties.nbuckets * 8, k_tie_scan, 1, 1024, st, ties.counts, ties.nbuckets, b.totals);
         {
             const unsigned grid = (unsigned)dmin<uint64_t>(ties.nbuckets, kMaxGrid);
-            SFX_LAUNCH("tie_collect", (double)ties.nbuckets * 8 + (double)kept * 28, k_tie_collect, grid, kBlock, st, ties.rec, ties.bstart,
-                       (const uint32_t*)ties.counts, ties.nbuckets, (const uint32_t*)b.totals, b.S0, V_next, b.G);
+            SFX_LAUNCH("tie_collect", (double)count * 0.25 + (double)ties.nbuckets * 8 + (double)kept * 16, k_tie_collect, grid, kBlock, st, ties.tmask,
+                       ties.hmask, ties.bstart, (const uint32_t*)ties.counts, ties.nbuckets, (const uint32_t*)b.totals, (const uint32_t*)sa, b.S0,
+                       V_next, b.G);
         }
         uint32_t* S_cur = b.S0;
         if (small_groups_pay(kept, groups))

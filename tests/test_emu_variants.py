@@ -52,8 +52,7 @@ if os.environ.get("SFX_HYBRID_MIN"):
     texts += [_gen.uniform_bytes(12000, 5, 2, base=65).tobytes(), _gen.uniform_bytes(12000, 16, 3, base=65).tobytes(),
               _gen.uniform_bytes(14000, 2, 4, base=65).tobytes()]
     # one 8-symbol block followed by one of 700 8-symbol tails, every tail twice: a sub-bucket of ~1400 suffixes in 700 runs of
-    # two equal keys, spread over the groups of the fast path -- more records than k_tie_direct stages per sub-bucket (256): the
-    # whole sub-bucket is left to the first active list (k_tie_scan, k_tie_collect: unordered records -> slot order)
+    # two equal keys, spread over the groups of the fast path (round 6: all of them ordered where they are by k_tie_direct)
     b8 = bytes(rngh.choice(list(b"ACGT"), 8).tolist())
     tails = [bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for _ in range(700)]
     order = rngh.permutation(1400) % 700
@@ -63,7 +62,8 @@ if os.environ.get("SFX_HYBRID_MIN"):
     # the LDS sort's fast path (the group is the top 10 of the 16 low key bits) -> the stable LSD rounds, with runs of ~11 equal
     # 16-symbol keys: the tie records (round 6) from neighbours in the staging buffer instead of from the group scan
     b13 = bytes(rngh.choice(list(b"ACGT"), 13).tolist())
-    texts.append(_gen.dna(9000, seed=21).tobytes() + b"".join(b13 + bytes(rngh.choice(list(b"ACGT"), 3).tolist()) for _ in range(700)))
+    runs_of_eleven = _gen.dna(9000, seed=21).tobytes() + b"".join(b13 + bytes(rngh.choice(list(b"ACGT"), 3).tolist()) for _ in range(700))
+    texts.append(runs_of_eleven)
     from suffix_amd import device as sdev
     for t in texts[:1]:                                 # the fused SA + LCP entry over the same initial sort
         import torch
@@ -90,10 +90,12 @@ if os.environ.get("SFX_HYBRID_MIN"):
     # round 6: with no oversized sub-bucket the LDS sort names the tied elements itself -- no keys written, none read back
     assert ("tie_direct" in names) == (cap > 10 and ties_on) and ("groups_reduce" in names) != ("tie_direct" in names), names
     if cap >= 100000 and ties_on:
-        # the sub-bucket of 700 runs of two: left to the list; random DNA: everything ordered where it is, no list at all
+        # random DNA and the 700 runs of two: every run ordered where it is, no list at all; runs of more than eight members (and
+        # the ones before the repeated block, equal for hundreds of symbols): ALL runs become the first active list
         names2 = kernels_of(runs_of_two)
-        assert "tie_collect" in names2 and "small_groups" in names2, names2
-        assert "tie_collect" not in names and "small_groups" not in names, names
+        assert "tie_collect" not in names and "small_groups" not in names and "tie_collect" not in names2, (names, names2)
+        names2 = kernels_of(runs_of_eleven)
+        assert "tie_scan" in names2 and "tie_collect" in names2 and "deep_wave" in names2, names2    # (runs of eleven: no direct pass of the list)
     names = kernels_of(planted)                                       # 0.8 % of it in the three planted sub-buckets
     assert ("bucket_sort_lds" in names) == (cap > 10) and ("oversize_gather" in names) == (10 < cap < 400), names
     assert ("tie_direct" in names) == (cap >= 400 and ties_on), names   # (an oversized sub-bucket: the sorted keys, as before)
