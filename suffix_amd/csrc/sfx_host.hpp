@@ -203,20 +203,14 @@ struct BuildStats;   // = sfx_build_stats
 uint64_t radix_scratch_words(uint64_t m);
 //    `ties` (with split_v; round 6): a caller that only needs to know WHICH elements share their whole key with a neighbour, not
 //    the sorted keys.  When the hybrid route runs and no sub-bucket is oversized, its LDS sort (k_bucket_sort<.., true>) writes no
-//    keys (*split_k_out = nullptr) and leaves, for every sub-bucket b of the top 16 key bits that holds at least two elements, two
-//    bit masks over its places (slot of a place = bstart[b] + place; split_v holds every suffix at its slot) from word
-//    tie_mask_word(bstart[b], b) on: tmask = the element shares its key with a neighbour, hmask = it is the first of such a run.
-//    counts (nbuckets words) is scratch for the caller.  produced = false: the sorted keys are in *split_k_out as always.  All
-//    pointers stay valid until the scratch or e0 / e1 are written again.
+//    keys (*split_k_out = nullptr) and leaves two bit masks over the m slots of split_v (bit r & 31 of word r / 32 = slot r): tmask
+//    = the element shares its key with a neighbour, hmask = it is the first of such a run.  produced = false: the sorted keys
+//    are in *split_k_out as always.  The masks stay valid until e0 / e1 are written again.
 struct TieRecords {
     bool produced;
     const uint32_t* tmask;
     const uint32_t* hmask;
-    const uint32_t* bstart;        // nbuckets + 1 starts
-    uint32_t* counts;              // nbuckets
-    uint32_t nbuckets;
 };
-__host__ __device__ inline uint64_t tie_mask_word(uint32_t begin, uint32_t b) { return (uint64_t)(begin >> 5) + b; }
 //    A producer that had the keys in registers anyway (the range filter) may have counted the
 //    digits itself: `hist_blocks` workgroups' counts at radix_partial(scratch)[(pass * 256 +
 //    digit) * hist_blocks + workgroup]; only honoured when radix_e64_presort_hist() said so.

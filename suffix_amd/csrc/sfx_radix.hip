@@ -1344,17 +1344,18 @@ constexpr int kGroups = 1 << kGroupBits;
 // TIES (round 6): the sort also says which of its elements share their whole key with a neighbour -- the members of the buckets
 // the refinement has to go on with -- so that nobody reads the sorted keys again (k_groups_reduce / k_groups_apply re-read 4 + 8
 // bytes per suffix that this kernel had in LDS a moment before: 0.19 of the headline's 1.50 ms).  Keys are not written at all.
-// What leaves instead is two bits per place of the sub-bucket, as two bit masks: `tied` (the element shares its key with another)
-// and `head` (it is the first of its run of equal keys: runs are runs of neighbours in the sorted order, so the masks say where
-// every run starts and ends, and the array itself holds the suffixes).  On the fast path the thread that places an element has
-// seen every member of its group, hence of its run: two fire-and-forget LDS atomics, no barrier of their own; after the LSD
-// rounds a run is a run of neighbours in the staging buffer.  The mask words of sub-bucket b go to word tie_mask_word(begin, b)
-// of two global arrays (a sub-bucket's words are its own: begin / 32 + b leaves every sub-bucket ceil(size / 32) words).
-// k_tie_direct (sfx_sa.hip) orders the runs on the text where they are; what it cannot finish goes through k_tie_scan /
-// k_tie_collect into the first active list.
+// What leaves instead is two bits per SLOT of the array, as two device-wide bit masks (bit r of the arrays = slot r): `tied` (the
+// element shares its key with another) and `head` (it is the first of its run of equal keys: runs are runs of neighbours in the
+// sorted order, so the masks say where every run starts and ends, and the array itself holds the suffixes).  On the fast path the
+// thread that places an element has seen every member of its group, hence of its run: two fire-and-forget LDS atomics, no
+// barrier of their own; after the LSD rounds a run is a run of neighbours in the staging buffer.  The LDS masks are kept in slot
+// alignment (bit (begin & 31) + place), so their words are words of the global arrays: the inner ones are stored, the first and
+// the last -- shared with the neighbouring sub-buckets -- or-ed in (the arrays are zeroed before the launch).
+// k_tie_direct (sfx_sa.hip) orders the runs on the text where they are; what it cannot finish goes through k_tie_list into the
+// first active list.
 template <int WORDS, bool ON>
 struct TieSmem {
-    uint32_t tmask[WORDS], hmask[WORDS];
+    uint32_t tmask[WORDS + 1], hmask[WORDS + 1];                    // (+ 1: the sub-bucket starts anywhere inside its first word)
 };
 template <int WORDS>
 struct TieSmem<WORDS, false> {};
@@ -1369,7 +1370,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
     constexpr int kMaskWords = (int)(kCap / 32u);
     static_assert(kWave * KPT >= kRadix, "the match masks must fit the staging buffer");
     static_assert(NW * kRadix >= kGroups && kGroups % (NW * kWave) == 0, "the group counts of the fast path live in cnt");
-    static_assert(kMaskWords <= kThreads, "one thread per mask word");
+    static_assert(kMaskWords < kThreads, "one thread per mask word");
     __shared__ struct {
         uint32_t cnt[NW][kRadix];                                   // LSD rounds: per-wave digit counts; fast path: the group counts
         uint16_t gstart[kGroups];                                   // (sub-buckets hold at most 4096 elements)
@@ -1389,7 +1390,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
         for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0u;
     }
     if constexpr (TIES) {
-        if (tid < (unsigned)kMaskWords) s.tie.tmask[tid] = s.tie.hmask[tid] = 0u;
+        if (tid <= (unsigned)kMaskWords) s.tie.tmask[tid] = s.tie.hmask[tid] = 0u;
     }
     __syncthreads();
     // Two sub-buckets ahead: the bounds of bucket b + 2 G and the elements of bucket b + G are requested before
@@ -1425,13 +1426,20 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
         bool pairs = false;
         // TIES: the sub-bucket's mask words leave for the global arrays (and the LDS copies are cleared for the next sub-bucket);
         // the caller has a barrier between the last atomic on the masks and this
+        const uint32_t tshift = begin & 31u;                                    // place p = bit tshift + p of the LDS masks
         auto tie_masks_out = [&]() {
           if constexpr (TIES) {
-            const uint32_t words = (size + 31u) >> 5;
+            const uint32_t words = (tshift + size + 31u) >> 5;
             if (tid < words) {
-                const uint64_t at = tie_mask_word(begin, b) + tid;
-                GT[at] = s.tie.tmask[tid];
-                GH[at] = s.tie.hmask[tid];
+                const uint64_t at = (uint64_t)(begin >> 5) + tid;
+                const uint32_t mt = s.tie.tmask[tid], mh = s.tie.hmask[tid];
+                if (tid == 0 || tid + 1u == words) {
+                    if (mt) atomicOr(&GT[at], mt);
+                    if (mh) atomicOr(&GH[at], mh);
+                } else {
+                    GT[at] = mt;
+                    GH[at] = mh;
+                }
                 s.tie.tmask[tid] = 0u;
                 s.tie.hmask[tid] = 0u;
             }
@@ -1486,8 +1494,9 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                         const unsigned place = gb + rank;
                         V[(uint64_t)begin + place] = (uint32_t)e;
                         if (same > 1u) {
-                            atomicOr(&s.tie.tmask[place >> 5], 1u << (place & 31u));
-                            if (same_below == 0u) atomicOr(&s.tie.hmask[place >> 5], 1u << (place & 31u));
+                            const unsigned bitp = tshift + place;
+                            atomicOr(&s.tie.tmask[bitp >> 5], 1u << (bitp & 31u));
+                            if (same_below == 0u) atomicOr(&s.tie.hmask[bitp >> 5], 1u << (bitp & 31u));
                         }
                     }
                 } else {
@@ -1564,8 +1573,9 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                         const bool eq_prev = idx > 0u && (uint32_t)(s.stage[idx - 1u] >> 32) == k32;
                         const bool eq_next = idx + 1u < size && (uint32_t)(s.stage[idx + 1u] >> 32) == k32;
                         if (eq_prev || eq_next) {
-                            atomicOr(&s.tie.tmask[idx >> 5], 1u << (idx & 31u));
-                            if (!eq_prev) atomicOr(&s.tie.hmask[idx >> 5], 1u << (idx & 31u));
+                            const unsigned bitp = tshift + idx;
+                            atomicOr(&s.tie.tmask[bitp >> 5], 1u << (bitp & 31u));
+                            if (!eq_prev) atomicOr(&s.tie.hmask[bitp >> 5], 1u << (bitp & 31u));
                         }
                     }
                 } else {
@@ -1981,16 +1991,11 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     // (development): the sorted keys, as rounds 3-5.
     static const int ties_on = [] { const char* e = dev_env("SFX_HYBRID_TIES"); return e ? atoi(e) : 1; }();
     const bool tie_mode = ties && ties_on && nover == 0;
-    uint32_t* tcount = reinterpret_cast<uint32_t*>(over);      // (the oversize list is idle: 4 * kOversizeMax = 65536 words; k_tie_direct fills them)
-    static_assert(4 * kOversizeMax >= kH16Bins, "the tie counts of all sub-buckets fit the oversize list");
-    // the mask words of all sub-buckets: two arrays of m / 32 + 65536 words -- in e0, which nobody needs once the elements are in
-    // e1; small inputs (the tests: e0 is shorter than that) keep them in the front part of the histogram scratch, idle without
-    // an oversized sub-bucket to sort
-    const uint64_t mask_words = m / 32 + kH16Bins + 64;
-    const bool masks_in_scratch = 2 * mask_words <= (uint64_t)kMaxPasses * kRadix * kHistAllGrid - kReserve;
-    uint32_t* const gt = masks_in_scratch ? scr.partial : reinterpret_cast<uint32_t*>(e0);
+    // the two masks: m / 32 + 2 words each, zeroed -- in e0, which nobody needs once the elements are in e1
+    const uint64_t mask_words = ((m + 31) / 32 + 64) & ~uint64_t(31);
+    uint32_t* const gt = reinterpret_cast<uint32_t*>(e0);
     uint32_t* const gh = gt + mask_words;
-    if (!masks_in_scratch && 2 * mask_words * sizeof(uint32_t) > m * sizeof(uint64_t)) return SFX_ERR_INTERNAL;
+    if (tie_mode) SFX_HIP(hipMemsetAsync(gt, 0, 2 * mask_words * sizeof(uint32_t), st));
 #define SFX_BUCKET_SORT(NW, KPT, LO, HI, GRID)                                                                              \
     do {                                                                                                                    \
         if (tie_mode)                                                                                                       \
@@ -2009,9 +2014,6 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
         ties->produced = true;
         ties->tmask = gt;
         ties->hmask = gh;
-        ties->bstart = bins;
-        ties->counts = tcount;
-        ties->nbuckets = (uint32_t)kH16Bins;
     }
     if (nover) {
         const unsigned g = (unsigned)dmin<uint64_t>(nover, kMaxGrid);

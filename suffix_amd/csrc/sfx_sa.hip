@@ -1160,192 +1160,122 @@ k_small_groups(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, c
 // ---- the tie masks of the hybrid initial sort (TieRecords, sfx_host.hpp; round 6) -------------------------------------------
 // The LDS sort of a sub-bucket knows which of its elements share their whole key with a neighbour; k_groups_reduce /
 // k_groups_apply found the same out by reading the sorted keys and suffixes again (12 bytes per suffix for the 2.3 % of them
-// that stay tied on uniform DNA).  Per sub-bucket b of at least two elements, from word tie_mask_word(bstart[b], b) on: tmask (bit
-// p: the element at place p shares its key with a neighbour), hmask (it is the first of its run).  A run = the tied places
-// from a head bit up to the next head bit or untied place; the array holds its suffixes at slots bstart[b] + place.
+// that stay tied on uniform DNA).  Two bit masks over the m slots of the array: tmask (the element shares its key with a
+// neighbour), hmask (it is the first of its run).  A run = the tied slots from a head bit up to the next head bit or untied
+// slot; the array holds its suffixes.
 //
-// k_tie_direct: one wave per sub-bucket; the lane that owns the mask word with a run's head bit orders the run on the text (runs
-// of up to kTieRunMax members: insertion sort with direct_compare, as k_small_groups orders the small buckets of an active
-// list) and writes it back in order.  A run it cannot finish -- longer, or two members equal for kSmallDepthWords more words --
-// stays as it is.  counts[b] = tied | runs << 16; totals[0] = tied elements, [1] = runs, [2] = members of unfinished runs.
-// Uniform DNA leaves none: the build is done.  Otherwise ALL runs become the first active list (k_tie_scan, k_tie_collect) and
-// the direct pass of the list redoes the finished ones, to the same places.
+// k_tie_direct: one lane per mask word; a lane whose word holds a run's head bit orders the run on the text (runs of up to
+// kTieRunMax members: insertion sort with direct_compare, as k_small_groups orders the small buckets of an active list) and
+// writes it back in order.  A run it cannot finish -- longer, or two members equal for kSmallDepthWords more words -- stays as it
+// is.  totals[0] = tied elements, [1] = runs, [2] = members of unfinished runs.  Uniform DNA leaves none: the build is done.
+// Otherwise ALL runs become the first active list (k_tie_list) and the direct pass of the list redoes the finished ones, to the
+// same places.
 constexpr uint32_t kTieRunMax = 8;
-constexpr int kTieMaskWords = 16384 / 32;                         // the LDS sort takes sub-buckets of 16384 at most
+__device__ __forceinline__ bool tie_bit(const uint32_t* __restrict__ mask, uint64_t r) { return (mask[r >> 5] >> (r & 31u)) & 1u; }
 __global__ void __launch_bounds__(kBlock)
-k_tie_direct(const uint32_t* __restrict__ tmask, const uint32_t* __restrict__ hmask, const uint32_t* __restrict__ bstart, uint32_t nb,
-             PackedText t, uint64_t h, uint32_t* __restrict__ sa, uint32_t* __restrict__ counts, uint32_t* __restrict__ totals)
+k_tie_direct(const uint32_t* __restrict__ tmask, const uint32_t* __restrict__ hmask, uint64_t m, PackedText t, uint64_t h,
+             uint32_t* __restrict__ sa, uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t s_t[kWavesPerBlock][kTieMaskWords + 1], s_h[kWavesPerBlock][kTieMaskWords + 1];
-    const unsigned lane = lane_id(), w = wave_id();
-    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    const uint64_t nwords = (m + 31) / 32, stride = (uint64_t)gridDim.x * kBlock;
     uint32_t n_tied = 0, n_runs = 0, n_left = 0;                  // (per lane; summed over the wave at the end)
-    for (uint32_t b = blockIdx.x * kWavesPerBlock + w; b < nb; b += nwaves) {
-        const uint32_t begin = bstart[b], size = bstart[b + 1u] - begin;
-        if (size < 2u) {
-            if (lane == 0) counts[b] = 0u;
-            continue;
-        }
-        const uint32_t words = (size + 31u) >> 5;                 // <= kTieMaskWords
-        const uint64_t at = tie_mask_word(begin, b);
-        uint32_t c_t = 0, c_h = 0;
-        for (uint32_t i = lane; i < words; i += kWave) {
-            const uint32_t mt = tmask[at + i], mh = hmask[at + i];
-            s_t[w][i] = mt;
-            s_h[w][i] = mh;
-            c_t += (uint32_t)__popc(mt);
-            c_h += (uint32_t)__popc(mh);
-        }
-        if (lane == 0) { s_t[w][words] = 0u; s_h[w][words] = 0u; }               // (a run ends at the end of the sub-bucket)
-        for (int d = 32; d >= 1; d >>= 1) {
-            c_t += (uint32_t)__shfl_xor(c_t, d);
-            c_h += (uint32_t)__shfl_xor(c_h, d);
-        }
-        if (lane == 0) { counts[b] = c_t | (c_h << 16); n_tied += c_t; n_runs += c_h; }
-        wave_sync();
-        if (c_t != 0u) {
-            for (uint32_t i = lane; i < words; i += kWave) {
-                uint32_t heads = s_h[w][i];
-                while (heads != 0u) {
-                    const uint32_t bit = (uint32_t)__ffs((int)heads) - 1u;
-                    heads &= heads - 1u;
-                    const uint32_t p0 = i * 32u + bit;
-                    // the run: tied places behind the head up to the next head or untied place
-                    uint32_t len = 1;
-                    while (len <= kTieRunMax) {
-                        const uint32_t p = p0 + len;
-                        const bool tied = (s_t[w][p >> 5] >> (p & 31u)) & 1u, head = (s_h[w][p >> 5] >> (p & 31u)) & 1u;
-                        if (!tied || head) break;
-                        len++;
-                    }
-                    if (len > kTieRunMax) {
-                        // (its length is not needed here: count the members for the statistics)
-                        uint32_t p = p0 + len;
-                        while (((s_t[w][p >> 5] >> (p & 31u)) & 1u) && !((s_h[w][p >> 5] >> (p & 31u)) & 1u)) { len++; p++; }
-                        n_left += len;
-                        continue;
-                    }
-                    uint32_t suf[kTieRunMax];
-                    uint32_t* const slot = sa + (uint64_t)begin + p0;
+    for (uint64_t wi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; wi < nwords; wi += stride) {
+        const uint32_t tw = tmask[wi];
+        if (tw == 0u) continue;
+        uint32_t heads = hmask[wi];
+        n_tied += (uint32_t)__popc(tw);
+        n_runs += (uint32_t)__popc(heads);
+        while (heads != 0u) {
+            const uint32_t bit = (uint32_t)__ffs((int)heads) - 1u;
+            heads &= heads - 1u;
+            const uint64_t r0 = wi * 32 + bit;
+            // the run: tied slots behind the head up to the next head or untied slot (the masks end in zero words)
+            uint32_t len = 1;
+            while (len <= kTieRunMax && tie_bit(tmask, r0 + len) && !tie_bit(hmask, r0 + len)) len++;
+            if (len > kTieRunMax) {
+                while (tie_bit(tmask, r0 + len) && !tie_bit(hmask, r0 + len)) len++;        // (counted for the statistics)
+                n_left += len;
+                continue;
+            }
+            uint32_t suf[kTieRunMax];
+            uint32_t* const slot = sa + r0;
 #pragma unroll
-                    for (uint32_t k = 0; k < kTieRunMax; k++) suf[k] = k < len ? slot[k] : 0u;
-                    // insertion sort on the text; a pair that stays equal leaves the run as it was
-                    bool undecided = false;
+            for (uint32_t k = 0; k < kTieRunMax; k++) suf[k] = k < len ? slot[k] : 0u;
+            // insertion sort on the text; a pair that stays equal leaves the run as it was
+            bool undecided = false;
 #pragma unroll
-                    for (uint32_t k = 1; k < kTieRunMax; k++) {
-                        if (k < len && !undecided) {
-                            const uint32_t x = suf[k];
-                            uint32_t pos = k;
+            for (uint32_t k = 1; k < kTieRunMax; k++) {
+                if (k < len && !undecided) {
+                    const uint32_t x = suf[k];
+                    uint32_t pos = k;
 #pragma unroll
-                            for (uint32_t q = kTieRunMax - 1; q >= 1; q--) {
-                                if (q <= k && pos == q && !undecided) {
-                                    const int cmp = direct_compare(t, (uint64_t)x, (uint64_t)suf[q - 1], h);
-                                    if (cmp == 0) undecided = true;
-                                    else if (cmp < 0) { suf[q] = suf[q - 1]; pos = q - 1; }
-                                }
-                            }
-                            if (!undecided) {
-#pragma unroll
-                                for (uint32_t q = 0; q < kTieRunMax; q++)
-                                    if (q == pos) suf[q] = x;
-                            }
+                    for (uint32_t q = kTieRunMax - 1; q >= 1; q--) {
+                        if (q <= k && pos == q && !undecided) {
+                            const int cmp = direct_compare(t, (uint64_t)x, (uint64_t)suf[q - 1], h);
+                            if (cmp == 0) undecided = true;
+                            else if (cmp < 0) { suf[q] = suf[q - 1]; pos = q - 1; }
                         }
                     }
-                    if (undecided) { n_left += len; continue; }
+                    if (!undecided) {
 #pragma unroll
-                    for (uint32_t k = 0; k < kTieRunMax; k++)
-                        if (k < len) slot[k] = suf[k];
+                        for (uint32_t q = 0; q < kTieRunMax; q++)
+                            if (q == pos) suf[q] = x;
+                    }
                 }
             }
+            if (undecided) { n_left += len; continue; }
+#pragma unroll
+            for (uint32_t k = 0; k < kTieRunMax; k++)
+                if (k < len) slot[k] = suf[k];
         }
-        wave_sync();                                                            // (the staged masks are read to the end)
     }
     for (int d = 32; d >= 1; d >>= 1) {
         n_tied += (uint32_t)__shfl_xor(n_tied, d);
         n_runs += (uint32_t)__shfl_xor(n_runs, d);
         n_left += (uint32_t)__shfl_xor(n_left, d);
     }
-    if (lane == 0) {
+    if (lane_id() == 0) {
         if (n_tied) atomicAdd(&totals[0], n_tied);
         if (n_runs) atomicAdd(&totals[1], n_runs);
         if (n_left) atomicAdd(&totals[2], n_left);
     }
 }
-// k_tie_scan: counts[b] -> where the sub-bucket's tied elements start in the list (in place; totals[0] = list length,
-// totals[1] = buckets).  One workgroup, nb <= 65536.
-__global__ void __launch_bounds__(1024)
-k_tie_scan(uint32_t* __restrict__ counts, uint32_t nb, uint32_t* __restrict__ totals)
-{
-    __shared__ uint32_t part[2][16];
-    unsigned par = 0;
-    uint32_t carry_t = 0, carry_r = 0;
-    for (uint32_t base = 0; base < nb; base += 1024u * 4u) {
-        // four consecutive sub-buckets per thread
-        const uint32_t i0 = base + threadIdx.x * 4u;
-        uint32_t c[4], t = 0, r = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            c[k] = i0 + k < nb ? counts[i0 + k] : 0u;
-            t += c[k] & 0xFFFFu;
-            r += c[k] >> 16;
-        }
-        uint32_t tot_t, tot_r;
-        uint32_t ex = block_scan_excl_1b_total<16>(t, part, par, tot_t);
-        (void)block_scan_excl_1b_total<16>(r, part, par, tot_r);
-        ex += carry_t;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (i0 + k < nb) counts[i0 + k] = ex;
-            ex += c[k] & 0xFFFFu;
-        }
-        carry_t += tot_t;
-        carry_r += tot_r;
-    }
-    if (threadIdx.x == 0) { totals[0] = carry_t; totals[1] = carry_r; }
-}
-// k_tie_collect: one workgroup per sub-bucket at a time; the tied places in ascending order are the list: position L = base[b] +
-// tied places below: suffix = the array's entry, slot = bstart[b] + place, bucket id = list position of the head of its run
-// (every place of a run is tied: the distance to the head is the same in the list as in the array).
+// k_tie_list: the tied slots in ascending order are the first active list.  Two phases over chunks of mask words, as
+// k_flag_compact: phase 0 counts the tied slots of every chunk (block_counts, then k_scan_block_counts); phase 1 writes, for the
+// tied slot r at list position L: suffix = the array's entry, slot = r, bucket id = list position of the head of its run (every
+// slot of a run is tied: the distance to the head is the same in the list as in the array).
 __global__ void __launch_bounds__(kBlock)
-k_tie_collect(const uint32_t* __restrict__ tmask, const uint32_t* __restrict__ hmask, const uint32_t* __restrict__ bstart,
-              const uint32_t* __restrict__ base, uint32_t nb, const uint32_t* __restrict__ totals, const uint32_t* __restrict__ sa,
-              uint32_t* __restrict__ S, uint32_t* __restrict__ V, uint32_t* __restrict__ G)
+k_tie_list(const uint32_t* __restrict__ tmask, const uint32_t* __restrict__ hmask, uint64_t nwords, uint64_t chunk, int phase,
+           uint32_t* __restrict__ block_counts, const uint32_t* __restrict__ sa, uint32_t* __restrict__ S, uint32_t* __restrict__ V,
+           uint32_t* __restrict__ G)
 {
-    __shared__ uint32_t s_t[kTieMaskWords], s_h[kTieMaskWords], wpre[kTieMaskWords];
-    __shared__ uint32_t part[2][kWavesPerBlock];
+    __shared__ uint32_t part[kWavesPerBlock];
     const unsigned tid = threadIdx.x;
-    unsigned par = 0;
-    const uint32_t total = totals[0];
-    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
-        const uint32_t at = base[b], cnt = (b + 1u < nb ? base[b + 1u] : total) - at;
-        if (cnt == 0u) continue;                                                // (block-uniform)
-        const uint32_t begin = bstart[b], size = bstart[b + 1u] - begin;
-        const uint32_t words = (size + 31u) >> 5;
-        const uint64_t mw = tie_mask_word(begin, b);
-        uint32_t carry = 0;
-        for (uint32_t w0 = 0; w0 < words; w0 += kBlock) {                       // (block-uniform trip count)
-            const uint32_t wd = w0 + tid;
-            uint32_t mt = 0;
-            if (wd < words) { mt = tmask[mw + wd]; s_t[wd] = mt; s_h[wd] = hmask[mw + wd]; }
-            uint32_t tot;
-            const uint32_t ex = block_scan_excl_1b_total<kWavesPerBlock>((uint32_t)__popc(mt), part, par, tot);
-            if (wd < words) wpre[wd] = carry + ex;
-            carry += tot;
+    const uint64_t wbegin = (uint64_t)blockIdx.x * chunk;
+    uint64_t wend = wbegin + chunk;
+    if (wend > nwords) wend = nwords;
+    uint64_t running = (phase == 1) ? (uint64_t)block_counts[blockIdx.x] : 0ull;
+    for (uint64_t base = wbegin; base < wend; base += kBlock) {
+        const uint64_t wi = base + tid;
+        const uint32_t tw = wi < wend ? tmask[wi] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_scan_add_excl<uint32_t>((uint32_t)__popc(tw), part, total);
+        if (phase == 1 && tw != 0u) {
+            uint32_t L = (uint32_t)(running + ex), bits = tw;
+            while (bits != 0u) {
+                const uint32_t bit = (uint32_t)__ffs((int)bits) - 1u;
+                bits &= bits - 1u;
+                const uint64_t r = wi * 32 + bit;
+                uint64_t hr = r;
+                while (!tie_bit(hmask, hr)) hr--;                               // (a run starts at its head: there is a bit at or below)
+                V[L] = sa[r];
+                S[L] = (uint32_t)r;
+                G[L] = L - (uint32_t)(r - hr);
+                L++;
+            }
         }
-        __syncthreads();
-        for (uint32_t p = tid; p < size; p += kBlock) {
-            const uint32_t wd = p >> 5, bit = p & 31u;
-            if (!((s_t[wd] >> bit) & 1u)) continue;
-            const uint32_t L = at + wpre[wd] + (uint32_t)__popc(s_t[wd] & ((1u << bit) - 1u));
-            uint32_t hw = wd, hm = s_h[wd] & (0xFFFFFFFFu >> (31u - bit));
-            while (hm == 0u) hm = s_h[--hw];                                    // (a run starts at its head: there is a bit at or below)
-            const uint32_t head = hw * 32u + 31u - (uint32_t)__clz((int)hm);
-            V[L] = sa[(uint64_t)begin + p];
-            S[L] = begin + p;
-            G[L] = L - (p - head);
-        }
-        __syncthreads();
+        running += total;
     }
+    if (phase == 0 && tid == 0) block_counts[blockIdx.x] = (uint32_t)running;
 }
 
 // stream compaction of the positions with flag != 0 (order kept): two-phase, per-workgroup
@@ -2128,7 +2058,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     uint32_t* V_next;
     bool in_place = false;
     int in1 = 0;
-    TieRecords ties = {false, nullptr, nullptr, nullptr, nullptr, 0};
+    TieRecords ties = {false, nullptr, nullptr};
     if (sizeof(KeyT) == 4) {
         // E64 elements; the last pass drops every suffix straight into its SA slot and
         // leaves the sorted 32-bit keys in the element buffer it did not read
@@ -2167,11 +2097,12 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     if (ties.produced) {
         // every suffix sits in a slot of its run of equal keys; the runs are ordered on the text where they are (k_tie_direct) ...
         if (ht || lcp_fuse) return SFX_ERR_INTERNAL;
+        const uint64_t nwords = (count + 31) / 32;
         SFX_HIP(hipMemsetAsync(b.totals, 0, 4 * sizeof(uint32_t), st));
         {
-            const unsigned grid = (unsigned)dmin<uint64_t>((ties.nbuckets + kWavesPerBlock - 1) / kWavesPerBlock, kMaxGrid);
-            SFX_LAUNCH("tie_direct", (double)count * 0.25 + (double)ties.nbuckets * 8, k_tie_direct, grid, kBlock, st, ties.tmask, ties.hmask,
-                       ties.bstart, ties.nbuckets, pt, (uint64_t)cpk, sa, ties.counts, b.totals);
+            const unsigned grid = (unsigned)dmin<uint64_t>((nwords + kBlock - 1) / kBlock, 4 * kMaxGrid);
+            SFX_LAUNCH("tie_direct", (double)count * 0.25, k_tie_direct, grid, kBlock, st, ties.tmask, ties.hmask, count, pt, (uint64_t)cpk, sa,
+                       b.totals);
         }
         uint32_t host_totals[3] = {0, 0, 0};
         SFX_TRY(read_back(host_totals, b.totals, sizeof(host_totals), st));
@@ -2183,14 +2114,16 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
             stats.small_bucket_resolved += kept;
             return SFX_OK;
         }
-        // ... and what that leaves tied (repeats beyond the direct pass's depth, large runs) goes on as the first active list: ALL
-        // the tied elements, from the records -- its direct pass redoes the runs that k_tie_direct finished, to the same places
-        SFX_LAUNCH("tie_scan", (double)ties.nbuckets * 8, k_tie_scan, 1, 1024, st, ties.counts, ties.nbuckets, b.totals);
+        // ... and what that leaves tied (repeats beyond the direct pass's depth, long runs) goes on as the first active list: ALL
+        // the tied slots, in order -- its direct pass redoes the runs that k_tie_direct finished, to the same places
         {
-            const unsigned grid = (unsigned)dmin<uint64_t>(ties.nbuckets, kMaxGrid);
-            SFX_LAUNCH("tie_collect", (double)count * 0.25 + (double)ties.nbuckets * 8 + (double)kept * 16, k_tie_collect, grid, kBlock, st, ties.tmask,
-                       ties.hmask, ties.bstart, (const uint32_t*)ties.counts, ties.nbuckets, (const uint32_t*)b.totals, (const uint32_t*)sa, b.S0,
-                       V_next, b.G);
+            Chunking ch = make_chunking(nwords, kBlock);
+            const uint64_t chunk = ch.tiles_per_block * kBlock;
+            SFX_LAUNCH("tie_list_count", (double)count * 0.125, k_tie_list, ch.blocks, kBlock, st, ties.tmask, ties.hmask, nwords, chunk, 0,
+                       b.block_counts, (const uint32_t*)sa, b.S0, V_next, b.G);
+            SFX_LAUNCH("flag_scan", 0.0, k_scan_block_counts, 1, kBlock, st, b.block_counts, ch.blocks, b.totals);
+            SFX_LAUNCH("tie_list", (double)count * 0.25 + (double)kept * 16, k_tie_list, ch.blocks, kBlock, st, ties.tmask, ties.hmask, nwords,
+                       chunk, 1, b.block_counts, (const uint32_t*)sa, b.S0, V_next, b.G);
         }
         uint32_t* S_cur = b.S0;
         if (small_groups_pay(kept, groups))

@@ -93,9 +93,9 @@ if os.environ.get("SFX_HYBRID_MIN"):
         # random DNA and the 700 runs of two: every run ordered where it is, no list at all; runs of more than eight members (and
         # the ones before the repeated block, equal for hundreds of symbols): ALL runs become the first active list
         names2 = kernels_of(runs_of_two)
-        assert "tie_collect" not in names and "small_groups" not in names and "tie_collect" not in names2, (names, names2)
+        assert "tie_list" not in names and "small_groups" not in names and "tie_list" not in names2, (names, names2)
         names2 = kernels_of(runs_of_eleven)
-        assert "tie_scan" in names2 and "tie_collect" in names2 and "deep_wave" in names2, names2    # (runs of eleven: no direct pass of the list)
+        assert "tie_list_count" in names2 and "tie_list" in names2 and "deep_wave" in names2, names2    # (runs of eleven: no direct pass of the list)
     names = kernels_of(planted)                                       # 0.8 % of it in the three planted sub-buckets
     assert ("bucket_sort_lds" in names) == (cap > 10) and ("oversize_gather" in names) == (10 < cap < 400), names
     assert ("tie_direct" in names) == (cap >= 400 and ties_on), names   # (an oversized sub-bucket: the sorted keys, as before)
