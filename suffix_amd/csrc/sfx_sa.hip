@@ -1171,6 +1171,7 @@ k_small_groups(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, c
 // Otherwise ALL runs become the first active list (k_tie_list) and the direct pass of the list redoes the finished ones, to the
 // same places.
 constexpr uint32_t kTieRunMax = 8;
+constexpr unsigned kTieSlots = 1024;                              // counter lines of k_tie_direct (4 words each: in deep_slots)
 __device__ __forceinline__ bool tie_bit(const uint32_t* __restrict__ mask, uint64_t r) { return (mask[r >> 5] >> (r & 31u)) & 1u; }
 __global__ void __launch_bounds__(kBlock)
 k_tie_direct(const uint32_t* __restrict__ tmask, const uint32_t* __restrict__ hmask, uint64_t m, PackedText t, uint64_t h,
@@ -1181,16 +1182,25 @@ k_tie_direct(const uint32_t* __restrict__ tmask, const uint32_t* __restrict__ hm
     for (uint64_t wi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; wi < nwords; wi += stride) {
         const uint32_t tw = tmask[wi];
         if (tw == 0u) continue;
-        uint32_t heads = hmask[wi];
+        const uint32_t hw = hmask[wi];
+        uint32_t heads = hw;
         n_tied += (uint32_t)__popc(tw);
         n_runs += (uint32_t)__popc(heads);
+        // (a run of up to kTieRunMax + 1 slots from a head in this word ends in this word or the next: one more pair of words at most)
+        uint64_t tw2 = (uint64_t)tw, hw2 = (uint64_t)hw;
+        bool have_next = false;
         while (heads != 0u) {
             const uint32_t bit = (uint32_t)__ffs((int)heads) - 1u;
             heads &= heads - 1u;
             const uint64_t r0 = wi * 32 + bit;
+            if (!have_next && bit + kTieRunMax >= 32u) {
+                tw2 |= (uint64_t)tmask[wi + 1] << 32;
+                hw2 |= (uint64_t)hmask[wi + 1] << 32;
+                have_next = true;
+            }
             // the run: tied slots behind the head up to the next head or untied slot (the masks end in zero words)
             uint32_t len = 1;
-            while (len <= kTieRunMax && tie_bit(tmask, r0 + len) && !tie_bit(hmask, r0 + len)) len++;
+            while (len <= kTieRunMax && ((tw2 >> (bit + len)) & 1u) && !((hw2 >> (bit + len)) & 1u)) len++;
             if (len > kTieRunMax) {
                 while (tie_bit(tmask, r0 + len) && !tie_bit(hmask, r0 + len)) len++;        // (counted for the statistics)
                 n_left += len;
@@ -1233,10 +1243,28 @@ k_tie_direct(const uint32_t* __restrict__ tmask, const uint32_t* __restrict__ hm
         n_runs += (uint32_t)__shfl_xor(n_runs, d);
         n_left += (uint32_t)__shfl_xor(n_left, d);
     }
+    // (one counter line per wave class, never one address for all waves: tens of thousands of atomics on one word are a queue at
+    // one L2 channel -- 0.65 of this kernel's 0.78 ms when it was written that way; k_tie_totals sums the lines)
     if (lane_id() == 0) {
-        if (n_tied) atomicAdd(&totals[0], n_tied);
-        if (n_runs) atomicAdd(&totals[1], n_runs);
-        if (n_left) atomicAdd(&totals[2], n_left);
+        uint32_t* const line = totals + (size_t)((blockIdx.x * (unsigned)kWavesPerBlock + wave_id()) % kTieSlots) * 4u;
+        if (n_tied) atomicAdd(&line[0], n_tied);
+        if (n_runs) atomicAdd(&line[1], n_runs);
+        if (n_left) atomicAdd(&line[2], n_left);
+    }
+}
+__global__ void __launch_bounds__(kBlock)
+k_tie_totals(const uint32_t* __restrict__ lines, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t part[3][kWavesPerBlock];
+    uint32_t a = 0, b = 0, c = 0;
+    for (unsigned i = threadIdx.x; i < kTieSlots; i += kBlock) { a += lines[i * 4u]; b += lines[i * 4u + 1u]; c += lines[i * 4u + 2u]; }
+    for (int d = 32; d >= 1; d >>= 1) { a += (uint32_t)__shfl_xor(a, d); b += (uint32_t)__shfl_xor(b, d); c += (uint32_t)__shfl_xor(c, d); }
+    if (lane_id() == 0) { part[0][wave_id()] = a; part[1][wave_id()] = b; part[2][wave_id()] = c; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t x = 0;
+        for (int w = 0; w < kWavesPerBlock; w++) x += part[threadIdx.x][w];
+        totals[threadIdx.x] = x;
     }
 }
 // k_tie_list: the tied slots in ascending order are the first active list.  Two phases over chunks of mask words, as
@@ -2098,11 +2126,14 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         // every suffix sits in a slot of its run of equal keys; the runs are ordered on the text where they are (k_tie_direct) ...
         if (ht || lcp_fuse) return SFX_ERR_INTERNAL;
         const uint64_t nwords = (count + 31) / 32;
-        SFX_HIP(hipMemsetAsync(b.totals, 0, 4 * sizeof(uint32_t), st));
+        uint32_t* const lines = reinterpret_cast<uint32_t*>(b.deep_slots);     // (idle until the first deep round)
+        static_assert(kTieSlots * 4 * sizeof(uint32_t) <= kDeepSlotWords * sizeof(unsigned long long), "the counter lines fit");
+        SFX_HIP(hipMemsetAsync(lines, 0, kTieSlots * 4 * sizeof(uint32_t), st));
         {
             const unsigned grid = (unsigned)dmin<uint64_t>((nwords + kBlock - 1) / kBlock, 4 * kMaxGrid);
             SFX_LAUNCH("tie_direct", (double)count * 0.25, k_tie_direct, grid, kBlock, st, ties.tmask, ties.hmask, count, pt, (uint64_t)cpk, sa,
-                       b.totals);
+                       lines);
+            SFX_LAUNCH("tie_totals", 0.0, k_tie_totals, 1, kBlock, st, (const uint32_t*)lines, b.totals);
         }
         uint32_t host_totals[3] = {0, 0, 0};
         SFX_TRY(read_back(host_totals, b.totals, sizeof(host_totals), st));
