@@ -47,7 +47,7 @@ NAMES = [
     ("k_key_hist_raw", "key_hist"), ("k_range_filter", "range_count"),
     ("k_groups_reduce", "groups_reduce"), ("k_groups_scan", "groups_scan"),
     ("k_groups_apply<unsigned int", "groups_apply_u32"), ("k_groups_apply<unsigned long", "groups_apply_u64"),
-    ("k_tie_direct", "tie_direct"), ("k_tie_totals", "tie_totals"), ("k_tie_list", "tie_list"),
+    ("k_tie_direct", "tie_direct"), ("k_tie_totals", "tie_totals"), ("k_tie_heads", "tie_heads"), ("k_tie_list", "tie_list"),
     ("k_small_groups", "small_groups"), ("k_flag_compact", "flag_compact"), ("k_scan_block_counts", "flag_scan"),
     ("k_fill_u16", "depth_fill"), ("k_flags_reduce", "flags_reduce"),
     ("k_compose_rank_keys", "compose_rank_keys"), ("k_compose_text_keys", "compose_text_keys"),

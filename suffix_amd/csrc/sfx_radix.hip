@@ -1344,26 +1344,24 @@ constexpr int kGroups = 1 << kGroupBits;
 // TIES (round 6): the sort also says which of its elements share their whole key with a neighbour -- the members of the buckets
 // the refinement has to go on with -- so that nobody reads the sorted keys again (k_groups_reduce / k_groups_apply re-read 4 + 8
 // bytes per suffix that this kernel had in LDS a moment before: 0.19 of the headline's 1.50 ms).  Keys are not written at all.
-// What leaves instead is two bits per SLOT of the array, as two device-wide bit masks (bit r of the arrays = slot r): `tied` (the
-// element shares its key with another) and `head` (it is the first of its run of equal keys: runs are runs of neighbours in the
-// sorted order, so the masks say where every run starts and ends, and the array itself holds the suffixes).  On the fast path the
-// thread that places an element has seen every member of its group, hence of its run: two fire-and-forget LDS atomics, no
-// barrier of their own; after the LSD rounds a run is a run of neighbours in the staging buffer.  The LDS masks are kept in slot
-// alignment (bit (begin & 31) + place), so their words are words of the global arrays: the inner ones are stored, the first and
-// the last -- shared with the neighbouring sub-buckets -- or-ed in (the arrays are zeroed before the launch).
-// k_tie_direct (sfx_sa.hip) orders the runs on the text where they are; what it cannot finish goes through k_tie_list into the
-// first active list.
+// What leaves instead is one bit per SLOT of the array, a device-wide bit mask (bit r = slot r): `tied`, the element shares its
+// key with another.  Equal keys are neighbours in the sorted order, so the mask -- with the array, which holds the suffixes --
+// says where the stretches of equal keys lie.  On the fast path the thread that places an element has seen every member of its
+// group, hence every element with its key: one fire-and-forget LDS atomic, no barrier of its own; after the LSD rounds equal
+// keys are neighbours in the staging buffer.  The LDS mask is kept in slot alignment (bit (begin & 31) + place), so its words are
+// words of the global array: the inner ones are stored, the first and the last -- shared with the neighbouring sub-buckets --
+// or-ed in (the array is zeroed before the launch).  k_tie_direct (sfx_sa.hip) orders the stretches on the text where they
+// are; what it cannot finish goes through k_tie_heads / k_tie_list into the first active list.
 template <int WORDS, bool ON>
 struct TieSmem {
-    uint32_t tmask[WORDS + 1], hmask[WORDS + 1];                    // (+ 1: the sub-bucket starts anywhere inside its first word)
+    uint32_t tmask[WORDS + 1];                                      // (+ 1: the sub-bucket starts anywhere inside its first word)
 };
 template <int WORDS>
 struct TieSmem<WORDS, false> {};
 template <int NW, int KPT, bool TIES = false>
 __global__ void __launch_bounds__(NW * kWave) SFX_WAVES_PER_EU(NW == 4 && KPT == 8 ? 6 : 1, 8)
 k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstart, uint32_t nbuckets, int low_bits,
-              uint32_t lo, uint32_t hi, uint32_t* __restrict__ K, uint32_t* __restrict__ V, uint32_t* __restrict__ GT = nullptr,
-              uint32_t* __restrict__ GH = nullptr)
+              uint32_t lo, uint32_t hi, uint32_t* __restrict__ K, uint32_t* __restrict__ V, uint32_t* __restrict__ GT = nullptr)
 {
     constexpr int kThreads = NW * kWave;
     constexpr uint32_t kCap = kThreads * KPT;
@@ -1390,7 +1388,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
         for (int k = 0; k < NW; k++) s.cnt[k][tid] = 0u;
     }
     if constexpr (TIES) {
-        if (tid <= (unsigned)kMaskWords) s.tie.tmask[tid] = s.tie.hmask[tid] = 0u;
+        if (tid <= (unsigned)kMaskWords) s.tie.tmask[tid] = 0u;
     }
     __syncthreads();
     // Two sub-buckets ahead: the bounds of bucket b + 2 G and the elements of bucket b + G are requested before
@@ -1432,16 +1430,13 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
             const uint32_t words = (tshift + size + 31u) >> 5;
             if (tid < words) {
                 const uint64_t at = (uint64_t)(begin >> 5) + tid;
-                const uint32_t mt = s.tie.tmask[tid], mh = s.tie.hmask[tid];
+                const uint32_t mt = s.tie.tmask[tid];
                 if (tid == 0 || tid + 1u == words) {
                     if (mt) atomicOr(&GT[at], mt);
-                    if (mh) atomicOr(&GH[at], mh);
                 } else {
                     GT[at] = mt;
-                    GH[at] = mh;
                 }
                 s.tie.tmask[tid] = 0u;
-                s.tie.hmask[tid] = 0u;
             }
           }
         };
@@ -1483,20 +1478,17 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                         const uint64_t e = s.stage[q];
                         const unsigned d = digit_of(e, gshift, gmask);
                         const unsigned gb = s.gstart[d], ge = gb + gcount[d];
-                        unsigned rank = 0, same = 0, same_below = 0;
+                        unsigned rank = 0, same = 0;
                         for (unsigned j = gb; j < ge; j++) {
                             const uint64_t x = s.stage[j];
-                            const bool below = x < e, eq = (uint32_t)(x >> 32) == (uint32_t)(e >> 32);
-                            rank += below ? 1u : 0u;
-                            same += eq ? 1u : 0u;                                  // (counts e itself)
-                            same_below += (eq && below) ? 1u : 0u;
+                            rank += x < e ? 1u : 0u;
+                            same += (uint32_t)((x ^ e) >> 32) == 0u ? 1u : 0u;     // (counts e itself)
                         }
                         const unsigned place = gb + rank;
                         V[(uint64_t)begin + place] = (uint32_t)e;
                         if (same > 1u) {
                             const unsigned bitp = tshift + place;
                             atomicOr(&s.tie.tmask[bitp >> 5], 1u << (bitp & 31u));
-                            if (same_below == 0u) atomicOr(&s.tie.hmask[bitp >> 5], 1u << (bitp & 31u));
                         }
                     }
                 } else {
@@ -1575,7 +1567,6 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                         if (eq_prev || eq_next) {
                             const unsigned bitp = tshift + idx;
                             atomicOr(&s.tie.tmask[bitp >> 5], 1u << (bitp & 31u));
-                            if (!eq_prev) atomicOr(&s.tie.hmask[bitp >> 5], 1u << (bitp & 31u));
                         }
                     }
                 } else {
@@ -1991,17 +1982,18 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     // (development): the sorted keys, as rounds 3-5.
     static const int ties_on = [] { const char* e = dev_env("SFX_HYBRID_TIES"); return e ? atoi(e) : 1; }();
     const bool tie_mode = ties && ties_on && nover == 0;
-    // the two masks: m / 32 + 2 words each, zeroed -- in e0, which nobody needs once the elements are in e1
+    // the mask (m / 32 words + zero words behind them) and a second array of the same size for the caller -- in e0, which nobody
+    // needs once the elements are in e1
     const uint64_t mask_words = ((m + 31) / 32 + 64) & ~uint64_t(31);
     uint32_t* const gt = reinterpret_cast<uint32_t*>(e0);
     uint32_t* const gh = gt + mask_words;
-    if (tie_mode) SFX_HIP(hipMemsetAsync(gt, 0, 2 * mask_words * sizeof(uint32_t), st));
+    if (tie_mode) SFX_HIP(hipMemsetAsync(gt, 0, mask_words * sizeof(uint32_t), st));      // (the second array is the caller's to fill)
 #define SFX_BUCKET_SORT(NW, KPT, LO, HI, GRID)                                                                              \
     do {                                                                                                                    \
         if (tie_mode)                                                                                                       \
-            SFX_LAUNCH("bucket_sort_lds", (double)m * 12.25, (k_bucket_sort<NW, KPT, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
+            SFX_LAUNCH("bucket_sort_lds", (double)m * 12.125, (k_bucket_sort<NW, KPT, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
                        (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, (uint32_t)(LO), (uint32_t)(HI), (uint32_t*)nullptr, split_v, \
-                       gt, gh);                                                                                             \
+                       gt);                                                                                                 \
         else                                                                                                                \
             SFX_LAUNCH("bucket_sort_lds", (double)m * 16.0, (k_bucket_sort<NW, KPT>), GRID, NW * kWave, st, (const uint64_t*)e1, \
                        (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, (uint32_t)(LO), (uint32_t)(HI), split_k, split_v); \

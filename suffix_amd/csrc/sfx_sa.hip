@@ -1157,85 +1157,138 @@ k_small_groups(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, c
     }
 }
 
-// ---- the tie masks of the hybrid initial sort (TieRecords, sfx_host.hpp; round 6) -------------------------------------------
+// ---- the tie mask of the hybrid initial sort (TieRecords, sfx_host.hpp; round 6) --------------------------------------------
 // The LDS sort of a sub-bucket knows which of its elements share their whole key with a neighbour; k_groups_reduce /
 // k_groups_apply found the same out by reading the sorted keys and suffixes again (12 bytes per suffix for the 2.3 % of them
-// that stay tied on uniform DNA).  Two bit masks over the m slots of the array: tmask (the element shares its key with a
-// neighbour), hmask (it is the first of its run).  A run = the tied slots from a head bit up to the next head bit or untied
-// slot; the array holds its suffixes.
+// that stay tied on uniform DNA).  One bit per slot of the array: tmask (the element shares its key with a neighbour).  Equal
+// keys are neighbours, so a STRETCH of consecutive tied slots is one run of equal keys or several adjacent ones, and the array
+// holds the suffixes.
 //
-// k_tie_direct: one lane per mask word; a lane whose word holds a run's head bit orders the run on the text (runs of up to
-// kTieRunMax members: insertion sort with direct_compare, as k_small_groups orders the small buckets of an active list) and
-// writes it back in order.  A run it cannot finish -- longer, or two members equal for kSmallDepthWords more words -- stays as it
-// is.  totals[0] = tied elements, [1] = runs, [2] = members of unfinished runs.  Uniform DNA leaves none: the build is done.
-// Otherwise ALL runs become the first active list (k_tie_list) and the direct pass of the list redoes the finished ones, to the
-// same places.
+// k_tie_direct orders every stretch of up to kTieRunMax slots on the text from the suffixes' first symbol on (so it need not
+// know where one run of a stretch ends and the next begins): a wave reads 64 x 4 mask words, every lane lists the stretches that
+// start in its 128 slots, the wave's list is worked off 64 stretches at a time -- the suffixes of one stretch in the registers
+// of one lane, insertion sort with direct_compare64 (as k_small_groups orders the small buckets of an active list, two key words
+// per step) -- and written back in order.  A stretch it cannot finish -- longer, or two members equal for 8 more key pairs --
+// stays as it is.  lines: counter lines [0] = tied slots, [1] = stretches, [2] = members of unfinished stretches.  Uniform DNA
+// leaves none: the build is done.  Otherwise k_tie_heads marks the first slot of every run (a key compare with the slot
+// before), ALL runs become the first active list (k_tie_list) and the direct pass of the list redoes the finished ones.
 constexpr uint32_t kTieRunMax = 8;
 constexpr unsigned kTieSlots = 1024;                              // counter lines of k_tie_direct (4 words each: in deep_slots)
+constexpr int kTieBatch = 2;                                      // stretches a lane lists per round of its wave
 __device__ __forceinline__ bool tie_bit(const uint32_t* __restrict__ mask, uint64_t r) { return (mask[r >> 5] >> (r & 31u)) & 1u; }
-__global__ void __launch_bounds__(kBlock)
-k_tie_direct(const uint32_t* __restrict__ tmask, const uint32_t* __restrict__ hmask, uint64_t m, PackedText t, uint64_t h,
-             uint32_t* __restrict__ sa, uint32_t* __restrict__ totals)
+
+// -1: suffix a < suffix b, +1: a > b, 0: equal for `steps` pairs of packed words beyond offset h (direct_compare, two words a step)
+__device__ __forceinline__ int direct_compare64(const PackedText& t, uint64_t a, uint64_t b, uint64_t h, int steps)
 {
-    const uint64_t nwords = (m + 31) / 32, stride = (uint64_t)gridDim.x * kBlock;
+    const int64_t sym = 2 * (int64_t)t.spw;
+    for (int s = 0; s < steps; s++) {
+        const int64_t la = (int64_t)t.n - (int64_t)(a + h), lb = (int64_t)t.n - (int64_t)(b + h);
+        const int64_t lim = la < lb ? la : lb;
+        if (lim <= 0) return la < lb ? -1 : 1;
+        uint64_t wa = packed_key64(t, a + h), wb = packed_key64(t, b + h);
+        if (lim < sym) {
+            const unsigned sh = (unsigned)(sym - lim) * (unsigned)t.bits;
+            wa >>= sh;
+            wb >>= sh;
+            if (wa != wb) return wa < wb ? -1 : 1;
+            return la < lb ? -1 : 1;
+        }
+        if (wa != wb) return wa < wb ? -1 : 1;
+        h += (uint64_t)sym;
+    }
+    return 0;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_tie_direct(const uint32_t* __restrict__ tmask, uint64_t m, PackedText t, uint32_t* __restrict__ sa, uint32_t* __restrict__ lines)
+{
+    __shared__ uint32_t s_ent[kWavesPerBlock][kWave * kTieBatch];
+    const unsigned lane = lane_id(), w = wave_id();
+    const uint64_t nquads = ((m + 31) / 32 + 3) / 4;              // (the mask is padded with zero words beyond that)
+    const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+    const uint4* const tmask4 = reinterpret_cast<const uint4*>(tmask);
     uint32_t n_tied = 0, n_runs = 0, n_left = 0;                  // (per lane; summed over the wave at the end)
-    for (uint64_t wi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; wi < nwords; wi += stride) {
-        const uint32_t tw = tmask[wi];
-        if (tw == 0u) continue;
-        const uint32_t hw = hmask[wi];
-        uint32_t heads = hw;
-        n_tied += (uint32_t)__popc(tw);
-        n_runs += (uint32_t)__popc(heads);
-        // (a run of up to kTieRunMax + 1 slots from a head in this word ends in this word or the next: one more pair of words at most)
-        uint64_t tw2 = (uint64_t)tw, hw2 = (uint64_t)hw;
-        bool have_next = false;
-        while (heads != 0u) {
-            const uint32_t bit = (uint32_t)__ffs((int)heads) - 1u;
-            heads &= heads - 1u;
-            const uint64_t r0 = wi * 32 + bit;
-            if (!have_next && bit + kTieRunMax >= 32u) {
-                tw2 |= (uint64_t)tmask[wi + 1] << 32;
-                hw2 |= (uint64_t)hmask[wi + 1] << 32;
-                have_next = true;
-            }
-            // the run: tied slots behind the head up to the next head or untied slot (the masks end in zero words)
-            uint32_t len = 1;
-            while (len <= kTieRunMax && ((tw2 >> (bit + len)) & 1u) && !((hw2 >> (bit + len)) & 1u)) len++;
-            if (len > kTieRunMax) {
-                while (tie_bit(tmask, r0 + len) && !tie_bit(hmask, r0 + len)) len++;        // (counted for the statistics)
-                n_left += len;
-                continue;
-            }
-            uint32_t suf[kTieRunMax];
-            uint32_t* const slot = sa + r0;
+    for (uint64_t qbase = ((uint64_t)blockIdx.x * kWavesPerBlock + w) * kWave; qbase < nquads; qbase += nwaves * kWave) {
+        const uint64_t q = qbase + lane;
+        uint4 T = {0u, 0u, 0u, 0u};
+        if (q < nquads) T = tmask4[q];
+        // the slot before this lane's 128 and the 32 behind them: the neighbouring lanes' words (the wave's ends: one more load)
+        uint32_t prev_top = (uint32_t)__shfl_up(T.w, 1) >> 31, next_w = (uint32_t)__shfl_down(T.x, 1);
+        if (lane == 0) prev_top = qbase ? tmask[qbase * 4 - 1] >> 31 : 0u;
+        if (lane == kWave - 1) next_w = qbase + kWave <= nquads ? tmask[(qbase + kWave) * 4] : 0u;
+        const uint64_t lo = (uint64_t)T.x | ((uint64_t)T.y << 32), hi = (uint64_t)T.z | ((uint64_t)T.w << 32);
+        n_tied += (uint32_t)__popcll(lo) + (uint32_t)__popcll(hi);
+        // bits [i, i + 64) of the lane's 160 (valid for the 33 bits a stretch can need)
+        auto window = [&](unsigned i) -> uint64_t {
+            if (i < 64u) return i ? (lo >> i) | (hi << (64u - i)) : lo;
+            const unsigned j = i - 64u;
+            return j ? (hi >> j) | ((uint64_t)next_w << (64u - j)) : (hi | 0ull);
+        };
+        // stretches that start here: a tied slot behind an untied one
+        uint64_t slo = lo & ~((lo << 1) | (uint64_t)prev_top), shi = hi & ~((hi << 1) | (lo >> 63));
+        while (__ballot((slo | shi) != 0ull) != 0ull) {
+            uint32_t ent[kTieBatch];
+            uint32_t mine = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < kTieRunMax; k++) suf[k] = k < len ? slot[k] : 0u;
-            // insertion sort on the text; a pair that stays equal leaves the run as it was
-            bool undecided = false;
-#pragma unroll
-            for (uint32_t k = 1; k < kTieRunMax; k++) {
-                if (k < len && !undecided) {
-                    const uint32_t x = suf[k];
-                    uint32_t pos = k;
-#pragma unroll
-                    for (uint32_t q = kTieRunMax - 1; q >= 1; q--) {
-                        if (q <= k && pos == q && !undecided) {
-                            const int cmp = direct_compare(t, (uint64_t)x, (uint64_t)suf[q - 1], h);
-                            if (cmp == 0) undecided = true;
-                            else if (cmp < 0) { suf[q] = suf[q - 1]; pos = q - 1; }
-                        }
-                    }
-                    if (!undecided) {
-#pragma unroll
-                        for (uint32_t q = 0; q < kTieRunMax; q++)
-                            if (q == pos) suf[q] = x;
+            for (int k = 0; k < kTieBatch; k++) {
+                ent[k] = 0u;
+                if ((slo | shi) != 0ull) {
+                    unsigned i;
+                    if (slo) { i = (unsigned)__ffsll((unsigned long long)slo) - 1u; slo &= slo - 1ull; }
+                    else { i = 64u + (unsigned)__ffsll((unsigned long long)shi) - 1u; shi &= shi - 1ull; }
+                    const uint64_t win = window(i);
+                    uint32_t len = (~win) ? (uint32_t)__ffsll((unsigned long long)~win) - 1u : 64u;
+                    const uint64_t r0 = q * 128 + i;
+                    n_runs++;
+                    if (len > kTieRunMax) {
+                        uint64_t r = r0 + (len < 33u ? len : 33u);                // (the window holds 33 bits for sure)
+                        if (len >= 33u) { len = 33u; while (tie_bit(tmask, r)) { len++; r++; } }
+                        n_left += len;
+                    } else {
+                        ent[mine++] = (uint32_t)r0 | (len << 28);              // (r0 < m <= 2^28: the hybrid route's limit)
                     }
                 }
             }
-            if (undecided) { n_left += len; continue; }
+            const uint32_t incl = wave_scan_add(mine);
+            const uint32_t total = (uint32_t)__shfl(incl, kWave - 1);
 #pragma unroll
-            for (uint32_t k = 0; k < kTieRunMax; k++)
-                if (k < len) slot[k] = suf[k];
+            for (int k = 0; k < kTieBatch; k++)
+                if ((uint32_t)k < mine) s_ent[w][incl - mine + (uint32_t)k] = ent[k];
+            wave_sync();
+            for (uint32_t e = lane; e < total; e += kWave) {
+                const uint32_t en = s_ent[w][e], len = en >> 28;
+                uint32_t* const slot = sa + (en & 0x0FFFFFFFu);
+                uint32_t suf[kTieRunMax];
+#pragma unroll
+                for (uint32_t k = 0; k < kTieRunMax; k++) suf[k] = k < len ? slot[k] : 0u;
+                // insertion sort on the text; a pair that stays equal leaves the stretch as it was
+                bool undecided = false;
+#pragma unroll
+                for (uint32_t k = 1; k < kTieRunMax; k++) {
+                    if (k < len && !undecided) {
+                        const uint32_t x = suf[k];
+                        uint32_t pos = k;
+#pragma unroll
+                        for (uint32_t j = kTieRunMax - 1; j >= 1; j--) {
+                            if (j <= k && pos == j && !undecided) {
+                                const int cmp = direct_compare64(t, (uint64_t)x, (uint64_t)suf[j - 1], 0, kSmallDepthWords / 2);
+                                if (cmp == 0) undecided = true;
+                                else if (cmp < 0) { suf[j] = suf[j - 1]; pos = j - 1; }
+                            }
+                        }
+                        if (!undecided) {
+#pragma unroll
+                            for (uint32_t j = 0; j < kTieRunMax; j++)
+                                if (j == pos) suf[j] = x;
+                        }
+                    }
+                }
+                if (undecided) { n_left += len; continue; }
+#pragma unroll
+                for (uint32_t k = 0; k < kTieRunMax; k++)
+                    if (k < len) slot[k] = suf[k];
+            }
+            wave_sync();                                                        // (the list is read to the end)
         }
     }
     for (int d = 32; d >= 1; d >>= 1) {
@@ -1245,8 +1298,8 @@ k_tie_direct(const uint32_t* __restrict__ tmask, const uint32_t* __restrict__ hm
     }
     // (one counter line per wave class, never one address for all waves: tens of thousands of atomics on one word are a queue at
     // one L2 channel -- 0.65 of this kernel's 0.78 ms when it was written that way; k_tie_totals sums the lines)
-    if (lane_id() == 0) {
-        uint32_t* const line = totals + (size_t)((blockIdx.x * (unsigned)kWavesPerBlock + wave_id()) % kTieSlots) * 4u;
+    if (lane == 0) {
+        uint32_t* const line = lines + (size_t)((blockIdx.x * (unsigned)kWavesPerBlock + w) % kTieSlots) * 4u;
         if (n_tied) atomicAdd(&line[0], n_tied);
         if (n_runs) atomicAdd(&line[1], n_runs);
         if (n_left) atomicAdd(&line[2], n_left);
@@ -1266,6 +1319,36 @@ k_tie_totals(const uint32_t* __restrict__ lines, uint32_t* __restrict__ totals)
         for (int w = 0; w < kWavesPerBlock; w++) x += part[threadIdx.x][w];
         totals[threadIdx.x] = x;
     }
+}
+// k_tie_heads (the leftover path): hmask bit r = slot r is tied and the first of its run -- the slot before is untied or holds
+// another key (the key the sort used: the suffix's first kbits, zero-padded past the end).  One lane per mask word; lines[0] +=
+// runs.
+__global__ void __launch_bounds__(kBlock)
+k_tie_heads(const uint32_t* __restrict__ tmask, uint64_t m, PackedText t, const uint32_t* __restrict__ sa, uint32_t* __restrict__ hmask,
+            uint32_t* __restrict__ lines)
+{
+    const uint64_t nwords = (m + 31) / 32, stride = (uint64_t)gridDim.x * kBlock;
+    uint32_t n_runs = 0;
+    for (uint64_t wi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; wi < nwords; wi += stride) {
+        const uint32_t tw = tmask[wi];
+        uint32_t hw = 0;
+        if (tw != 0u) {
+            const uint32_t prev_top = wi ? tmask[wi - 1] >> 31 : 0u;
+            uint32_t starts = tw & ~((tw << 1) | prev_top), inner = tw & ~starts;     // (a tied slot behind a tied one: compare the keys)
+            hw = starts;
+            while (inner != 0u) {
+                const uint32_t bit = (uint32_t)__ffs((int)inner) - 1u;
+                inner &= inner - 1u;
+                const uint64_t r = wi * 32 + bit;
+                if (packed_key32(t, (uint64_t)sa[r]) != packed_key32(t, (uint64_t)sa[r - 1])) hw |= 1u << bit;
+            }
+            n_runs += (uint32_t)__popc(hw);
+        }
+        hmask[wi] = hw;
+    }
+    for (int d = 32; d >= 1; d >>= 1) n_runs += (uint32_t)__shfl_xor(n_runs, d);
+    if (lane_id() == 0 && n_runs)
+        atomicAdd(&lines[(size_t)((blockIdx.x * (unsigned)kWavesPerBlock + wave_id()) % kTieSlots) * 4u], n_runs);
 }
 // k_tie_list: the tied slots in ascending order are the first active list.  Two phases over chunks of mask words, as
 // k_flag_compact: phase 0 counts the tied slots of every chunk (block_counts, then k_scan_block_counts); phase 1 writes, for the
@@ -2130,31 +2213,39 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         static_assert(kTieSlots * 4 * sizeof(uint32_t) <= kDeepSlotWords * sizeof(unsigned long long), "the counter lines fit");
         SFX_HIP(hipMemsetAsync(lines, 0, kTieSlots * 4 * sizeof(uint32_t), st));
         {
-            const unsigned grid = (unsigned)dmin<uint64_t>((nwords + kBlock - 1) / kBlock, 4 * kMaxGrid);
-            SFX_LAUNCH("tie_direct", (double)count * 0.25, k_tie_direct, grid, kBlock, st, ties.tmask, ties.hmask, count, pt, (uint64_t)cpk, sa,
-                       lines);
+            const uint64_t waves = (nwords / 4 + kWave - 1) / kWave + 1;
+            const unsigned grid = (unsigned)dmin<uint64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, kMaxGrid);
+            SFX_LAUNCH("tie_direct", (double)count * 0.125, k_tie_direct, grid, kBlock, st, ties.tmask, count, pt, sa, lines);
             SFX_LAUNCH("tie_totals", 0.0, k_tie_totals, 1, kBlock, st, (const uint32_t*)lines, b.totals);
         }
         uint32_t host_totals[3] = {0, 0, 0};
         SFX_TRY(read_back(host_totals, b.totals, sizeof(host_totals), st));
         kept = host_totals[0];
-        groups = host_totals[1];
-        if (kept > count || groups * 2 > kept || host_totals[2] > kept) return SFX_ERR_INTERNAL;
+        if (kept > count || (uint64_t)host_totals[1] * 2 > kept || host_totals[2] > kept) return SFX_ERR_INTERNAL;
         stats.active_after_initial = kept;
         if (host_totals[2] == 0) {
             stats.small_bucket_resolved += kept;
             return SFX_OK;
         }
         // ... and what that leaves tied (repeats beyond the direct pass's depth, long runs) goes on as the first active list: ALL
-        // the tied slots, in order -- its direct pass redoes the runs that k_tie_direct finished, to the same places
+        // the tied slots, in order, as the runs they are (k_tie_heads) -- its direct pass redoes the runs that k_tie_direct finished
         {
+            SFX_HIP(hipMemsetAsync(lines, 0, kTieSlots * 4 * sizeof(uint32_t), st));
+            const unsigned hgrid = (unsigned)dmin<uint64_t>((nwords + kBlock - 1) / kBlock, kMaxGrid);
+            SFX_LAUNCH("tie_heads", (double)count * 0.25 + (double)kept * 8, k_tie_heads, hgrid, kBlock, st, ties.tmask, count, pt, (const uint32_t*)sa,
+                       ties.hmask, lines);
+            SFX_LAUNCH("tie_totals", 0.0, k_tie_totals, 1, kBlock, st, (const uint32_t*)lines, b.totals);
+            uint32_t runs = 0;
+            SFX_TRY(read_back(&runs, b.totals, sizeof(runs), st));
+            groups = runs;
+            if (groups * 2 > kept) return SFX_ERR_INTERNAL;
             Chunking ch = make_chunking(nwords, kBlock);
             const uint64_t chunk = ch.tiles_per_block * kBlock;
-            SFX_LAUNCH("tie_list_count", (double)count * 0.125, k_tie_list, ch.blocks, kBlock, st, ties.tmask, ties.hmask, nwords, chunk, 0,
-                       b.block_counts, (const uint32_t*)sa, b.S0, V_next, b.G);
+            SFX_LAUNCH("tie_list_count", (double)count * 0.125, k_tie_list, ch.blocks, kBlock, st, ties.tmask, (const uint32_t*)ties.hmask, nwords, chunk,
+                       0, b.block_counts, (const uint32_t*)sa, b.S0, V_next, b.G);
             SFX_LAUNCH("flag_scan", 0.0, k_scan_block_counts, 1, kBlock, st, b.block_counts, ch.blocks, b.totals);
-            SFX_LAUNCH("tie_list", (double)count * 0.25 + (double)kept * 16, k_tie_list, ch.blocks, kBlock, st, ties.tmask, ties.hmask, nwords,
-                       chunk, 1, b.block_counts, (const uint32_t*)sa, b.S0, V_next, b.G);
+            SFX_LAUNCH("tie_list", (double)count * 0.25 + (double)kept * 16, k_tie_list, ch.blocks, kBlock, st, ties.tmask, (const uint32_t*)ties.hmask,
+                       nwords, chunk, 1, b.block_counts, (const uint32_t*)sa, b.S0, V_next, b.G);
         }
         uint32_t* S_cur = b.S0;
         if (small_groups_pay(kept, groups))

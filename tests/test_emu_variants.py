@@ -52,7 +52,7 @@ if os.environ.get("SFX_HYBRID_MIN"):
     texts += [_gen.uniform_bytes(12000, 5, 2, base=65).tobytes(), _gen.uniform_bytes(12000, 16, 3, base=65).tobytes(),
               _gen.uniform_bytes(14000, 2, 4, base=65).tobytes()]
     # one 8-symbol block followed by one of 700 8-symbol tails, every tail twice: a sub-bucket of ~1400 suffixes in 700 runs of
-    # two equal keys, spread over the groups of the fast path (round 6: all of them ordered where they are by k_tie_direct)
+    # two equal keys, spread over the groups of the fast path and side by side in the sorted order
     b8 = bytes(rngh.choice(list(b"ACGT"), 8).tolist())
     tails = [bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for _ in range(700)]
     order = rngh.permutation(1400) % 700
@@ -90,10 +90,12 @@ if os.environ.get("SFX_HYBRID_MIN"):
     # round 6: with no oversized sub-bucket the LDS sort names the tied elements itself -- no keys written, none read back
     assert ("tie_direct" in names) == (cap > 10 and ties_on) and ("groups_reduce" in names) != ("tie_direct" in names), names
     if cap >= 100000 and ties_on:
-        # random DNA and the 700 runs of two: every run ordered where it is, no list at all; runs of more than eight members (and
-        # the ones before the repeated block, equal for hundreds of symbols): ALL runs become the first active list
+        # random DNA: every stretch of tied slots ordered where it is, no list at all; the 700 runs of two lie side by side in their
+        # sub-bucket -- ONE stretch of 1400 tied slots, more than k_tie_direct takes -- and the runs of eleven are too long: ALL
+        # runs become the first active list (k_tie_heads tells the runs of a stretch apart)
         names2 = kernels_of(runs_of_two)
-        assert "tie_list" not in names and "small_groups" not in names and "tie_list" not in names2, (names, names2)
+        assert "tie_list" not in names and "small_groups" not in names, names
+        assert "tie_heads" in names2 and "tie_list" in names2 and "small_groups" in names2, names2
         names2 = kernels_of(runs_of_eleven)
         assert "tie_list_count" in names2 and "tie_list" in names2 and "deep_wave" in names2, names2    # (runs of eleven: no direct pass of the list)
     names = kernels_of(planted)                                       # 0.8 % of it in the three planted sub-buckets
