@@ -1165,8 +1165,8 @@ k_small_groups(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, c
 // holds the suffixes.
 //
 // k_tie_direct orders every stretch of up to kTieRunMax slots on the text from the suffixes' first symbol on (so it need not
-// know where one run of a stretch ends and the next begins): a wave reads 64 x 4 mask words, every lane lists the stretches that
-// start in its 128 slots, the wave's list is worked off 64 stretches at a time -- the suffixes of one stretch in the registers
+// know where one run of a stretch ends and the next begins): a wave reads 64 x 2 mask words, every lane lists the stretches that
+// start in its 64 slots, the wave's list is worked off 64 stretches at a time -- the suffixes of one stretch in the registers
 // of one lane, insertion sort with direct_compare64 (as k_small_groups orders the small buckets of an active list, two key words
 // per step) -- and written back in order.  A stretch it cannot finish -- longer, or two members equal for 8 more key pairs --
 // stays as it is.  lines: counter lines [0] = tied slots, [1] = stretches, [2] = members of unfinished stretches.  Uniform DNA
@@ -1204,41 +1204,39 @@ k_tie_direct(const uint32_t* __restrict__ tmask, uint64_t m, PackedText t, uint3
 {
     __shared__ uint32_t s_ent[kWavesPerBlock][kWave * kTieBatch];
     const unsigned lane = lane_id(), w = wave_id();
-    const uint64_t nquads = ((m + 31) / 32 + 3) / 4;              // (the mask is padded with zero words beyond that)
+    // The kernel is a chain of dependent misses (mask word -> the stretch's slots -> the text -> the slots again) and nothing
+    // else: what counts is how few links a wave works off one after the other.  A lane owns 64 slots (0.7 stretches on uniform
+    // DNA): most waves list their stretches in one round and order them in one pass.
+    const uint64_t npairs = ((m + 31) / 32 + 1) / 2;              // (the mask is padded with zero words beyond that)
     const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
-    const uint4* const tmask4 = reinterpret_cast<const uint4*>(tmask);
+    const uint2* const tmask2 = reinterpret_cast<const uint2*>(tmask);
     uint32_t n_tied = 0, n_runs = 0, n_left = 0;                  // (per lane; summed over the wave at the end)
-    for (uint64_t qbase = ((uint64_t)blockIdx.x * kWavesPerBlock + w) * kWave; qbase < nquads; qbase += nwaves * kWave) {
+    for (uint64_t qbase = ((uint64_t)blockIdx.x * kWavesPerBlock + w) * kWave; qbase < npairs; qbase += nwaves * kWave) {
         const uint64_t q = qbase + lane;
-        uint4 T = {0u, 0u, 0u, 0u};
-        if (q < nquads) T = tmask4[q];
-        // the slot before this lane's 128 and the 32 behind them: the neighbouring lanes' words (the wave's ends: one more load)
-        uint32_t prev_top = (uint32_t)__shfl_up(T.w, 1) >> 31, next_w = (uint32_t)__shfl_down(T.x, 1);
-        if (lane == 0) prev_top = qbase ? tmask[qbase * 4 - 1] >> 31 : 0u;
-        if (lane == kWave - 1) next_w = qbase + kWave <= nquads ? tmask[(qbase + kWave) * 4] : 0u;
-        const uint64_t lo = (uint64_t)T.x | ((uint64_t)T.y << 32), hi = (uint64_t)T.z | ((uint64_t)T.w << 32);
-        n_tied += (uint32_t)__popcll(lo) + (uint32_t)__popcll(hi);
-        // bits [i, i + 64) of the lane's 160 (valid for the 33 bits a stretch can need)
-        auto window = [&](unsigned i) -> uint64_t {
-            if (i < 64u) return i ? (lo >> i) | (hi << (64u - i)) : lo;
-            const unsigned j = i - 64u;
-            return j ? (hi >> j) | ((uint64_t)next_w << (64u - j)) : (hi | 0ull);
-        };
+        uint2 T = {0u, 0u};
+        if (q < npairs) T = tmask2[q];
+        // the slot before this lane's 64 and the 32 behind them: the neighbouring lanes' words (the wave's ends: one more load)
+        uint32_t prev_top = (uint32_t)__shfl_up(T.y, 1) >> 31, next_w = (uint32_t)__shfl_down(T.x, 1);
+        if (lane == 0) prev_top = qbase ? tmask[qbase * 2 - 1] >> 31 : 0u;
+        if (lane == kWave - 1) next_w = qbase + kWave <= npairs ? tmask[(qbase + kWave) * 2] : 0u;
+        const uint64_t lo = (uint64_t)T.x | ((uint64_t)T.y << 32);
+        n_tied += (uint32_t)__popcll(lo);
+        // bits [i, i + 64) of the lane's 96 (valid for the 33 bits a stretch can need)
+        auto window = [&](unsigned i) -> uint64_t { return i ? (lo >> i) | ((uint64_t)next_w << (64u - i)) : lo; };
         // stretches that start here: a tied slot behind an untied one
-        uint64_t slo = lo & ~((lo << 1) | (uint64_t)prev_top), shi = hi & ~((hi << 1) | (lo >> 63));
-        while (__ballot((slo | shi) != 0ull) != 0ull) {
+        uint64_t slo = lo & ~((lo << 1) | (uint64_t)prev_top);
+        while (__ballot(slo != 0ull) != 0ull) {
             uint32_t ent[kTieBatch];
             uint32_t mine = 0;
 #pragma unroll
             for (int k = 0; k < kTieBatch; k++) {
                 ent[k] = 0u;
-                if ((slo | shi) != 0ull) {
-                    unsigned i;
-                    if (slo) { i = (unsigned)__ffsll((unsigned long long)slo) - 1u; slo &= slo - 1ull; }
-                    else { i = 64u + (unsigned)__ffsll((unsigned long long)shi) - 1u; shi &= shi - 1ull; }
+                if (slo != 0ull) {
+                    const unsigned i = (unsigned)__ffsll((unsigned long long)slo) - 1u;
+                    slo &= slo - 1ull;
                     const uint64_t win = window(i);
                     uint32_t len = (~win) ? (uint32_t)__ffsll((unsigned long long)~win) - 1u : 64u;
-                    const uint64_t r0 = q * 128 + i;
+                    const uint64_t r0 = q * 64 + i;
                     n_runs++;
                     if (len > kTieRunMax) {
                         uint64_t r = r0 + (len < 33u ? len : 33u);                // (the window holds 33 bits for sure)
@@ -2213,8 +2211,8 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         static_assert(kTieSlots * 4 * sizeof(uint32_t) <= kDeepSlotWords * sizeof(unsigned long long), "the counter lines fit");
         SFX_HIP(hipMemsetAsync(lines, 0, kTieSlots * 4 * sizeof(uint32_t), st));
         {
-            const uint64_t waves = (nwords / 4 + kWave - 1) / kWave + 1;
-            const unsigned grid = (unsigned)dmin<uint64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, kMaxGrid);
+            const uint64_t waves = (nwords / 2 + kWave - 1) / kWave + 1;          // (a wave: 64 lanes x 2 mask words)
+            const unsigned grid = (unsigned)dmin<uint64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, 4 * kMaxGrid);
             SFX_LAUNCH("tie_direct", (double)count * 0.125, k_tie_direct, grid, kBlock, st, ties.tmask, count, pt, sa, lines);
             SFX_LAUNCH("tie_totals", 0.0, k_tie_totals, 1, kBlock, st, (const uint32_t*)lines, b.totals);
         }
