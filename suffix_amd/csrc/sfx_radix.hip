@@ -1982,12 +1982,13 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     // (development): the sorted keys, as rounds 3-5.
     static const int ties_on = [] { const char* e = dev_env("SFX_HYBRID_TIES"); return e ? atoi(e) : 1; }();
     const bool tie_mode = ties && ties_on && nover == 0;
-    // the mask (m / 32 words + zero words behind them) and a second array of the same size for the caller -- in e0, which nobody
+    // the mask (m / 32 words + zero words behind them) and two more arrays of the same size for the caller -- in e0, which nobody
     // needs once the elements are in e1
     const uint64_t mask_words = ((m + 31) / 32 + 64) & ~uint64_t(31);
     uint32_t* const gt = reinterpret_cast<uint32_t*>(e0);
-    uint32_t* const gh = gt + mask_words;
-    if (tie_mode) SFX_HIP(hipMemsetAsync(gt, 0, mask_words * sizeof(uint32_t), st));      // (the second array is the caller's to fill)
+    uint32_t* const gl = gt + mask_words;
+    uint32_t* const gh = gl + mask_words;
+    if (tie_mode) SFX_HIP(hipMemsetAsync(gt, 0, 2 * mask_words * sizeof(uint32_t), st));  // (the third array is the caller's to fill)
 #define SFX_BUCKET_SORT(NW, KPT, LO, HI, GRID)                                                                              \
     do {                                                                                                                    \
         if (tie_mode)                                                                                                       \
@@ -2005,6 +2006,7 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     if (tie_mode) {
         ties->produced = true;
         ties->tmask = gt;
+        ties->lmask = gl;
         ties->hmask = gh;
     }
     if (nover) {

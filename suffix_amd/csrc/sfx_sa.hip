@@ -1169,13 +1169,25 @@ k_small_groups(const uint32_t* __restrict__ V, const uint32_t* __restrict__ S, c
 // start in its 64 slots, the wave's list is worked off 64 stretches at a time -- the suffixes of one stretch in the registers
 // of one lane, insertion sort with direct_compare64 (as k_small_groups orders the small buckets of an active list, two key words
 // per step) -- and written back in order.  A stretch it cannot finish -- longer, or two members equal for 8 more key pairs --
-// stays as it is.  lines: counter lines [0] = tied slots, [1] = stretches, [2] = members of unfinished stretches.  Uniform DNA
-// leaves none: the build is done.  Otherwise k_tie_heads marks the first slot of every run (a key compare with the slot
-// before), ALL runs become the first active list (k_tie_list) and the direct pass of the list redoes the finished ones.
+// stays as it is and is marked in lmask.  lines: counter lines [0] = tied slots, [1] = stretches, [2] = members of unfinished
+// stretches.  Uniform DNA leaves none: the build is done.  Otherwise k_tie_heads marks the first slot of every run of the
+// unfinished stretches (a key compare with the slot before) and they become the first active list (k_tie_list).
 constexpr uint32_t kTieRunMax = 8;
 constexpr unsigned kTieSlots = 1024;                              // counter lines of k_tie_direct (4 words each: in deep_slots)
 constexpr int kTieBatch = 2;                                      // stretches a lane lists per round of its wave
 __device__ __forceinline__ bool tie_bit(const uint32_t* __restrict__ mask, uint64_t r) { return (mask[r >> 5] >> (r & 31u)) & 1u; }
+// bits [r0, r0 + len) of a mask that other lanes mark too
+__device__ __forceinline__ void tie_mark(uint32_t* __restrict__ mask, uint64_t r0, uint32_t len)
+{
+    uint64_t r = r0;
+    const uint64_t end = r0 + len;
+    while (r < end) {
+        const uint32_t bit = (uint32_t)(r & 31u);
+        const uint64_t room = 32u - bit, take = end - r < room ? end - r : room;
+        atomicOr(&mask[r >> 5], (take == 32u ? 0xFFFFFFFFu : ((1u << take) - 1u)) << bit);
+        r += take;
+    }
+}
 
 // -1: suffix a < suffix b, +1: a > b, 0: equal for `steps` pairs of packed words beyond offset h (direct_compare, two words a step)
 __device__ __forceinline__ int direct_compare64(const PackedText& t, uint64_t a, uint64_t b, uint64_t h, int steps)
@@ -1200,7 +1212,8 @@ __device__ __forceinline__ int direct_compare64(const PackedText& t, uint64_t a,
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_tie_direct(const uint32_t* __restrict__ tmask, uint64_t m, PackedText t, uint32_t* __restrict__ sa, uint32_t* __restrict__ lines)
+k_tie_direct(const uint32_t* __restrict__ tmask, uint64_t m, PackedText t, uint32_t* __restrict__ sa, uint32_t* __restrict__ lines,
+             uint32_t run_max, uint32_t* __restrict__ lmask)
 {
     __shared__ uint32_t s_ent[kWavesPerBlock][kWave * kTieBatch];
     const unsigned lane = lane_id(), w = wave_id();
@@ -1238,10 +1251,11 @@ k_tie_direct(const uint32_t* __restrict__ tmask, uint64_t m, PackedText t, uint3
                     uint32_t len = (~win) ? (uint32_t)__ffsll((unsigned long long)~win) - 1u : 64u;
                     const uint64_t r0 = q * 64 + i;
                     n_runs++;
-                    if (len > kTieRunMax) {
+                    if (len > run_max) {
                         uint64_t r = r0 + (len < 33u ? len : 33u);                // (the window holds 33 bits for sure)
                         if (len >= 33u) { len = 33u; while (tie_bit(tmask, r)) { len++; r++; } }
                         n_left += len;
+                        tie_mark(lmask, r0, len);
                     } else {
                         ent[mine++] = (uint32_t)r0 | (len << 28);              // (r0 < m <= 2^28: the hybrid route's limit)
                     }
@@ -1256,9 +1270,9 @@ k_tie_direct(const uint32_t* __restrict__ tmask, uint64_t m, PackedText t, uint3
             for (uint32_t e = lane; e < total; e += kWave) {
                 const uint32_t en = s_ent[w][e], len = en >> 28;
                 uint32_t* const slot = sa + (en & 0x0FFFFFFFu);
-                uint32_t suf[kTieRunMax];
+                uint32_t suf[kTieRunMax], slot_was[kTieRunMax];
 #pragma unroll
-                for (uint32_t k = 0; k < kTieRunMax; k++) suf[k] = k < len ? slot[k] : 0u;
+                for (uint32_t k = 0; k < kTieRunMax; k++) suf[k] = slot_was[k] = k < len ? slot[k] : 0u;
                 // insertion sort on the text; a pair that stays equal leaves the stretch as it was
                 bool undecided = false;
 #pragma unroll
@@ -1281,10 +1295,12 @@ k_tie_direct(const uint32_t* __restrict__ tmask, uint64_t m, PackedText t, uint3
                         }
                     }
                 }
-                if (undecided) { n_left += len; continue; }
+                if (undecided) { n_left += len; tie_mark(lmask, (uint64_t)(en & 0x0FFFFFFFu), len); continue; }
+                // (only what moved: a store into the array is a partial block at the memory side, and half of the pairs lie in
+                // order already)
 #pragma unroll
                 for (uint32_t k = 0; k < kTieRunMax; k++)
-                    if (k < len) slot[k] = suf[k];
+                    if (k < len && slot_was[k] != suf[k]) slot[k] = suf[k];
             }
             wave_sync();                                                        // (the list is read to the end)
         }
@@ -2167,7 +2183,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     uint32_t* V_next;
     bool in_place = false;
     int in1 = 0;
-    TieRecords ties = {false, nullptr, nullptr};
+    TieRecords ties = {false, nullptr, nullptr, nullptr};
     if (sizeof(KeyT) == 4) {
         // E64 elements; the last pass drops every suffix straight into its SA slot and
         // leaves the sorted 32-bit keys in the element buffer it did not read
@@ -2213,7 +2229,9 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         {
             const uint64_t waves = (nwords / 2 + kWave - 1) / kWave + 1;          // (a wave: 64 lanes x 2 mask words)
             const unsigned grid = (unsigned)dmin<uint64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, 4 * kMaxGrid);
-            SFX_LAUNCH("tie_direct", (double)count * 0.125, k_tie_direct, grid, kBlock, st, ties.tmask, count, pt, sa, lines);
+            // SFX_TIE_RUN_MAX=<2 .. 8> (development): the longest stretch k_tie_direct takes
+            static const uint32_t run_max = [] { const char* e = dev_env("SFX_TIE_RUN_MAX"); const int v = e ? atoi(e) : (int)kTieRunMax; return (uint32_t)(v >= 2 && v <= (int)kTieRunMax ? v : (int)kTieRunMax); }();
+            SFX_LAUNCH("tie_direct", (double)count * 0.125, k_tie_direct, grid, kBlock, st, ties.tmask, count, pt, sa, lines, run_max, ties.lmask);
             SFX_LAUNCH("tie_totals", 0.0, k_tie_totals, 1, kBlock, st, (const uint32_t*)lines, b.totals);
         }
         uint32_t host_totals[3] = {0, 0, 0};
@@ -2225,13 +2243,15 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
             stats.small_bucket_resolved += kept;
             return SFX_OK;
         }
-        // ... and what that leaves tied (repeats beyond the direct pass's depth, long runs) goes on as the first active list: ALL
-        // the tied slots, in order, as the runs they are (k_tie_heads) -- its direct pass redoes the runs that k_tie_direct finished
+        // ... and what that leaves tied (repeats beyond its depth, long stretches: marked in lmask) goes on as the first active
+        // list, as the runs of equal keys it is made of (k_tie_heads)
+        stats.small_bucket_resolved += kept - host_totals[2];
+        kept = host_totals[2];
         {
             SFX_HIP(hipMemsetAsync(lines, 0, kTieSlots * 4 * sizeof(uint32_t), st));
             const unsigned hgrid = (unsigned)dmin<uint64_t>((nwords + kBlock - 1) / kBlock, kMaxGrid);
-            SFX_LAUNCH("tie_heads", (double)count * 0.25 + (double)kept * 8, k_tie_heads, hgrid, kBlock, st, ties.tmask, count, pt, (const uint32_t*)sa,
-                       ties.hmask, lines);
+            SFX_LAUNCH("tie_heads", (double)count * 0.25 + (double)kept * 8, k_tie_heads, hgrid, kBlock, st, (const uint32_t*)ties.lmask, count, pt,
+                       (const uint32_t*)sa, ties.hmask, lines);
             SFX_LAUNCH("tie_totals", 0.0, k_tie_totals, 1, kBlock, st, (const uint32_t*)lines, b.totals);
             uint32_t runs = 0;
             SFX_TRY(read_back(&runs, b.totals, sizeof(runs), st));
@@ -2239,11 +2259,11 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
             if (groups * 2 > kept) return SFX_ERR_INTERNAL;
             Chunking ch = make_chunking(nwords, kBlock);
             const uint64_t chunk = ch.tiles_per_block * kBlock;
-            SFX_LAUNCH("tie_list_count", (double)count * 0.125, k_tie_list, ch.blocks, kBlock, st, ties.tmask, (const uint32_t*)ties.hmask, nwords, chunk,
-                       0, b.block_counts, (const uint32_t*)sa, b.S0, V_next, b.G);
+            SFX_LAUNCH("tie_list_count", (double)count * 0.125, k_tie_list, ch.blocks, kBlock, st, (const uint32_t*)ties.lmask, (const uint32_t*)ties.hmask,
+                       nwords, chunk, 0, b.block_counts, (const uint32_t*)sa, b.S0, V_next, b.G);
             SFX_LAUNCH("flag_scan", 0.0, k_scan_block_counts, 1, kBlock, st, b.block_counts, ch.blocks, b.totals);
-            SFX_LAUNCH("tie_list", (double)count * 0.25 + (double)kept * 16, k_tie_list, ch.blocks, kBlock, st, ties.tmask, (const uint32_t*)ties.hmask,
-                       nwords, chunk, 1, b.block_counts, (const uint32_t*)sa, b.S0, V_next, b.G);
+            SFX_LAUNCH("tie_list", (double)count * 0.25 + (double)kept * 16, k_tie_list, ch.blocks, kBlock, st, (const uint32_t*)ties.lmask,
+                       (const uint32_t*)ties.hmask, nwords, chunk, 1, b.block_counts, (const uint32_t*)sa, b.S0, V_next, b.G);
         }
         uint32_t* S_cur = b.S0;
         if (small_groups_pay(kept, groups))
