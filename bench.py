@@ -11,7 +11,10 @@ timed region).  N = 1 runs BASELINE.json configs[1]: 100 MB synthetic DNA
 (launched by torch.distributed.run, one rank per GPU) runs the range-partitioned
 build of suffix_amd/dist.py: every rank contributes a 100 MB shard, the job
 builds the SA of the N*100 MB text, each rank producing its contiguous slice
-("weak" scaling: suffixes sorted per GPU stay fixed).
+("weak" scaling: suffixes sorted per GPU stay fixed).  --total-size T is the
+STRONG series instead: ONE text of T bytes (uniform DNA, seed 0x5AF1C5 + 4 --
+BASELINE config 4 at T = 4000000000) cut into N equal shards, at N = 1 the
+single-GPU build of the same text; the line then says "scaling": "strong".
 
 Rank 0 prints the full records on lines that start with "DETAIL " (headline, then one per full-size config) and, last,
 ONE compact JSON line (< 4 KB; see DESIGN.md "Measurement" for every field) that carries, per config, {sa_ms, lcp_ms,
@@ -393,6 +396,10 @@ def main():
                          "configs 3 / 5 on round 1's easier inputs, for a like-for-like comparison with round 1 -- their "
                          "numpy generators take ~1 min each, so they are skipped once the run is past --config-budget seconds); "
                          "'' = none")
+    ap.add_argument("--total-size", type=int, default=0,
+                    help="STRONG scaling: the bytes of ONE text (uniform DNA, seed 0x5AF1C5 + 4: BASELINE config 4 at 4000000000) cut into "
+                         "N equal shards, rank r generating bytes [r T / N, (r + 1) T / N) -- total work fixed as N grows; --size is "
+                         "ignored.  The line then says \"scaling\": \"strong\" and names the config in config.workload")
     ap.add_argument("--dev-lib", default=None,
                     help="development A/B runs only (scripts/gpu_ab.sh): bind this build of the C ABI (libsuffix_hip_dev.so, hooks "
                          "compiled in) instead of the product library; the line then carries config.dev_lib")
@@ -471,7 +478,17 @@ def main():
 
     n_local = args.size - ((4097 * rank + 1) if (args.ragged and world > 1) else 0)
     seed = 0x5AF1C5 + 1 + rank                 # seed = 0x5AF1C5 + config index
-    if args.input == "periodic":
+    strong = args.total_size > 0
+    shard_begin = 0
+    if strong:
+        # ONE text for every N: rank r holds bytes [r T / N, (r + 1) T / N) of the stream of seed 0x5AF1C5 + 4 (config 4's)
+        if args.total_size > 0xFFFFFFFF:
+            raise SystemExit("--total-size beyond u32::MAX bytes (src/table.rs:380)")
+        shard_begin = args.total_size * rank // world
+        n_local = args.total_size * (rank + 1) // world - shard_begin
+    if strong:
+        host_text = _gen.dna_slice(shard_begin, n_local, seed=0x5AF1C5 + 4)
+    elif args.input == "periodic":
         # every shard a stretch of ONE periodic text (period 24, a different phase per rank): suffixes tie for the whole
         # length of the text, the range build reports SFX_ERR_NEEDS_RANKS and every rank builds the whole array
         unit = np.frombuffer(b"ACGTTGCAACGGTTCAGTCATGCA", dtype=np.uint8)
@@ -480,6 +497,8 @@ def main():
         host_text = _gen.dna(n_local, seed=seed)
     text = torch.from_numpy(host_text).to(dev)
     n_total = sum(args.size - ((4097 * r + 1) if (args.ragged and world > 1) else 0) for r in range(world))
+    if strong:
+        n_total = args.total_size
 
     def barrier():
         if world > 1:
@@ -536,7 +555,7 @@ def main():
     # separate call, :130-138) ----
     lcp_info = None
     e2e = None
-    if world == 1:
+    if world == 1 and not strong:                # (the strong-scaling series times the build alone, at every N)
         lcp_ws = sdev.lcp_workspace(n_local, dev)
         lcp = torch.empty(n_local, dtype=torch.int32, device=dev)
         sdev.build_lcp(text, sa, out=lcp, workspace=lcp_ws)
@@ -658,7 +677,9 @@ def main():
     # ---- correctness gates ----
     verified, how = None, "skipped"
     if not args.no_verify:
-        if world == 1:
+        if world == 1 and n_local > (1 << 30):
+            verified, how = verify_sa_chunked(torch, sdev, text, sa)     # (the int64 temporaries of the plain gate would not fit)
+        elif world == 1:
             verified, how = verify_sa_on_device(torch, sdev, text, sa)
         else:
             part, offset, n_all = result["part"]
@@ -673,7 +694,7 @@ def main():
 
     # ---- CPU baseline: the oracle (C restatement of the reference's sais), 1 thread ----
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and not strong:
         import oracle
         m = min(args.cpu_sample, n_local)
         sample = host_text[:m]
@@ -724,7 +745,7 @@ def main():
                "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
 
     configs = None
-    if rank == 0 and world == 1 and args.configs:
+    if rank == 0 and world == 1 and args.configs and not strong:
         del text, sa
         torch.cuda.empty_cache()
         pins = {}
@@ -747,6 +768,11 @@ def main():
         # DETAIL lines first (one JSON object each, never the last line): everything round 3 packed into one 25 KB line
         workload = (f"{n_local} B synthetic DNA (sigma=4, uniform, splitmix64) per GPU, u32 indices, device-resident text -> device SA"
                     + ("" if world == 1 else f"; range-partitioned over {world} GPUs, text {n_total} B"))
+        if strong:
+            workload = (f"{n_total} B synthetic DNA (sigma=4, uniform, splitmix64 seed 0x5AF1C5 + 4"
+                        + (": BASELINE config 4's text" if n_total == 4_000_000_000 else "")
+                        + f"), ONE text cut into {world} shard(s) of {n_total // world} B, u32 indices, device-resident shards -> "
+                        + ("device SA" if world == 1 else f"one contiguous slice of the SA per GPU (range-partitioned, suffix_amd/dist.py)"))
         print("DETAIL " + json.dumps({"detail": "headline", "config": {"workload": workload, "text_bytes_total": n_total, "build": stats,
                                                                         "partitioned_phases_ms": phases},
                                       "roofline": roofline, "cpu_baseline": cpu, "lcp": lcp_info, "verification": how}))
@@ -778,7 +804,7 @@ def main():
         out = {
             "metric": METRIC, "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": workload, "text_bytes_total": n_total, "partitioned_phases_ms": phases,
                        **({"dev_lib": os.path.basename(args.dev_lib)} if args.dev_lib else {})},

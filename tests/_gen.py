@@ -53,7 +53,7 @@ def _gen_lib():
         _lib = ctypes.CDLL(os.path.join(_GEN_DIR, "libsfxgen.so"))
         vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
         for name, args in (("sfxgen_english", [vp, u64, u64, i32]), ("sfxgen_utf8", [vp, u64, u64, i32]),
-                           ("sfxgen_dna", [vp, u64, u64, i32]),
+                           ("sfxgen_dna", [vp, u64, u64, i32]), ("sfxgen_dna_slice", [vp, u64, u64, u64, i32]),
                            ("sfxgen_near_duplicates", [vp, u64, u64, u32, u32, i32]),
                            ("sfxgen_queries", [vp, u64, u64, u64, vp, vp])):
             fn = getattr(_lib, name)
@@ -72,6 +72,13 @@ def dna_fast(n, seed=0x5AF1C5 + 1):
     """dna() through the C generator (identical bytes, ~100x faster at 1 GB)."""
     out = np.empty(n, dtype=np.uint8)
     assert _gen_lib().sfxgen_dna(out.ctypes.data, n, seed, _threads()) == 0
+    return out
+
+
+def dna_slice(begin, n, seed=0x5AF1C5 + 1):
+    """bytes [begin, begin + n) of dna(begin + n, seed) without making the rest: a rank's shard of ONE text."""
+    out = np.empty(n, dtype=np.uint8)
+    assert _gen_lib().sfxgen_dna_slice(out.ctypes.data, begin, n, seed, _threads()) == 0
     return out
 
 

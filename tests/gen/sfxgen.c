@@ -224,6 +224,24 @@ int sfxgen_dna(uint8_t* out, uint64_t n, uint64_t seed, int threads)
     return 0;
 }
 
+/* bytes [begin, begin + n) of the same stream (a rank's shard of ONE text: bench.py --total-size) */
+int sfxgen_dna_slice(uint8_t* out, uint64_t begin, uint64_t n, uint64_t seed, int threads)
+{
+    static const char sym[4] = {'A', 'C', 'G', 'T'};
+    const int64_t w0 = (int64_t)(begin / 32), w1 = (int64_t)((begin + n + 31) / 32);
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int64_t j = w0; j < w1; j++) {
+        uint64_t s = seed + (uint64_t)j * 0x9E3779B97F4A7C15ull;
+        uint64_t w = sm_next(&s);
+        for (int c = 0; c < 32; c++) {
+            const uint64_t p = (uint64_t)j * 32 + (uint64_t)c;
+            if (p >= begin && p < begin + n) out[p - begin] = (uint8_t)sym[(w >> (2 * c)) & 3];
+        }
+    }
+    return 0;
+}
+
 /* config 5 queries: nq substrings of `text` (valid UTF-8) starting at code-point boundaries, 1-16 code
  * points long; the second half has its last code point replaced by another one of the same script
  * (mostly misses).  qbytes must hold 64 * nq bytes, qoff nq + 1 entries.  Returns total bytes via qoff[nq]. */

@@ -216,7 +216,7 @@ def _bench_over_rccl(extra, size="20000000", share_gpu=False):
     return rec
 
 
-@pytest.mark.parametrize("case", ["even-packed", "ragged-packed", "replicated-fallback"])
+@pytest.mark.parametrize("case", ["even-packed", "ragged-packed", "replicated-fallback", "strong"])
 def test_two_gpu_bench_over_rccl(case):
     """bench.py --gpus 2 under torch.distributed.run with the nccl (= RCCL) backend, one rank per GPU: the partitioned build's
     first contact with RCCL, one sub-case per branch of suffix_amd/dist.py -- shards of equal length (packed exchange on the
@@ -238,13 +238,17 @@ def test_two_gpu_bench_over_rccl(case):
         assert ph["range_build"] > 0 and "fallback" not in ph, ph
         assert rec["config"]["text_bytes_total"] == 2 * 20000000 - 1 - 4098
         assert "packed" in str(ph.get("text_exchange", "packed")), ph
+    elif case == "strong":
+        # --total-size: ONE text cut into N shards (the strong series of BASELINE config 4, here at 40 MB)
+        rec = _bench_over_rccl(["--total-size", "40000001"])
+        assert rec["scaling"] == "strong" and rec["config"]["text_bytes_total"] == 40000001, rec
     else:
         rec = _bench_over_rccl(["--input", "periodic"], size="3000000")
         ph = rec["config"]["partitioned_phases_ms"]
         assert "fallback" in ph, ph
 
 
-@pytest.mark.parametrize("case", ["even-packed", "ragged-packed", "replicated-fallback"])
+@pytest.mark.parametrize("case", ["even-packed", "ragged-packed", "replicated-fallback", "strong"])
 def test_two_rank_bench_rehearsal_on_one_gpu(case):
     """The same three sub-cases as test_two_gpu_bench_over_rccl on the 1-GPU boxes of this pool: both ranks on cuda:0, gloo in
     place of RCCL (which refuses two ranks on one device) -- bench.py's N > 1 code, its --ragged / --input flags and every
@@ -257,6 +261,19 @@ def test_two_rank_bench_rehearsal_on_one_gpu(case):
         ph = rec["config"]["partitioned_phases_ms"]
         assert "fallback" not in ph and rec["config"]["text_bytes_total"] == 6000000 - 1 - 4098, rec["config"]
         assert "packed" in str(ph.get("text_exchange", "")), ph
+    elif case == "strong":
+        # the strong series: the same 6 000 001-byte text at N = 2 (two shards of one stream) and at N = 1 (bench.py alone) --
+        # scaling "strong", total work fixed
+        rec = _bench_over_rccl(["--total-size", "6000001"], share_gpu=True)
+        assert rec["scaling"] == "strong" and rec["config"]["text_bytes_total"] == 6000001, rec
+        assert "ONE text cut into 2" in rec["config"]["workload"], rec["config"]
+        import subprocess
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--total-size", "6000001",
+                              "--no-microbench"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+        one = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert one["scaling"] == "strong" and one["n_gpus"] == 1 and one["verified"] is True, one
+        assert one["config"]["text_bytes_total"] == 6000001 and one["cpu_baseline"] is None, one
     else:
         rec = _bench_over_rccl(["--input", "periodic"], size="1000000", share_gpu=True)
         assert "fallback" in rec["config"]["partitioned_phases_ms"], rec["config"]
