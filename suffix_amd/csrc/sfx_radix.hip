@@ -73,6 +73,22 @@ struct SrcText32 {
     }
     __device__ __forceinline__ uint32_t val(uint64_t) const { return 0u; }
 };
+// The same with `extra` more key bits in the element where the suffix index leaves room (round 6; the hybrid route, m <= 2^28:
+// a suffix index needs 28 bits): element = key of 32 + extra bits << (32 - extra) | suffix.  The order of whole elements is
+// the order of (longer key, suffix); the top 32 bits are the 32-bit key as before.  Two more symbols of DNA in the key: a
+// sixteenth of the ties (k_bucket_sort<.., true>, sbits).
+struct SrcText36 {
+    static constexpr bool kHasVal = false;
+    static constexpr bool kFromText = true;
+    PackedText t;
+    int extra;                      // whole symbols' worth of bits, <= 4
+    __device__ __forceinline__ uint64_t key(uint64_t i) const
+    {
+        const uint64_t k64 = packed_key64(t, i);                         // 2 * kbits = 64 bits of symbols (kbits == 32 here)
+        return ((k64 >> (32 - extra)) << (32 - extra)) | (uint64_t)(uint32_t)i;
+    }
+    __device__ __forceinline__ uint32_t val(uint64_t) const { return 0u; }
+};
 struct SrcKV {
     static constexpr bool kHasVal = true;
     static constexpr bool kFromText = false;
@@ -1361,11 +1377,16 @@ struct TieSmem<WORDS, false> {};
 template <int NW, int KPT, bool TIES = false>
 __global__ void __launch_bounds__(NW * kWave) SFX_WAVES_PER_EU(NW == 4 && KPT == 8 ? 6 : 1, 8)
 k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstart, uint32_t nbuckets, int low_bits,
-              uint32_t lo, uint32_t hi, uint32_t* __restrict__ K, uint32_t* __restrict__ V, uint32_t* __restrict__ GT = nullptr)
+              uint32_t lo, uint32_t hi, uint32_t* __restrict__ K, uint32_t* __restrict__ V, uint32_t* __restrict__ GT = nullptr,
+              int sbits_arg = 32)
 {
     constexpr int kThreads = NW * kWave;
     constexpr uint32_t kCap = kThreads * KPT;
     constexpr int kMaskWords = (int)(kCap / 32u);
+    // sbits: the low bits of an element that hold the suffix index; the key lies above them, its low_bits low bits are what is
+    // sorted here (TIES: 28 when the elements carry 36 key bits, SrcText36; the keys-out form is always 32 + 32)
+    const int sbits = TIES ? sbits_arg : 32;
+    const uint64_t smask = (1ull << sbits) - 1ull;
     static_assert(kWave * KPT >= kRadix, "the match masks must fit the staging buffer");
     static_assert(NW * kRadix >= kGroups && kGroups % (NW * kWave) == 0, "the group counts of the fast path live in cnt");
     static_assert(kMaskWords < kThreads, "one thread per mask word");
@@ -1443,7 +1464,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
         if (size > 1) {
             // group by the top bits of the low key part: place inside the group from a returning atomic, group starts by a scan
             const int gbits = low_bits < kGroupBits ? low_bits : kGroupBits;
-            const int gshift = 32 + low_bits - gbits;
+            const int gshift = sbits + low_bits - gbits;
             const unsigned gmask = (1u << gbits) - 1u;
             uint32_t* const gcount = &s.cnt[0][0];
 #pragma unroll
@@ -1482,10 +1503,10 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                         for (unsigned j = gb; j < ge; j++) {
                             const uint64_t x = s.stage[j];
                             rank += x < e ? 1u : 0u;
-                            same += (uint32_t)((x ^ e) >> 32) == 0u ? 1u : 0u;     // (counts e itself)
+                            same += ((x ^ e) >> sbits) == 0ull ? 1u : 0u;          // (counts e itself)
                         }
                         const unsigned place = gb + rank;
-                        V[(uint64_t)begin + place] = (uint32_t)e;
+                        V[(uint64_t)begin + place] = (uint32_t)(e & smask);
                         if (same > 1u) {
                             const unsigned bitp = tshift + place;
                             atomicOr(&s.tie.tmask[bitp >> 5], 1u << (bitp & 31u));
@@ -1510,9 +1531,9 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
             if (pairs) tie_masks_out();
             __syncthreads();
         }
-        for (int pass = 0; pass < 2 && size > 1 && !pairs; pass++) {
-            const int shift = 32 + 8 * pass;
-            const int nb = pass == 0 ? (low_bits < 8 ? low_bits : 8) : low_bits - 8;
+        for (int pass = 0; pass < 3 && size > 1 && !pairs; pass++) {           // (low_bits <= 16, or 20 with the longer keys: 3 rounds)
+            const int shift = sbits + 8 * pass;
+            const int nb = low_bits - 8 * pass < 8 ? low_bits - 8 * pass : 8;
             if (nb <= 0) break;
             const unsigned mask = (1u << nb) - 1u;
 #pragma unroll
@@ -1557,13 +1578,13 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
         for (int r = 0; r < KPT; r++) {
             const unsigned idx = w * per + r * kWave + lane;
             if ((unsigned)r < kpt && idx < size && !pairs) {
-                V[(uint64_t)begin + idx] = (uint32_t)key[r];
+                V[(uint64_t)begin + idx] = (uint32_t)(key[r] & smask);
                 if constexpr (TIES) {
                     // (after the LSD rounds the sub-bucket lies sorted in the staging buffer: a run of equal keys is a run of neighbours)
                     if (size > 1u) {
-                        const uint32_t k32 = (uint32_t)(key[r] >> 32);
-                        const bool eq_prev = idx > 0u && (uint32_t)(s.stage[idx - 1u] >> 32) == k32;
-                        const bool eq_next = idx + 1u < size && (uint32_t)(s.stage[idx + 1u] >> 32) == k32;
+                        const uint64_t kk = key[r] >> sbits;
+                        const bool eq_prev = idx > 0u && (s.stage[idx - 1u] >> sbits) == kk;
+                        const bool eq_next = idx + 1u < size && (s.stage[idx + 1u] >> sbits) == kk;
                         if (eq_prev || eq_next) {
                             const unsigned bitp = tshift + idx;
                             atomicOr(&s.tie.tmask[bitp >> 5], 1u << (bitp & 31u));
@@ -1881,6 +1902,18 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     }
     const bool sweep = true;
     static const int partition = [] { const char* e = dev_env("SFX_HYBRID_PARTITION"); return e ? atoi(e) : 1; }();
+    // With no oversized sub-bucket the LDS sort can name the tied elements itself (k_bucket_sort<.., true>): no sorted keys are
+    // written, the caller orders the ties from the mask (TieRecords, sfx_host.hpp).  SFX_HYBRID_TIES=0 (development): the
+    // sorted keys, as rounds 3-5.
+    static const int ties_on = [] { const char* e = dev_env("SFX_HYBRID_TIES"); return e ? atoi(e) : 1; }();
+    const bool tie_mode = ties && ties_on && nover == 0;
+    // ... and then nobody reads a 32-bit key out of an element again: a text-fed sort lets the key grow into the four bits that the
+    // suffix index (m <= 2^28) leaves free -- two more symbols of DNA, a sixteenth of the ties (SrcText36).  SFX_HYBRID_KEY36=0
+    // (development): 32 + 32 bits.
+    static const int key36_on = [] { const char* e = dev_env("SFX_HYBRID_KEY36"); return e ? atoi(e) : 1; }();
+    const int extra = (tie_mode && key36_on && partition && !from_elems && text.kbits == 32 && text.bits <= 4 && m <= (1ull << 28))
+                          ? (4 / text.bits) * text.bits : 0;
+    const int sbits = 32 - extra;
     if (partition) {
         // two partition passes (k_partition: no order inside a sub-bucket, none needed): top 8 bits, then the next 8 inside
         // every top-8 bucket; cursors behind the oversize list
@@ -1919,6 +1952,10 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
                                SrcE64{e1}, e0, m, top_hi - 16, cursor16, (const uint32_t*)bins, class_len);                                 \
                     uint64_t* t = e0; e0 = e1; e1 = t;     /* (from here on: e1 = the array grouped by its top 16 bits, e0 = free) */      \
                 } else {                                                                                                                    \
+                    if (extra)                                                                                                              \
+                        SFX_LAUNCH("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), (k_partition<SrcText36, kPKpt, DNW, false>), \
+                                   g1, (DNW) * kWave, st, SrcText36{text, extra}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len); \
+                    else                                                                                                                    \
                     SFX_LAUNCH("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), (k_partition<SrcText32, kPKpt, DNW, false>),  \
                                g1, (DNW) * kWave, st, SrcText32{text}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len);        \
                     SFX_LAUNCH("radix_scatter_u32", (double)m * 16.0, (k_partition<SrcE64, kPKpt, DNW, true>), g2, (DNW) * kWave, st,       \
@@ -1936,6 +1973,10 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
                        m, top_hi - 16, cursor16, (const uint32_t*)bins, class_len);
             uint64_t* t = e0; e0 = e1; e1 = t;                 // (from here on: e1 = the array grouped by its top 16 bits, e0 = free)
         } else {
+            if (extra)
+                SFX_LAUNCH("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), (k_partition<SrcText36, kPKpt, kPNw, false>), grid1,
+                           kPNw * kWave, st, SrcText36{text, extra}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len);
+            else
             SFX_LAUNCH("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), (k_partition<SrcText32, kPKpt, kPNw, false>), grid1,
                        kPNw * kWave, st, SrcText32{text}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len);
             SFX_LAUNCH("radix_scatter_u32", (double)m * 16.0, (k_partition<SrcE64, kPKpt, kPNw, true>), grid2, kPNw * kWave, st, SrcE64{e0}, e1,
@@ -1977,11 +2018,6 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     const uint32_t top = dmin(host_max, cap);                  // the largest sub-bucket the LDS sort takes
     const uint32_t c1 = force_geom >= 1 ? 0u : dmin(2048u, cap), c2 = force_geom == 2 ? c1 : dmin(4096u, cap);
     const unsigned grid = (unsigned)dmin<uint64_t>(kH16Bins, (uint64_t)grid_cap() * 2);
-    // With no oversized sub-bucket the LDS sort can name the tied elements itself (k_bucket_sort<.., true>): no sorted keys are
-    // written, the caller builds its first active list from the records (TieRecords, sfx_host.hpp).  SFX_HYBRID_TIES=0
-    // (development): the sorted keys, as rounds 3-5.
-    static const int ties_on = [] { const char* e = dev_env("SFX_HYBRID_TIES"); return e ? atoi(e) : 1; }();
-    const bool tie_mode = ties && ties_on && nover == 0;
     // the mask (m / 32 words + zero words behind them) and two more arrays of the same size for the caller -- in e0, which nobody
     // needs once the elements are in e1
     const uint64_t mask_words = ((m + 31) / 32 + 64) & ~uint64_t(31);
@@ -1993,8 +2029,8 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     do {                                                                                                                    \
         if (tie_mode)                                                                                                       \
             SFX_LAUNCH("bucket_sort_lds", (double)m * 12.125, (k_bucket_sort<NW, KPT, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
-                       (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, (uint32_t)(LO), (uint32_t)(HI), (uint32_t*)nullptr, split_v, \
-                       gt);                                                                                                 \
+                       (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits + extra, (uint32_t)(LO), (uint32_t)(HI), (uint32_t*)nullptr, split_v, \
+                       gt, sbits);                                                                                          \
         else                                                                                                                \
             SFX_LAUNCH("bucket_sort_lds", (double)m * 16.0, (k_bucket_sort<NW, KPT>), GRID, NW * kWave, st, (const uint64_t*)e1, \
                        (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, (uint32_t)(LO), (uint32_t)(HI), split_k, split_v); \

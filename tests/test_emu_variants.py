@@ -51,17 +51,19 @@ if os.environ.get("SFX_HYBRID_MIN"):
     texts.append(b"".join(blocks[int(k)] + bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for k in rngh.integers(0, 4, 3600)))
     texts += [_gen.uniform_bytes(12000, 5, 2, base=65).tobytes(), _gen.uniform_bytes(12000, 16, 3, base=65).tobytes(),
               _gen.uniform_bytes(14000, 2, 4, base=65).tobytes()]
-    # one 8-symbol block followed by one of 700 8-symbol tails, every tail twice: a sub-bucket of ~1400 suffixes in 700 runs of
-    # two equal keys, spread over the groups of the fast path and side by side in the sorted order
+    # one 8-symbol block followed by one of 700 10-symbol tails, every tail twice: a sub-bucket of ~1400 suffixes in 700 runs of
+    # two equal keys (equal over the 18 symbols of the longer keys of round 6 as well), spread over the groups of the fast path
+    # and side by side in the sorted order
     b8 = bytes(rngh.choice(list(b"ACGT"), 8).tolist())
-    tails = [bytes(rngh.choice(list(b"ACGT"), 8).tolist()) for _ in range(700)]
+    tails = [bytes(rngh.choice(list(b"ACGT"), 10).tolist()) for _ in range(700)]
     order = rngh.permutation(1400) % 700
     runs_of_two = b"".join(b8 + tails[int(k)] + bytes(rngh.choice(list(b"ACGT"), 9).tolist()) for k in order)
     texts.append(runs_of_two)
-    # one 13-symbol block, each copy followed by 3 random symbols: a sub-bucket of ~700 suffixes that all fall into ONE group of
-    # the LDS sort's fast path (the group is the top 10 of the 16 low key bits) -> the stable LSD rounds, with runs of ~11 equal
-    # 16-symbol keys: the tie records (round 6) from neighbours in the staging buffer instead of from the group scan
-    b13 = bytes(rngh.choice(list(b"ACGT"), 13).tolist())
+    # one 15-symbol block, each copy followed by 3 random symbols: a sub-bucket of ~700 suffixes that all fall into ONE group of
+    # the LDS sort's fast path (the group is the top 10 of the low key bits) -> the stable LSD rounds (three of them over the 20 low
+    # bits of the longer keys), with runs of ~11 equal 18-symbol keys: the tie bits (round 6) from neighbours in the staging
+    # buffer instead of from the group scan
+    b13 = bytes(rngh.choice(list(b"ACGT"), 15).tolist())
     runs_of_eleven = _gen.dna(9000, seed=21).tobytes() + b"".join(b13 + bytes(rngh.choice(list(b"ACGT"), 3).tolist()) for _ in range(700))
     texts.append(runs_of_eleven)
     from suffix_amd import device as sdev
@@ -220,6 +222,9 @@ VARIANTS = {
     "hybrid-initial-sort-one-sweep-passes": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_PARTITION": "0", "TEST_TEXTS": "2"},
     # ... with the sorted keys written and read back by the bucket pass, as rounds 3-5 (round 6: the LDS sort leaves tie records)
     "hybrid-initial-sort-sorted-keys": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_TIES": "0"},
+    # ... the tie bits over elements of 32 + 32 bits (round 6's default lets a text-fed key grow into the 4 bits a suffix index of
+    # <= 2^28 leaves free)
+    "hybrid-initial-sort-32-bit-keys": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_KEY36": "0", "TEST_TEXTS": "9"},
     # ... the tie records from the 1024 x 16 geometry (sub-buckets of up to 16384), several sub-buckets per workgroup
     "hybrid-initial-sort-1024x16": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_GEOM": "2", "SFX_MAX_GRID": "2"},
     # a few oversized sub-buckets (gathered, sorted device-wide, copied back), the 256 x 16 geometry, several sub-buckets
