@@ -82,9 +82,21 @@ struct SrcText36 {
     static constexpr bool kFromText = true;
     PackedText t;
     int extra;                      // whole symbols' worth of bits, <= 4
+    bool wide;                      // more than one symbol: the window of two packed words does not always hold them
     __device__ __forceinline__ uint64_t key(uint64_t i) const
     {
-        const uint64_t k64 = packed_key64(t, i);                         // 2 * kbits = 64 bits of symbols (kbits == 32 here)
+        uint64_t k64;
+        if (wide) {
+            k64 = packed_key64(t, i);                                    // 2 * kbits = 64 bits of symbols (kbits == 32 here), a 12-byte load
+        } else {
+            // (one symbol more than the 32-bit key: the two words packed_key32 loads hold it at any offset)
+            const uint64_t q = packed_word_index(t, i);
+            const unsigned off = packed_word_offset(t, i, q);
+            uint64_t pair;
+            __builtin_memcpy(&pair, t.words + q, 8);
+            const uint64_t both = ((pair & 0xFFFFFFFFull) << 32) | (pair >> 32);
+            k64 = both << (off * (unsigned)t.bits);
+        }
         return ((k64 >> (32 - extra)) << (32 - extra)) | (uint64_t)(uint32_t)i;
     }
     __device__ __forceinline__ uint32_t val(uint64_t) const { return 0u; }
@@ -1910,9 +1922,13 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     // ... and then nobody reads a 32-bit key out of an element again: a text-fed sort lets the key grow into the four bits that the
     // suffix index (m <= 2^28) leaves free -- two more symbols of DNA, a sixteenth of the ties (SrcText36).  SFX_HYBRID_KEY36=0
     // (development): 32 + 32 bits.
+    // One symbol more comes out of the two packed words the 32-bit key is read from; two symbols of DNA (SFX_HYBRID_KEY36=2) need
+    // a third word now and then -- a 12-byte load per element: the text-fed pass 0.347 -> 0.381 ms for 0.048 -> 0.033 in k_tie_direct.
     static const int key36_on = [] { const char* e = dev_env("SFX_HYBRID_KEY36"); return e ? atoi(e) : 1; }();
-    const int extra = (tie_mode && key36_on && partition && !from_elems && text.kbits == 32 && text.bits <= 4 && m <= (1ull << 28))
-                          ? (4 / text.bits) * text.bits : 0;
+    int extra = 0;
+    if (tie_mode && key36_on && partition && !from_elems && text.kbits == 32 && text.bits <= 4 && m <= (1ull << 28))
+        extra = key36_on >= 2 ? (4 / text.bits) * text.bits : text.bits;
+    const bool wide_key = extra > text.bits;
     const int sbits = 32 - extra;
     if (partition) {
         // two partition passes (k_partition: no order inside a sub-bucket, none needed): top 8 bits, then the next 8 inside
@@ -1954,7 +1970,7 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
                 } else {                                                                                                                    \
                     if (extra)                                                                                                              \
                         SFX_LAUNCH("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), (k_partition<SrcText36, kPKpt, DNW, false>), \
-                                   g1, (DNW) * kWave, st, SrcText36{text, extra}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len); \
+                                   g1, (DNW) * kWave, st, SrcText36{text, extra, wide_key}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len); \
                     else                                                                                                                    \
                     SFX_LAUNCH("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), (k_partition<SrcText32, kPKpt, DNW, false>),  \
                                g1, (DNW) * kWave, st, SrcText32{text}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len);        \
@@ -1975,7 +1991,7 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
         } else {
             if (extra)
                 SFX_LAUNCH("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), (k_partition<SrcText36, kPKpt, kPNw, false>), grid1,
-                           kPNw * kWave, st, SrcText36{text, extra}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len);
+                           kPNw * kWave, st, SrcText36{text, extra, wide_key}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len);
             else
             SFX_LAUNCH("radix_scatter_text_u32", (double)m * (text.bits / 8.0 + 8.0), (k_partition<SrcText32, kPKpt, kPNw, false>), grid1,
                        kPNw * kWave, st, SrcText32{text}, e0, m, top_hi - 8, cursor8, (const uint32_t*)bins, class_len);

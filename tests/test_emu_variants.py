@@ -222,9 +222,11 @@ VARIANTS = {
     "hybrid-initial-sort-one-sweep-passes": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_PARTITION": "0", "TEST_TEXTS": "2"},
     # ... with the sorted keys written and read back by the bucket pass, as rounds 3-5 (round 6: the LDS sort leaves tie records)
     "hybrid-initial-sort-sorted-keys": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_TIES": "0"},
-    # ... the tie bits over elements of 32 + 32 bits (round 6's default lets a text-fed key grow into the 4 bits a suffix index of
-    # <= 2^28 leaves free)
+    # ... the tie bits over elements of 32 + 32 bits (round 6's default lets a text-fed key grow by one symbol into the bits a suffix
+    # index of <= 2^28 leaves free)
     "hybrid-initial-sort-32-bit-keys": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_KEY36": "0", "TEST_TEXTS": "9"},
+    # ... and two more symbols of DNA instead of one (a 12-byte load per element: measured, not the default)
+    "hybrid-initial-sort-two-more-symbols": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_KEY36": "2", "TEST_TEXTS": "9"},
     # ... the tie records from the 1024 x 16 geometry (sub-buckets of up to 16384), several sub-buckets per workgroup
     "hybrid-initial-sort-1024x16": {"SFX_HYBRID_MIN": "1", "SFX_HYBRID_GEOM": "2", "SFX_MAX_GRID": "2"},
     # a few oversized sub-buckets (gathered, sorted device-wide, copied back), the 256 x 16 geometry, several sub-buckets
