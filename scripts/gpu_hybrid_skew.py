@@ -21,7 +21,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
         eng.profile(True); eng.profile_reset(); sdev.build_sa(text, out=sa, workspace=ws); torch.cuda.synchronize()
         k = {r["name"]: round(r["total_ms"], 3) for r in eng.profile_report()}; eng.profile(False)
-        print(json.dumps({"text": name, "hybrid": os.environ.get("SFX_HYBRID", "1"), "ms": round(ms, 3), "lds": k.get("bucket_sort_lds"),
+        print(json.dumps({"text": name, "hybrid": os.environ.get("SFX_HYBRID", "1"), "ms": round(ms, 3), "lds": k.get("bucket_sort_ties", k.get("bucket_sort_lds")),
                           "oversize": [k.get("oversize_gather"), k.get("oversize_return")], "radix_scatter_u32": k.get("radix_scatter_u32"),
                           "active_after_initial": eng.build_stats()["active_after_initial"]}), flush=True)
         del text, ws, sa

@@ -24,7 +24,7 @@ from collections import defaultdict
 # (symbol prefix as rocprofv3 prints it after "sfx::", profile name of the engine).  Longest prefix wins.
 NAMES = [
     # -- device-wide passes (sfx_radix.hip)
-    ("k_partition<sfx::SrcText32", "radix_scatter_text_u32"), ("k_partition<sfx::SrcE64", "radix_scatter_u32"),
+    ("k_partition<sfx::SrcText32", "radix_scatter_text_u32"), ("k_partition<sfx::SrcText36", "radix_scatter_text_u32"), ("k_partition<sfx::SrcE64", "radix_scatter_u32"),
     ("k_radix_sweep<sfx::SrcE64", "radix_scatter_u32"), ("k_radix_sweep<sfx::SrcText32", "radix_scatter_text_u32"),
     ("k_radix_sweep<sfx::SrcKV", "radix_scatter_u64"), ("k_radix_sweep<sfx::SrcKeyIota", "radix_scatter_u64"),
     ("k_radix_sweep<sfx::SrcText64", "radix_scatter_text_u64"),
@@ -39,7 +39,8 @@ NAMES = [
     ("k_window_hist", "radix_hist_all_text_u32"), ("k_window_fix", "radix_window_fix"), ("k_window_from_hist16", "radix_window_from_hist16"),
     ("k_hist16_text", "radix_hist16_text"), ("k_hist16_e64", "radix_hist16_elems"), ("k_hist16_reduce", "radix_hist16_reduce"),
     ("k_hist16_scan", "radix_hist16_scan"), ("k_hist16_oversize", "radix_hist16_oversize"), ("k_partition_cursors", "partition_cursors"),
-    ("k_bucket_sort", "bucket_sort_lds"), ("k_oversize_gather", "oversize_gather"), ("k_oversize_return", "oversize_return"),
+    ("k_bucket_sort<4, 8, true", "bucket_sort_ties"), ("k_bucket_sort<4, 16, true", "bucket_sort_ties"),
+    ("k_bucket_sort<16, 16, true", "bucket_sort_ties"), ("k_bucket_sort", "bucket_sort_lds"), ("k_oversize_gather", "oversize_gather"), ("k_oversize_return", "oversize_return"),
     ("k_ht_keys", "ht_keys"), ("k_seg_layout", "seg_layout"), ("k_seg_gather", "seg_gather"), ("k_seg_hist", "seg_hist"),
     ("k_seg_scan", "seg_scan"), ("k_seg_finish", "seg_finish"), ("k_scatter_pairs", "scatter_pairs"),
     # -- the build (sfx_sa.hip, sfx_tile.hip, sfx_tiny.hip)
@@ -148,7 +149,7 @@ def main(args):
     w = csv.writer(sys.stdout)
     w.writerow(["Kernel", "Counter", "Dispatches", "MeanPerDispatch"])
     for (k, c), (tot, cnt) in sorted(acc.items()):
-        w.writerow([k, c, cnt, f"{tot / max(cnt, 1):.1f}"])
+        w.writerow([k, c, cnt, f"{tot / max(cnt, 1):.4f}"])
     if not (json_out or full_out):
         return
     fetch, unm = totals_by_profile(acc, "FETCH_SIZE")

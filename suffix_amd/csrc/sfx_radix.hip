@@ -2044,7 +2044,7 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
 #define SFX_BUCKET_SORT(NW, KPT, LO, HI, GRID)                                                                              \
     do {                                                                                                                    \
         if (tie_mode)                                                                                                       \
-            SFX_LAUNCH("bucket_sort_lds", (double)m * 12.125, (k_bucket_sort<NW, KPT, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
+            SFX_LAUNCH("bucket_sort_ties", (double)m * 12.125, (k_bucket_sort<NW, KPT, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
                        (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits + extra, (uint32_t)(LO), (uint32_t)(HI), (uint32_t*)nullptr, split_v, \
                        gt, sbits);                                                                                          \
         else                                                                                                                \
