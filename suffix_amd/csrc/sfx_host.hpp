@@ -203,7 +203,7 @@ struct BuildStats;   // = sfx_build_stats
 uint64_t radix_scratch_words(uint64_t m);
 //    `ties` (with split_v; round 6): a caller that only needs to know WHICH elements share their whole key with a neighbour, not
 //    the sorted keys.  When the hybrid route runs and no sub-bucket is oversized, its LDS sort (k_bucket_sort<.., true>) writes no
-//    keys (*split_k_out = nullptr) and leaves one bit mask over the m slots of split_v (bit r & 31 of word r / 32 = slot r, zero
+//    keys (*split_k_out = nullptr, unless want_keys) and leaves one bit mask over the m slots of split_v (bit r & 31 of word r / 32 = slot r, zero
 //    words behind): tmask = the element shares its key with a neighbour.  lmask, hmask: two more arrays of the same size for the
 //    caller (lmask zeroed).  produced = false: the sorted keys are in *split_k_out as always.  The masks stay valid until e0 /
 //    e1 are written again.
@@ -212,6 +212,7 @@ struct TieRecords {
     const uint32_t* tmask;
     uint32_t* lmask;
     uint32_t* hmask;
+    bool want_keys;                // in: leave the sorted 32-bit keys in *split_k_out as well (the fused LCP reads them once)
 };
 //    A producer that had the keys in registers anyway (the range filter) may have counted the
 //    digits itself: `hist_blocks` workgroups' counts at radix_partial(scratch)[(pass * 256 +

@@ -1519,6 +1519,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                         }
                         const unsigned place = gb + rank;
                         V[(uint64_t)begin + place] = (uint32_t)(e & smask);
+                        if (K) K[(uint64_t)begin + place] = (uint32_t)(e >> 32);  // (the fused LCP: the 32-bit key, whatever sbits is)
                         if (same > 1u) {
                             const unsigned bitp = tshift + place;
                             atomicOr(&s.tie.tmask[bitp >> 5], 1u << (bitp & 31u));
@@ -1592,6 +1593,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
             if ((unsigned)r < kpt && idx < size && !pairs) {
                 V[(uint64_t)begin + idx] = (uint32_t)(key[r] & smask);
                 if constexpr (TIES) {
+                    if (K) K[(uint64_t)begin + idx] = (uint32_t)(key[r] >> 32);
                     // (after the LSD rounds the sub-bucket lies sorted in the staging buffer: a run of equal keys is a run of neighbours)
                     if (size > 1u) {
                         const uint64_t kk = key[r] >> sbits;
@@ -2037,16 +2039,18 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     // the mask (m / 32 words + zero words behind them) and two more arrays of the same size for the caller -- in e0, which nobody
     // needs once the elements are in e1
     const uint64_t mask_words = ((m + 31) / 32 + 64) & ~uint64_t(31);
-    uint32_t* const gt = reinterpret_cast<uint32_t*>(e0);
+    const bool tie_keys = tie_mode && ties->want_keys;         // (the sorted 32-bit keys too: the first half of e0, the masks behind them)
+    uint32_t* const gt = reinterpret_cast<uint32_t*>(e0) + (tie_keys ? ((m + 63) & ~uint64_t(63)) : 0);
+    if (tie_keys && (((m + 63) & ~uint64_t(63)) + 3 * mask_words) * sizeof(uint32_t) > m * sizeof(uint64_t)) return SFX_ERR_INTERNAL;
     uint32_t* const gl = gt + mask_words;
     uint32_t* const gh = gl + mask_words;
     if (tie_mode) SFX_HIP(hipMemsetAsync(gt, 0, 2 * mask_words * sizeof(uint32_t), st));  // (the third array is the caller's to fill)
 #define SFX_BUCKET_SORT(NW, KPT, LO, HI, GRID)                                                                              \
     do {                                                                                                                    \
         if (tie_mode)                                                                                                       \
-            SFX_LAUNCH("bucket_sort_ties", (double)m * 12.125, (k_bucket_sort<NW, KPT, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
-                       (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits + extra, (uint32_t)(LO), (uint32_t)(HI), (uint32_t*)nullptr, split_v, \
-                       gt, sbits);                                                                                          \
+            SFX_LAUNCH("bucket_sort_ties", (double)m * (tie_keys ? 16.125 : 12.125), (k_bucket_sort<NW, KPT, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
+                       (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits + extra, (uint32_t)(LO), (uint32_t)(HI),             \
+                       tie_keys ? split_k : (uint32_t*)nullptr, split_v, gt, sbits);                                        \
         else                                                                                                                \
             SFX_LAUNCH("bucket_sort_lds", (double)m * 16.0, (k_bucket_sort<NW, KPT>), GRID, NW * kWave, st, (const uint64_t*)e1, \
                        (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, (uint32_t)(LO), (uint32_t)(HI), split_k, split_v); \
@@ -2066,7 +2070,7 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
         SFX_LAUNCH("oversize_return", (double)nlarge * 16, k_oversize_return, g, kBlock, st, over_sorted, (const OversizeEntry*)over, nover,
                    low_bits, split_k, split_v);
     }
-    if (split_k_out) *split_k_out = tie_mode ? (uint32_t*)nullptr : split_k;
+    if (split_k_out) *split_k_out = (tie_mode && !tie_keys) ? (uint32_t*)nullptr : split_k;
     if (stats) { stats->radix_passes += 2; stats->elements_sorted += 2 * m; }
     *done = true;
     return SFX_OK;

@@ -2183,15 +2183,15 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     uint32_t* V_next;
     bool in_place = false;
     int in1 = 0;
-    TieRecords ties = {false, nullptr, nullptr, nullptr};
+    TieRecords ties = {false, nullptr, nullptr, nullptr, lcp_fuse != nullptr};
     if (sizeof(KeyT) == 4) {
         // E64 elements; the last pass drops every suffix straight into its SA slot and
         // leaves the sorted 32-bit keys in the element buffer it did not read
         uint32_t* k32 = nullptr;
-        // (without the fused LCP, which reads the common prefix of neighbours off the sorted keys, nobody needs them: the hybrid
-        // route may leave the records of the tied elements instead -- TieRecords)
+        // (nobody needs the sorted keys to find the buckets: the hybrid route leaves one tie bit per slot instead -- TieRecords; the
+        // fused LCP reads the common prefix of neighbours off them once and has them written as well)
         SFX_TRY(radix_sort_e64(b.K0, b.K1, count, 32, 32 + pt.bits * cpk, b.hist, st, &in1, &stats,
-                               from_text ? &pt : nullptr, sa, &k32, hist_blocks, from_text ? 0 : elem_bits, lcp_fuse ? nullptr : &ties));
+                               from_text ? &pt : nullptr, sa, &k32, hist_blocks, from_text ? 0 : elem_bits, &ties));
         Kr = (const KeyT*)k32;
         Vr = sa;
         V_next = b.VA;
@@ -2221,7 +2221,17 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     }
     if (ties.produced) {
         // every suffix sits in a slot of its run of equal keys; the runs are ordered on the text where they are (k_tie_direct) ...
-        if (ht || lcp_fuse) return SFX_ERR_INTERNAL;
+        if (ht) return SFX_ERR_INTERNAL;
+        if (lcp_fuse) {
+            // the LCP of neighbours with different 32-bit keys from the keys themselves, `pending` (>= cpk symbols) where they are
+            // equal -- k_groups_reduce's emission; its flags and partial counts go unused.  Whatever order k_tie_direct or the rounds
+            // give the members of a stretch, the pending entries are finished on the final array (lcp_finish_pending_dev), and the pair
+            // at a seam of two runs shares what the two keys share whichever members meet there.
+            if (!Kr) return SFX_ERR_INTERNAL;
+            Chunking ch = make_chunking(count, kApplyTile);
+            SFX_LAUNCH("groups_reduce", (double)count * 8, (k_groups_reduce<KeyT>), ch.blocks, kBlock, st, Kr, count, ch.tiles_per_block * kApplyTile,
+                       b.part_head, b.part_keep, b.part_ghead, b.F, fuse);
+        }
         const uint64_t nwords = (count + 31) / 32;
         uint32_t* const lines = reinterpret_cast<uint32_t*>(b.deep_slots);     // (idle until the first deep round)
         static_assert(kTieSlots * 4 * sizeof(uint32_t) <= kDeepSlotWords * sizeof(unsigned long long), "the counter lines fit");
@@ -2267,12 +2277,12 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
         }
         uint32_t* S_cur = b.S0;
         if (small_groups_pay(kept, groups))
-            SFX_TRY(small_groups_pass(pt, (uint64_t)cpk, b, sa, nullptr, &S_cur, &V_next, &kept, st, stats, nullptr, false));
+            SFX_TRY(small_groups_pass(pt, (uint64_t)cpk, b, sa, nullptr, &S_cur, &V_next, &kept, st, stats, lcp_fuse, false));
         if (kept > 0) {
             const unsigned grid = (unsigned)dmin<uint64_t>((kept + kBlock * 4 - 1) / (kBlock * 4), kMaxGrid);
             SFX_LAUNCH("depth_fill", (double)kept * 2, k_fill_u16, grid, kBlock, st, hd_of(b, S_cur), kept, (uint16_t)cpk);
         }
-        return refine(pt, cpk, b, sa, isa, S_cur, V_next, kept, st, stats, nullptr, false);
+        return refine(pt, cpk, b, sa, isa, S_cur, V_next, kept, st, stats, lcp_fuse, false);
     }
     SFX_TRY(round_totals<KeyT>(Kr, count, b, st, &kept, &groups, fuse));
     stats.active_after_initial = kept;

@@ -67,7 +67,7 @@ if os.environ.get("SFX_HYBRID_MIN"):
     runs_of_eleven = _gen.dna(9000, seed=21).tobytes() + b"".join(b13 + bytes(rngh.choice(list(b"ACGT"), 3).tolist()) for _ in range(700))
     texts.append(runs_of_eleven)
     from suffix_amd import device as sdev
-    for t in texts[:1]:                                 # the fused SA + LCP entry over the same initial sort
+    for t in texts:                                     # the fused SA + LCP entry over the same initial sort (round 6: tie bits AND sorted keys)
         import torch
         d = torch.frombuffer(bytearray(t), dtype=torch.uint8)
         sa, lcp = sdev.build_sa_lcp(d, engine=eng)
