@@ -372,17 +372,38 @@ __global__ void __launch_bounds__(kBlock)
 k_lcp_pending(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint32_t* __restrict__ lcp,
               unsigned long long* __restrict__ counters)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    // A lane reads eight entries at a time (32 bytes, the wave 2 KB in a row) and then works off the pending ones among them: a
+    // few per cent of the entries are pending, and with one entry per lane and iteration nearly every iteration of a wave had a
+    // lane in the dependent chain array -> text -> compare while 63 waited (round 6: 0.28 -> 0.1 ms per 10^8 on uniform DNA).
+    constexpr unsigned kPer = 8;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock * kPer;
     uint32_t capped = 0;
-    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) {
-        const uint32_t v = lcp[r];
-        if (!(v & kLcpBoundFlag)) continue;
-        const uint64_t h0 = v & ~kLcpBoundFlag;
-        const uint64_t a = sa[r - 1], b = sa[r];                     // (r = 0 is never pending)
-        const uint64_t h = (a + h0 <= n && b + h0 <= n) ? h0 : 0;    // equal keys = equal symbols, padding aside
-        const uint64_t l = extend_match_capped(text, n, a, b, h, h + kDirectCap);
-        if (l >= h + kDirectCap) capped++;
-        lcp[r] = (uint32_t)l;
+    for (uint64_t r0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * kPer; r0 < n; r0 += stride) {
+        uint32_t v[kPer];
+        if (r0 + kPer <= n) {
+            const uint4 x = *reinterpret_cast<const uint4*>(lcp + r0), y = *reinterpret_cast<const uint4*>(lcp + r0 + 4);
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+        } else {
+#pragma unroll
+            for (unsigned k = 0; k < kPer; k++) v[k] = r0 + k < n ? lcp[r0 + k] : 0u;
+        }
+        unsigned pend = 0;
+#pragma unroll
+        for (unsigned k = 0; k < kPer; k++) pend |= ((v[k] & kLcpBoundFlag) ? 1u : 0u) << k;
+        while (pend) {
+            const unsigned k = (unsigned)__ffs((int)pend) - 1u;
+            pend &= pend - 1u;
+            uint32_t vk = v[0];
+#pragma unroll
+            for (unsigned j = 1; j < kPer; j++) vk = k == j ? v[j] : vk;
+            const uint64_t r = r0 + k;
+            const uint64_t h0 = vk & ~kLcpBoundFlag;
+            const uint64_t a = sa[r - 1], b = sa[r];                     // (r = 0 is never pending)
+            const uint64_t h = (a + h0 <= n && b + h0 <= n) ? h0 : 0;    // equal keys = equal symbols, padding aside
+            const uint64_t l = extend_match_capped(text, n, a, b, h, h + kDirectCap);
+            if (l >= h + kDirectCap) capped++;
+            lcp[r] = (uint32_t)l;
+        }
     }
     if (capped) atomicAdd(&counters[1], (unsigned long long)capped);
 }
@@ -401,15 +422,30 @@ __global__ void __launch_bounds__(kBlock)
 k_lcp_tail_fix(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint32_t* __restrict__ lcp,
                uint64_t h0)
 {
-    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x + 1;
-    if (k >= h0 || k > n) return;
+    // One WAVE per short suffix i = n - k: its rank by a 64-ary search -- every step the lanes probe 64 ranks spread over what is
+    // left of [lo, hi) and a ballot says where "the suffix at that rank is less than suffix i" ends (the predicate is monotone
+    // over the ranks): 5 steps of two dependent loads instead of the 27 of a lane's own binary search (0.07 -> 0.02 ms).
+    const unsigned lane = lane_id();
+    const uint64_t k = (uint64_t)blockIdx.x * kWavesPerBlock + wave_id() + 1;
+    if (k >= h0 || k > n) return;                                     // (the whole wave)
     const uint64_t i = n - k;
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {                                                // first rank whose suffix is not less than suffix i
-        const uint64_t mid = (lo + hi) / 2;
-        if (suffix_less(text, n, (uint64_t)sa[mid], i)) lo = mid + 1; else hi = mid;
+    uint64_t lo = 0, hi = n;                                          // first rank whose suffix is not less than suffix i: in [lo, hi]
+    while (lo < hi) {
+        const uint64_t span = hi - lo;
+        uint64_t probe;
+        if (span <= kWave) probe = lo + lane;                         // every rank of [lo, hi)
+        else probe = lo + (span * (uint64_t)(lane + 1u)) / (uint64_t)(kWave + 1u);   // 64 ranks strictly inside, ascending
+        const bool less = probe < hi && suffix_less(text, n, (uint64_t)sa[probe], i);
+        const unsigned long long bal = __ballot(less);
+        const unsigned nless = (unsigned)__popcll(bal);               // (monotone: the lanes that say "less" are the first nless)
+        if (span <= kWave) { lo = lo + nless; hi = lo; break; }
+        const uint64_t below = nless ? lo + (span * (uint64_t)nless) / (uint64_t)(kWave + 1u) : lo;          // last probe that was less (or lo)
+        const uint64_t above = nless < kWave ? lo + (span * (uint64_t)(nless + 1u)) / (uint64_t)(kWave + 1u) : hi;   // first probe that was not
+        lo = nless ? below + 1 : lo;
+        hi = above;
     }
     const uint64_t r = lo;
+    if (lane != 0) return;
     if (r >= n || sa[r] != (uint32_t)i) return;                      // (cannot happen on a valid suffix array)
     lcp[r] = r ? (uint32_t)extend_match(text, n, (uint64_t)sa[r - 1], i, 0) : 0u;
     if (r + 1 < n) lcp[r + 1] = (uint32_t)extend_match(text, n, i, (uint64_t)sa[r + 1], 0);
@@ -425,7 +461,7 @@ int lcp_finish_pending_dev(const uint8_t* d_text, uint64_t n, const uint32_t* d_
     SFX_HIP(hipMemsetAsync(counters, 0, sizeof(host), st));
     const unsigned grid = (unsigned)dmin<uint64_t>((n + kBlock - 1) / kBlock, kMaxGrid);
     SFX_LAUNCH("lcp_pending", (double)n * 4, k_lcp_pending, grid, kBlock, st, d_text, n, d_sa, d_lcp, counters);
-    SFX_LAUNCH("lcp_tail_fix", 0.0, k_lcp_tail_fix, (unsigned)((h0 + kBlock - 1) / kBlock), kBlock, st, d_text, n, d_sa,
+    SFX_LAUNCH("lcp_tail_fix", 0.0, k_lcp_tail_fix, (unsigned)((h0 + kWavesPerBlock - 1) / kWavesPerBlock), kBlock, st, d_text, n, d_sa,
                d_lcp, h0);
     SFX_TRY(read_back(host, counters, sizeof(host), st));
     *done = host[1] == 0;
