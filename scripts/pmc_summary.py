@@ -39,9 +39,11 @@ NAMES = [
     ("k_window_hist", "radix_hist_all_text_u32"), ("k_window_fix", "radix_window_fix"), ("k_window_from_hist16", "radix_window_from_hist16"),
     ("k_hist16_text", "radix_hist16_text"), ("k_hist16_e64", "radix_hist16_elems"), ("k_hist16_reduce", "radix_hist16_reduce"),
     ("k_hist16_scan", "radix_hist16_scan"), ("k_hist16_oversize", "radix_hist16_oversize"), ("k_partition_cursors", "partition_cursors"),
+    ("k_bucket_sort<4, 8, true, true", "bucket_sort_ties_keys"), ("k_bucket_sort<4, 16, true, true", "bucket_sort_ties_keys"),
+    ("k_bucket_sort<16, 16, true, true", "bucket_sort_ties_keys"),
     ("k_bucket_sort<4, 8, true", "bucket_sort_ties"), ("k_bucket_sort<4, 16, true", "bucket_sort_ties"),
     ("k_bucket_sort<16, 16, true", "bucket_sort_ties"), ("k_bucket_sort", "bucket_sort_lds"), ("k_oversize_gather", "oversize_gather"), ("k_oversize_return", "oversize_return"),
-    ("k_ht_keys", "ht_keys"), ("k_seg_layout", "seg_layout"), ("k_seg_gather", "seg_gather"), ("k_seg_hist", "seg_hist"),
+    ("k_ht_keys_ctx", "ht_keys"), ("k_ht_keys", "ht_keys"), ("k_bigram_hist", "bigram_hist"), ("k_seg_layout", "seg_layout"), ("k_seg_gather", "seg_gather"), ("k_seg_hist", "seg_hist"),
     ("k_seg_scan", "seg_scan"), ("k_seg_finish", "seg_finish"), ("k_scatter_pairs", "scatter_pairs"),
     # -- the build (sfx_sa.hip, sfx_tile.hip, sfx_tiny.hip)
     ("k_byte_presence", "byte_presence"), ("k_byte_hist", "byte_hist"), ("k_make_lut", "make_lut"), ("k_pack_text", "pack_text"),

@@ -331,6 +331,13 @@ constexpr int kHtFastBits = 12;
 // English-like text per key instead of 13.8 leave 649 M suffixes to the rounds instead of 540 M -- 116.9 against 111.4 ms;
 // mixed-script UTF-8 229 against 223, near-duplicate documents 399 against 390.  All 64 bits it is.)
 constexpr int kHtKeyBits = 64;
+// Context codes (round 6, k_ht_keys_ctx): one code table per class of the preceding symbol.  Device layout behind the order-0
+// tables: at word kHtCtxOff the class of every dense symbol (256 bytes), then kHtCtxClasses x 256 entries (code | length).
+constexpr int kHtCtxClasses = 16;
+constexpr int kHtCtxSigmaMax = 160;                  // alphabets the bigram counts and the class tables are sized for
+constexpr unsigned kHtCtxOff = 256 + 64 + (1u << 12) / 2;     // = kHtTableWords + the fast table (sfx_sa.hip)
+constexpr unsigned kHtCtxWords = 64 + kHtCtxClasses * 256;
+constexpr int kHtCtxCountBits = 4;                   // low bits of a context key: the number of symbols it holds
 static_assert(kHtKeyBits % 8 == 0 && kHtKeyBits >= 32 && kHtKeyBits <= 64, "whole radix digits");
 // the kHtFastBits key bits from bit `used` on (zeros past the key's end), used < 64.  32-bit funnel shifts: the 64-bit
 // shift pair (key << used) >> 52 is two quarter-rate instructions, and the decode loops run this once per two or three

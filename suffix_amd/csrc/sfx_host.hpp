@@ -234,7 +234,7 @@ int radix_sort_kv64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
 // the same over the compressed keys (k_ht_keys) of all m = text.n suffixes; ht = the code table on the device
 int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, uint32_t* scratch, hipStream_t st,
                     int* result_in_1, sfx_build_stats* stats, const PackedText& text, const uint32_t* ht, uint32_t* last_v = nullptr,
-                    uint64_t kv12_cap = 0);
+                    uint64_t kv12_cap = 0, int ctx_sigma = 0);         // ctx_sigma > 0: context codes (k_ht_keys_ctx), ht holds their tables
 // Segmented sort of the large buckets of a refinement round (sfx_radix.hip).  Scratch:
 //   segs      8 B per segment, filled by the caller          tiles    32 B per tile (<= nlarge / tile + nseg)
 //   tilehist  4 KiB per tile of a multi-tile segment (<= 2 * nlarge / tile)

@@ -1386,7 +1386,7 @@ struct TieSmem {
 };
 template <int WORDS>
 struct TieSmem<WORDS, false> {};
-template <int NW, int KPT, bool TIES = false>
+template <int NW, int KPT, bool TIES = false, bool TIE_KEYS = false>
 __global__ void __launch_bounds__(NW * kWave) SFX_WAVES_PER_EU(NW == 4 && KPT == 8 ? 6 : 1, 8)
 k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstart, uint32_t nbuckets, int low_bits,
               uint32_t lo, uint32_t hi, uint32_t* __restrict__ K, uint32_t* __restrict__ V, uint32_t* __restrict__ GT = nullptr,
@@ -1519,7 +1519,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
                         }
                         const unsigned place = gb + rank;
                         V[(uint64_t)begin + place] = (uint32_t)(e & smask);
-                        if (K) K[(uint64_t)begin + place] = (uint32_t)(e >> 32);  // (the fused LCP: the 32-bit key, whatever sbits is)
+                        if constexpr (TIE_KEYS) K[(uint64_t)begin + place] = (uint32_t)(e >> 32);  // (the fused LCP: the 32-bit key, whatever sbits is)
                         if (same > 1u) {
                             const unsigned bitp = tshift + place;
                             atomicOr(&s.tie.tmask[bitp >> 5], 1u << (bitp & 31u));
@@ -1593,7 +1593,7 @@ k_bucket_sort(const uint64_t* __restrict__ X, const uint32_t* __restrict__ bstar
             if ((unsigned)r < kpt && idx < size && !pairs) {
                 V[(uint64_t)begin + idx] = (uint32_t)(key[r] & smask);
                 if constexpr (TIES) {
-                    if (K) K[(uint64_t)begin + idx] = (uint32_t)(key[r] >> 32);
+                    if constexpr (TIE_KEYS) K[(uint64_t)begin + idx] = (uint32_t)(key[r] >> 32);
                     // (after the LSD rounds the sub-bucket lies sorted in the staging buffer: a run of equal keys is a run of neighbours)
                     if (size > 1u) {
                         const uint64_t kk = key[r] >> sbits;
@@ -2047,10 +2047,13 @@ static int hybrid_sort_e64_text(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_
     if (tie_mode) SFX_HIP(hipMemsetAsync(gt, 0, 2 * mask_words * sizeof(uint32_t), st));  // (the third array is the caller's to fill)
 #define SFX_BUCKET_SORT(NW, KPT, LO, HI, GRID)                                                                              \
     do {                                                                                                                    \
-        if (tie_mode)                                                                                                       \
-            SFX_LAUNCH("bucket_sort_ties", (double)m * (tie_keys ? 16.125 : 12.125), (k_bucket_sort<NW, KPT, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
-                       (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits + extra, (uint32_t)(LO), (uint32_t)(HI),             \
-                       tie_keys ? split_k : (uint32_t*)nullptr, split_v, gt, sbits);                                        \
+        if (tie_mode && tie_keys)                                                                                           \
+            SFX_LAUNCH("bucket_sort_ties_keys", (double)m * 16.125, (k_bucket_sort<NW, KPT, true, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
+                       (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits + extra, (uint32_t)(LO), (uint32_t)(HI), split_k, split_v, gt, sbits); \
+        else if (tie_mode)                                                                                                  \
+            SFX_LAUNCH("bucket_sort_ties", (double)m * 12.125, (k_bucket_sort<NW, KPT, true>), GRID, NW * kWave, st, (const uint64_t*)e1, \
+                       (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits + extra, (uint32_t)(LO), (uint32_t)(HI), (uint32_t*)nullptr, split_v, \
+                       gt, sbits);                                                                                          \
         else                                                                                                                \
             SFX_LAUNCH("bucket_sort_lds", (double)m * 16.0, (k_bucket_sort<NW, KPT>), GRID, NW * kWave, st, (const uint64_t*)e1, \
                        (const uint32_t*)bins, (uint32_t)kH16Bins, low_bits, (uint32_t)(LO), (uint32_t)(HI), split_k, split_v); \
@@ -2266,6 +2269,117 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
         for (int p = 0; p < npass; p++) partial[((uint64_t)p * kRadix + tid) * gridDim.x + blockIdx.x] = h[p][tid];
 }
 
+// ---- compressed keys over CONTEXTS (round 6) ---------------------------------------------------------------------------
+// An order-preserving prefix code per class of the PRECEDING symbol: the key of position i = the order-0 code of symbol i, then
+// for j = i + 1, i + 2, ... the code of symbol j in the table of class(symbol j - 1).  Equal prefixes of two suffixes have equal
+// contexts, so the concatenation is still order-preserving and prefix-free; and the stream from i + 1 on does not depend on i,
+// so the rolling buffer of k_ht_keys survives: it holds the stream, the first symbol's order-0 code goes in front.  Mixed-script
+// UTF-8 (config 5): 4.7 instead of 6.25 bits per symbol with 16 classes.  How many WHOLE code words a key holds cannot be
+// read off it with the order-0 end-mask table any more, so the kernel counts them where it knows them -- a second rolling
+// buffer with one bit per code-word end -- and stores the count in the key's LOW 4 BITS (kHtCtxCountBits; the code string
+// takes the top 60): equal 60-bit prefixes of a prefix code hold the same code words, so order and tie classes are what the
+// 60 bits alone give, and a bucket's depth is key & 15 (k_groups_apply).
+// tab: [0, 256) order-0 entries, then at kHtCtxOff: class of every dense symbol (256 bytes), then 16 x 256 class entries.
+constexpr unsigned kHtCtxMaxSym = 15;                         // symbols a context key is made from at most (the count's range)
+__global__ void __launch_bounds__(kBlock)
+k_ht_keys_ctx(PackedText t, const uint32_t* __restrict__ tab, int sigma, uint64_t m, uint64_t tiles_per_block, int npass,
+              uint64_t* __restrict__ K, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t s_tab0[256];
+    __shared__ uint8_t s_cls[256];
+    __shared__ uint32_t s_tab1[kHtCtxClasses * kHtCtxSigmaMax];
+    __shared__ uint32_t s_words[(kHtTile + kHtPad) / 4 + 8];
+    __shared__ uint8_t s_sym[kHtTile + kHtPad + 8];
+    __shared__ uint32_t s_ent1[kHtTile + kHtPad + (kHtTile + kHtPad) / 8 + 1];
+    __shared__ uint64_t s_key[kHtTile + kHtTile / 8];
+    __shared__ uint32_t h[kMaxPasses][kRadix];
+    const unsigned tid = threadIdx.x;
+    s_tab0[tid] = tab[tid];
+    s_cls[tid] = reinterpret_cast<const uint8_t*>(tab + kHtCtxOff)[tid];
+    for (unsigned i = tid; i < (unsigned)(kHtCtxClasses * sigma); i += kBlock)
+        s_tab1[i] = tab[kHtCtxOff + 64 + (i / (unsigned)sigma) * 256u + (i % (unsigned)sigma)];
+    for (unsigned i = tid; i < kMaxPasses * kRadix; i += kBlock) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const unsigned bits = (unsigned)t.bits;
+    const uint32_t smask = (1u << bits) - 1u;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * tiles_per_block;
+    for (uint64_t tile = tile0; tile < tile0 + tiles_per_block; tile++) {
+        const uint64_t base = tile * kHtTile;
+        if (base >= m) break;
+        // the tile's packed words (from the symbol BEFORE the tile on: the first stream code needs its context)
+        const uint64_t first = base ? base - 1 : 0;
+        const uint64_t q0 = packed_word_index(t, first);
+        const uint64_t qlast = (t.n + (uint64_t)t.spw - 1) / (uint64_t)t.spw + 2;         // (three zero words behind the text)
+        const unsigned nw = (unsigned)(packed_word_index(t, base + kHtTile + kHtPad - 1) - q0) + 1u;
+#pragma unroll
+        for (int k = 0; k < (int)(((kHtTile + kHtPad) / 4 + 8 + kBlock - 1) / kBlock); k++) {
+            const unsigned w = tid + (unsigned)k * kBlock;
+            if (w < nw) s_words[w] = q0 + w <= qlast ? t.words[q0 + w] : 0u;
+        }
+        __syncthreads();
+        // symbols of positions base - 1 .. base + tile + pad - 1 at s_sym[1 + i] (i = -1: the context of the tile's first stream code)
+        for (unsigned i = tid; i < (unsigned)(kHtTile + kHtPad + 1); i += kBlock) {
+            const uint64_t p = base + i - 1;                 // (i = 0 with base = 0: no such position, class of symbol 0)
+            unsigned sym = 0;
+            if ((base || i) && p < t.n) {
+                const uint64_t q = packed_word_index(t, p);
+                const unsigned off = packed_word_offset(t, p, q);
+                sym = (s_words[(unsigned)(q - q0)] >> (((unsigned)t.spw - 1u - off) * bits)) & smask;
+            }
+            s_sym[i] = (uint8_t)sym;
+        }
+        __syncthreads();
+        for (unsigned i = tid; i < (unsigned)(kHtTile + kHtPad); i += kBlock)
+            s_ent1[ht_skew(i)] = s_tab1[(unsigned)s_cls[s_sym[i]] * (unsigned)sigma + (unsigned)s_sym[i + 1]];   // symbol i after symbol i - 1
+        __syncthreads();
+        {
+            const unsigned i0 = tid * (unsigned)kHtRun;
+            // the stream codes of symbols [i + 1, j): nb bits, left-aligned in hi:lo; ehi:elo = one bit per code-word END
+            uint64_t hi = 0, lo = 0, ehi = 0, elo = 0;
+            unsigned nb = 0, j = i0 + 1u;
+            for (unsigned i = i0; i < i0 + (unsigned)kHtRun; i++) {
+                while (nb < 64u && j < i + kHtCtxMaxSym) {
+                    const uint32_t e = s_ent1[ht_skew(j)];
+                    j++;
+                    const uint64_t c = (uint64_t)(e & ~31u) << 32;
+                    const unsigned len = e & 31u;
+                    hi |= c >> nb;
+                    if (nb + len > 64u) lo |= c << (64u - nb);           // (nb >= 38 here: the shift is < 64)
+                    const unsigned endb = nb + len - 1u;
+                    if (endb < 64u) ehi |= 1ull << (63u - endb); else elo |= 1ull << (127u - endb);
+                    nb += len;
+                }
+                const uint32_t e0 = s_tab0[s_sym[i + 1u]];
+                const unsigned len0 = e0 & 31u;
+                const unsigned room = 64u - (unsigned)kHtCtxCountBits - len0;     // stream bits that fit behind the first code
+                const unsigned have = nb < room ? nb : room;                     // (fewer only where the symbol cap stopped the fill)
+                const uint64_t code = ((uint64_t)(e0 & ~31u) << 32) | (hi >> len0);
+                unsigned cnt = 1u + (have ? (unsigned)__popcll(ehi >> (64u - have)) : 0u);
+                if (cnt > kHtCtxMaxSym) cnt = kHtCtxMaxSym;
+                s_key[ht_skew(i)] = (code & ~((1ull << kHtCtxCountBits) - 1ull)) | (uint64_t)cnt;
+                const unsigned len = s_ent1[ht_skew(i + 1u)] & 31u;      // symbol i + 1 leaves the stream (it is in the buffer: j > i + 1)
+                hi = (hi << len) | (lo >> (64u - len));
+                lo <<= len;
+                ehi = (ehi << len) | (elo >> (64u - len));
+                elo <<= len;
+                nb -= len;
+            }
+        }
+        __syncthreads();
+        for (unsigned i = tid; i < (unsigned)kHtTile; i += kBlock) {
+            if (base + i < m) {
+                const uint64_t key = s_key[ht_skew(i)];
+                K[base + i] = key;
+                if (partial)
+                    for (int p = 0; p < npass; p++) atomicAdd(&h[p][(unsigned)(key >> (8 * p)) & 255u], 1u);
+            }
+        }
+        __syncthreads();
+    }
+    if (partial)
+        for (int p = 0; p < npass; p++) partial[((uint64_t)p * kRadix + tid) * gridDim.x + blockIdx.x] = h[p][tid];
+}
+
 // ---- 64-bit keys: the passes between the first and the last move 12-byte (key, suffix) elements (KV12 above) -----------------
 // (k, v) can serve as ONE array of m <= cap 12-byte elements when the caller carved it as cap keys followed by cap values
 // (kv12_cap of radix_sort_kv64 / radix_sort_ht64: a statement of the caller, not something inferred from pointer distances --
@@ -2303,7 +2417,7 @@ static int kv_pass_out(const char* name, double algo, const Src& src, bool out12
 // lands in its slot without a copy); the keys still end in k0 / k1 as *result_in_1 says.
 int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint64_t m, uint32_t* scratch, hipStream_t st,
                     int* result_in_1, sfx_build_stats* stats, const PackedText& text, const uint32_t* ht, uint32_t* last_v,
-                    uint64_t kv12_cap)
+                    uint64_t kv12_cap, int ctx_sigma)
 {
     *result_in_1 = 0;
     if (m == 0) return SFX_OK;
@@ -2315,6 +2429,11 @@ int radix_sort_ht64(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint
     {
         Chunking ch = make_chunking(m, kHtTile, kHistAllGrid);
         SFX_HIP(hipMemsetAsync(scr.tickets, 0, 64 * sizeof(uint32_t), st));
+        if (ctx_sigma > 0) {
+            if (ctx_sigma > kHtCtxSigmaMax || kHtKeyBits != 64) return SFX_ERR_INTERNAL;
+            SFX_LAUNCH("ht_keys", (double)m * (text.bits / 8.0 + 8.0), k_ht_keys_ctx, ch.blocks, kBlock, st, text, ht, ctx_sigma, m, ch.tiles_per_block,
+                       npass, k0, sweep ? scr.partial : (uint32_t*)nullptr);
+        } else
         SFX_LAUNCH("ht_keys", (double)m * (text.bits / 8.0 + 8.0), k_ht_keys, ch.blocks, kBlock, st, text, ht, m, ch.tiles_per_block, npass, k0,
                    sweep ? scr.partial : (uint32_t*)nullptr);
         if (sweep)

@@ -127,6 +127,46 @@ k_byte_presence(const uint8_t* __restrict__ text, uint64_t n, unsigned long long
 }
 
 // dense symbol codes from the 256 global byte counts (one workgroup, thread = byte value)
+// counts of the (previous symbol, symbol) pairs of the text in dense symbol codes (make_lut's), for the context codes of
+// k_ht_keys_ctx: out[prev * sigma + cur] (u64).  One workgroup per CU, sigma^2 LDS counters (sigma <= kHtCtxSigmaMax), 16 bytes
+// per thread and step; the pair that starts a thread's 16 bytes takes the byte before them.
+__global__ void __launch_bounds__(1024)
+k_bigram_hist(const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ lut, int sigma, unsigned long long* __restrict__ out)
+{
+    __shared__ uint32_t h[kHtCtxSigmaMax * kHtCtxSigmaMax];
+    __shared__ uint8_t s_lut[256];
+    const unsigned tid = threadIdx.x;
+    if (tid < 256u) s_lut[tid] = lut[tid];
+    for (unsigned i = tid; i < (unsigned)(sigma * sigma); i += 1024u) h[i] = 0u;
+    __syncthreads();
+    const uint64_t nvec = n / 16, stride = (uint64_t)gridDim.x * 1024u;
+    const bool aligned = (reinterpret_cast<uintptr_t>(text) & 15u) == 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 1024u + tid; i < nvec; i += stride) {
+        uint8_t b[16];
+        if (aligned) {
+            const uint4 v = reinterpret_cast<const uint4*>(text)[i];
+            __builtin_memcpy(b, &v, 16);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) b[k] = text[i * 16 + k];
+        }
+        unsigned prev = i ? (unsigned)s_lut[text[i * 16 - 1]] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const unsigned cur = (unsigned)s_lut[b[k]];
+            if (prev != 0xFFFFFFFFu) atomicAdd(&h[prev * (unsigned)sigma + cur], 1u);
+            prev = cur;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {                                  // the tail behind the last whole 16 bytes
+        for (uint64_t p = dmax<uint64_t>(nvec * 16, 1); p < n; p++)
+            atomicAdd(&h[(unsigned)s_lut[text[p - 1]] * (unsigned)sigma + (unsigned)s_lut[text[p]]], 1u);
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < (unsigned)(sigma * sigma); i += 1024u)
+        if (h[i]) atomicAdd(&out[i], (unsigned long long)h[i]);
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_make_lut(const unsigned long long* __restrict__ bins, uint8_t* __restrict__ lut)
 {
@@ -594,6 +634,7 @@ constexpr unsigned kHtTableWords = 256 + 64;                 // device layout: c
 struct HtDepth {
     const uint32_t* ent;        // [256] code table ... [kHtTableWords ..] the 4096-entry fast table (bytes)
     int sigma;
+    int count_bits;             // > 0 (context codes, k_ht_keys_ctx): the key's low bits ARE the number of symbols it holds
 };
 struct LcpFuse {
     uint32_t* lcp;          // nullptr = off
@@ -888,7 +929,8 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                     if (HT && ht.ent) {
                         unsigned used = 0, cnt = 0;
                         const uint64_t k64 = (uint64_t)K[i];
-                        while (ht_depth_step(k64, used, cnt, reinterpret_cast<const uint16_t*>(s_t12))) {}
+                        if (ht.count_bits) cnt = (unsigned)(k64 & ((1ull << ht.count_bits) - 1ull));
+                        else while (ht_depth_step(k64, used, cnt, reinterpret_cast<const uint16_t*>(s_t12))) {}
                         d = cnt < kHtMaxSym ? cnt : kHtMaxSym;
                     }
                     my_min = dmin(my_min, d);
@@ -941,7 +983,8 @@ k_groups_apply(const KeyT* __restrict__ K, const uint32_t* __restrict__ V,
                     const uint64_t one[1] = {kx};
                     const unsigned all[1] = {(unsigned)kHtKeyBits};
                     uint32_t d1[1];
-                    ht_common_n<1>(one, all, reinterpret_cast<const uint16_t*>(s_t12), d1);
+                    if (ht.count_bits) d1[0] = (uint32_t)(kx & ((1ull << ht.count_bits) - 1ull));
+                    else ht_common_n<1>(one, all, reinterpret_cast<const uint16_t*>(s_t12), d1);
 #pragma unroll
                     for (int q = 0; q < kGroupItems; q++) dep[q] = j == (unsigned)q ? d1[0] : dep[q];
                 }
@@ -1552,67 +1595,28 @@ struct HtHost {
     uint16_t t12[1 << kHtFastBits];
     int sigma;
     double avg_len;
+    // context codes (round 6): ctx != 0 -> the keys are k_ht_keys_ctx's; cls / ent1 are what the device tables at kHtCtxOff hold
+    int ctx;
+    uint8_t cls[256];
+    uint32_t ent1[kHtCtxClasses][256];
+    double avg_ctx;                 // mean length of a stream code word (weighted by the pair counts)
 };
+// optimal alphabetic (order-preserving) prefix code of ns >= 2 symbols with weights w, code words of at most kHtMaxLen bits:
+// ent[i] = code left-aligned | length.  (The DP of ht_build, without the table.)
+static bool ht_codes(const double* wd, int ns, uint32_t* ent, double* avg_out);
 static bool ht_build(const unsigned long long* counts256, int fixed_bits, HtHost* out)
 {
     unsigned long long w[256];
     int ns = 0;
     unsigned long long total = 0;
+    out->ctx = 0;
     for (int c = 0; c < 256; c++)
         if (counts256[c]) { w[ns++] = counts256[c]; total += counts256[c]; }
     if (ns < 2 || total == 0) return false;
-    std::vector<double> cost_v((size_t)ns * ns);
-    std::vector<unsigned short> root_v((size_t)ns * ns);
-    double* const C = cost_v.data();
-    unsigned short* const R = root_v.data();
-    auto at = [ns](int i, int j) { return (size_t)i * ns + j; };
-    int len[256];
-    for (int shift = 16; shift >= 4; shift--) {
-        double ww[256], pre[257];
-        const double floor_w = (double)total / (double)(1ull << shift);
-        pre[0] = 0;
-        for (int i = 0; i < ns; i++) { ww[i] = (double)w[i] > floor_w ? (double)w[i] : floor_w; pre[i + 1] = pre[i] + ww[i]; }
-        for (int i = 0; i < ns; i++) { C[at(i, i)] = 0; R[at(i, i)] = (unsigned short)i; }
-        for (int L = 2; L <= ns; L++) {
-            for (int i = 0; i + L <= ns; i++) {
-                const int j = i + L - 1;
-                double best = 1e300;
-                int bk = i;
-                // (Knuth / Yao: the range weight is monotone and satisfies the quadrangle inequality, so an optimal root of
-                // (i, j) lies between those of (i, j - 1) and (i + 1, j) -- O(sigma^2) in all)
-                int klo = R[at(i, j - 1)], khi = R[at(i + 1, j)];
-                if (klo < i) klo = i;
-                if (khi > j - 1) khi = j - 1;
-                if (khi < klo) khi = klo;
-                for (int k = klo; k <= khi; k++) {
-                    const double v = C[at(i, k)] + C[at(k + 1, j)];
-                    if (v < best) { best = v; bk = k; }
-                }
-                C[at(i, j)] = best + (pre[j + 1] - pre[i]);
-                R[at(i, j)] = (unsigned short)bk;
-            }
-        }
-        // codes by descent (explicit stack): left = 0, right = 1
-        struct Item { int i, j, d; uint32_t code; } stack[512];
-        int sp = 0;
-        stack[sp++] = Item{0, ns - 1, 0, 0u};
-        bool ok = true;
-        while (sp) {
-            const Item it = stack[--sp];
-            if (it.i == it.j) {
-                len[it.i] = it.d ? it.d : 1;
-                if (len[it.i] > kHtMaxLen) { ok = false; break; }
-                out->ent[it.i] = (it.d ? (it.code << (32 - it.d)) : 0u) | (uint32_t)len[it.i];
-                continue;
-            }
-            if (it.d >= kHtMaxLen) { ok = false; break; }
-            const int k = R[at(it.i, it.j)];
-            stack[sp++] = Item{k + 1, it.j, it.d + 1, (it.code << 1) | 1u};
-            stack[sp++] = Item{it.i, k, it.d + 1, it.code << 1};
-        }
-        if (!ok) continue;
-        double avg = 0;
-        for (int i = 0; i < ns; i++) avg += (double)w[i] / (double)total * len[i];
+    {
+        double wd[256], avg = 0;
+        for (int i = 0; i < ns; i++) wd[i] = (double)w[i];
+        if (!ht_codes(wd, ns, out->ent, &avg)) return false;
         for (int i = ns; i < 256; i++) out->ent[i] = 0xFFFFFFFFu;
         out->sigma = ns;
         out->avg_len = avg;
@@ -1635,7 +1639,150 @@ static bool ht_build(const unsigned long long* counts256, int fixed_bits, HtHost
         }
         return avg + 0.75 < (double)fixed_bits;
     }
+}
+
+static bool ht_codes(const double* wd, int ns, uint32_t* ent, double* avg_out)
+{
+    if (ns < 2 || ns > 256) return false;
+    double total = 0;
+    for (int i = 0; i < ns; i++) total += wd[i];
+    if (!(total > 0)) return false;
+    std::vector<double> cost_v((size_t)ns * ns);
+    std::vector<unsigned short> root_v((size_t)ns * ns);
+    double* const C = cost_v.data();
+    unsigned short* const R = root_v.data();
+    auto at = [ns](int i, int j) { return (size_t)i * ns + j; };
+    int len[256];
+    for (int shift = 16; shift >= 4; shift--) {
+        double ww[256], pre[257];
+        const double floor_w = total / (double)(1ull << shift);
+        pre[0] = 0;
+        for (int i = 0; i < ns; i++) { ww[i] = wd[i] > floor_w ? wd[i] : floor_w; pre[i + 1] = pre[i] + ww[i]; }
+        for (int i = 0; i < ns; i++) { C[at(i, i)] = 0; R[at(i, i)] = (unsigned short)i; }
+        for (int L = 2; L <= ns; L++) {
+            for (int i = 0; i + L <= ns; i++) {
+                const int j = i + L - 1;
+                double best = 1e300;
+                int bk = i;
+                int klo = R[at(i, j - 1)], khi = R[at(i + 1, j)];
+                if (klo < i) klo = i;
+                if (khi > j - 1) khi = j - 1;
+                if (khi < klo) khi = klo;
+                for (int k = klo; k <= khi; k++) {
+                    const double v = C[at(i, k)] + C[at(k + 1, j)];
+                    if (v < best) { best = v; bk = k; }
+                }
+                C[at(i, j)] = best + (pre[j + 1] - pre[i]);
+                R[at(i, j)] = (unsigned short)bk;
+            }
+        }
+        struct Item { int i, j, d; uint32_t code; } stack[512];
+        int sp = 0;
+        stack[sp++] = Item{0, ns - 1, 0, 0u};
+        bool ok = true;
+        while (sp) {
+            const Item it = stack[--sp];
+            if (it.i == it.j) {
+                len[it.i] = it.d ? it.d : 1;
+                if (len[it.i] > kHtMaxLen) { ok = false; break; }
+                ent[it.i] = (it.d ? (it.code << (32 - it.d)) : 0u) | (uint32_t)len[it.i];
+                continue;
+            }
+            if (it.d >= kHtMaxLen) { ok = false; break; }
+            const int k = R[at(it.i, it.j)];
+            stack[sp++] = Item{k + 1, it.j, it.d + 1, (it.code << 1) | 1u};
+            stack[sp++] = Item{it.i, k, it.d + 1, it.code << 1};
+        }
+        if (!ok) continue;
+        double avg = 0;
+        for (int i = 0; i < ns; i++) avg += wd[i] / total * len[i];
+        *avg_out = avg;
+        return true;
+    }
     return false;
+}
+
+// Context codes for a text whose pair counts are big[prev * sigma + cur] (dense symbols; `base` = its order-0 code, whose ent
+// gives the first symbol of every key).  The predecessors are put into at most kHtCtxClasses classes -- the high nibble of their
+// byte value to begin with (UTF-8 lead and continuation bytes, the ASCII ranges), then a few rounds of moving every predecessor
+// to the class whose successor distribution it fits best (the gain in sum of n log n / N) -- and every class gets the optimal
+// alphabetic code of ITS successor counts (all sigma symbols, a weight floor for those that never follow the class).  Taken
+// when the symbols a key holds on average -- 1 + (60 - order-0 length) / stream length -- beat the order-0 key's 64 / length by
+// 10 %: the count costs 4 key bits, the class tables a bigram pass over the text.
+static bool ht_ctx_build(const std::vector<unsigned long long>& big, int sigma, const unsigned char* dense_byte, HtHost* out)
+{
+    out->ctx = 0;
+    if (sigma < 2 || sigma > kHtCtxSigmaMax || out->sigma != sigma) return false;
+    const int NC = kHtCtxClasses;
+    std::vector<double> W((size_t)NC * sigma, 0.0), tot(NC, 0.0), row(sigma);
+    int cls[256];
+    {   // initial classes: the high nibbles that occur, in order
+        int map[16], used = 0;
+        for (int k = 0; k < 16; k++) map[k] = -1;
+        for (int p = 0; p < sigma; p++) {
+            const int nib = dense_byte[p] >> 4;
+            if (map[nib] < 0) map[nib] = used++;
+            cls[p] = map[nib];
+        }
+    }
+    auto xlogx = [](double x) { return x > 0 ? x * log2(x) : 0.0; };
+    auto add = [&](int c, int p, double sign) {
+        for (int q = 0; q < sigma; q++) { const double v = (double)big[(size_t)p * sigma + q]; W[(size_t)c * sigma + q] += sign * v; tot[c] += sign * v; }
+    };
+    for (int p = 0; p < sigma; p++) add(cls[p], p, 1.0);
+    // cost of a class = N log N - sum n log n (N times its entropy); a move is judged by the change of both classes
+    auto cost_with = [&](int c, int p, double sign) {
+        double N = tot[c], sum = 0;
+        for (int q = 0; q < sigma; q++) {
+            const double v = W[(size_t)c * sigma + q] + sign * (double)big[(size_t)p * sigma + q];
+            sum += xlogx(v);
+        }
+        for (int q = 0; q < sigma; q++) N += sign * (double)big[(size_t)p * sigma + q];
+        return xlogx(N) - sum;
+    };
+    auto cost_of = [&](int c) {
+        double sum = 0;
+        for (int q = 0; q < sigma; q++) sum += xlogx(W[(size_t)c * sigma + q]);
+        return xlogx(tot[c]) - sum;
+    };
+    for (int round = 0; round < 3; round++) {
+        bool moved = false;
+        for (int p = 0; p < sigma; p++) {
+            double np = 0;
+            for (int q = 0; q < sigma; q++) np += (double)big[(size_t)p * sigma + q];
+            if (np == 0) continue;
+            const int a = cls[p];
+            const double without_a = cost_with(a, p, -1.0), with_a = cost_of(a);
+            double best_gain = 0;
+            int best = a;
+            for (int c = 0; c < NC; c++) {
+                if (c == a) continue;
+                const double gain = (with_a - without_a) - (cost_with(c, p, 1.0) - cost_of(c));   // bits saved by moving p from a to c
+                if (gain > best_gain + 1e-9) { best_gain = gain; best = c; }
+            }
+            if (best != a) { add(a, p, -1.0); add(best, p, 1.0); cls[p] = best; moved = true; }
+        }
+        if (!moved) break;
+    }
+    double bits = 0, pairs = 0;
+    for (int c = 0; c < NC; c++) {
+        for (int q = 0; q < 256; q++) out->ent1[c][q] = out->ent[q < sigma ? q : 0];
+        if (!(tot[c] > 0)) continue;                                   // (an empty class: the order-0 code, never looked up)
+        for (int q = 0; q < sigma; q++) row[q] = W[(size_t)c * sigma + q];
+        double avg = 0;
+        if (!ht_codes(row.data(), sigma, out->ent1[c], &avg)) return false;
+        bits += avg * tot[c];
+        pairs += tot[c];
+    }
+    if (!(pairs > 0)) return false;
+    for (int p = 0; p < 256; p++) out->cls[p] = (uint8_t)(p < sigma ? cls[p] : 0);
+    out->avg_ctx = bits / pairs;
+    const double sym_ctx = 1.0 + (64.0 - kHtCtxCountBits - out->avg_len) / out->avg_ctx;
+    const double sym_0 = (double)kHtKeyBits / out->avg_len;
+    static const int force = [] { const char* e = dev_env("SFX_HT_CTX"); return e ? atoi(e) : 1; }();   // 0: never, 2: always (development)
+    if (force == 0) return false;
+    out->ctx = (force == 2 || sym_ctx >= 1.10 * sym_0) ? 1 : 0;
+    return out->ctx != 0;
 }
 
 struct SaBuffers {
@@ -1701,7 +1848,8 @@ static void carve_sa(A& ar, uint64_t n, uint64_t cap, uint64_t isa_len, SaBuffer
     uint32_t* totals = ar.template take<uint32_t>(64);
     unsigned long long* bins = ar.template take<unsigned long long>(256);
     uint8_t* lut = ar.template take<uint8_t>(256);
-    uint32_t* ht = ar.template take<uint32_t>(kHtTableWords + (1u << kHtFastBits) / 2);
+    static_assert(kHtCtxOff == kHtTableWords + (1u << kHtFastBits) / 2, "the context tables lie behind the fast table");
+    uint32_t* ht = ar.template take<uint32_t>(kHtCtxOff + kHtCtxWords);
     if (b) {
         b->ht = ht;
         b->kv_cap = cap;
@@ -1754,7 +1902,7 @@ static int round_apply(const KeyT* K, const uint32_t* V, const uint32_t* S, uint
                        uint32_t* sa, uint32_t* isa, uint32_t* S_next, uint32_t* V_next,
                        uint32_t* R_next, hipStream_t st, int sa_mode, uint64_t n, sfx_build_stats& stats,
                        uint64_t kept, const uint16_t* Hd = nullptr, uint16_t* Hd_next = nullptr, uint32_t hd_floor = 0,
-                       HtDepth ht = HtDepth{nullptr, 0}, uint32_t* min_depth = nullptr, const uint8_t* rank_flags = nullptr,
+                       HtDepth ht = HtDepth{nullptr, 0, 0}, uint32_t* min_depth = nullptr, const uint8_t* rank_flags = nullptr,
                        const uint32_t* part_pairs = nullptr, uint64_t npairs = 0)
 {
     // rank_flags / part_pairs / npairs (rank rounds after an LDS or segmented sort): only the members whose rank changes
@@ -2114,7 +2262,7 @@ static int refine(const PackedText& pt, int cpk, SaBuffers& b, uint32_t* sa, uin
         if (min_depth) SFX_HIP(hipMemsetAsync(min_depth, 0xFF, sizeof(uint32_t), st));
         SFX_TRY(round_apply<uint64_t>(b.K0, V_cur, S_cur, m, b, sa, rank_mode ? isa : nullptr, S_next, V_next, nullptr,
                                       st, 2, n, stats, kept, tr.Hd, deep_round ? hd_of(b, S_next) : nullptr, 0u,
-                                      HtDepth{nullptr, 0}, min_depth, rank_mode ? b.F8 : nullptr, tr.part_pairs, rank_changes));
+                                      HtDepth{nullptr, 0, 0}, min_depth, rank_mode ? b.F8 : nullptr, tr.part_pairs, rank_changes));
         // SFX_TRACE=1 (development): one line per round
         static const bool trace = [] { const char* e = dev_env("SFX_TRACE"); return e && atoi(e) != 0; }();
         if (trace)
@@ -2199,7 +2347,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     } else {
         // (the last pass drops every suffix straight into its SA slot, as the E64 sort does)
         if (ht && from_text && count == pt.n)
-            SFX_TRY(radix_sort_ht64(b.K0, b.VA, b.K1, b.VB, count, b.hist, st, &in1, &stats, pt, b.ht, sa, b.kv_cap));
+            SFX_TRY(radix_sort_ht64(b.K0, b.VA, b.K1, b.VB, count, b.hist, st, &in1, &stats, pt, b.ht, sa, b.kv_cap, ht->ctx ? ht->sigma : 0));
         else
             SFX_TRY(radix_sort_kv64(b.K0, b.VA, b.K1, b.VB, count, 0, pt.bits * cpk, b.hist, st, &in1, &stats,
                                     from_text ? &pt : nullptr, sa, b.kv_cap));
@@ -2299,7 +2447,7 @@ static int sort_and_refine(const PackedText& pt, int cpk, uint64_t count, bool f
     if (ht && kept > 0) {
         SFX_HIP(hipMemsetAsync(b.ht + 256, 0xFF, sizeof(uint32_t), st));
         SFX_TRY(round_apply<KeyT>(Kr, Vr, nullptr, count, b, sa, nullptr, b.S0, V_next, nullptr, st, in_place ? 1 : 0, pt.n, stats,
-                                  kept, nullptr, b.Hd0, 0u, HtDepth{b.ht, ht->sigma}, b.ht + 256));
+                                  kept, nullptr, b.Hd0, 0u, HtDepth{b.ht, ht->sigma, ht->ctx ? kHtCtxCountBits : 0}, b.ht + 256));
         uint32_t md = 0;
         SFX_TRY(read_back(&md, b.ht + 256, sizeof(md), st));
         if (md == 0xFFFFFFFFu || md == 0) return SFX_ERR_INTERNAL;
@@ -2402,8 +2550,36 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
         use_ht = ht_build(counts, alpha.bits, &ht);
         if (use_ht) {
             stats.symbols_per_key = (uint32_t)((double)kHtKeyBits / ht.avg_len);   // (on average: the code words differ in length)
+            // Context codes (round 6, k_ht_keys_ctx) where they buy 10 % more symbols per key -- large alphabets with structure
+            // between neighbouring bytes (mixed-script UTF-8: 13 symbols instead of 10).  Not with the fused LCP: the symbols two
+            // different keys share cannot be counted off a context code with the order-0 end-mask table.
+            static const uint64_t ctx_min = [] { const char* e = dev_env("SFX_HT_CTX_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 24); }();
+            if (!lcp_fuse && (int)alpha.sigma <= kHtCtxSigmaMax && n >= ctx_min && kHtKeyBits == 64) {
+                const int sg = (int)alpha.sigma;
+                unsigned long long* d_big = reinterpret_cast<unsigned long long*>(b.K0);           // (idle until the keys are made)
+                SFX_HIP(hipMemsetAsync(d_big, 0, (size_t)sg * sg * sizeof(unsigned long long), st));
+                int dev = 0, cus = 256;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+                const unsigned grid = (unsigned)dmin<uint64_t>((n / 16 + 1023) / 1024 + 1, dmin((unsigned)cus, grid_cap()));
+                SFX_LAUNCH("bigram_hist", (double)n, k_bigram_hist, grid, 1024, st, d_text, n, (const uint8_t*)b.lut, sg, d_big);
+                std::vector<unsigned long long> big((size_t)sg * sg);
+                SFX_HIP(hipMemcpyAsync(big.data(), d_big, big.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                SFX_HIP(hipStreamSynchronize(st));
+                unsigned char dense_byte[256];
+                int q = 0;
+                for (int c = 0; c < 256; c++)
+                    if (counts[c]) dense_byte[q++] = (unsigned char)c;
+                if (q == sg && ht_ctx_build(big, sg, dense_byte, &ht)) {
+                    stats.symbols_per_key = (uint32_t)(1.0 + (64.0 - kHtCtxCountBits - ht.avg_len) / ht.avg_ctx);
+                    stats.reserved |= 2u;                                          // (bit 1: context codes)
+                }
+            }
             SFX_HIP(hipMemcpyAsync(b.ht, ht.ent, sizeof(ht.ent), hipMemcpyHostToDevice, st));
             SFX_HIP(hipMemcpyAsync(b.ht + kHtTableWords, ht.t12, sizeof(ht.t12), hipMemcpyHostToDevice, st));
+            if (ht.ctx) {
+                SFX_HIP(hipMemcpyAsync(b.ht + kHtCtxOff, ht.cls, sizeof(ht.cls), hipMemcpyHostToDevice, st));
+                SFX_HIP(hipMemcpyAsync(b.ht + kHtCtxOff + 64, ht.ent1, sizeof(ht.ent1), hipMemcpyHostToDevice, st));
+            }
         }
     }
     // (compressed keys, round 4: the symbols two different keys share are the code words that end inside their common

@@ -82,7 +82,7 @@ if os.environ.get("SFX_HYBRID_MIN"):
         eng.profile(True); eng.profile_reset()
         SuffixTable(t, engine=eng).table()
         # (the LDS sort of the sub-buckets reports as bucket_sort_ties when it leaves tie bits, bucket_sort_lds when sorted keys)
-        names = ["bucket_sort_lds" if r["name"] == "bucket_sort_ties" else r["name"] for r in eng.profile_report()]
+        names = ["bucket_sort_lds" if r["name"].startswith("bucket_sort_ties") else r["name"] for r in eng.profile_report()]
         eng.profile(False)
         return names
     cap = int(os.environ.get("SFX_HYBRID_CAP", "100000"))
@@ -117,7 +117,7 @@ if os.environ.get("SFX_HYBRID_MIN"):
     for nr in ((3, 7) if cap < 400 else (1, 3)):
         eng.profile(True); eng.profile_reset()
         _cases.range_slices(eng, oracle, _gen.dna(56001, seed=8).tobytes(), nr, packed=True)
-        seen = set("bucket_sort_lds" if r["name"] == "bucket_sort_ties" else r["name"] for r in eng.profile_report())
+        seen = set("bucket_sort_lds" if r["name"].startswith("bucket_sort_ties") else r["name"] for r in eng.profile_report())
         eng.profile(False)
         # (one rank = the whole key space: no filter, the text-fed route of the full build)
         assert ("radix_hist16_elems" in seen) == (nr == 3) and ("radix_hist16_text" in seen) == (nr == 1), (nr, seen)
@@ -242,6 +242,11 @@ VARIANTS = {
     # >= 95 % of the suffixes tied and NOT adopted, sort_and_refine), over compressed 64-bit keys; with the fused LCP (the deep-round
     # texts) the values are bounds from the start
     "start-with-rank-rounds-compressed-keys": {"SFX_START_RANKS": "1", "SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_DEEP_ITERS": "24"},
+    # context codes (round 6, k_ht_keys_ctx): one order-preserving code per class of the preceding symbol, the number of symbols a
+    # key holds in its low 4 bits -- forced on small inputs (the build takes them from 2^24 bytes on, where they buy 10 % more symbols)
+    "context-codes": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_HT_CTX": "2", "SFX_HT_CTX_MIN": "1"},
+    "context-codes-small-tiles": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_HT_CTX": "2", "SFX_HT_CTX_MIN": "1", "SFX_TILE_SMALL": "1",
+                                  "SFX_MAX_GRID": "3"},
     # rank rounds through round 1's composite-key sort (the fallback for key2 = rank + h beyond 32 bits)
     "composite-rank-rounds": {"SFX_FORCE_COMPOSITE": "1"},
     "tile-1024x4-pair32": {"SFX_TILE_GEOM": "1", "SFX_TILE_PAIR": "32"},
