@@ -2329,8 +2329,11 @@ k_ht_keys_ctx(PackedText t, const uint32_t* __restrict__ tab, int sigma, uint64_
             s_sym[i] = (uint8_t)sym;
         }
         __syncthreads();
-        for (unsigned i = tid; i < (unsigned)(kHtTile + kHtPad); i += kBlock)
+        for (unsigned i = tid; i < (unsigned)(kHtTile + kHtPad); i += kBlock) {
             s_ent1[ht_skew(i)] = s_tab1[(unsigned)s_cls[s_sym[i]] * (unsigned)sigma + (unsigned)s_sym[i + 1]];   // symbol i after symbol i - 1
+            // (the order-0 entry of symbol i waits in the slot its key will take: the thread that makes key i reads it first)
+            if (i < (unsigned)kHtTile) s_key[ht_skew(i)] = (uint64_t)s_tab0[s_sym[i + 1]];
+        }
         __syncthreads();
         {
             const unsigned i0 = tid * (unsigned)kHtRun;
@@ -2349,7 +2352,7 @@ k_ht_keys_ctx(PackedText t, const uint32_t* __restrict__ tab, int sigma, uint64_
                     if (endb < 64u) ehi |= 1ull << (63u - endb); else elo |= 1ull << (127u - endb);
                     nb += len;
                 }
-                const uint32_t e0 = s_tab0[s_sym[i + 1u]];
+                const uint32_t e0 = (uint32_t)s_key[ht_skew(i)];
                 const unsigned len0 = e0 & 31u;
                 const unsigned room = 64u - (unsigned)kHtCtxCountBits - len0;     // stream bits that fit behind the first code
                 const unsigned have = nb < room ? nb : room;                     // (fewer only where the symbol cap stopped the fill)
