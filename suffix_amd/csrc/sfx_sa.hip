@@ -2554,7 +2554,11 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
             // between neighbouring bytes (mixed-script UTF-8: 13 symbols instead of 10).  Not with the fused LCP: the symbols two
             // different keys share cannot be counted off a context code with the order-0 end-mask table.
             static const uint64_t ctx_min = [] { const char* e = dev_env("SFX_HT_CTX_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 24); }();
-            if (!lcp_fuse && (int)alpha.sigma <= kHtCtxSigmaMax && n >= ctx_min && kHtKeyBits == 64) {
+            // (the bigram pass is only paid where contexts can buy 10 %: the count's 4 bits cost 4 / length symbols, and the order-1
+            // entropy of text whose order-0 code already averages under 5 bits -- English-like: 4.6 -- is never that far below it)
+            static const int ctx_force = [] { const char* e = dev_env("SFX_HT_CTX"); return e ? atoi(e) : 1; }();
+            if (!lcp_fuse && ctx_force != 0 && (ht.avg_len >= 5.0 || ctx_force == 2) && (int)alpha.sigma <= kHtCtxSigmaMax && n >= ctx_min &&
+                kHtKeyBits == 64) {
                 const int sg = (int)alpha.sigma;
                 unsigned long long* d_big = reinterpret_cast<unsigned long long*>(b.K0);           // (idle until the keys are made)
                 SFX_HIP(hipMemsetAsync(d_big, 0, (size_t)sg * sg * sizeof(unsigned long long), st));
