@@ -41,6 +41,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <vector>
+#include <chrono>
 #include <string.h>
 
 #include "sfx_host.hpp"
@@ -1725,42 +1726,54 @@ static bool ht_ctx_build(const std::vector<unsigned long long>& big, int sigma, 
             cls[p] = map[nib];
         }
     }
-    auto xlogx = [](double x) { return x > 0 ? x * log2(x) : 0.0; };
-    auto add = [&](int c, int p, double sign) {
-        for (int q = 0; q < sigma; q++) { const double v = (double)big[(size_t)p * sigma + q]; W[(size_t)c * sigma + q] += sign * v; tot[c] += sign * v; }
-    };
-    for (int p = 0; p < sigma; p++) add(cls[p], p, 1.0);
-    // cost of a class = N log N - sum n log n (N times its entropy); a move is judged by the change of both classes
-    auto cost_with = [&](int c, int p, double sign) {
-        double N = tot[c], sum = 0;
+    // cost of a class = N log N - sum n log n (N times its entropy).  A move of predecessor p changes the terms of ITS successors
+    // only -- the rows of the pair counts are sparse (a UTF-8 lead byte is followed by 64 values at most) -- so a candidate move
+    // costs nnz(p) logarithms, single precision: the gains need no more (the whole refinement: < 1 ms on the host).
+    auto xlogx = [](double x) { return x > 0 ? x * (double)log2f((float)x) : 0.0; };
+    std::vector<int> nz_start(sigma + 1, 0), nz_q;
+    std::vector<double> nz_v, rowsum(sigma, 0.0);
+    for (int p = 0; p < sigma; p++) {
+        nz_start[p] = (int)nz_q.size();
         for (int q = 0; q < sigma; q++) {
-            const double v = W[(size_t)c * sigma + q] + sign * (double)big[(size_t)p * sigma + q];
-            sum += xlogx(v);
+            const double v = (double)big[(size_t)p * sigma + q];
+            if (v > 0) { nz_q.push_back(q); nz_v.push_back(v); rowsum[p] += v; }
         }
-        for (int q = 0; q < sigma; q++) N += sign * (double)big[(size_t)p * sigma + q];
-        return xlogx(N) - sum;
-    };
-    auto cost_of = [&](int c) {
-        double sum = 0;
-        for (int q = 0; q < sigma; q++) sum += xlogx(W[(size_t)c * sigma + q]);
-        return xlogx(tot[c]) - sum;
+    }
+    nz_start[sigma] = (int)nz_q.size();
+    for (int p = 0; p < sigma; p++)
+        for (int k = nz_start[p]; k < nz_start[p + 1]; k++) { W[(size_t)cls[p] * sigma + nz_q[k]] += nz_v[k]; tot[cls[p]] += nz_v[k]; }
+    // bits the code of class c grows by when p joins it (sign = +1), or shrinks by when p leaves it (sign = -1, negated)
+    auto delta = [&](int c, int p, double sign) {
+        double d = xlogx(tot[c] + sign * rowsum[p]) - xlogx(tot[c]);
+        for (int k = nz_start[p]; k < nz_start[p + 1]; k++) {
+            const double w = W[(size_t)c * sigma + nz_q[k]];
+            d -= xlogx(w + sign * nz_v[k]) - xlogx(w);
+        }
+        return d;
     };
     for (int round = 0; round < 3; round++) {
         bool moved = false;
         for (int p = 0; p < sigma; p++) {
-            double np = 0;
-            for (int q = 0; q < sigma; q++) np += (double)big[(size_t)p * sigma + q];
-            if (np == 0) continue;
+            if (!(rowsum[p] > 0)) continue;
             const int a = cls[p];
-            const double without_a = cost_with(a, p, -1.0), with_a = cost_of(a);
+            const double leave = -delta(a, p, -1.0);                   // bits class a's code loses when p leaves
             double best_gain = 0;
             int best = a;
             for (int c = 0; c < NC; c++) {
                 if (c == a) continue;
-                const double gain = (with_a - without_a) - (cost_with(c, p, 1.0) - cost_of(c));   // bits saved by moving p from a to c
-                if (gain > best_gain + 1e-9) { best_gain = gain; best = c; }
+                const double gain = leave - delta(c, p, 1.0);          // bits saved by moving p from a to c
+                if (gain > best_gain + 1e-6 * rowsum[p]) { best_gain = gain; best = c; }
             }
-            if (best != a) { add(a, p, -1.0); add(best, p, 1.0); cls[p] = best; moved = true; }
+            if (best != a) {
+                for (int k = nz_start[p]; k < nz_start[p + 1]; k++) {
+                    W[(size_t)a * sigma + nz_q[k]] -= nz_v[k];
+                    W[(size_t)best * sigma + nz_q[k]] += nz_v[k];
+                }
+                tot[a] -= rowsum[p];
+                tot[best] += rowsum[p];
+                cls[p] = best;
+                moved = true;
+            }
         }
         if (!moved) break;
     }
@@ -2573,7 +2586,13 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
                 int q = 0;
                 for (int c = 0; c < 256; c++)
                     if (counts[c]) dense_byte[q++] = (unsigned char)c;
-                if (q == sg && ht_ctx_build(big, sg, dense_byte, &ht)) {
+                const auto t_host0 = std::chrono::steady_clock::now();
+                const bool took = q == sg && ht_ctx_build(big, sg, dense_byte, &ht);
+                static const bool trace = [] { const char* e = dev_env("SFX_TRACE"); return e && atoi(e) != 0; }();
+                if (trace)
+                    fprintf(stderr, "[sfx] context codes: %s, order-0 %.3f bits, stream %.3f bits, host %.3f ms\n", took ? "taken" : "not taken", ht.avg_len,
+                            ht.avg_ctx, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count());
+                if (took) {
                     stats.symbols_per_key = (uint32_t)(1.0 + (64.0 - kHtCtxCountBits - ht.avg_len) / ht.avg_ctx);
                     stats.reserved |= 2u;                                          // (bit 1: context codes)
                 }
