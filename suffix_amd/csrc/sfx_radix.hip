@@ -2185,25 +2185,90 @@ int radix_sort_e64(uint64_t* e0, uint64_t* e1, uint64_t m, int bit_lo, int bit_h
 
 // ---- compressed keys of a whole text ---------------------------------------------------------------
 // key of position i = the codes of symbols i, i + 1, ... (at most kHtMaxSym of them) cut to 64 bits (sfx_device.hpp).
-// A thread takes kHtRun CONSECUTIVE positions and keeps the codes of the symbols ahead of it in a 128-bit buffer: the
-// key of the next position is the buffer shifted by the length of the symbol that leaves, topped up with the codes of
-// the symbols that now fit -- about two table look-ups per position instead of one per symbol and position.  A
-// workgroup takes tiles of kHtTile positions: the code table entries of the tile's symbols (+ the kHtMaxSym - 1 beyond
-// it) go to LDS first, the keys leave through LDS in coalesced order, and the digit counts of all eight radix passes
-// are taken on the way out (the role of k_radix_hist_all).  LDS rows are skewed by one word per run: a lane's run
-// starts 9 words after its neighbour's, not 8 (a quarter of the banks).
+// A workgroup takes tiles of kHtTile positions and first lays the codes of the tile's symbols (+ the kHtPad beyond it) end to
+// end as ONE BIT STRING in LDS: a thread concatenates the codes of kHtRun consecutive symbols in registers (at most 96 bits), a
+// block-wide scan of the run lengths gives every run its bit offset, the runs are OR-ed into the zeroed string (four LDS
+// atomics per run) and the offset of every symbol is kept (16 bits).  The key of position i is then the 64-bit WINDOW of
+// the string at symbol i's offset, cut where symbol i + kHtMaxSym starts: three LDS words and two funnel shifts per key, any
+// thread for any position -- so the keys leave the registers in coalesced order, and the digit counts of all eight radix
+// passes are taken on the way out (the role of k_radix_hist_all).  (Rounds 4-6 kept a rolling 128-bit buffer per thread over 8
+// consecutive positions: ~90 VALU instructions per key in a divergent refill loop with an LDS round trip per symbol, the
+// kernel 90 % VALU-busy at 2.5x its HBM time.)
 constexpr int kHtRun = 8;
-constexpr int kHtTile = kBlock * kHtRun;                     // 2048 positions
-constexpr int kHtPad = 16;                                   // >= kHtMaxSym - 1
-__device__ __forceinline__ unsigned ht_skew(unsigned i) { return i + (i >> 3); }
+constexpr int kHtPad = 16;                                   // >= kHtMaxSym: the symbols beyond the tile its last keys hold
+constexpr int kHtSpan = kBlock * kHtRun;                     // 2048 symbols laid out per tile: one run per thread
+constexpr int kHtTile = kHtSpan - kHtPad;                    // 2032 positions (16 256 bytes of keys: whole 128-byte lines)
+constexpr int kHtStreamWords = kHtSpan * kHtMaxLen / 32 + 4; // the bit string (+ the window's two words of slack)
+static_assert(kHtPad >= (int)kHtMaxSym && kHtRun * kHtMaxLen <= 96, "a run fits 96 bits");
+// the digits of all passes of one key into the tile's counters: with all 64 bits sorted, eight byte extractions from the two
+// halves (a loop over a run-time pass count shifts 64 bits by a variable eight times)
+__device__ __forceinline__ void ht_count_digits(uint32_t (*h)[kRadix], uint64_t key, int npass)
+{
+    if (kHtKeyBits == 64 && npass == 8) {
+        const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            atomicAdd(&h[p][(klo >> (8 * p)) & 255u], 1u);
+            atomicAdd(&h[p + 4][(khi >> (8 * p)) & 255u], 1u);
+        }
+    } else {
+        for (int p = 0; p < npass; p++) atomicAdd(&h[p][(unsigned)(key >> (64 - kHtKeyBits + 8 * p)) & 255u], 1u);
+    }
+}
+// exclusive block-wide prefix sum of v (s_wsum: one word per wave; one barrier)
+__device__ __forceinline__ unsigned ht_block_scan(unsigned v, uint32_t* s_wsum, unsigned tid)
+{
+    const unsigned lane = tid & (kWave - 1);
+    unsigned incl = v;
+#pragma unroll
+    for (unsigned d = 1; d < (unsigned)kWave; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == (unsigned)kWave - 1u) s_wsum[tid / kWave] = incl;
+    __syncthreads();
+    unsigned add = 0;
+#pragma unroll
+    for (unsigned w = 0; w < (unsigned)(kBlock / kWave); w++)
+        if (w < tid / kWave) add += s_wsum[w];
+    return add + incl - v;
+}
+// bits [S, S + 96) of the LDS bit string (big-endian inside its 32-bit words) |= a run, left-aligned in hi:lo (<= 96 bits)
+__device__ __forceinline__ void ht_stream_or(uint32_t* stream, unsigned S, uint64_t hi, uint64_t lo)
+{
+    const unsigned w = S >> 5, sh = S & 31u;
+    const uint32_t x0 = (uint32_t)(hi >> 32), x1 = (uint32_t)hi, x2 = (uint32_t)(lo >> 32);
+    atomicOr(&stream[w], x0 >> sh);
+    atomicOr(&stream[w + 1], (uint32_t)((((uint64_t)x0 << 32) | x1) >> sh));
+    atomicOr(&stream[w + 2], (uint32_t)((((uint64_t)x1 << 32) | x2) >> sh));
+    atomicOr(&stream[w + 3], (uint32_t)(((uint64_t)x2 << 32) >> sh));
+}
+// the 64 bits of the string from bit o on
+__device__ __forceinline__ uint64_t ht_stream_window(const uint32_t* stream, unsigned o)
+{
+    const unsigned w = o >> 5, sh = o & 31u;
+    const uint64_t w0 = stream[w], w1 = stream[w + 1], w2 = stream[w + 2];
+    return (((w0 << 32) | w1) << sh & 0xFFFFFFFF00000000ull) | ((((w1 << 32) | w2) << sh) >> 32);
+}
+// one code (c: left-aligned in 64 bits, len bits) behind the pos bits a run holds so far
+__device__ __forceinline__ void ht_run_append(uint64_t& hi, uint64_t& lo, unsigned pos, uint64_t c, unsigned len)
+{
+    if (pos < 64u) {
+        hi |= c >> pos;
+        if (pos + len > 64u) lo |= c << (64u - pos);          // (pos >= 52 here: the shift is < 64)
+    } else {
+        lo |= c >> (pos - 64u);
+    }
+}
 __global__ void __launch_bounds__(kBlock)
 k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t tiles_per_block, int npass,
           uint64_t* __restrict__ K, uint32_t* __restrict__ partial)
 {
     __shared__ uint32_t s_tab[256];
-    __shared__ uint32_t s_words[(kHtTile + kHtPad) / 4 + 4];            // the tile's packed words (at least 4 symbols per word)
-    __shared__ uint32_t s_ent[kHtTile + kHtPad + (kHtTile + kHtPad) / 8 + 1];
-    __shared__ uint64_t s_key[kHtTile + kHtTile / 8];
+    __shared__ uint32_t s_words[kHtSpan / 4 + 4];                    // the span's packed words (at least 4 symbols per word)
+    __shared__ uint32_t s_stream[kHtStreamWords];
+    __shared__ __attribute__((aligned(16))) uint16_t s_off[kHtSpan];
+    __shared__ uint32_t s_wsum[kBlock / kWave];
     __shared__ uint32_t h[kMaxPasses][kRadix];                       // (one copy: the key bytes are spread evenly)
     const unsigned tid = threadIdx.x;
     s_tab[tid] = ent[tid];
@@ -2211,56 +2276,62 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
     __syncthreads();
     const unsigned bits = (unsigned)t.bits;
     const uint32_t smask = (1u << bits) - 1u;
+    const float inv_spw = 1.0f / (float)t.spw;
     const uint64_t tile0 = (uint64_t)blockIdx.x * tiles_per_block;
     for (uint64_t tile = tile0; tile < tile0 + tiles_per_block; tile++) {
         const uint64_t base = tile * kHtTile;
         if (base >= m) break;
-        // the tile's packed words first, two or three independent loads per thread (a load per symbol made the tile wait
-        // for eight global round trips in a row: 5.9 ms per 10^9 positions, most of it latency)
+        // the span's packed words, two or three independent loads per thread; the bit string zeroed
         const uint64_t q0 = packed_word_index(t, base);
         const uint64_t qlast = (t.n + (uint64_t)t.spw - 1) / (uint64_t)t.spw + 2;         // (three zero words behind the text)
-        const unsigned nw = (unsigned)(packed_word_index(t, base + kHtTile + kHtPad - 1) - q0) + 1u;
+        const unsigned nw = (unsigned)(packed_word_index(t, base + kHtSpan - 1) - q0) + 1u;
 #pragma unroll
-        for (int k = 0; k < (int)(((kHtTile + kHtPad) / 4 + 4 + kBlock - 1) / kBlock); k++) {
+        for (int k = 0; k < (int)((kHtSpan / 4 + 4 + kBlock - 1) / kBlock); k++) {
             const unsigned w = tid + (unsigned)k * kBlock;
             if (w < nw) s_words[w] = q0 + w <= qlast ? t.words[q0 + w] : 0u;
         }
-        __syncthreads();
-        for (unsigned i = tid; i < (unsigned)(kHtTile + kHtPad); i += kBlock) {
-            const uint64_t p = base + i;                     // (positions past the text read as the padding's zero symbol)
-            const uint64_t q = packed_word_index(t, p);
-            const unsigned off = packed_word_offset(t, p, q);
-            s_ent[ht_skew(i)] = s_tab[p < t.n ? (s_words[(unsigned)(q - q0)] >> (((unsigned)t.spw - 1u - off) * bits)) & smask : 0u];
-        }
+        for (unsigned w = tid; w < (unsigned)kHtStreamWords; w += kBlock) s_stream[w] = 0u;
         __syncthreads();
         {
+            // the run of symbols [8 tid, 8 tid + 8): word and offset of the first in single precision (exact for the < 2^12
+            // symbols of a span), a step per symbol; positions past the text read as the padding's zero symbol
+            const unsigned off0 = (unsigned)(base - q0 * (uint64_t)t.spw);
+            const unsigned lim = (unsigned)dmin<uint64_t>(t.n - base, 0xFFFFFFu);
             const unsigned i0 = tid * (unsigned)kHtRun;
-            uint64_t hi = 0, lo = 0;                         // the codes of symbols [i, j), nb bits, left-aligned in hi:lo
-            unsigned nb = 0, j = i0;
-            for (unsigned i = i0; i < i0 + (unsigned)kHtRun; i++) {
-                while (nb < 64u && j < i + kHtMaxSym) {
-                    const uint32_t e = s_ent[ht_skew(j)];
-                    j++;
-                    const uint64_t c = (uint64_t)(e & ~31u) << 32;
-                    const unsigned len = e & 31u;
-                    hi |= c >> nb;
-                    if (nb + len > 64u) lo |= c << (64u - nb);           // (nb >= 38 here: the shift is < 64)
-                    nb += len;
-                }
-                s_key[ht_skew(i)] = kHtKeyBits == 64 ? hi : (hi & ~((1ull << (64 - kHtKeyBits)) - 1ull));   // (the bits that are sorted)
-                const unsigned len = s_ent[ht_skew(i)] & 31u;            // symbol i leaves (it is in the buffer: j > i)
-                hi = (hi << len) | (lo >> (64u - len));
-                lo <<= len;
-                nb -= len;
+            unsigned wq = (unsigned)(((float)(off0 + i0) + 0.5f) * inv_spw);
+            unsigned off = off0 + i0 - wq * (unsigned)t.spw;
+            uint64_t hi = 0, lo = 0;
+            unsigned pos = 0;
+            uint32_t offs[kHtRun];
+#pragma unroll
+            for (int k = 0; k < kHtRun; k++) {
+                const uint32_t e = s_tab[i0 + (unsigned)k < lim ? (s_words[wq] >> (((unsigned)t.spw - 1u - off) * bits)) & smask : 0u];
+                if (++off == (unsigned)t.spw) { off = 0; wq++; }
+                const unsigned len = e & 31u;
+                offs[k] = pos;
+                ht_run_append(hi, lo, pos, (uint64_t)(e & ~31u) << 32, len);
+                pos += len;
             }
+            const unsigned S = ht_block_scan(pos, s_wsum, tid);
+            uint4 o;
+            o.x = (S + offs[0]) | ((S + offs[1]) << 16);
+            o.y = (S + offs[2]) | ((S + offs[3]) << 16);
+            o.z = (S + offs[4]) | ((S + offs[5]) << 16);
+            o.w = (S + offs[6]) | ((S + offs[7]) << 16);
+            __builtin_memcpy(&s_off[i0], &o, sizeof(o));                 // (16-byte aligned: one LDS store)
+            ht_stream_or(s_stream, S, hi, lo);
         }
         __syncthreads();
-        for (unsigned i = tid; i < (unsigned)kHtTile; i += kBlock) {
-            if (base + i < m) {
-                const uint64_t key = s_key[ht_skew(i)];
+#pragma unroll
+        for (int k = 0; k < kHtRun; k++) {
+            const unsigned i = tid + (unsigned)k * kBlock;
+            if (i < (unsigned)kHtTile && base + i < m) {
+                const unsigned o = s_off[i], nb = (unsigned)s_off[i + kHtMaxSym] - o;      // (symbol i + kHtMaxSym stays out)
+                uint64_t key = ht_stream_window(s_stream, o);
+                if (nb < 64u) key &= ~0ull << (64u - nb);
+                if (kHtKeyBits < 64) key &= ~((1ull << (64 - kHtKeyBits)) - 1ull);       // (the bits that are sorted)
                 K[base + i] = key;
-                if (partial)
-                    for (int p = 0; p < npass; p++) atomicAdd(&h[p][(unsigned)(key >> (64 - kHtKeyBits + 8 * p)) & 255u], 1u);
+                if (partial) ht_count_digits(h, key, npass);
             }
         }
         __syncthreads();
@@ -2273,14 +2344,15 @@ k_ht_keys(PackedText t, const uint32_t* __restrict__ ent, uint64_t m, uint64_t t
 // An order-preserving prefix code per class of the PRECEDING symbol: the key of position i = the order-0 code of symbol i, then
 // for j = i + 1, i + 2, ... the code of symbol j in the table of class(symbol j - 1).  Equal prefixes of two suffixes have equal
 // contexts, so the concatenation is still order-preserving and prefix-free; and the stream from i + 1 on does not depend on i,
-// so the rolling buffer of k_ht_keys survives: it holds the stream, the first symbol's order-0 code goes in front.  Mixed-script
-// UTF-8 (config 5): 4.7 instead of 6.25 bits per symbol with 16 classes.  How many WHOLE code words a key holds cannot be
-// read off it with the order-0 end-mask table any more, so the kernel counts them where it knows them -- a second rolling
-// buffer with one bit per code-word end -- and stores the count in the key's LOW 4 BITS (kHtCtxCountBits; the code string
-// takes the top 60): equal 60-bit prefixes of a prefix code hold the same code words, so order and tie classes are what the
-// 60 bits alone give, and a bucket's depth is key & 15 (k_groups_apply).
+// so k_ht_keys' bit string survives: it holds the stream, the key is the first symbol's order-0 code and the window behind
+// symbol i.  Mixed-script UTF-8 (config 5): 5.0 instead of 6.4 bits per symbol with 16 classes.  How many WHOLE code words a
+// key holds cannot be read off it with the order-0 end-mask table any more, so the kernel counts them where it knows them -- a
+// second bit string with one bit per code-word END, the population count of ITS window -- and stores the count in the key's
+// LOW 4 BITS (kHtCtxCountBits; the code string takes the top 60): equal 60-bit prefixes of a prefix code hold the same code
+// words, so order and tie classes are what the 60 bits alone give, and a bucket's depth is key & 15 (k_groups_apply).
 // tab: [0, 256) order-0 entries, then at kHtCtxOff: class of every dense symbol (256 bytes), then 16 x 256 class entries.
 constexpr unsigned kHtCtxMaxSym = 15;                         // symbols a context key is made from at most (the count's range)
+static_assert(kHtPad >= (int)kHtCtxMaxSym, "the stream symbols of the tile's last key");
 __global__ void __launch_bounds__(kBlock)
 k_ht_keys_ctx(PackedText t, const uint32_t* __restrict__ tab, int sigma, uint64_t m, uint64_t tiles_per_block, int npass,
               uint64_t* __restrict__ K, uint32_t* __restrict__ partial)
@@ -2288,10 +2360,12 @@ k_ht_keys_ctx(PackedText t, const uint32_t* __restrict__ tab, int sigma, uint64_
     __shared__ uint32_t s_tab0[256];
     __shared__ uint8_t s_cls[256];
     __shared__ uint32_t s_tab1[kHtCtxClasses * kHtCtxSigmaMax];
-    __shared__ uint32_t s_words[(kHtTile + kHtPad) / 4 + 8];
-    __shared__ uint8_t s_sym[kHtTile + kHtPad + 8];
-    __shared__ uint32_t s_ent1[kHtTile + kHtPad + (kHtTile + kHtPad) / 8 + 1];
-    __shared__ uint64_t s_key[kHtTile + kHtTile / 8];
+    __shared__ uint32_t s_words[kHtSpan / 4 + 8];
+    __shared__ __attribute__((aligned(8))) uint8_t s_sym[kHtSpan];
+    __shared__ uint32_t s_stream[kHtStreamWords];
+    __shared__ uint32_t s_ends[kHtStreamWords];
+    __shared__ __attribute__((aligned(16))) uint16_t s_off[kHtSpan];
+    __shared__ uint32_t s_wsum[kBlock / kWave];
     __shared__ uint32_t h[kMaxPasses][kRadix];
     const unsigned tid = threadIdx.x;
     s_tab0[tid] = tab[tid];
@@ -2302,79 +2376,86 @@ k_ht_keys_ctx(PackedText t, const uint32_t* __restrict__ tab, int sigma, uint64_
     __syncthreads();
     const unsigned bits = (unsigned)t.bits;
     const uint32_t smask = (1u << bits) - 1u;
+    const float inv_spw = 1.0f / (float)t.spw;
     const uint64_t tile0 = (uint64_t)blockIdx.x * tiles_per_block;
     for (uint64_t tile = tile0; tile < tile0 + tiles_per_block; tile++) {
         const uint64_t base = tile * kHtTile;
         if (base >= m) break;
-        // the tile's packed words (from the symbol BEFORE the tile on: the first stream code needs its context)
+        // the span's packed words (from the symbol BEFORE the tile on: the first stream code needs its context)
         const uint64_t first = base ? base - 1 : 0;
         const uint64_t q0 = packed_word_index(t, first);
         const uint64_t qlast = (t.n + (uint64_t)t.spw - 1) / (uint64_t)t.spw + 2;         // (three zero words behind the text)
-        const unsigned nw = (unsigned)(packed_word_index(t, base + kHtTile + kHtPad - 1) - q0) + 1u;
+        const unsigned nw = (unsigned)(packed_word_index(t, base + kHtSpan - 1) - q0) + 1u;
 #pragma unroll
-        for (int k = 0; k < (int)(((kHtTile + kHtPad) / 4 + 8 + kBlock - 1) / kBlock); k++) {
+        for (int k = 0; k < (int)((kHtSpan / 4 + 8 + kBlock - 1) / kBlock); k++) {
             const unsigned w = tid + (unsigned)k * kBlock;
             if (w < nw) s_words[w] = q0 + w <= qlast ? t.words[q0 + w] : 0u;
         }
-        __syncthreads();
-        // symbols of positions base - 1 .. base + tile + pad - 1 at s_sym[1 + i] (i = -1: the context of the tile's first stream code)
-        for (unsigned i = tid; i < (unsigned)(kHtTile + kHtPad + 1); i += kBlock) {
-            const uint64_t p = base + i - 1;                 // (i = 0 with base = 0: no such position, class of symbol 0)
-            unsigned sym = 0;
-            if ((base || i) && p < t.n) {
-                const uint64_t q = packed_word_index(t, p);
-                const unsigned off = packed_word_offset(t, p, q);
-                sym = (s_words[(unsigned)(q - q0)] >> (((unsigned)t.spw - 1u - off) * bits)) & smask;
-            }
-            s_sym[i] = (uint8_t)sym;
-        }
-        __syncthreads();
-        for (unsigned i = tid; i < (unsigned)(kHtTile + kHtPad); i += kBlock) {
-            s_ent1[ht_skew(i)] = s_tab1[(unsigned)s_cls[s_sym[i]] * (unsigned)sigma + (unsigned)s_sym[i + 1]];   // symbol i after symbol i - 1
-            // (the order-0 entry of symbol i waits in the slot its key will take: the thread that makes key i reads it first)
-            if (i < (unsigned)kHtTile) s_key[ht_skew(i)] = (uint64_t)s_tab0[s_sym[i + 1]];
-        }
+        for (unsigned w = tid; w < (unsigned)kHtStreamWords; w += kBlock) { s_stream[w] = 0u; s_ends[w] = 0u; }
         __syncthreads();
         {
+            // the run of span symbols [8 tid, 8 tid + 8), from the symbol before it on (its first context; before position 0:
+            // the class of symbol 0).  Span symbol j = position base + j; li = its index among the symbols of s_words
+            const unsigned off0 = (unsigned)(first - q0 * (uint64_t)t.spw);
+            const unsigned lead = base ? 1u : 0u;            // span symbol 0 sits at li = off0 + lead
+            const unsigned lim = (unsigned)dmin<uint64_t>(t.n - base, 0xFFFFFFu);      // span symbols inside the text
             const unsigned i0 = tid * (unsigned)kHtRun;
-            // the stream codes of symbols [i + 1, j): nb bits, left-aligned in hi:lo; ehi:elo = one bit per code-word END
-            uint64_t hi = 0, lo = 0, ehi = 0, elo = 0;
-            unsigned nb = 0, j = i0 + 1u;
-            for (unsigned i = i0; i < i0 + (unsigned)kHtRun; i++) {
-                while (nb < 64u && j < i + kHtCtxMaxSym) {
-                    const uint32_t e = s_ent1[ht_skew(j)];
-                    j++;
-                    const uint64_t c = (uint64_t)(e & ~31u) << 32;
-                    const unsigned len = e & 31u;
-                    hi |= c >> nb;
-                    if (nb + len > 64u) lo |= c << (64u - nb);           // (nb >= 38 here: the shift is < 64)
-                    const unsigned endb = nb + len - 1u;
-                    if (endb < 64u) ehi |= 1ull << (63u - endb); else elo |= 1ull << (127u - endb);
-                    nb += len;
-                }
-                const uint32_t e0 = (uint32_t)s_key[ht_skew(i)];
-                const unsigned len0 = e0 & 31u;
-                const unsigned room = 64u - (unsigned)kHtCtxCountBits - len0;     // stream bits that fit behind the first code
-                const unsigned have = nb < room ? nb : room;                     // (fewer only where the symbol cap stopped the fill)
-                const uint64_t code = ((uint64_t)(e0 & ~31u) << 32) | (hi >> len0);
-                unsigned cnt = 1u + (have ? (unsigned)__popcll(ehi >> (64u - have)) : 0u);
-                if (cnt > kHtCtxMaxSym) cnt = kHtCtxMaxSym;
-                s_key[ht_skew(i)] = (code & ~((1ull << kHtCtxCountBits) - 1ull)) | (uint64_t)cnt;
-                const unsigned len = s_ent1[ht_skew(i + 1u)] & 31u;      // symbol i + 1 leaves the stream (it is in the buffer: j > i + 1)
-                hi = (hi << len) | (lo >> (64u - len));
-                lo <<= len;
-                ehi = (ehi << len) | (elo >> (64u - len));
-                elo <<= len;
-                nb -= len;
+            unsigned prev = 0;
+            unsigned wq = 0, off = 0;
+            if (i0 + lead > 0u) {
+                const unsigned li = off0 + i0 + lead - 1u;   // the symbol before the run
+                wq = (unsigned)(((float)li + 0.5f) * inv_spw);
+                off = li - wq * (unsigned)t.spw;
+                prev = i0 <= lim ? (s_words[wq] >> (((unsigned)t.spw - 1u - off) * bits)) & smask : 0u;   // (position base + i0 - 1 < n)
+                if (++off == (unsigned)t.spw) { off = 0; wq++; }
             }
+            uint64_t hi = 0, lo = 0, ehi = 0, elo = 0;
+            unsigned pos = 0;
+            uint32_t offs[kHtRun];
+            uint64_t syms = 0;
+#pragma unroll
+            for (int k = 0; k < kHtRun; k++) {
+                const unsigned sym = i0 + (unsigned)k < lim ? (s_words[wq] >> (((unsigned)t.spw - 1u - off) * bits)) & smask : 0u;
+                if (++off == (unsigned)t.spw) { off = 0; wq++; }
+                const uint32_t e = s_tab1[(unsigned)s_cls[prev] * (unsigned)sigma + sym];   // symbol j after symbol j - 1
+                prev = sym;
+                syms |= (uint64_t)sym << (8 * k);
+                const unsigned len = e & 31u;
+                offs[k] = pos;
+                ht_run_append(hi, lo, pos, (uint64_t)(e & ~31u) << 32, len);
+                pos += len;
+                ht_run_append(ehi, elo, pos - 1u, 1ull << 63, 1u);                         // (one bit where the code word ends)
+            }
+            *reinterpret_cast<uint64_t*>(&s_sym[i0]) = syms;
+            const unsigned S = ht_block_scan(pos, s_wsum, tid);
+            uint4 o;
+            o.x = (S + offs[0]) | ((S + offs[1]) << 16);
+            o.y = (S + offs[2]) | ((S + offs[3]) << 16);
+            o.z = (S + offs[4]) | ((S + offs[5]) << 16);
+            o.w = (S + offs[6]) | ((S + offs[7]) << 16);
+            __builtin_memcpy(&s_off[i0], &o, sizeof(o));                 // (16-byte aligned: one LDS store)
+            ht_stream_or(s_stream, S, hi, lo);
+            ht_stream_or(s_ends, S, ehi, elo);
         }
         __syncthreads();
-        for (unsigned i = tid; i < (unsigned)kHtTile; i += kBlock) {
-            if (base + i < m) {
-                const uint64_t key = s_key[ht_skew(i)];
+#pragma unroll
+        for (int k = 0; k < kHtRun; k++) {
+            const unsigned i = tid + (unsigned)k * kBlock;
+            if (i < (unsigned)kHtTile && base + i < m) {
+                // the stream behind symbol i: symbols i + 1 .. i + kHtCtxMaxSym - 1
+                const unsigned o = s_off[i + 1u], nb = (unsigned)s_off[i + kHtCtxMaxSym] - o;
+                uint64_t win = ht_stream_window(s_stream, o);
+                if (nb < 64u) win = nb ? win & (~0ull << (64u - nb)) : 0ull;
+                const uint32_t e0 = s_tab0[s_sym[i]];
+                const unsigned len0 = e0 & 31u;
+                const unsigned room = 64u - (unsigned)kHtCtxCountBits - len0;     // stream bits that fit behind the first code
+                const unsigned have = nb < room ? nb : room;                     // (fewer only where the symbol cap cut the stream)
+                const uint64_t code = ((uint64_t)(e0 & ~31u) << 32) | (win >> len0);
+                unsigned cnt = 1u + (have ? (unsigned)__popcll(ht_stream_window(s_ends, o) >> (64u - have)) : 0u);
+                if (cnt > kHtCtxMaxSym) cnt = kHtCtxMaxSym;
+                const uint64_t key = (code & ~((1ull << kHtCtxCountBits) - 1ull)) | (uint64_t)cnt;
                 K[base + i] = key;
-                if (partial)
-                    for (int p = 0; p < npass; p++) atomicAdd(&h[p][(unsigned)(key >> (8 * p)) & 255u], 1u);
+                if (partial) ht_count_digits(h, key, npass);
             }
         }
         __syncthreads();

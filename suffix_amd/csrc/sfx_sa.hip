@@ -40,6 +40,7 @@
 // refines with text rounds only (no ranks of foreign suffixes needed).
 #include <math.h>
 #include <stdio.h>
+#include <thread>
 #include <vector>
 #include <chrono>
 #include <string.h>
@@ -1654,7 +1655,13 @@ static bool ht_codes(const double* wd, int ns, uint32_t* ent, double* avg_out)
     unsigned short* const R = root_v.data();
     auto at = [ns](int i, int j) { return (size_t)i * ns + j; };
     int len[256];
-    for (int shift = 16; shift >= 4; shift--) {
+    // the weight floor total / 2^shift caps the depth of the rare symbols: the largest shift (the least distortion) whose tree has
+    // no code word above kHtMaxLen -- feasibility is monotone in the shift, so a bisection over [4, 16] (4 trees instead of up to 13)
+    int lo_s = 4, hi_s = 16, good = -1;
+    uint32_t best_ent[256];
+    double best_avg = 0;
+    while (lo_s <= hi_s) {
+        const int shift = (lo_s + hi_s) / 2;
         double ww[256], pre[257];
         const double floor_w = total / (double)(1ull << shift);
         pre[0] = 0;
@@ -1694,13 +1701,18 @@ static bool ht_codes(const double* wd, int ns, uint32_t* ent, double* avg_out)
             stack[sp++] = Item{k + 1, it.j, it.d + 1, (it.code << 1) | 1u};
             stack[sp++] = Item{it.i, k, it.d + 1, it.code << 1};
         }
-        if (!ok) continue;
+        if (!ok) { hi_s = shift - 1; continue; }
         double avg = 0;
         for (int i = 0; i < ns; i++) avg += wd[i] / total * len[i];
-        *avg_out = avg;
-        return true;
+        good = shift;
+        best_avg = avg;
+        for (int i = 0; i < ns; i++) best_ent[i] = ent[i];
+        lo_s = shift + 1;
     }
-    return false;
+    if (good < 0) return false;
+    for (int i = 0; i < ns; i++) ent[i] = best_ent[i];
+    *avg_out = best_avg;
+    return true;
 }
 
 // Context codes for a text whose pair counts are big[prev * sigma + cur] (dense symbols; `base` = its order-0 code, whose ent
@@ -1715,7 +1727,7 @@ static bool ht_ctx_build(const std::vector<unsigned long long>& big, int sigma, 
     out->ctx = 0;
     if (sigma < 2 || sigma > kHtCtxSigmaMax || out->sigma != sigma) return false;
     const int NC = kHtCtxClasses;
-    std::vector<double> W((size_t)NC * sigma, 0.0), tot(NC, 0.0), row(sigma);
+    std::vector<double> W((size_t)NC * sigma, 0.0), tot(NC, 0.0);
     int cls[256];
     {   // initial classes: the high nibbles that occur, in order
         int map[16], used = 0;
@@ -1777,14 +1789,23 @@ static bool ht_ctx_build(const std::vector<unsigned long long>& big, int sigma, 
         }
         if (!moved) break;
     }
+    // (the classes' code trees are independent: one host thread each -- 16 x 4 trees of sigma^2 cells are 3 ms in a row)
     double bits = 0, pairs = 0;
+    double avg_c[kHtCtxClasses];
+    bool ok_c[kHtCtxClasses];
+    std::vector<std::thread> workers;
     for (int c = 0; c < NC; c++) {
         for (int q = 0; q < 256; q++) out->ent1[c][q] = out->ent[q < sigma ? q : 0];
+        ok_c[c] = true;
+        avg_c[c] = 0;
         if (!(tot[c] > 0)) continue;                                   // (an empty class: the order-0 code, never looked up)
-        for (int q = 0; q < sigma; q++) row[q] = W[(size_t)c * sigma + q];
-        double avg = 0;
-        if (!ht_codes(row.data(), sigma, out->ent1[c], &avg)) return false;
-        bits += avg * tot[c];
+        auto job = [&W, &ok_c, &avg_c, out, sigma, c] { ok_c[c] = ht_codes(&W[(size_t)c * sigma], sigma, out->ent1[c], &avg_c[c]); };
+        try { workers.emplace_back(job); } catch (...) { job(); }       // (no thread to be had: in line)
+    }
+    for (auto& w : workers) w.join();
+    for (int c = 0; c < NC; c++) {
+        if (!ok_c[c]) return false;
+        bits += avg_c[c] * tot[c];
         pairs += tot[c];
     }
     if (!(pairs > 0)) return false;
@@ -2566,12 +2587,33 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
             // Context codes (round 6, k_ht_keys_ctx) where they buy 10 % more symbols per key -- large alphabets with structure
             // between neighbouring bytes (mixed-script UTF-8: 13 symbols instead of 10).  Not with the fused LCP: the symbols two
             // different keys share cannot be counted off a context code with the order-0 end-mask table.
-            static const uint64_t ctx_min = [] { const char* e = dev_env("SFX_HT_CTX_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 24); }();
+            static const uint64_t ctx_min = [] { const char* e = dev_env("SFX_HT_CTX_MIN"); return e ? (uint64_t)strtoull(e, nullptr, 10) : (1ull << 26); }();
             // (the bigram pass is only paid where contexts can buy 10 %: the count's 4 bits cost 4 / length symbols, and the order-1
             // entropy of text whose order-0 code already averages under 5 bits -- English-like: 4.6 -- is never that far below it)
             static const int ctx_force = [] { const char* e = dev_env("SFX_HT_CTX"); return e ? atoi(e) : 1; }();
-            if (!lcp_fuse && ctx_force != 0 && (ht.avg_len >= 5.0 || ctx_force == 2) && (int)alpha.sigma <= kHtCtxSigmaMax && n >= ctx_min &&
-                kHtKeyBits == 64) {
+            static const bool trace = [] { const char* e = dev_env("SFX_TRACE"); return e && atoi(e) != 0; }();
+            bool ctx_try = !lcp_fuse && ctx_force != 0 && (ht.avg_len >= 5.0 || ctx_force == 2) && (int)alpha.sigma <= kHtCtxSigmaMax && n >= ctx_min &&
+                           kHtKeyBits == 64;
+            if (ctx_try && ctx_force != 2) {
+                // Longer keys only pay where the order-0 keys leave many suffixes tied (word-structured text: most of them), and a
+                // text of the same bytes without repeats (independent code points) has the same symbol statistics: a PILOT decides --
+                // the first 2^22 suffixes sorted by their order-0 keys (0.3 % of the build), the share that stays tied.  The share only
+                // grows with the number of suffixes sorted, so the pilot errs towards the plain keys.
+                static const int pilot_log = [] { const char* e = dev_env("SFX_HT_CTX_PILOT"); const int v = e ? atoi(e) : 22; return v >= 4 && v <= 28 ? v : 22; }();
+                const uint64_t mp = dmin<uint64_t>(1ull << pilot_log, n / 4);
+                SFX_HIP(hipMemcpyAsync(b.ht, ht.ent, sizeof(ht.ent), hipMemcpyHostToDevice, st));
+                SFX_HIP(hipMemcpyAsync(b.ht + kHtTableWords, ht.t12, sizeof(ht.t12), hipMemcpyHostToDevice, st));
+                int pin1 = 0;
+                sfx_build_stats pstats = {};
+                SFX_TRY(radix_sort_ht64(b.K0, b.VA, b.K1, b.VB, mp, b.hist, st, &pin1, &pstats, pt, b.ht, nullptr, b.kv_cap, 0));
+                uint64_t ptied = 0, pgroups = 0;
+                SFX_TRY(round_totals<uint64_t>(pin1 ? b.K1 : b.K0, mp, b, st, &ptied, &pgroups));
+                ctx_try = ptied * 16 >= mp;
+                if (trace)
+                    fprintf(stderr, "[sfx] context codes: pilot of %llu suffixes, %llu tied in %llu runs -> %s\n", (unsigned long long)mp,
+                            (unsigned long long)ptied, (unsigned long long)pgroups, ctx_try ? "bigram pass" : "order-0 keys");
+            }
+            if (ctx_try) {
                 const int sg = (int)alpha.sigma;
                 unsigned long long* d_big = reinterpret_cast<unsigned long long*>(b.K0);           // (idle until the keys are made)
                 SFX_HIP(hipMemsetAsync(d_big, 0, (size_t)sg * sg * sizeof(unsigned long long), st));
@@ -2588,7 +2630,6 @@ static int build_sa_impl(const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void
                     if (counts[c]) dense_byte[q++] = (unsigned char)c;
                 const auto t_host0 = std::chrono::steady_clock::now();
                 const bool took = q == sg && ht_ctx_build(big, sg, dense_byte, &ht);
-                static const bool trace = [] { const char* e = dev_env("SFX_TRACE"); return e && atoi(e) != 0; }();
                 if (trace)
                     fprintf(stderr, "[sfx] context codes: %s, order-0 %.3f bits, stream %.3f bits, host %.3f ms\n", took ? "taken" : "not taken", ht.avg_len,
                             ht.avg_ctx, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count());

@@ -156,7 +156,7 @@ def test_committed_bench_record_has_a_measured_traffic_for_every_large_kernel():
         if k["share"] >= 0.15:
             assert k["traffic_ratio"] is not None and k["traffic_ratio"] >= 0.98, ("headline", k)
     seen = set()
-    for c in final["configs"]:
+    for c in final["roofline"]["configs"]:
         assert c.get("dominant"), c
         seen.add(c["key"])
         assert c["dominant"]["traffic_ratio"] is not None and c["dominant"]["traffic_ratio"] >= 0.98, c

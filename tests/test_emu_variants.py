@@ -245,6 +245,8 @@ VARIANTS = {
     # context codes (round 6, k_ht_keys_ctx): one order-preserving code per class of the preceding symbol, the number of symbols a
     # key holds in its low 4 bits -- forced on small inputs (the build takes them from 2^24 bytes on, where they buy 10 % more symbols)
     "context-codes": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_HT_CTX": "2", "SFX_HT_CTX_MIN": "1"},
+    # ... and left to the build's own decision: the 10 % rule on the code lengths, then the pilot sort (here of 2^6 .. n / 4 suffixes)
+    "context-codes-by-pilot": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_HT_CTX": "1", "SFX_HT_CTX_MIN": "1", "SFX_HT_CTX_PILOT": "6"},
     "context-codes-small-tiles": {"SFX_FORCE_KEY64": "1", "SFX_HT_MIN": "1", "SFX_HT_CTX": "2", "SFX_HT_CTX_MIN": "1", "SFX_TILE_SMALL": "1",
                                   "SFX_MAX_GRID": "3"},
     # rank rounds through round 1's composite-key sort (the fallback for key2 = rank + h beyond 32 bits)
