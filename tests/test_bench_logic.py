@@ -139,7 +139,9 @@ def test_fullsize_pmc_record_is_recomputable_from_the_committed_summaries(tmp_pa
         by_hand = (tot["FETCH_SIZE"] * ent["fetch_calibration_copy"] + tot["WRITE_SIZE"] * ent["write_calibration_copy"]) * 1024.0 / ent["builds"]
         k = ent["kernels"]["radix_scatter_u64"]
         # (the record keeps its calibration factors to four decimals)
-        assert abs(by_hand - k["hbm_bytes_per_build"]) <= 1e-4 * k["hbm_bytes_per_build"] and k["launches"] == n // ent["builds"] == 8, key
+        # (config 5 and its round-1 input sort twice: the pilot of 2^22 suffixes that decides on the context codes, then the text)
+        assert abs(by_hand - k["hbm_bytes_per_build"]) <= 1e-4 * k["hbm_bytes_per_build"], key
+        assert k["launches"] == n // ent["builds"] == (16 if key in ("c5", "c5r1") else 8), key
 
 
 def test_committed_bench_record_has_a_measured_traffic_for_every_large_kernel():
