@@ -250,7 +250,8 @@ typedef struct {
     uint32_t key_bits;        /* width of the initial k-mer key (32 or 64)     */
     uint32_t symbols_per_key; /* k (compressed 64-bit keys: the average, 64 / mean code length) */
     uint32_t rounds;          /* refinement rounds after the initial sort      */
-    uint32_t reserved;        /* bit 0: sfx_build_sa_lcp_u32 stopped reading LCP values off the sort (most suffixes tied on the initial key) */
+    uint32_t reserved;        /* bit 0: sfx_build_sa_lcp_u32 stopped reading LCP values off the sort (most suffixes tied on the initial key);
+                                 bit 1: the initial keys are context codes (a code per class of the preceding symbol) */
     uint64_t active_after_initial;
     uint64_t radix_passes;
     uint64_t elements_sorted; /* sum over passes of elements moved             */

@@ -229,6 +229,41 @@ def test_compressed_keys_symbol_distributions(eng, oracle):
         del text, sa, sa2, lcp2
 
 
+def test_context_codes_and_their_pilot_68mb(eng, oracle):
+    """Context codes (round 6, k_ht_keys_ctx) at the smallest size that considers them (2^26 bytes): mixed-script UTF-8 of
+    Zipf words leaves most of the pilot sort's 2^22 suffixes tied and takes them (bigram pass, stats.reserved bit 1 through the
+    key kernel's profile name staying `ht_keys`); the same generator's bytes drawn as independent code points (round 1's form
+    of config 5) has the same symbol statistics and no ties: the pilot keeps the order-0 keys.  Complete SA against the
+    oracle for both, the LCP array of the first."""
+    import torch
+    from suffix_amd import device as sdev
+    n = (1 << 26) + 1_000_000
+    words = np.ascontiguousarray(_gen.utf8_mixed(n))
+    rng = np.random.default_rng(99)
+    # independent code points of the four scripts, encoded: no word is ever repeated
+    cps = np.concatenate([rng.integers(0x61, 0x7B, n // 8), rng.integers(0x410, 0x450, n // 8), rng.integers(0x4E00, 0x9FFF, n // 8),
+                          rng.integers(0x1F300, 0x1F600, n // 16)])
+    rng.shuffle(cps)
+    indep = np.frombuffer("".join(map(chr, cps.tolist())).encode("utf-8"), dtype=np.uint8).copy()      # (n bytes: 1 + 2 + 3 eighths, 4 sixteenths)
+    assert len(indep) >= 1 << 26
+    for host, taken in ((words, True), (indep, False)):
+        text = torch.from_numpy(host).cuda()
+        eng.profile(True); eng.profile_reset()
+        sa = sdev.build_sa(text)
+        torch.cuda.synchronize()
+        rep = {r["name"]: r for r in eng.profile_report()}
+        eng.profile(False)
+        st = eng.build_stats()
+        # the pilot sorts before the text does: two key kernels, sixteen passes; the bigram pass only behind a pilot that says "tied"
+        assert st["key_bits"] == 64 and rep["ht_keys"]["launches"] == 2 and rep["radix_scatter_u64"]["launches"] == 16, (st, sorted(rep))
+        assert ("bigram_hist" in rep) == taken, sorted(rep)
+        exp = oracle.sais(host.tobytes())
+        assert np.array_equal(sa.cpu().numpy().view(np.uint32), exp)
+        if taken:
+            assert np.array_equal(sdev.build_lcp(text, sa).cpu().numpy().view(np.uint32), oracle.lcp_kasai(host.tobytes(), exp))
+        del text, sa
+
+
 @pytest.mark.parametrize("sigma", [2, 5, 16])
 def test_hybrid_initial_sort_other_alphabets(eng, sigma):
     """The hybrid route on keys of 32 one-bit symbols and 8 four-bit symbols, 56 * 10^6 suffixes each, through the
