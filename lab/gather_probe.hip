@@ -29,6 +29,30 @@ __global__ void __launch_bounds__(256) k_gather(const V* __restrict__ base, uint
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
+// (e) round 6: the same 4-byte gather with a non-temporal load / with system-scope bits -- does the L2 still fill a whole 128-byte line
+// per miss?  (FETCH_SIZE per member from `rocprofv3 --pmc FETCH_SIZE` over this binary; kernel names tell the variants apart)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_gather4_mode(const uint32_t* __restrict__ base, uint64_t nlines, uint64_t members, uint32_t* sink)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint32_t acc = 0;
+    for (uint64_t m = (uint64_t)blockIdx.x * 256 + threadIdx.x; m < members; m += stride * 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t mm = m + u * stride;
+            const uint32_t* a = base + (mix(mm) % nlines) * 32;
+            if (mm >= members) { v[u] = 0; continue; }
+            if (MODE == 0) v[u] = *a;
+            else if (MODE == 1) v[u] = __builtin_nontemporal_load(a);
+            else if (MODE == 2) asm volatile("global_load_dword %0, %1, off sc0 sc1\n s_waitcnt vmcnt(0)" : "=v"(v[u]) : "v"(a) : "memory");
+            else asm volatile("global_load_dword %0, %1, off sc0 sc1 nt\n s_waitcnt vmcnt(0)" : "=v"(v[u]) : "v"(a) : "memory");
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc ^= v[u];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
 template <class F> static float time_ms(F&& f, int reps = 3)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -53,5 +77,20 @@ int main()
     RUN(4, uint4, "(d) 4 lanes/member, 64 B");
     RUN(8, uint4, "(b) 8 lanes/member, whole line");
     RUN(16, uint2, "(b) 16 lanes/member x 8 B, whole line");
+#define RUNM(MODE, label) { float t = time_ms([&] { hipLaunchKernelGGL((k_gather4_mode<MODE>), dim3(grid), dim3(256), 0, 0, (const uint32_t*)buf, nlines, members, sink); }); \
+        printf("%-44s %.3f ms  %.1f G members/s\n", label, t, members / t * 1e-6); }
+    RUNM(0, "(e) 4 B, plain load");
+    RUNM(1, "(e) 4 B, non-temporal load");
+    RUNM(2, "(e) 4 B, sc0 sc1 (waits per load)");
+    RUNM(3, "(e) 4 B, sc0 sc1 nt (waits per load)");
+    // the same plain gather from memory allocated uncached / fine-grained
+    for (int kind = 0; kind < 2; kind++) {
+        void* ub = nullptr;
+        if (hipExtMallocWithFlags(&ub, bytes, kind == 0 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained) != hipSuccess) { printf("allocation kind %d refused\n", kind); continue; }
+        CK(hipMemset(ub, 1, bytes));
+        float t = time_ms([&] { hipLaunchKernelGGL((k_gather4_mode<0>), dim3(grid), dim3(256), 0, 0, (const uint32_t*)ub, nlines, members, sink); });
+        printf("%-44s %.3f ms  %.1f G members/s\n", kind == 0 ? "(f) 4 B, plain load, hipDeviceMallocUncached" : "(f) 4 B, plain load, hipDeviceMallocFinegrained", t, members / t * 1e-6);
+        hipFree(ub);
+    }
     return 0;
 }
